@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X DiffeRT hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Metric (BASELINE.json): ray-triangle tests/s of `ray_intersect_triangle` (dense Moller-Trumbore,
+reference geometry/_utils.py:1157-1322) on BASELINE configs[1]'s scene (10k random triangles),
+fwd-only.  One *step* = one pass of the dense operator over one batch of rays that is already
+resident in HBM: `--rays` rays x 10 000 triangles -> t f32[R,T] + hit u8[R,T].
+
+configs[1] quotes 256 rays; 2.56e6 tests finish in a few microseconds (launch-bound), so the timed
+batch extends the ray axis to 65 536 rays of the same seeded distribution;
+the literal 256-ray launch is timed too and reported under "cfg2_literal".
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the ray axis is sharded: every
+rank traces its own `--rays` rays against a replicated triangle set -- no data-path collective,
+"scaling": "weak".  Time = max over ranks between two barriers.
+
+Extra objects on the JSON line: "roofline" (dominant kernel vs the HBM roofline, kernel time from
+device events on the launch stream), "cpu_baseline" (the CPU oracle timed on this box's host cores
+on a bounded sample, rank 0 at N=1 only), "paths" (image-method trace numbers when available).
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_cfg2(num_rays: int, num_triangles: int, seed: int = 1234):
+    """origins U([-1,1]^3)*50, directions = second point - origin
+    (un-normalised segments); triangles = centre U*50 + two edge vectors N(0,1)*2."""
+    rng = np.random.default_rng(seed)
+    o = (rng.uniform(-1, 1, (num_rays, 3)) * 50).astype(np.float32)
+    d = (rng.uniform(-1, 1, (num_rays, 3)) * 50).astype(np.float32) - o
+    c = (rng.uniform(-1, 1, (num_triangles, 1, 3)) * 50).astype(np.float32)
+    e = (rng.normal(size=(num_triangles, 2, 3)) * 2).astype(np.float32)
+    tv = np.concatenate([c, c + e[:, :1], c + e[:, 1:]], axis=1).astype(np.float32)
+    return o, d, tv
+
+
+def cpu_baseline(num_triangles: int, budget_s: float = 12.0):
+    """Time the CPU oracle (dense MT, OpenMP over rays) on a bounded sample of the workload."""
+    import oracle as orc
+
+    kind_note = "oracle/differt_oracle.c (C restatement), gcc -O3 -march=native -fopenmp, -ffp-contract=off"
+    try:
+        L = orc.lib(orc.build(native=True))
+    except Exception:  # noqa: BLE001 - no compiler on the box: use the prebuilt generic oracle
+        L = orc.lib()
+        kind_note = "oracle/differt_oracle.c prebuilt (generic x86-64), -fopenmp, -ffp-contract=off"
+    cores = os.cpu_count() or 1
+    rs = 8192
+    o, d, tv = make_cfg2(rs, num_triangles, seed=4321)
+    t = np.empty((rs, num_triangles), np.float32)
+    h = np.empty((rs, num_triangles), np.uint8)
+    eps = C.c_float(10.0 * float(np.finfo(np.float32).eps))
+
+    def run():
+        L.orc_ray_intersect_triangle_dense(
+            orc._p(o), orc._p(d), rs, orc._p(tv), num_triangles, eps, orc._p(t), orc._p(h)
+        )
+
+    run()  # warm-up (page faults)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        reps += 1
+        el = time.perf_counter() - t0
+        if (el >= budget_s and reps >= 3) or reps >= 200:
+            break
+    return {
+        "value": rs * num_triangles * reps / el,
+        "unit": "ray-triangle tests/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{reps} passes of {rs} rays x {num_triangles} triangles (dense MT, same distribution), "
+        f"{el:.1f} s; {kind_note}",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
+    ap.add_argument("--triangles", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-paths", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import differt_amd._lib as lib
+    from differt_amd._tensors import ptr, stream
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    lib.require_device()
+    dev = torch.device("cuda", local_rank)
+
+    R, T = args.rays, args.triangles
+    o_h, d_h, tv_h = make_cfg2(R, T, seed=1234 + rank)
+    _, _, tv_h = make_cfg2(1, T, seed=1234)  # the triangle set is replicated on every rank
+    o, d, tv = (torch.as_tensor(x, device=dev) for x in (o_h, d_h, tv_h))
+    t_out = torch.empty((R, T), dtype=torch.float32, device=dev)
+    hit_out = torch.empty((R, T), dtype=torch.uint8, device=dev)
+    eps = 10.0 * float(np.finfo(np.float32).eps)
+
+    def step():
+        lib.call("drt_ray_intersect_triangle_dense", ptr(o), ptr(d), R, ptr(tv), T, eps, ptr(t_out),
+                 ptr(hit_out), stream())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()  # recorded on torch's current stream == the stream handed to the C ABI
+        step()
+        ev1[i].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    # light self-check so that a broken kernel cannot post a number
+    nhit = int(hit_out[:256].sum().item())
+    finite = bool(torch.isfinite(t_out[:4]).any().item())
+    assert finite and 0 <= nhit < 256 * T
+
+    result = None
+    if rank == 0:
+        tests_per_step = R * T * world
+        algo_bytes = 5 * R * T + 24 * R + 36 * T  # 5 B out/test + inputs once
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get("mt_dense_kernel_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        result = {
+            "metric": "ray-triangle tests/s (ray_intersect_triangle dense fwd, 10k random triangles)",
+            "value": tests_per_step * args.steps / elapsed,
+            "unit": "ray-triangle tests/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1] (cfg2): rays x 10k random triangles, dense "
+                "ray_intersect_triangle fwd; ray axis extended from 256 to --rays (same seeded "
+                "distribution) so that one launch moves GBs, rays sharded over GPUs",
+                "rays_per_gpu": R,
+                "triangles": T,
+                "outputs": "t f32[R,T] + hit u8[R,T]",
+            },
+            "roofline": {
+                "kernel": "drt::mt_dense_kernel<true>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+
+    # literal configs[1]: 256 rays (launch-bound), rank 0 only, outside the timed region
+    if rank == 0:
+        Rl = 256
+        ol, dl, _ = make_cfg2(Rl, T, seed=99)
+        ol, dl = torch.as_tensor(ol, device=dev), torch.as_tensor(dl, device=dev)
+        tl = torch.empty((Rl, T), dtype=torch.float32, device=dev)
+        hl = torch.empty((Rl, T), dtype=torch.uint8, device=dev)
+
+        def step_l():
+            lib.call("drt_ray_intersect_triangle_dense", ptr(ol), ptr(dl), Rl, ptr(tv), T, eps,
+                     ptr(tl), ptr(hl), stream())
+
+        for _ in range(10):
+            step_l()
+        n = 200
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            step_l()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        result["cfg2_literal"] = {
+            "rays": Rl,
+            "triangles": T,
+            "us_per_launch_back_to_back": us,
+            "tests_per_s": Rl * T / (us * 1e-6),
+            "hbm_frac": (5 * Rl * T + 24 * Rl + 36 * T) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        }
+
+    if rank == 0 and not args.no_paths:
+        try:
+            import bench_paths
+
+            result["paths"] = bench_paths.run(dev)
+        except ImportError:
+            pass
+        except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
+            result["paths"] = {"error": repr(exc)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(T)
+
+    barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

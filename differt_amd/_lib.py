@@ -1,0 +1,182 @@
+"""ctypes binding of ``libdiffert_amd.so`` (the C ABI declared in ``include/differt_amd.h``).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, we raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("DIFFERT_AMD_LIB", _HERE / "lib" / "libdiffert_amd.so"))
+HEADER_PATH = _HERE.parent / "include" / "differt_amd.h"
+
+DRT_OK = 0
+DRT_E_INVALID, DRT_E_HIP, DRT_E_NO_DEVICE, DRT_E_CAPACITY, DRT_E_OVERFLOW, DRT_E_UNSUPPORTED = (
+    -1,
+    -2,
+    -3,
+    -4,
+    -5,
+    -6,
+)
+DRT_MAX_ORDER = 8
+
+
+class DrtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libdiffert_amd error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class CapacityError(DrtError):
+    """A caller-provided capacity (survivor queue / output rows) was too small."""
+
+
+class TraceParams(C.Structure):
+    _fields_ = [
+        ("epsilon", C.c_float),
+        ("hit_tol", C.c_float),
+        ("min_len", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Candidates(C.Structure):
+    _fields_ = [
+        ("table", C.c_void_p),
+        ("num_candidates", C.c_int64),
+        ("rank_lo", C.c_int64),
+        ("num_nodes", C.c_int64),
+        ("node_map", C.c_void_p),
+        ("order", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_vp, _i64, _u64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); restype int32 means "status code, checked"
+_SIGNATURES = {
+    "drt_abi_version": (_i32, []),
+    "drt_last_error": (C.c_char_p, []),
+    "drt_device_check": (_i32, []),
+    "drt_ray_intersect_triangle_dense": (_i32, [_vp, _vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "drt_ray_intersect_triangle_paired": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "drt_ray_intersect_any_triangle": (
+        _i32,
+        [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _f32, _vp, _vp],
+    ),
+    "drt_first_triangle_hit_by_ray_workspace_size": (_sz, [_i64]),
+    "drt_first_triangle_hit_by_ray": (
+        _i32,
+        [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp],
+    ),
+    "drt_first_hit_vjp": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "drt_image_method": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "drt_image_method_vjp": (
+        _i32,
+        [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "drt_consecutive_vertices_same_side": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "drt_mesh_create": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, C.POINTER(_vp)]),
+    "drt_mesh_destroy": (_i32, [_vp]),
+    "drt_mesh_num_triangles": (_i64, [_vp]),
+    "drt_mesh_triangle_vertices": (_vp, [_vp]),
+    "drt_mesh_normals": (_vp, [_vp]),
+    "drt_complete_graph_count": (_i32, [_u64, _u64, _u64, _u64, C.POINTER(_u64), C.POINTER(_i32)]),
+    "drt_complete_graph_count_exact": (_i32, [_u64, _u64, _u64, _u64, C.POINTER(_u64), C.POINTER(_i32)]),
+    "drt_complete_graph_fill_host": (_i32, [_u64, _u64, _u64, _u64, _i32, _u64, _u64, _vp]),
+    "drt_candidates_fill": (_i32, [_i64, _i32, _i64, _i64, _vp, _i32, _vp, _vp]),
+    "drt_digraph_from_complete_graph": (_i32, [_u64, C.POINTER(_vp)]),
+    "drt_digraph_from_adjacency_matrix": (_i32, [_vp, _u64, C.POINTER(_vp)]),
+    "drt_digraph_destroy": (_i32, [_vp]),
+    "drt_digraph_num_nodes": (_u64, [_vp]),
+    "drt_digraph_insert_from_and_to_nodes": (
+        _i32,
+        [_vp, _i32, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)],
+    ),
+    "drt_digraph_filter_by_mask": (_i32, [_vp, _vp, _u64, _i32]),
+    "drt_digraph_disconnect_nodes": (_i32, [_vp, _vp, _u64, _i32]),
+    "drt_digraph_iter_create": (_i32, [_vp, _u64, _u64, _u64, _i32, C.POINTER(_vp)]),
+    "drt_digraph_iter_destroy": (_i32, [_vp]),
+    "drt_digraph_iter_next_chunk": (_i32, [_vp, _u64, _vp, C.POINTER(_u64)]),
+    "drt_trace_dense_workspace_size": (_sz, [_i64, _i64, _i64]),
+    "drt_trace_paths_dense": (
+        _i32,
+        [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _vp, _vp, _vp,
+         _vp, _sz, _vp],
+    ),
+    "drt_trace_compact_workspace_size": (_sz, [_i64, _i64]),
+    "drt_trace_paths_compact": (
+        _i32,
+        [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _i64, _i64, _vp,
+         _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
+    ),
+    "drt_trace_paths_vjp": (
+        _i32,
+        [_vp, _vp, _i64, _vp, _i64, C.POINTER(Candidates), _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    ),
+}
+
+# functions whose int32 result is NOT a status code
+_NOT_STATUS = {"drt_abi_version"}
+
+_LIB = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/differt_amd.h."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(drt_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the shared library (raises if it has not been built: no CPU fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m differt_amd.build` "
+            "(hipcc, gfx950).  differt_amd has no CPU fallback."
+        )
+    L = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is None:  # reported by tests/test_abi.py and __graft_entry__.build(); calling it raises
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(code: int) -> None:
+    if code == DRT_OK:
+        return
+    msg = load().drt_last_error().decode(errors="replace")
+    if code == DRT_E_CAPACITY:
+        raise CapacityError(code, msg)
+    if code == DRT_E_INVALID:
+        raise ValueError(msg)
+    raise DrtError(code, msg)
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point and raise on error."""
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if _SIGNATURES[name][0] is _i32 and name not in _NOT_STATUS:
+        check(rc)
+    return rc
+
+
+def require_device() -> None:
+    """Raise unless a gfx950 GPU is usable (the product never runs on CPU)."""
+    check(load().drt_device_check())

@@ -1,0 +1,129 @@
+// geom.hpp -- float32 device arithmetic of the hot path, one IEEE rounding per operation.
+//
+// Every decision the reference takes (u >= 0, u + v <= 1, t > eps, sign(dot), ...) flips on a
+// 1-ulp difference, so these routines fix the operation order and are compiled WITHOUT FMA
+// contraction (-ffp-contract=off plus the pragma below) and with correctly rounded / and sqrt
+// (-fhip-fp32-correctly-rounded-divide-sqrt, hipcc's default).  3-term sums are associated
+// left to right: (x0*y0 + x1*y1) + x2*y2.
+//
+// Reference formulas: Moller-Trumbore differt/src/differt/geometry/_utils.py:1263-1322;
+// image / ray-plane differt/src/differt/geometry/_solver_image_method.py:68-79, 110-135, 152-182.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+struct V3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float *p, V3 a) {
+    p[0] = a.x;
+    p[1] = a.y;
+    p[2] = a.z;
+}
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+
+__device__ __forceinline__ float dot(V3 a, V3 b) {
+    float p0 = a.x * b.x;
+    float p1 = a.y * b.y;
+    float p2 = a.z * b.z;
+    float s = p0 + p1;
+    return s + p2;
+}
+
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+constexpr float kInf = __builtin_inff();
+
+__device__ __forceinline__ bool is_inf(float x) { return __builtin_fabsf(x) == kInf; }
+__device__ __forceinline__ bool is_finite(float x) { return __builtin_fabsf(x) < kInf; }
+
+// A triangle prepared for Moller-Trumbore: v0 and the two edges e1 = v1 - v0, e2 = v2 - v0
+// (_utils.py:1269-1271; computing the edges once per triangle is value-identical).
+struct TriE {
+    V3 v0, e1, e2;
+};
+
+__device__ __forceinline__ TriE make_tri(V3 v0, V3 v1, V3 v2) { return TriE{v0, v1 - v0, v2 - v0}; }
+__device__ __forceinline__ TriE load_tri(const float *tv) {
+    return make_tri(ld3(tv), ld3(tv + 3), ld3(tv + 6));
+}
+
+// _utils.py:1273-1322, hard mode.  Returns hit; t always written (also for misses).
+__device__ __forceinline__ bool moller_trumbore(V3 o, V3 d, const TriE &tr, float eps, float &t_out) {
+    V3 h = cross(d, tr.e2);
+    float a = dot(h, tr.e1);
+    a = (a == 0.0f) ? kInf : a;
+    bool hit = __builtin_fabsf(a) > eps;
+    float f = 1.0f / a;
+    V3 s = o - tr.v0;
+    float u = f * dot(s, h);
+    hit = hit && (u >= 0.0f) && (u <= 1.0f);
+    V3 q = cross(s, tr.e1);
+    float v = f * dot(q, d);
+    float upv = u + v;
+    hit = hit && (v >= 0.0f) && (upv <= 1.0f);
+    float t = f * dot(q, tr.e2);
+    hit = hit && (t > eps);
+    t_out = t;
+    return hit;
+}
+
+// _solver_image_method.py:73-79: x - (2 * <x - p, n>) * n
+__device__ __forceinline__ V3 image_of_vertex(V3 x, V3 p, V3 n) {
+    float c = 2.0f * dot(x - p, n);
+    return V3{x.x - c * n.x, x.y - c * n.y, x.z - c * n.z};
+}
+
+// _solver_image_method.py:116-135
+__device__ __forceinline__ V3 ray_plane(V3 o, V3 d, V3 p, V3 n) {
+    V3 v = p - o;
+    float un = dot(d, n);
+    float vn = dot(v, n);
+    bool parallel = (un == 0.0f);
+    un = parallel ? 1.0f : un;
+    float t = vn / un;
+    V3 r = V3{o.x + d.x * t, o.y + d.y * t, o.z + d.z * t};
+    bool bad = parallel && (vn != 0.0f);
+    return bad ? V3{kInf, kInf, kInf} : r;
+}
+
+// _solver_image_method.py:160-182 (_backward): one reverse-scan step from `prev` through mirror
+// (p, n) towards `image`; infinite components of prev are zeroed for the arithmetic and the
+// corresponding output components forced back to +inf.
+__device__ __forceinline__ V3 backward_step(V3 prev, V3 image, V3 p, V3 n) {
+    bool ix = is_inf(prev.x), iy = is_inf(prev.y), iz = is_inf(prev.z);
+    V3 pi = V3{ix ? 0.0f : prev.x, iy ? 0.0f : prev.y, iz ? 0.0f : prev.z};
+    V3 x = ray_plane(pi, image - pi, p, n);
+    return V3{ix ? kInf : x.x, iy ? kInf : x.y, iz ? kInf : x.z};
+}
+
+// jnp.sign semantics for the same-side test (_solver_image_method.py:443-454): nan != nan.
+__device__ __forceinline__ bool same_sign(float a, float b) {
+    float sa = (a > 0.0f) ? 1.0f : ((a < 0.0f) ? -1.0f : ((a == a) ? 0.0f : a));
+    float sb = (b > 0.0f) ? 1.0f : ((b < 0.0f) ? -1.0f : ((b == b) ? 0.0f : b));
+    return sa == sb;
+}
+
+// monotone map float -> uint32 (total order of finite values and infinities; used for packed
+// (t, tie) first-hit keys).
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(b);
+}
+
+}  // namespace drt

@@ -1,0 +1,484 @@
+// ray_ops.hip -- batched ray/triangle operators for gfx950:
+//   (a1) dense / paired Moller-Trumbore          reference geometry/_utils.py:1157-1322
+//   (a2) any-hit reduction over a triangle set     reference geometry/_utils.py:1353-1537
+//   (a4) first-hit (argmin, min) with tile ties    reference geometry/_utils.py:1775-1960
+//   (a5) VJP of the first-hit distance             reference geometry/_mesh.py:226-344
+//
+// Mapping choices (wave = 64 lanes, 256 CUs):
+//   dense MT   : HBM-write bound (5 B out per test).  One lane owns 4 consecutive triangles in
+//                registers and walks a chunk of rays whose origin/direction are wave-uniform
+//                (scalar loads); every lane stores 16 B of t and 4 B of hit per ray -> each wave
+//                writes full 1 KiB / 256 B segments of an output row.
+//   any/first  : FP32-VALU bound.  One lane owns one ray; the block stages triangle tiles in LDS
+//                as (v0, e1, e2, active) records read back with broadcast ds_read_b128; triangle
+//                ranges are split over blockIdx.y so that small ray batches still fill the chip.
+//   per-ray triangle sets: one wavefront per ray, lanes stride over the ray's triangles,
+//                ballot / shuffle reduction.
+#include "common.hpp"
+#include "geom.hpp"
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+// ------------------------------------------------------------------------------------------
+// (a1) dense
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kDenseThreads = 256;
+constexpr int kTriPerLane = 4;
+constexpr int kTriPerBlock = kDenseThreads * kTriPerLane;  // 1024
+
+template <bool VEC>
+__global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
+    const float *__restrict__ tv, int64_t T, float eps, float *__restrict__ t_out,
+    uint8_t *__restrict__ hit_out, int rays_per_block) {
+    const int64_t j0 = ((int64_t)blockIdx.y * kDenseThreads + threadIdx.x) * kTriPerLane;
+    if (j0 >= T) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
+    const int64_t r1 = (r0 + rays_per_block < R) ? r0 + rays_per_block : R;
+
+    TriE tri[kTriPerLane];
+#pragma unroll
+    for (int q = 0; q < kTriPerLane; ++q) {
+        // lanes past the end re-read the last triangle; their results are never stored
+        const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
+        tri[q] = load_tri(tv + 9 * j);
+        // keep the edges live in VGPRs: without this the compiler re-derives e1/e2 from the
+        // vertices on every ray (6 extra VALU ops per test) to save registers
+        asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z),
+                          "+v"(tri[q].e2.x), "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
+    }
+
+    for (int64_t r = r0; r < r1; ++r) {
+        const V3 o = ld3(ro + 3 * r);  // wave-uniform -> scalar loads
+        const V3 d = ld3(rd + 3 * r);
+        float t[kTriPerLane];
+        bool h[kTriPerLane];
+#pragma unroll
+        for (int q = 0; q < kTriPerLane; ++q) h[q] = moller_trumbore(o, d, tri[q], eps, t[q]);
+        const int64_t base = r * T + j0;
+        if (VEC) {
+            f32x4 tt = {t[0], t[1], t[2], t[3]};
+            uint32_t hh = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) |
+                          ((uint32_t)h[3] << 24);
+            __builtin_nontemporal_store(tt, reinterpret_cast<f32x4 *>(t_out + base));
+            __builtin_nontemporal_store(hh, reinterpret_cast<uint32_t *>(hit_out + base));
+        } else {
+#pragma unroll
+            for (int q = 0; q < kTriPerLane; ++q)
+                if (j0 + q < T) {
+                    t_out[base + q] = t[q];
+                    hit_out[base + q] = (uint8_t)h[q];
+                }
+        }
+    }
+}
+
+// (a1) paired: one lane per element
+__global__ __launch_bounds__(256) void mt_paired_kernel(const float *__restrict__ ro,
+                                                        const float *__restrict__ rd,
+                                                        const float *__restrict__ tv, int64_t n,
+                                                        float eps, float *__restrict__ t_out,
+                                                        uint8_t *__restrict__ hit_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t;
+    bool h = moller_trumbore(ld3(ro + 3 * i), ld3(rd + 3 * i), load_tri(tv + 9 * i), eps, t);
+    t_out[i] = t;
+    hit_out[i] = (uint8_t)h;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS triangle tile shared by the any-hit / first-hit kernels
+// ------------------------------------------------------------------------------------------
+constexpr int kQueryThreads = 256;
+constexpr int kTile = 256;  // triangles per LDS tile: 256 * 48 B = 12 KiB
+
+struct __attribute__((aligned(16))) TriRec {
+    float v0x, v0y, v0z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z;
+    uint32_t active;
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 3 x 16 B");
+
+__device__ __forceinline__ void stage_tile(TriRec *lds, const float *__restrict__ tv,
+                                           const uint8_t *__restrict__ active, int64_t base,
+                                           int64_t end) {
+    const int64_t j = base + threadIdx.x;
+    if (threadIdx.x < kTile && j < end) {
+        TriE tr = load_tri(tv + 9 * j);
+        TriRec rec;
+        rec.v0x = tr.v0.x; rec.v0y = tr.v0.y; rec.v0z = tr.v0.z;
+        rec.e1x = tr.e1.x; rec.e1y = tr.e1.y; rec.e1z = tr.e1.z;
+        rec.e2x = tr.e2.x; rec.e2y = tr.e2.y; rec.e2z = tr.e2.z;
+        rec.active = active ? (uint32_t)active[j] : 1u;
+        rec.pad0 = rec.pad1 = 0;
+        lds[threadIdx.x] = rec;
+    }
+}
+
+__device__ __forceinline__ TriE rec_tri(const TriRec &r) {
+    return TriE{V3{r.v0x, r.v0y, r.v0z}, V3{r.e1x, r.e1y, r.e1z}, V3{r.e2x, r.e2y, r.e2z}};
+}
+
+// (a2) shared triangle set, lane = ray.  out must be zero-initialised.
+__global__ __launch_bounds__(kQueryThreads) void any_hit_shared_kernel(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
+    const float *__restrict__ tv, int64_t T, const uint8_t *__restrict__ active, float eps,
+    float thr, uint8_t *__restrict__ out, int64_t tri_per_split) {
+    __shared__ TriRec lds[kTile];
+    const int64_t r = (int64_t)blockIdx.x * kQueryThreads + threadIdx.x;
+    const bool valid = r < R;
+    const V3 o = valid ? ld3(ro + 3 * r) : V3{0, 0, 0};
+    const V3 d = valid ? ld3(rd + 3 * r) : V3{0, 0, 0};
+    const int64_t begin = (int64_t)blockIdx.y * tri_per_split;
+    const int64_t end = (begin + tri_per_split < T) ? begin + tri_per_split : T;
+    bool any = !valid;  // idle lanes count as "done" for the wave-level early exit
+    for (int64_t base = begin; base < end; base += kTile) {
+        __syncthreads();
+        stage_tile(lds, tv, active, base, end);
+        __syncthreads();
+        if (__all(any)) continue;  // wave-uniform: every ray of this wave is already blocked
+        const int n = (int)((end - base < kTile) ? end - base : kTile);
+        for (int j = 0; j < n; ++j) {
+            const TriRec rec = lds[j];  // broadcast read
+            float t;
+            bool h = moller_trumbore(o, d, rec_tri(rec), eps, t);
+            any = any || (h && (t < thr) && rec.active);
+        }
+    }
+    if (valid && any) out[r] = 1;
+}
+
+// (a4) key = (ordered(t) << 32) | tie, tie = (num_tiles-1-tile)*bs + idx_in_tile:
+// the smallest key is the smallest t; among equal t the LATEST tile, then the lowest index.
+struct TileTie {
+    int64_t bs, nb, ntiles;
+};
+__device__ __forceinline__ uint64_t first_hit_key(float t, int64_t j, const TileTie &tt) {
+    int64_t tile = (j < tt.nb * tt.bs) ? j / tt.bs : tt.nb;
+    int64_t in_tile = j - tile * tt.bs;
+    uint64_t tie = (uint64_t)((tt.ntiles - 1 - tile) * tt.bs + in_tile);
+    return ((uint64_t)float_to_ordered(t) << 32) | tie;
+}
+
+__global__ __launch_bounds__(kQueryThreads) void first_hit_shared_kernel(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
+    const float *__restrict__ tv, int64_t T, const uint8_t *__restrict__ active, float eps,
+    TileTie tt, unsigned long long *__restrict__ keys, int64_t tri_per_split) {
+    __shared__ TriRec lds[kTile];
+    const int64_t r = (int64_t)blockIdx.x * kQueryThreads + threadIdx.x;
+    const bool valid = r < R;
+    const V3 o = valid ? ld3(ro + 3 * r) : V3{0, 0, 0};
+    const V3 d = valid ? ld3(rd + 3 * r) : V3{0, 0, 0};
+    const int64_t begin = (int64_t)blockIdx.y * tri_per_split;
+    const int64_t end = (begin + tri_per_split < T) ? begin + tri_per_split : T;
+    uint64_t best = ~0ull;
+    for (int64_t base = begin; base < end; base += kTile) {
+        __syncthreads();
+        stage_tile(lds, tv, active, base, end);
+        __syncthreads();
+        const int n = (int)((end - base < kTile) ? end - base : kTile);
+        for (int j = 0; j < n; ++j) {
+            const TriRec rec = lds[j];
+            float t;
+            bool h = moller_trumbore(o, d, rec_tri(rec), eps, t);
+            // a hit with t == +inf is treated as a miss by the reference (isinf/isfinite fix-ups)
+            if (h && rec.active && is_finite(t)) {
+                uint64_t k = first_hit_key(t, base + j, tt);
+                best = (k < best) ? k : best;
+            }
+        }
+    }
+    if (valid && best != ~0ull) atomicMin(keys + r, (unsigned long long)best);
+}
+
+__global__ __launch_bounds__(256) void first_hit_finalize_kernel(
+    const unsigned long long *__restrict__ keys, int64_t R, TileTie tt, int32_t *__restrict__ idx,
+    float *__restrict__ t_out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const uint64_t k = keys[r];
+    if (k == ~0ull) {
+        idx[r] = -1;
+        t_out[r] = kInf;
+        return;
+    }
+    const uint64_t tie = k & 0xffffffffull;
+    const int64_t tile = tt.ntiles - 1 - (int64_t)(tie / (uint64_t)tt.bs);
+    const int64_t in_tile = (int64_t)(tie % (uint64_t)tt.bs);
+    idx[r] = (int32_t)(tile * tt.bs + in_tile);
+    t_out[r] = ordered_to_float((uint32_t)(k >> 32));
+}
+
+// per-ray triangle sets and/or per-ray active masks: one wavefront per ray
+template <bool FIRST>
+__global__ __launch_bounds__(256) void per_ray_kernel(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
+    const float *__restrict__ tv, int64_t T, int64_t tv_stride, const uint8_t *__restrict__ active,
+    int64_t act_stride, float eps, float thr, TileTie tt, uint8_t *__restrict__ any_out,
+    int32_t *__restrict__ idx_out, float *__restrict__ t_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (r >= R) return;  // wave-uniform
+    const V3 o = ld3(ro + 3 * r), d = ld3(rd + 3 * r);
+    const float *tvr = tv + r * tv_stride;
+    const uint8_t *act = active ? active + r * act_stride : nullptr;
+    bool any = false;
+    uint64_t best = ~0ull;
+    for (int64_t j = lane; j < T; j += 64) {
+        float t;
+        bool h = moller_trumbore(o, d, load_tri(tvr + 9 * j), eps, t);
+        h = h && (!act || act[j]);
+        if (FIRST) {
+            if (h && is_finite(t)) {
+                uint64_t k = first_hit_key(t, j, tt);
+                best = (k < best) ? k : best;
+            }
+        } else {
+            any = any || (h && (t < thr));
+        }
+    }
+    if (FIRST) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            uint32_t lo = __shfl_xor((uint32_t)best, off, 64);
+            uint32_t hi = __shfl_xor((uint32_t)(best >> 32), off, 64);
+            uint64_t other = ((uint64_t)hi << 32) | lo;
+            best = (other < best) ? other : best;
+        }
+        if (lane == 0) {
+            if (best == ~0ull) {
+                idx_out[r] = -1;
+                t_out[r] = kInf;
+            } else {
+                const uint64_t tie = best & 0xffffffffull;
+                const int64_t tile = tt.ntiles - 1 - (int64_t)(tie / (uint64_t)tt.bs);
+                idx_out[r] = (int32_t)(tile * tt.bs + (int64_t)(tie % (uint64_t)tt.bs));
+                t_out[r] = ordered_to_float((uint32_t)(best >> 32));
+            }
+        }
+    } else {
+        const bool w = __ballot(any) != 0ull;
+        if (lane == 0) any_out[r] = (uint8_t)w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// (a5) reverse mode of t = f * <q, e2> on the hit face (geometry/_mesh.py:226-255, 327-338)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void first_hit_vjp_kernel(
+    const float *__restrict__ vertices, const int32_t *__restrict__ triangles,
+    const float *__restrict__ ro, const float *__restrict__ rd, const int32_t *__restrict__ face,
+    const float *__restrict__ tbar_in, int64_t R, float *__restrict__ gv, float *__restrict__ go,
+    float *__restrict__ gd) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int32_t f_id = face[r];
+    V3 obar{0, 0, 0}, dbar{0, 0, 0};
+    if (f_id >= 0) {
+        const int32_t i0 = triangles[3 * (int64_t)f_id], i1 = triangles[3 * (int64_t)f_id + 1],
+                      i2 = triangles[3 * (int64_t)f_id + 2];
+        const V3 v0 = ld3(vertices + 3 * (int64_t)i0), v1 = ld3(vertices + 3 * (int64_t)i1),
+                 v2 = ld3(vertices + 3 * (int64_t)i2);
+        const V3 o = ld3(ro + 3 * r), d = ld3(rd + 3 * r);
+        const float tbar = tbar_in[r];
+        const V3 e1 = v1 - v0, e2 = v2 - v0;
+        const V3 h = cross(d, e2);
+        float a = dot(h, e1);
+        const bool degenerate = (a == 0.0f);
+        a = degenerate ? kInf : a;
+        const float f = 1.0f / a;
+        const V3 s = o - v0;
+        const V3 q = cross(s, e1);
+        const float w = dot(q, e2);
+        // t = f * w
+        const float fbar = tbar * w, wbar = tbar * f;
+        const V3 qbar = e2 * wbar;
+        V3 e2bar = q * wbar;
+        const V3 sbar = cross(e1, qbar);  // q = s x e1
+        V3 e1bar = cross(qbar, s);
+        const float abar = degenerate ? 0.0f : -(fbar * f) * f;  // f = 1/a
+        const V3 hbar = e1 * abar;                               // a = <h, e1>
+        e1bar = e1bar + h * abar;
+        dbar = cross(e2, hbar);                                  // h = d x e2
+        e2bar = e2bar + cross(hbar, d);
+        obar = sbar;                                             // s = o - v0
+        if (gv) {
+            const V3 v0bar = V3{0, 0, 0} - sbar - e1bar - e2bar;
+            atomicAdd(gv + 3 * (int64_t)i0 + 0, v0bar.x);
+            atomicAdd(gv + 3 * (int64_t)i0 + 1, v0bar.y);
+            atomicAdd(gv + 3 * (int64_t)i0 + 2, v0bar.z);
+            atomicAdd(gv + 3 * (int64_t)i1 + 0, e1bar.x);
+            atomicAdd(gv + 3 * (int64_t)i1 + 1, e1bar.y);
+            atomicAdd(gv + 3 * (int64_t)i1 + 2, e1bar.z);
+            atomicAdd(gv + 3 * (int64_t)i2 + 0, e2bar.x);
+            atomicAdd(gv + 3 * (int64_t)i2 + 1, e2bar.y);
+            atomicAdd(gv + 3 * (int64_t)i2 + 2, e2bar.z);
+        }
+    }
+    if (go) st3(go + 3 * r, obar);
+    if (gd) st3(gd + 3 * r, dbar);
+}
+
+static TileTie make_tie(int64_t T, int64_t batch_size) {
+    int64_t bs = batch_size <= 0 ? T : batch_size;  // _utils.py:1832-1834
+    if (bs > T) bs = T;
+    if (bs < 1) bs = 1;
+    TileTie tt;
+    tt.bs = bs;
+    tt.nb = T / bs;
+    tt.ntiles = tt.nb + ((T % bs) ? 1 : 0);
+    return tt;
+}
+
+// triangles per blockIdx.y split so that small ray batches still launch >= ~2048 blocks
+static int64_t choose_split(int64_t ray_blocks, int64_t T, int64_t *nsplit_out) {
+    int64_t tiles = ceil_div(T, kTile);
+    int64_t want = ceil_div(2048, ray_blocks);
+    if (want < 1) want = 1;
+    if (want > tiles) want = tiles;
+    if (want > 65535) want = 65535;
+    int64_t tiles_per_split = ceil_div(tiles, want);
+    *nsplit_out = ceil_div(tiles, tiles_per_split);
+    return tiles_per_split * kTile;
+}
+
+}  // namespace drt
+
+using namespace drt;
+
+extern "C" {
+
+int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64_t R,
+                                         const float *tv, int64_t T, float eps, float *t_out,
+                                         uint8_t *hit_out, void *stream) {
+    DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
+    if (R == 0 || T == 0) return DRT_OK;
+    DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
+    const int64_t cols = ceil_div(T, kTriPerBlock);
+    DRT_REQUIRE(cols <= 65535, "too many triangles for one launch (%lld)", (long long)T);
+    // rays per block: as many as possible (amortises the triangle loads) while keeping >= ~4096 blocks
+    int64_t rpb = (R * cols) / 4096;
+    if (rpb < 1) rpb = 1;
+    if (rpb > 64) rpb = 64;
+    const int64_t rows = ceil_div(R, rpb);
+    DRT_REQUIRE(rows < (1ll << 31), "too many rays for one launch");
+    const bool vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(hit_out) & 3) == 0);
+    dim3 grid((unsigned)rows, (unsigned)cols);
+    if (vec)
+        hipLaunchKernelGGL(mt_dense_kernel<true>, grid, dim3(kDenseThreads), 0, as_stream(stream),
+                           ro, rd, R, tv, T, eps, t_out, hit_out, (int)rpb);
+    else
+        hipLaunchKernelGGL(mt_dense_kernel<false>, grid, dim3(kDenseThreads), 0, as_stream(stream),
+                           ro, rd, R, tv, T, eps, t_out, hit_out, (int)rpb);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_ray_intersect_triangle_paired(const float *ro, const float *rd, const float *tv,
+                                          int64_t n, float eps, float *t_out, uint8_t *hit_out,
+                                          void *stream) {
+    DRT_REQUIRE(n >= 0, "negative size");
+    if (n == 0) return DRT_OK;
+    DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
+    hipLaunchKernelGGL(mt_paired_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       as_stream(stream), ro, rd, tv, n, eps, t_out, hit_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_ray_intersect_any_triangle(const float *ro, const float *rd, int64_t R,
+                                       const float *tv, int64_t T, int64_t tv_ray_stride,
+                                       const uint8_t *active, int64_t active_ray_stride, float eps,
+                                       float hit_tol, uint8_t *out, void *stream) {
+    DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
+    if (R == 0) return DRT_OK;
+    DRT_REQUIRE(out, "null output");
+    DRT_HIP(hipMemsetAsync(out, 0, (size_t)R, as_stream(stream)));
+    if (T == 0) return DRT_OK;  // _utils.py:1441-1450
+    DRT_REQUIRE(ro && rd && tv, "null pointer");
+    DRT_REQUIRE(tv_ray_stride == 0 || tv_ray_stride == 9 * T, "tv_ray_stride must be 0 or 9*T");
+    DRT_REQUIRE(active_ray_stride == 0 || active_ray_stride == T, "active_ray_stride must be 0 or T");
+    const float thr = 1.0f - hit_tol;  // _utils.py:1422
+    if (tv_ray_stride == 0 && active_ray_stride == 0) {
+        const int64_t ray_blocks = ceil_div(R, kQueryThreads);
+        int64_t nsplit;
+        const int64_t tps = choose_split(ray_blocks, T, &nsplit);
+        hipLaunchKernelGGL(any_hit_shared_kernel, dim3((unsigned)ray_blocks, (unsigned)nsplit),
+                           dim3(kQueryThreads), 0, as_stream(stream), ro, rd, R, tv, T, active, eps,
+                           thr, out, tps);
+    } else {
+        TileTie tt = make_tie(T, 0);
+        hipLaunchKernelGGL(per_ray_kernel<false>, dim3((unsigned)ceil_div(R * 64, 256)), dim3(256),
+                           0, as_stream(stream), ro, rd, R, tv, T, tv_ray_stride, active,
+                           active_ray_stride, eps, thr, tt, out, (int32_t *)nullptr,
+                           (float *)nullptr);
+    }
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+size_t drt_first_triangle_hit_by_ray_workspace_size(int64_t num_rays) {
+    return num_rays > 0 ? (size_t)num_rays * 8 : 0;
+}
+
+int32_t drt_first_triangle_hit_by_ray(const float *ro, const float *rd, int64_t R,
+                                      const float *tv, int64_t T, int64_t tv_ray_stride,
+                                      const uint8_t *active, int64_t active_ray_stride, float eps,
+                                      int64_t batch_size, int32_t *idx, float *t_out, void *ws,
+                                      size_t ws_bytes, void *stream) {
+    DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
+    if (R == 0) return DRT_OK;
+    DRT_REQUIRE(idx && t_out, "null output");
+    DRT_REQUIRE(T < (1ll << 31), "too many triangles");
+    DRT_REQUIRE(tv_ray_stride == 0 || tv_ray_stride == 9 * T, "tv_ray_stride must be 0 or 9*T");
+    DRT_REQUIRE(active_ray_stride == 0 || active_ray_stride == T, "active_ray_stride must be 0 or T");
+    hipStream_t s = as_stream(stream);
+    TileTie tt = make_tie(T > 0 ? T : 1, batch_size);
+    if (T == 0 || (tv_ray_stride == 0 && active_ray_stride == 0)) {
+        if (ws_bytes < (size_t)R * 8 || !ws)
+            return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", (size_t)R * 8);
+        auto *keys = reinterpret_cast<unsigned long long *>(ws);
+        DRT_HIP(hipMemsetAsync(keys, 0xff, (size_t)R * 8, s));
+        if (T > 0) {
+            DRT_REQUIRE(ro && rd && tv, "null pointer");
+            const int64_t ray_blocks = ceil_div(R, kQueryThreads);
+            int64_t nsplit;
+            const int64_t tps = choose_split(ray_blocks, T, &nsplit);
+            hipLaunchKernelGGL(first_hit_shared_kernel,
+                               dim3((unsigned)ray_blocks, (unsigned)nsplit), dim3(kQueryThreads), 0,
+                               s, ro, rd, R, tv, T, active, eps, tt, keys, tps);
+            DRT_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(first_hit_finalize_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256),
+                           0, s, keys, R, tt, idx, t_out);
+    } else {
+        DRT_REQUIRE(ro && rd && tv, "null pointer");
+        hipLaunchKernelGGL(per_ray_kernel<true>, dim3((unsigned)ceil_div(R * 64, 256)), dim3(256), 0,
+                           s, ro, rd, R, tv, T, tv_ray_stride, active, active_ray_stride, eps, 0.0f,
+                           tt, (uint8_t *)nullptr, idx, t_out);
+    }
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_first_hit_vjp(const float *vertices, const int32_t *triangles, const float *ro,
+                          const float *rd, const int32_t *hit_index, const float *t_cotangent,
+                          int64_t R, float *gv, float *go, float *gd, void *stream) {
+    DRT_REQUIRE(R >= 0, "negative size");
+    if (R == 0) return DRT_OK;
+    DRT_REQUIRE(vertices && triangles && ro && rd && hit_index && t_cotangent, "null pointer");
+    hipLaunchKernelGGL(first_hit_vjp_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0,
+                       as_stream(stream), vertices, triangles, ro, rd, hit_index, t_cotangent, R, gv,
+                       go, gd);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+}  // extern "C"

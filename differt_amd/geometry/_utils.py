@@ -1,0 +1,271 @@
+"""Ray/triangle operators and path-candidate wrappers with the reference's signatures.
+
+Mirrors ``differt/src/differt/geometry/_utils.py`` of the reference (file:line in each docstring);
+the arithmetic runs in hand-written HIP kernels behind the C ABI (``include/differt_amd.h``).
+Inputs may be NumPy arrays, sequences or torch tensors; outputs are torch tensors in HBM.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Iterator
+from typing import Any
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._tensors import F32_EPS, as_f32, as_u8, device, ptr, stream
+
+__all__ = [
+    "SizedIterator",
+    "assemble_path",
+    "first_triangle_hit_by_ray",
+    "generate_all_path_candidates",
+    "generate_all_path_candidates_chunks_iter",
+    "generate_all_path_candidates_iter",
+    "normalize",
+    "ray_intersect_any_triangle",
+    "ray_intersect_triangle",
+]
+
+
+def _no_smoothing(smoothing_factor) -> None:
+    if smoothing_factor is not None:
+        raise NotImplementedError(
+            "smoothing_factor (soft masks, reference _utils.py:1279-1320) is not part of the "
+            "MI355X hot path yet: only the hard-mask operators are implemented"
+        )
+
+
+def normalize(vectors, keepdims: bool = False):
+    """Reference ``normalize`` (_utils.py:29-72): zero-length vectors are divided by one."""
+    v = as_f32(vectors)
+    lengths = torch.sqrt((v * v).sum(dim=-1, keepdim=True))
+    safe = torch.where(lengths == 0.0, torch.ones_like(lengths), lengths)
+    return v / safe, (lengths if keepdims else lengths.squeeze(-1))
+
+
+def assemble_path(from_vertex, intermediate_vertices, to_vertex=None):
+    """Reference ``assemble_path`` (_utils.py:514-565): concatenate [from, inter..., to]."""
+    a = as_f32(from_vertex)
+    m = as_f32(intermediate_vertices)
+    if to_vertex is None:
+        b = m
+        batch = torch.broadcast_shapes(a.shape[:-1], b.shape[:-1])
+        return torch.cat(
+            (a[..., None, :].expand(*batch, 1, 3), b[..., None, :].expand(*batch, 1, 3)), dim=-2
+        )
+    b = as_f32(to_vertex)
+    batch = torch.broadcast_shapes(a.shape[:-1], m.shape[:-2], b.shape[:-1])
+    return torch.cat(
+        (
+            a[..., None, :].expand(*batch, 1, 3),
+            m.expand(*batch, *m.shape[-2:]),
+            b[..., None, :].expand(*batch, 1, 3),
+        ),
+        dim=-2,
+    )
+
+
+def ray_intersect_triangle(
+    ray_origins,
+    ray_directions,
+    triangle_vertices,
+    *,
+    epsilon: float | None = None,
+    smoothing_factor=None,
+):
+    """Moller-Trumbore for every broadcast (ray, triangle) pair; returns ``(t, hit)``.
+
+    Reference: ``ray_intersect_triangle`` _utils.py:1157-1322 (default ``epsilon = 10*eps``,
+    :1257-1259; ``t`` is returned for misses too).  The ``o[..., None, :]`` x ``tv[T,3,3]`` outer
+    form runs the dense kernel (no input materialisation); any other broadcast runs paired.
+    """
+    _no_smoothing(smoothing_factor)
+    dev = device()
+    o, d, tv = as_f32(ray_origins, dev), as_f32(ray_directions, dev), as_f32(triangle_vertices, dev)
+    eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+    batch = torch.broadcast_shapes(o.shape[:-1], d.shape[:-1], tv.shape[:-2])
+    t = torch.empty(batch, dtype=torch.float32, device=dev)
+    hit = torch.empty(batch, dtype=torch.uint8, device=dev)
+    if t.numel() == 0:
+        return t, hit.bool()
+    # outer-product form: rays [..., 1, 3] against one shared triangle list [T, 3, 3]
+    nb = len(batch)
+    tvb = (1,) * (nb - (tv.dim() - 2)) + tuple(tv.shape[:-2])
+    ob = (1,) * (nb - (o.dim() - 1)) + tuple(o.shape[:-1])
+    db = (1,) * (nb - (d.dim() - 1)) + tuple(d.shape[:-1])
+    dense = (
+        nb >= 1
+        and all(s == 1 for s in tvb[:-1])
+        and ob[-1] == 1
+        and db[-1] == 1
+    )
+    if dense:
+        T = batch[-1]
+        rb = batch[:-1]
+        of = o.reshape(ob[:-1] + (3,)).expand(*rb, 3).contiguous().reshape(-1, 3)
+        df = d.reshape(db[:-1] + (3,)).expand(*rb, 3).contiguous().reshape(-1, 3)
+        tvf = tv.reshape(T, 3, 3).contiguous()
+        _lib.call(
+            "drt_ray_intersect_triangle_dense",
+            ptr(of), ptr(df), of.shape[0], ptr(tvf), T, eps, ptr(t), ptr(hit), stream(),
+        )
+    else:
+        of = o.expand(*batch, 3).contiguous()
+        df = d.expand(*batch, 3).contiguous()
+        tvf = tv.expand(*batch, 3, 3).contiguous()
+        _lib.call(
+            "drt_ray_intersect_triangle_paired",
+            ptr(of), ptr(df), ptr(tvf), t.numel(), eps, ptr(t), ptr(hit), stream(),
+        )
+    return t, hit.bool()
+
+
+def _flatten_query(ray_origins, ray_directions, triangle_vertices, active_triangles):
+    dev = device()
+    o, d, tv = as_f32(ray_origins, dev), as_f32(ray_directions, dev), as_f32(triangle_vertices, dev)
+    T = tv.shape[-3]
+    act = None if active_triangles is None else as_u8(active_triangles, dev)
+    batch = torch.broadcast_shapes(
+        o.shape[:-1], d.shape[:-1], tv.shape[:-3], act.shape[:-1] if act is not None else ()
+    )
+    R = int(np.prod(batch, dtype=np.int64))
+    of = o.expand(*batch, 3).contiguous().reshape(R, 3)
+    df = d.expand(*batch, 3).contiguous().reshape(R, 3)
+    if all(s == 1 for s in tv.shape[:-3]):
+        tvf, tv_stride = tv.reshape(T, 3, 3).contiguous(), 0
+    else:
+        tvf, tv_stride = tv.expand(*batch, T, 3, 3).contiguous().reshape(R, T, 3, 3), 9 * T
+    if act is None:
+        actf, act_stride = None, 0
+    elif all(s == 1 for s in act.shape[:-1]):
+        actf, act_stride = act.reshape(T).contiguous(), 0
+    else:
+        actf, act_stride = act.expand(*batch, T).contiguous().reshape(R, T), T
+    return dev, batch, R, T, of, df, tvf, tv_stride, actf, act_stride
+
+
+def ray_intersect_any_triangle(
+    ray_origins,
+    ray_directions,
+    triangle_vertices,
+    active_triangles=None,
+    *,
+    hit_tol: float | None = None,
+    smoothing_factor=None,
+    batch_size: int | None = 512,  # noqa: ARG001 - tiling does not change an OR
+    **kwargs: Any,
+):
+    """Whether each ray hits any triangle before ``t = 1 - hit_tol``.
+
+    Reference: ``ray_intersect_any_triangle`` _utils.py:1353-1537 (``hit_tol = 100*eps`` default
+    :1418-1420, ``T == 0 -> False`` :1441-1450, ``active_triangles`` :1468-1469).  ``epsilon`` is
+    forwarded to Moller-Trumbore through ``**kwargs`` like in the reference.
+    """
+    _no_smoothing(smoothing_factor)
+    epsilon = kwargs.pop("epsilon", None)
+    if kwargs:
+        raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
+    dev, batch, R, T, o, d, tv, tvs, act, acts = _flatten_query(
+        ray_origins, ray_directions, triangle_vertices, active_triangles
+    )
+    eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+    tol = 100.0 * F32_EPS if hit_tol is None else float(hit_tol)
+    out = torch.zeros(R, dtype=torch.uint8, device=dev)
+    if R:
+        _lib.call(
+            "drt_ray_intersect_any_triangle",
+            ptr(o), ptr(d), R, ptr(tv), T, tvs, ptr(act), acts, eps, tol, ptr(out), stream(),
+        )
+    return out.bool().reshape(batch)
+
+
+def first_triangle_hit_by_ray(
+    ray_origins,
+    ray_directions,
+    triangle_vertices,
+    active_triangles=None,
+    batch_size: int | None = 512,
+    **kwargs: Any,
+):
+    """Index of and distance to the first triangle hit by each ray; miss = ``(-1, inf)``.
+
+    Reference: ``first_triangle_hit_by_ray`` _utils.py:1775-1960, including the tie-break that its
+    tiling implies (lowest index inside a ``batch_size`` tile, the later tile wins: :1865-1867,
+    :1886; remainder tile last :1939-1955), so hit indices are bit-exact with the reference.
+    """
+    epsilon = kwargs.pop("epsilon", None)
+    _no_smoothing(kwargs.pop("smoothing_factor", None))
+    if kwargs:
+        raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
+    dev, batch, R, T, o, d, tv, tvs, act, acts = _flatten_query(
+        ray_origins, ray_directions, triangle_vertices, active_triangles
+    )
+    eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+    idx = torch.full((R,), -1, dtype=torch.int32, device=dev)
+    t = torch.full((R,), float("inf"), dtype=torch.float32, device=dev)
+    if R:
+        ws = torch.empty(R, dtype=torch.int64, device=dev)
+        _lib.call(
+            "drt_first_triangle_hit_by_ray",
+            ptr(o), ptr(d), R, ptr(tv), T, tvs, ptr(act), acts, eps,
+            0 if batch_size is None else int(batch_size), ptr(idx), ptr(t), ptr(ws), R * 8, stream(),
+        )
+    return idx.reshape(batch), t.reshape(batch)
+
+
+# ------------------------------------------------------------------------------------------
+# path candidates (reference _utils.py:1004-1132 over differt-core graph.rs)
+# ------------------------------------------------------------------------------------------
+class SizedIterator:
+    """Reference ``SizedIterator`` (_utils.py:1004-1044): an iterator with a known length."""
+
+    def __init__(self, iter_: Iterator, size) -> None:
+        self.iter_ = iter_
+        self.size = size
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self.iter_)
+
+    def __len__(self) -> int:
+        return self.size() if callable(self.size) else self.size
+
+
+def generate_all_path_candidates(num_primitives: int, order: int) -> np.ndarray:
+    """All path candidates, lexicographic, shape ``[n*(n-1)**(order-1), order]`` (int32, host).
+
+    Reference: ``generate_all_path_candidates`` _utils.py:1047-1081 over
+    ``CompleteGraph.all_paths_array`` (graph.rs:222-233).  The table is produced by closed-form
+    unranking in the native library (no odometer).
+    """
+    from ._graph import CompleteGraph
+
+    return CompleteGraph(num_primitives).all_paths_array(
+        num_primitives, num_primitives + 1, order + 2, include_from_and_to=False
+    ).astype(np.int32)
+
+
+def generate_all_path_candidates_iter(num_primitives: int, order: int) -> SizedIterator:
+    """Reference ``generate_all_path_candidates_iter`` (_utils.py:1084-1105)."""
+    from ._graph import CompleteGraph
+
+    it = CompleteGraph(num_primitives).all_paths(
+        num_primitives, num_primitives + 1, order + 2, include_from_and_to=False
+    )
+    return SizedIterator((np.asarray(a, dtype=np.int32) for a in it), size=it.__len__)
+
+
+def generate_all_path_candidates_chunks_iter(
+    num_primitives: int, order: int, chunk_size: int = 1000
+) -> SizedIterator:
+    """Reference ``generate_all_path_candidates_chunks_iter`` (_utils.py:1108-1132)."""
+    from ._graph import CompleteGraph
+
+    it = CompleteGraph(num_primitives).all_paths_array_chunks(
+        num_primitives, num_primitives + 1, order + 2, include_from_and_to=False, chunk_size=chunk_size
+    )
+    return SizedIterator((np.asarray(a, dtype=np.int32) for a in it), size=it.__len__)

@@ -1,0 +1,243 @@
+/*
+ * differt_amd.h -- C ABI of the MI355X-native DiffeRT ray-tracing core (libdiffert_amd.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  In the reference the same
+ * boundary is `wp.jax_callable(func, output_dims=...)` (flat contiguous device buffers in,
+ * flat buffers out, static shapes, no gradients: differt/src/differt/geometry/_mesh.py:266-276,
+ * 3082-3092, 3239-3250) for the ray queries, XLA-jitted JAX for the image method
+ * (geometry/_solver_image_method.py:206-363, geometry/_solvers.py:499-770) and a PyO3 module for
+ * the candidate generator (differt-core/src/geometry/graph.rs:1194-1205,
+ * differt-core/python/differt_core/_differt_core/geometry/graph.pyi:1-103).
+ *
+ * Conventions
+ *   - every function returns an int32 status: 0 = ok, <0 = error (see DRT_E_*); the message is
+ *     available from drt_last_error() (thread-local).  Nothing throws, nothing aborts.
+ *   - all array pointers are DEVICE pointers (HBM) unless the name ends in `_host`.
+ *   - float = IEEE binary32, row-major, densely packed.  Indices are int32 (reference:
+ *     `dtype=int` under x64-off JAX), candidate ranks / flat path keys are int64.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
+ *     on that stream unless documented otherwise; the caller owns every buffer.
+ *   - the library keeps no hidden global state: device state lives in explicit handles.
+ */
+#ifndef DIFFERT_AMD_H
+#define DIFFERT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRT_ABI_VERSION 1
+
+enum {
+    DRT_OK = 0,
+    DRT_E_INVALID = -1,    /* invalid argument */
+    DRT_E_HIP = -2,        /* HIP runtime error */
+    DRT_E_NO_DEVICE = -3,  /* no usable GPU */
+    DRT_E_CAPACITY = -4,   /* an output/workspace capacity given by the caller is too small */
+    DRT_E_OVERFLOW = -5,   /* a count does not fit in 64 bits */
+    DRT_E_UNSUPPORTED = -6
+};
+
+#define DRT_MAX_ORDER 8
+
+int32_t drt_abi_version(void);
+const char *drt_last_error(void);
+/* 0 if a gfx950 device is visible and usable, DRT_E_NO_DEVICE otherwise (never aborts). */
+int32_t drt_device_check(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a1) ray_intersect_triangle -- reference: geometry/_utils.py:1157-1322 (hard mode).
+ * dense : rays [R,3] x triangles [T,3,3] -> t [R,T] f32, hit [R,T] u8   (the o[...,None,:] form)
+ * paired: element i of each input -> t[i], hit[i]                        (fully broadcast form)
+ * ------------------------------------------------------------------------------------------- */
+int32_t drt_ray_intersect_triangle_dense(const float *ray_origins, const float *ray_directions,
+                                         int64_t num_rays, const float *triangle_vertices,
+                                         int64_t num_triangles, float epsilon, float *t_out,
+                                         uint8_t *hit_out, void *stream);
+int32_t drt_ray_intersect_triangle_paired(const float *ray_origins, const float *ray_directions,
+                                          const float *triangle_vertices, int64_t n, float epsilon,
+                                          float *t_out, uint8_t *hit_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a2) ray_intersect_any_triangle -- reference: geometry/_utils.py:1353-1537 (hard mode), and the
+ * mesh-bound form geometry/_mesh.py:3018-3094.
+ *   out[r] = any_j [ (t_rj < 1 - hit_tol) & hit_rj & active_j ]
+ * tv_ray_stride: 0 = one triangle set [T,3,3] shared by all rays; 9*T = one set per ray.
+ * active: NULL or u8; active_ray_stride: 0 = shared [T], T = per ray [R,T].
+ * ------------------------------------------------------------------------------------------- */
+int32_t drt_ray_intersect_any_triangle(const float *ray_origins, const float *ray_directions,
+                                       int64_t num_rays, const float *triangle_vertices,
+                                       int64_t num_triangles, int64_t tv_ray_stride,
+                                       const uint8_t *active, int64_t active_ray_stride,
+                                       float epsilon, float hit_tol, uint8_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a4) first_triangle_hit_by_ray -- reference: geometry/_utils.py:1775-1960, incl. its tile
+ * tie-break (lowest index inside a `batch_size` tile, the LATER tile wins ties, remainder tile
+ * last: _utils.py:1865-1867, 1886, 1939-1955).  batch_size <= 0 means "None" (one tile).
+ * Miss: index -1, t = +inf.  workspace: num_rays * 8 bytes (device), see the _workspace_size query.
+ * ------------------------------------------------------------------------------------------- */
+size_t drt_first_triangle_hit_by_ray_workspace_size(int64_t num_rays);
+int32_t drt_first_triangle_hit_by_ray(const float *ray_origins, const float *ray_directions,
+                                      int64_t num_rays, const float *triangle_vertices,
+                                      int64_t num_triangles, int64_t tv_ray_stride,
+                                      const uint8_t *active, int64_t active_ray_stride,
+                                      float epsilon, int64_t batch_size, int32_t *index_out,
+                                      float *t_out, void *workspace, size_t workspace_bytes,
+                                      void *stream);
+
+/* (a5) backward of the first-hit distance -- reference: geometry/_mesh.py:226-344: the cotangent of
+ * t flows through Moller-Trumbore on the hit face only.  Gradients are ACCUMULATED (atomic adds)
+ * into grad_vertices [Nv,3] (may be NULL); grad_origins / grad_directions [R,3] are written. */
+int32_t drt_first_hit_vjp(const float *vertices, const int32_t *triangles,
+                          const float *ray_origins, const float *ray_directions,
+                          const int32_t *hit_index, const float *t_cotangent, int64_t num_rays,
+                          float *grad_vertices, float *grad_origins, float *grad_directions,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a6-a10) image method -- reference: geometry/_solver_image_method.py:11-454.
+ * Flat batches: from/to [B,3], mirrors [B,k,3] -> paths [B,k,3] (end points excluded).
+ * ------------------------------------------------------------------------------------------- */
+int32_t drt_image_method(const float *from_vertices, const float *to_vertices,
+                         const float *mirror_vertices, const float *mirror_normals, int64_t batch,
+                         int32_t num_mirrors, float *paths_out, void *stream);
+/* VJP of drt_image_method w.r.t. all four inputs (any grad pointer may be NULL). */
+int32_t drt_image_method_vjp(const float *from_vertices, const float *to_vertices,
+                             const float *mirror_vertices, const float *mirror_normals,
+                             const float *paths_cotangent, int64_t batch, int32_t num_mirrors,
+                             float *grad_from, float *grad_to, float *grad_mirror_vertices,
+                             float *grad_mirror_normals, void *stream);
+int32_t drt_consecutive_vertices_same_side(const float *vertices, const float *mirror_vertices,
+                                           const float *mirror_normals, int64_t batch,
+                                           int32_t num_mirrors, uint8_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a16) mesh handle: device-resident copy of what the path needs from `Mesh`
+ * (geometry/_mesh.py:624-688 fields; triangle_vertices :899-905; normals :950-956).
+ * Replaces the reference's hidden `_WARP_MESHES_CACHE` keyed on Python id() (_mesh.py:55, 170-174).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct drt_mesh *drt_mesh_t;
+int32_t drt_mesh_create(const float *vertices, int64_t num_vertices, const int32_t *triangles,
+                        int64_t num_triangles, const uint8_t *mask /* NULL = all active */,
+                        int32_t assume_quads, void *stream, drt_mesh_t *mesh_out);
+int32_t drt_mesh_destroy(drt_mesh_t mesh);
+int64_t drt_mesh_num_triangles(drt_mesh_t mesh);
+/* borrowed device pointers, valid until drt_mesh_destroy */
+const float *drt_mesh_triangle_vertices(drt_mesh_t mesh); /* [T,3,3] */
+const float *drt_mesh_normals(drt_mesh_t mesh);           /* [T,3]   */
+
+/* ---------------------------------------------------------------------------------------------
+ * (a12-a14) path-candidate enumeration -- reference: differt-core/src/geometry/graph.rs
+ * (CompleteGraph :127-277, iterator :286-491, count :314-377) and geometry/_utils.py:1047-1132.
+ * Host-side (no GPU needed): exact count and lexicographic unranking of "no two equal neighbours"
+ * tuples; rows are produced for ranks [rank_lo, rank_hi).
+ * ------------------------------------------------------------------------------------------- */
+/* count of paths of `depth` nodes from `from_` to `to` in the complete graph on num_nodes nodes
+ * (from_/to may be outside the graph, i.e. >= num_nodes).  *overflow_out = 1 and *count_out =
+ * UINT64_MAX when the count does not fit (graph.rs:368-375). */
+int32_t drt_complete_graph_count(uint64_t num_nodes, uint64_t from_, uint64_t to, uint64_t depth,
+                                 uint64_t *count_out, int32_t *overflow_out);
+/* the true number of paths (the closed form above reports an overflow in a few degenerate cases
+ * where the real count is small, e.g. num_nodes = 1); saturates at UINT64_MAX with *exceeds_out = 1. */
+int32_t drt_complete_graph_count_exact(uint64_t num_nodes, uint64_t from_, uint64_t to,
+                                       uint64_t depth, uint64_t *count_out, int32_t *exceeds_out);
+/* rows [rank_lo, rank_hi) into out_host (uint64 [rank_hi-rank_lo, depth or depth-2]). */
+int32_t drt_complete_graph_fill_host(uint64_t num_nodes, uint64_t from_, uint64_t to,
+                                     uint64_t depth, int32_t include_from_and_to,
+                                     uint64_t rank_lo, uint64_t rank_hi, uint64_t *out_host);
+/* GPU-resident table for the tracer: candidates of `order` interactions among num_nodes primitives
+ * (from/to outside the graph), ranks [rank_lo, rank_hi), optional node_map [num_nodes] (device)
+ * from compact node id to primitive id, ids multiplied by id_scale (2 for assume_quads).
+ * out: device int32 [rank_hi-rank_lo, order]. */
+int32_t drt_candidates_fill(int64_t num_nodes, int32_t order, int64_t rank_lo, int64_t rank_hi,
+                            const int32_t *node_map, int32_t id_scale, int32_t *out, void *stream);
+
+/* DiGraph (graph.rs:594-1120): adjacency lists + DFS path iterator, host side. */
+typedef struct drt_digraph *drt_digraph_t;
+int32_t drt_digraph_from_complete_graph(uint64_t num_nodes, drt_digraph_t *out);
+int32_t drt_digraph_from_adjacency_matrix(const uint8_t *matrix_host, uint64_t num_nodes,
+                                          drt_digraph_t *out);
+int32_t drt_digraph_destroy(drt_digraph_t g);
+uint64_t drt_digraph_num_nodes(drt_digraph_t g);
+int32_t drt_digraph_insert_from_and_to_nodes(drt_digraph_t g, int32_t direct_path,
+                                             const uint8_t *from_adjacency_host,
+                                             const uint8_t *to_adjacency_host, uint64_t *from_out,
+                                             uint64_t *to_out);
+int32_t drt_digraph_filter_by_mask(drt_digraph_t g, const uint8_t *mask_host, uint64_t mask_len,
+                                   int32_t fast_mode);
+int32_t drt_digraph_disconnect_nodes(drt_digraph_t g, const uint64_t *nodes_host, uint64_t n,
+                                     int32_t fast_mode);
+typedef struct drt_digraph_iter *drt_digraph_iter_t;
+int32_t drt_digraph_iter_create(drt_digraph_t g, uint64_t from_, uint64_t to, uint64_t depth,
+                                int32_t include_from_and_to, drt_digraph_iter_t *out);
+int32_t drt_digraph_iter_destroy(drt_digraph_iter_t it);
+/* up to max_rows rows into out_host (uint64 [max_rows, path_depth]); *rows_out = rows written
+ * (0 = exhausted). */
+int32_t drt_digraph_iter_next_chunk(drt_digraph_iter_t it, uint64_t max_rows, uint64_t *out_host,
+                                    uint64_t *rows_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a11) fused trace -- reference: geometry/_solvers.py:499-770 (_trace_path_candidates), hard mask.
+ * Candidate source: either an explicit table (device int32 [C,order], negative ids = padding rows,
+ * invalid) or a rank interval of the complete graph, unranked on the GPU (no table in HBM).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct drt_trace_params {
+    float epsilon;          /* MT epsilon; reference default 10*eps (_utils.py:1257-1259) */
+    float hit_tol;          /* occlusion tolerance; default 100*eps (_utils.py:1418-1420) */
+    float min_len;          /* squared-length threshold; default 10*eps (_solvers.py:514-516) */
+    int32_t reserved;
+} drt_trace_params;
+
+typedef struct drt_candidates {
+    const int32_t *table;   /* device [num_candidates, order] or NULL */
+    int64_t num_candidates; /* rows of `table`, or rank_hi - rank_lo */
+    int64_t rank_lo;        /* used when table == NULL */
+    int64_t num_nodes;      /* primitives in the complete graph (table == NULL) */
+    const int32_t *node_map;/* device [num_nodes] compact node -> primitive, or NULL */
+    int32_t order;          /* interactions per path (0..DRT_MAX_ORDER) */
+    int32_t reserved;
+} drt_candidates;
+
+/* Dense reference layout for every (tx, rx, candidate):
+ *   vertices [Ntx,Nrx,C,order+2,3] f32 (zeroed where not finite, _solvers.py:696-699)
+ *   objects  [Ntx,Nrx,C,order+2] i32  (_solvers.py:723-748)
+ *   mask     [Ntx,Nrx,C] u8           (_solvers.py:715-717)
+ * workspace: drt_trace_dense_workspace_size bytes. */
+size_t drt_trace_dense_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_candidates);
+int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
+                              int64_t num_tx, const float *rx, int64_t num_rx,
+                              const drt_candidates *cands, float *vertices, int32_t *objects,
+                              uint8_t *mask, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Compacted output: only valid paths, in the order of TracedPaths.masked_vertices
+ * (geometry/_paths.py:274-297: row-major over [tx, rx, candidate]).
+ *   keys     [max_paths] i64 : flat index (tx*Nrx + rx)*C + candidate_row of each valid path
+ *   vertices [max_paths,order+2,3], objects [max_paths,order+2]
+ * *num_valid_host receives the number of valid paths (the call synchronises the stream).
+ * Returns DRT_E_CAPACITY (and the required count in *num_valid_host) if max_paths is too small. */
+size_t drt_trace_compact_workspace_size(int64_t max_survivors, int64_t max_paths);
+int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
+                                int64_t num_tx, const float *rx, int64_t num_rx,
+                                const drt_candidates *cands, int64_t max_survivors,
+                                int64_t max_paths, int64_t *keys, float *vertices,
+                                int32_t *objects, int64_t *num_valid_host, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
+/* VJP of the path vertices of `num_paths` traced paths w.r.t. transmitters, receivers and mesh
+ * vertices (hand-derived reverse of the image method; the mask is a constant, as in the reference:
+ * SURVEY.md section 3.2).  keys are those returned by drt_trace_paths_compact (or flat dense
+ * indices); cotangent [num_paths,order+2,3].  Gradients are ACCUMULATED with atomic adds into
+ * grad_tx [Ntx,3], grad_rx [Nrx,3], grad_vertices [Nv,3] (each may be NULL). */
+int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, const float *rx,
+                            int64_t num_rx, const drt_candidates *cands, const int64_t *keys,
+                            const float *vertices_cotangent, int64_t num_paths, float *grad_tx,
+                            float *grad_rx, float *grad_vertices, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFERT_AMD_H */

@@ -446,9 +446,23 @@ class CompleteGraphIter:
 
     def collect_array(self, max_paths=None):
         n = self.remaining if max_paths is None else int(max_paths)
-        out = np.zeros((n, self.path_depth), dtype=np.uint64)
-        got = self._L.orc_cg_iter_collect(self._h, _p(out), n)
-        return out[:got].astype(np.int64)
+        if n <= (1 << 24):
+            out = np.zeros((n, self.path_depth), dtype=np.uint64)
+            got = self._L.orc_cg_iter_collect(self._h, _p(out), n)
+            return out[:got].astype(np.int64)
+        # declared length is huge (or the reference's overflow sentinel): iterate like collect_array
+        # of graph.rs:40-62 does, growing as we go
+        chunks, total = [], 0
+        while total < n:
+            buf = np.zeros((1 << 16, self.path_depth), dtype=np.uint64)
+            got = int(self._L.orc_cg_iter_collect(self._h, _p(buf), 1 << 16))
+            if got == 0:
+                break
+            chunks.append(buf[:got].astype(np.int64))
+            total += got
+        if not chunks:
+            return np.zeros((0, self.path_depth), dtype=np.int64)
+        return np.concatenate(chunks)
 
 
 def generate_all_path_candidates(num_primitives: int, order: int) -> np.ndarray:

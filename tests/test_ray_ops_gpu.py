@@ -1,0 +1,170 @@
+"""GPU parity: HIP ray/triangle operators (through the C ABI) vs the CPU oracle.
+
+Bar: bit-exact hit masks and hit indices; `t` bit-exact too (same operation order, no FMA).
+Mirrors differt/tests/geometry/test_utils.py:555-714, 910-962 of the reference.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import differt_amd.geometry as g
+
+    return g
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def test_known_answers(G, goldens):
+    """test_utils.py:555-606."""
+    g = goldens["ray_intersect_triangle_t_and_hit"]
+    o = np.asarray(g["ray_origin"], np.float32)
+    d = np.asarray(g["ray_directions"], np.float32)
+    tv = np.asarray(g["triangle_vertices"], np.float32)
+    t, hit = G.ray_intersect_triangle(o[None, None, :], d[:, None, :], tv)
+    np.testing.assert_array_equal(_np(t), np.asarray(g["expected_t"], np.float32))
+    np.testing.assert_array_equal(_np(hit), np.asarray(g["expected_hit"]))
+    g = goldens["ray_intersect_triangle_hits"]
+    tri = np.asarray([g["triangle"]], np.float32)
+    for case in g["cases"]:
+        o = np.asarray(case["orig"], np.float32)
+        dd = np.asarray(case["dest"], np.float32) - o
+        t, hit = G.ray_intersect_triangle(o, dd, tri)
+        assert bool(_np((t < 1.0) & hit)[0]) == case["expected"]
+
+
+@pytest.mark.parametrize("R,T", [(1, 1), (7, 5), (256, 10000), (33, 1023), (64, 4099), (300, 1028)])
+def test_dense_bit_exact(G, rng, R, T):
+    """cfg2 shape (256 x 10000) and ragged sizes (T % 4 != 0 -> scalar-store path)."""
+    o = (rng.uniform(-1, 1, (R, 3)) * 50).astype(np.float32)
+    d = (rng.uniform(-1, 1, (R, 3)) * 50).astype(np.float32) - o
+    c = (rng.uniform(-1, 1, (T, 1, 3)) * 50).astype(np.float32)
+    tv = (c + np.concatenate([np.zeros((T, 1, 3)), rng.normal(size=(T, 2, 3)) * 2], axis=1)).astype(np.float32)
+    et, eh = orc.ray_intersect_triangle_dense(o, d, tv)
+    t, hit = G.ray_intersect_triangle(o[:, None, :], d[:, None, :], tv)
+    assert t.shape == (R, T)
+    np.testing.assert_array_equal(_np(hit), eh)
+    np.testing.assert_array_equal(_np(t).view(np.uint32), et.view(np.uint32))
+
+
+def test_dense_hits_present(G, rng):
+    """Make sure the parity above is not vacuous: rays aimed at triangle centroids do hit."""
+    T = 2048
+    tv = rng.normal(size=(T, 3, 3)).astype(np.float32) * 3
+    cen = tv.mean(axis=1)
+    o = cen + rng.normal(size=(T, 3)).astype(np.float32) * 5
+    d = (cen - o) * np.float32(2.0)
+    et, eh = orc.ray_intersect_triangle_dense(o[:64], d[:64], tv)
+    t, hit = G.ray_intersect_triangle(o[:64, None, :], d[:64, None, :], tv)
+    assert eh.sum() >= 32
+    np.testing.assert_array_equal(_np(hit), eh)
+    np.testing.assert_array_equal(_np(t).view(np.uint32), et.view(np.uint32))
+
+
+@pytest.mark.parametrize("shapes", [((3,), (3,), (3, 3)), ((15, 5, 3), (15, 5, 3), (5, 3, 3)), ((4, 1, 3), (1, 6, 3), (4, 6, 3, 3))])
+def test_paired_broadcast(G, rng, shapes):
+    """test_utils.py:609-646."""
+    so, sd, st = shapes
+    o = rng.normal(size=so).astype(np.float32)
+    d = rng.normal(size=sd).astype(np.float32)
+    tv = rng.normal(size=st).astype(np.float32)
+    et, eh = orc.ray_intersect_triangle(o, d, tv)
+    t, hit = G.ray_intersect_triangle(o, d, tv)
+    assert tuple(t.shape) == et.shape
+    np.testing.assert_array_equal(_np(hit), eh)
+    np.testing.assert_array_equal(_np(t).view(np.uint32), et.view(np.uint32))
+    assert (_np(t)[_np(hit)] > 0).all()
+
+
+@pytest.mark.parametrize("epsilon", [None, 1e-6, 1e-2])
+@pytest.mark.parametrize("hit_tol", [None, 0.0, 0.001, -0.5, 0.5])
+@pytest.mark.parametrize("with_active", [True, False])
+@pytest.mark.parametrize(
+    "shapes",
+    [((20, 10, 3), (20, 10, 3), (20, 10, 5, 3, 3)), ((10, 3), (10, 3), (1, 3, 3)), ((3,), (3,), (1, 3, 3)),
+     ((700, 3), (700, 3), (777, 3, 3))],
+)
+def test_any_triangle(G, rng, shapes, epsilon, hit_tol, with_active):
+    """test_utils.py:649-714 + a shared-triangle case with random active mask and real hits."""
+    so, sd, st = shapes
+    o = rng.normal(size=so).astype(np.float32)
+    d = rng.normal(size=sd).astype(np.float32) * 3
+    tv = rng.normal(size=st).astype(np.float32)
+    act = (rng.random(st[:-2]) > 0.3) if with_active else None
+    exp = orc.ray_intersect_any_triangle(o, d, tv, act, epsilon=epsilon, hit_tol=hit_tol)
+    got = G.ray_intersect_any_triangle(o, d, tv, act, epsilon=epsilon, hit_tol=hit_tol, batch_size=11)
+    assert tuple(got.shape) == exp.shape
+    np.testing.assert_array_equal(_np(got), exp)
+
+
+@pytest.mark.parametrize("epsilon", [None, 1e-2])
+@pytest.mark.parametrize("with_active", [True, False])
+@pytest.mark.parametrize("batch_size", [11, 512, None])
+@pytest.mark.parametrize(
+    "shapes",
+    [((10, 3), (1, 3), (30, 3, 3)), ((100, 3), (100, 3), (1, 300, 3, 3)), ((4, 3), (4, 3), (0, 3, 3)),
+     ((5, 3), (5, 3), (5, 40, 3, 3)), ((1000, 3), (1000, 3), (1500, 3, 3))],
+)
+def test_first_triangle_hit(G, rng, shapes, epsilon, with_active, batch_size):
+    """test_utils.py:910-962, with index equality (the reference leaves it commented out)."""
+    so, sd, st = shapes
+    o = rng.normal(size=so).astype(np.float32)
+    d = rng.normal(size=sd).astype(np.float32) * 3
+    tv = rng.normal(size=st).astype(np.float32)
+    act = (rng.random(st[:-2]) > 0.3) if with_active else None
+    ei, et = orc.first_triangle_hit_by_ray(o, d, tv, act, batch_size=batch_size, epsilon=epsilon)
+    gi, gt = G.first_triangle_hit_by_ray(o, d, tv, act, batch_size=batch_size, epsilon=epsilon)
+    np.testing.assert_array_equal(_np(gi), ei)
+    np.testing.assert_array_equal(_np(gt).view(np.uint32), et.view(np.uint32))
+    if st[-3] > 0:
+        assert (ei >= 0).any()
+
+
+@pytest.mark.parametrize("batch_size,expected", [(4, 4), (6, 0), (2, 4), (512, 0), (1, 5)])
+def test_first_hit_tie_break(G, batch_size, expected):
+    """_utils.py:1865-1867, 1886: duplicate triangles."""
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    tv = np.stack([tri] * 6)
+    o = np.array([[0.25, 0.25, 1.0]], np.float32)
+    d = np.array([[0.0, 0.0, -1.0]], np.float32)
+    ei, _ = orc.first_triangle_hit_by_ray(o, d, tv, batch_size=batch_size)
+    gi, gt = G.first_triangle_hit_by_ray(o, d, tv, batch_size=batch_size)
+    assert int(ei[0]) == expected and int(_np(gi)[0]) == expected and float(_np(gt)[0]) == 1.0
+
+
+def test_tie_break_across_splits(G, rng):
+    """Many duplicated triangles spread over several LDS tiles / blockIdx.y splits."""
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    T = 5000
+    tv = rng.normal(size=(T, 3, 3)).astype(np.float32) + 10
+    dup = rng.choice(T, size=40, replace=False)
+    tv[dup] = tri
+    o = np.tile(np.array([[0.25, 0.25, 1.0]], np.float32), (3, 1))
+    d = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (3, 1))
+    for bs in (512, 100, 7):
+        ei, et = orc.first_triangle_hit_by_ray(o, d, tv, batch_size=bs)
+        gi, gt = G.first_triangle_hit_by_ray(o, d, tv, batch_size=bs)
+        np.testing.assert_array_equal(_np(gi), ei)
+        np.testing.assert_array_equal(_np(gt), et)
+
+
+def test_empty(G):
+    """_utils.py:1441-1450, 1848-1857."""
+    o = np.zeros((4, 3), np.float32)
+    d = np.ones((4, 3), np.float32)
+    tv = np.zeros((0, 3, 3), np.float32)
+    assert not _np(G.ray_intersect_any_triangle(o, d, tv)).any()
+    i, t = G.first_triangle_hit_by_ray(o, d, tv)
+    assert (_np(i) == -1).all() and np.isinf(_np(t)).all()
+    t, h = G.ray_intersect_triangle(np.zeros((0, 1, 3), np.float32), np.zeros((0, 1, 3), np.float32), np.zeros((5, 3, 3), np.float32))
+    assert t.shape == (0, 5)
