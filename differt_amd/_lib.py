@@ -77,6 +77,8 @@ _SIGNATURES = {
         [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp],
     ),
     "drt_first_hit_vjp": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "drt_image_of_vertex": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "drt_intersection_of_ray_with_plane": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "drt_image_method": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "drt_image_method_vjp": (
         _i32,
@@ -88,6 +90,7 @@ _SIGNATURES = {
     "drt_mesh_num_triangles": (_i64, [_vp]),
     "drt_mesh_triangle_vertices": (_vp, [_vp]),
     "drt_mesh_normals": (_vp, [_vp]),
+    "drt_mesh_copy": (_i32, [_vp, _vp, _vp, _vp]),
     "drt_complete_graph_count": (_i32, [_u64, _u64, _u64, _u64, C.POINTER(_u64), C.POINTER(_i32)]),
     "drt_complete_graph_count_exact": (_i32, [_u64, _u64, _u64, _u64, C.POINTER(_u64), C.POINTER(_i32)]),
     "drt_complete_graph_fill_host": (_i32, [_u64, _u64, _u64, _u64, _i32, _u64, _u64, _vp]),

@@ -70,6 +70,26 @@ __global__ __launch_bounds__(256) void same_side_kernel(const float *__restrict_
     out[i] = (uint8_t)same_sign(dot(vp - p, n), dot(vn - p, n));
 }
 
+// _solver_image_method.py:68-79 and :110-135, one lane per element
+__global__ __launch_bounds__(256) void image_of_vertex_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ p,
+                                                              const float *__restrict__ n, int64_t B,
+                                                              float *__restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    st3(out + 3 * b, image_of_vertex(ld3(x + 3 * b), ld3(p + 3 * b), ld3(n + 3 * b)));
+}
+
+__global__ __launch_bounds__(256) void ray_plane_kernel(const float *__restrict__ o,
+                                                        const float *__restrict__ d,
+                                                        const float *__restrict__ p,
+                                                        const float *__restrict__ n, int64_t B,
+                                                        float *__restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    st3(out + 3 * b, ray_plane(ld3(o + 3 * b), ld3(d + 3 * b), ld3(p + 3 * b), ld3(n + 3 * b)));
+}
+
 template <int K>
 static void launch_fwd(const float *from, const float *to, const float *mv, const float *mn,
                        int64_t B, float *out, hipStream_t s) {
@@ -104,6 +124,28 @@ using namespace drt;
     }
 
 extern "C" {
+
+int32_t drt_image_of_vertex(const float *x, const float *p, const float *n, int64_t B, float *out,
+                            void *stream) {
+    DRT_REQUIRE(B >= 0, "negative size");
+    if (B == 0) return DRT_OK;
+    DRT_REQUIRE(x && p && n && out, "null pointer");
+    hipLaunchKernelGGL(image_of_vertex_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+                       as_stream(stream), x, p, n, B, out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_intersection_of_ray_with_plane(const float *o, const float *d, const float *p,
+                                           const float *n, int64_t B, float *out, void *stream) {
+    DRT_REQUIRE(B >= 0, "negative size");
+    if (B == 0) return DRT_OK;
+    DRT_REQUIRE(o && d && p && n && out, "null pointer");
+    hipLaunchKernelGGL(ray_plane_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+                       as_stream(stream), o, d, p, n, B, out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
 
 int32_t drt_image_method(const float *from, const float *to, const float *mv, const float *mn,
                          int64_t B, int32_t k, float *out, void *stream) {

@@ -116,6 +116,18 @@ int32_t drt_mesh_create(const float *vertices, int64_t num_vertices, const int32
     return DRT_OK;
 }
 
+int32_t drt_mesh_copy(drt_mesh_t m, float *tv_out, float *normals_out, void *stream) {
+    DRT_REQUIRE(m, "mesh is null");
+    const size_t T = (size_t)m->num_triangles;
+    if (T == 0) return DRT_OK;
+    if (tv_out)
+        DRT_HIP(hipMemcpyAsync(tv_out, m->tri_verts, T * 36, hipMemcpyDeviceToDevice, as_stream(stream)));
+    if (normals_out)
+        DRT_HIP(hipMemcpyAsync(normals_out, m->normals, T * 12, hipMemcpyDeviceToDevice,
+                               as_stream(stream)));
+    return DRT_OK;
+}
+
 int64_t drt_mesh_num_triangles(drt_mesh_t m) { return m ? m->num_triangles : 0; }
 const float *drt_mesh_triangle_vertices(drt_mesh_t m) { return m ? m->tri_verts : nullptr; }
 const float *drt_mesh_normals(drt_mesh_t m) { return m ? m->normals : nullptr; }

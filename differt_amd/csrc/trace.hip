@@ -1,0 +1,749 @@
+// trace.hip -- the fused image-method tracer (reference geometry/_solvers.py:499-770,
+// `_trace_path_candidates`, hard-mask mode) and its VJP, for gfx950.
+//
+// Pipeline (all device-resident, candidates are never materialised when given as a rank window):
+//   stage A  trace_filter_kernel     one LANE per candidate row, looping over every (tx, rx) pair:
+//            GPU unranking of the candidate (replaces differt-core's host generator), mirror
+//            gather, image chain in registers, then the four cheap validity checks of the
+//            reference (inside-triangle SV:637-642, same-side SV:655-659, too-small SV:684-693,
+//            finite SV:696-699, active SV:544-549), most selective first with wave-uniform
+//            early-outs.  Survivors are compacted into a queue with one ballot + one atomic per
+//            wave.
+//   stage B  trace_occlusion_kernel  one WAVEFRONT per surviving candidate: its order+1 segments
+//            are tested against the whole mesh, lanes striding over LDS-staged triangle tiles
+//            shared by the block's waves; ballot any-hit with early exit ("blocked", SV:676-680,
+//            predicate of _utils.py:1469).
+//   sort     radix sort of the (few) valid flat indices -> the stable order of
+//            TracedPaths.masked_vertices (geometry/_paths.py:274-297), independent of atomics.
+//   emit     trace_emit_kernel       vertices / objects of the valid paths.
+//   vjp      trace_vjp_kernel        hand-derived reverse of the image chain per valid path.
+// The dense mode writes the reference's full [Ntx,Nrx,C,...] layout (parity tests, small sizes).
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+#include "geom.hpp"
+#include "image_chain.hpp"
+#include "mesh.hpp"
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+template <int K>
+struct KA {
+    static constexpr int n = K > 0 ? K : 1;  // array extent that is legal for K == 0
+};
+
+struct CandSrc {
+    const int32_t *table;
+    int64_t count;    // number of candidate rows
+    int64_t rank_lo;
+    int64_t num_nodes;
+    const int32_t *node_map;
+    int32_t id_scale;
+    int64_t pw[DRT_MAX_ORDER];  // pw[j] = (num_nodes-1)^(K-1-j)
+};
+
+struct TraceArgs {
+    const float *tri_verts;  // [T,3,3]
+    const float *normals;    // [T,3]
+    const uint8_t *mask;     // [T] or null
+    int64_t T;
+    const float *tx;
+    int64_t ntx;
+    const float *rx;
+    int64_t nrx;
+    float eps, thr, min_len;
+};
+
+// candidate row -> K primitive ids (table value or GPU unranking of rank_lo + row):
+// c_0 = r / (n-1)^(K-1);  d_j = (r / (n-1)^(K-1-j)) mod (n-1);  c_j = d_j + (d_j >= c_{j-1})
+// which enumerates "no two equal neighbours" tuples in lexicographic order (graph.rs:400-470).
+template <int K>
+__device__ __forceinline__ void load_candidate(const CandSrc &s, int64_t row,
+                                               int32_t (&id)[KA<K>::n]) {
+    if (K == 0) return;
+    if (s.table) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) id[j] = s.table[row * K + j];
+    } else {
+        uint64_t r = (uint64_t)(s.rank_lo + row);
+        int64_t prev = -1;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint64_t q = r / (uint64_t)s.pw[j];
+            r -= q * (uint64_t)s.pw[j];
+            int64_t c = (int64_t)q;
+            if (j > 0) c += (c >= prev) ? 1 : 0;
+            prev = c;
+            int32_t v = (int32_t)c;
+            if (s.node_map) v = s.node_map[c];
+            id[j] = v * s.id_scale;
+        }
+    }
+}
+
+template <int K, bool QUADS>
+struct Mirrors {
+    V3 p[KA<K>::n], n[KA<K>::n];
+    TriE tri[KA<K>::n];
+    TriE tri2[QUADS ? KA<K>::n : 1];
+    bool ok;      // ids in range (negative / out-of-range ids = padding rows: invalid)
+    bool active;  // every touched triangle unmasked
+};
+
+template <int K, bool QUADS>
+__device__ __forceinline__ void load_mirrors(const TraceArgs &a, const int32_t (&id)[KA<K>::n],
+                                             Mirrors<K, QUADS> &m) {
+    m.ok = true;
+    m.active = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int64_t i = id[j];
+        const bool ok = (i >= 0) && (i + (QUADS ? 1 : 0) < a.T);
+        m.ok = m.ok && ok;
+        const int64_t s = ok ? i : 0;
+        m.tri[j] = load_tri(a.tri_verts + 9 * s);
+        m.p[j] = m.tri[j].v0;                 // SV:552-557: first vertex of the (even) triangle
+        m.n[j] = ld3(a.normals + 3 * s);      // SV:560-562
+        if (QUADS) m.tri2[j] = load_tri(a.tri_verts + 9 * (s + 1));
+        if (a.mask) {
+            m.active = m.active && (a.mask[s] != 0);
+            if (QUADS) m.active = m.active && (a.mask[s + 1] != 0);
+        }
+    }
+}
+
+enum : uint32_t { F_INSIDE = 1, F_SAME = 2, F_LEN = 4, F_FINITE = 8, F_ALL = 15 };
+
+template <int K>
+__device__ __forceinline__ bool path_finite(const V3 (&full)[K + 2]) {
+    bool fin = true;
+#pragma unroll
+    for (int j = 0; j < K + 2; ++j)
+        fin = fin && is_finite(full[j].x) && is_finite(full[j].y) && is_finite(full[j].z);
+    return fin;
+}
+
+template <int K, bool QUADS>
+__device__ __forceinline__ bool inside_one(const Mirrors<K, QUADS> &m, const V3 (&full)[K + 2], int j,
+                                           float eps) {
+    const V3 o = full[j];
+    const V3 d = full[j + 1] - full[j];
+    float t;
+    bool h = moller_trumbore(o, d, m.tri[j], eps, t);
+    if (QUADS) h = h || moller_trumbore(o, d, m.tri2[j], eps, t);  // SV:615-627 any over the pair
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage A
+// ------------------------------------------------------------------------------------------
+template <int K, bool QUADS, bool DENSE>
+__global__ __launch_bounds__(256) void trace_filter_kernel(
+    TraceArgs a, CandSrc cs, unsigned long long *__restrict__ q_count,
+    long long *__restrict__ queue, int64_t q_cap, int64_t tx_per_block,
+    float *__restrict__ d_vertices, int32_t *__restrict__ d_objects, uint8_t *__restrict__ d_mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t it0 = (int64_t)blockIdx.y * tx_per_block;
+    const int64_t it1 = (it0 + tx_per_block < a.ntx) ? it0 + tx_per_block : a.ntx;
+    for (int64_t row0 = (int64_t)blockIdx.x * 256; row0 < cs.count; row0 += (int64_t)gridDim.x * 256) {
+        const int64_t row = row0 + threadIdx.x;
+        const bool in_range = row < cs.count;
+        int32_t id[KA<K>::n];
+        Mirrors<K, QUADS> m;
+        load_candidate<K>(cs, in_range ? row : 0, id);
+        load_mirrors<K, QUADS>(a, id, m);
+        const bool cand_ok = in_range && m.ok;
+
+        for (int64_t it = it0; it < it1; ++it) {
+            const V3 tx = ld3(a.tx + 3 * it);
+            V3 img[KA<K>::n];
+            {
+                V3 prev = tx;  // forward scan, IM:191-195
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    img[j] = image_of_vertex(prev, m.p[j], m.n[j]);
+                    prev = img[j];
+                }
+            }
+            for (int64_t ir = 0; ir < a.nrx; ++ir) {
+                const V3 rx = ld3(a.rx + 3 * ir);
+                V3 full[K + 2];
+                full[0] = tx;
+                full[K + 1] = rx;
+                {
+                    V3 cur = rx;  // reverse scan, IM:196-201
+#pragma unroll
+                    for (int j = K - 1; j >= 0; --j) {
+                        cur = backward_step(cur, img[j], m.p[j], m.n[j]);
+                        full[j + 1] = cur;
+                    }
+                }
+                bool alive = cand_ok && m.active;
+                // most selective test first: the last reflection point lies in its triangle
+                if (K > 0) alive = alive && inside_one<K, QUADS>(m, full, K - 1, a.eps);
+                bool fin = true;
+                if (DENSE || __any(alive)) {
+                    fin = path_finite<K>(full);
+                    alive = alive && fin;
+#pragma unroll
+                    for (int j = K - 2; j >= 0; --j)
+                        alive = alive && inside_one<K, QUADS>(m, full, j, a.eps);
+#pragma unroll
+                    for (int j = 0; j < K; ++j)  // IM:443-454
+                        alive = alive && same_sign(dot(full[j] - m.p[j], m.n[j]),
+                                                   dot(full[j + 2] - m.p[j], m.n[j]));
+#pragma unroll
+                    for (int s = 0; s <= K; ++s) {  // SV:684-693 (squared length)
+                        const V3 d = full[s + 1] - full[s];
+                        alive = alive && !(dot(d, d) < a.min_len);
+                    }
+                }
+                const int64_t flat = (it * a.nrx + ir) * cs.count + row;
+                if (DENSE && in_range) {
+                    float *v = d_vertices + flat * 3 * (K + 2);
+#pragma unroll
+                    for (int j = 0; j < K + 2; ++j)
+                        st3(v + 3 * j, (fin && cand_ok) ? full[j] : V3{0, 0, 0});  // SV:696-699
+                    int32_t *ob = d_objects + flat * (K + 2);
+                    ob[0] = (int32_t)it;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) ob[1 + j] = id[j];
+                    ob[K + 1] = (int32_t)ir;
+                    d_mask[flat] = (uint8_t)alive;  // stage B clears it when the path is blocked
+                }
+                // wave-level compaction of the survivors: one ballot + one atomic per wave
+                const unsigned long long vote = __ballot(alive);
+                if (vote) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(q_count, (unsigned long long)__popcll(vote));
+                    base = __shfl(base, 0, 64);
+                    if (alive) {
+                        const unsigned long long below = vote & ((1ull << lane) - 1ull);
+                        const unsigned long long slot = base + (unsigned long long)__popcll(below);
+                        if ((int64_t)slot < q_cap) queue[slot] = flat;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// path reconstruction from a flat key (stage B, emit, vjp)
+// ------------------------------------------------------------------------------------------
+// Returns false for padding rows (ids out of range): nothing may be read or written for them.
+template <int K>
+__device__ __forceinline__ bool key_to_path(const TraceArgs &a, const CandSrc &cs, int64_t flat,
+                                            int64_t &it, int64_t &ir, int32_t (&id)[KA<K>::n],
+                                            V3 (&p)[KA<K>::n], V3 (&n)[KA<K>::n], V3 (&full)[K + 2]) {
+    const int64_t pair = flat / cs.count;
+    const int64_t row = flat - pair * cs.count;
+    it = pair / a.nrx;
+    ir = pair - it * a.nrx;
+    load_candidate<K>(cs, row, id);
+    bool ok = (flat >= 0) && (it < a.ntx);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool in = (id[j] >= 0) && ((int64_t)id[j] < a.T);
+        ok = ok && in;
+        const int64_t s = in ? id[j] : 0;
+        p[j] = ld3(a.tri_verts + 9 * s);
+        n[j] = ld3(a.normals + 3 * s);
+    }
+    if (!ok) it = 0;
+    full[0] = ld3(a.tx + 3 * it);
+    full[K + 1] = ld3(a.rx + 3 * ir);
+    if constexpr (K > 0) {
+        V3 path[KA<K>::n];
+        image_chain<KA<K>::n>(full[0], full[K + 1], p, n, path);
+#pragma unroll
+        for (int j = 0; j < K; ++j) full[j + 1] = path[j];
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage B: one wavefront per surviving candidate
+// ------------------------------------------------------------------------------------------
+constexpr int kOccTile = 256;
+
+struct __attribute__((aligned(16))) OccRec {
+    float v0x, v0y, v0z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z;
+    uint32_t active;
+    uint32_t pad0, pad1;
+};
+
+template <int K, bool DENSE>
+__global__ __launch_bounds__(256) void trace_occlusion_kernel(
+    TraceArgs a, CandSrc cs, const unsigned long long *__restrict__ q_count,
+    const long long *__restrict__ queue, int64_t q_cap, unsigned long long *__restrict__ v_count,
+    long long *__restrict__ valid, int64_t v_cap, uint8_t *__restrict__ d_mask) {
+    __shared__ OccRec lds[kOccTile];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int64_t count = (int64_t)*q_count;
+    if (count > q_cap) count = q_cap;
+    for (int64_t e0 = (int64_t)blockIdx.x * 4; e0 < count; e0 += (int64_t)gridDim.x * 4) {
+        const int64_t e = e0 + wave;
+        const bool have = e < count;  // wave-uniform
+        V3 full[K + 2];
+        int64_t flat = 0;
+        if (have) {
+            flat = queue[e];
+            int64_t it, ir;
+            int32_t id[KA<K>::n];
+            V3 p[KA<K>::n], n[KA<K>::n];
+            key_to_path<K>(a, cs, flat, it, ir, id, p, n, full);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K + 2; ++j) full[j] = V3{0, 0, 0};
+        }
+        V3 dir[K + 1];
+#pragma unroll
+        for (int s = 0; s <= K; ++s) dir[s] = full[s + 1] - full[s];
+        bool blocked = !have;  // idle waves count as done
+        for (int64_t base = 0; base < a.T; base += kOccTile) {
+            // block-wide early exit (also the barrier that protects the previous tile's readers)
+            if (__syncthreads_and(blocked ? 1 : 0)) break;
+            {
+                const int64_t j = base + threadIdx.x;
+                if (j < a.T) {
+                    const TriE tr = load_tri(a.tri_verts + 9 * j);
+                    OccRec rec;
+                    rec.v0x = tr.v0.x; rec.v0y = tr.v0.y; rec.v0z = tr.v0.z;
+                    rec.e1x = tr.e1.x; rec.e1y = tr.e1.y; rec.e1z = tr.e1.z;
+                    rec.e2x = tr.e2.x; rec.e2y = tr.e2.y; rec.e2z = tr.e2.z;
+                    rec.active = a.mask ? (uint32_t)a.mask[j] : 1u;
+                    rec.pad0 = rec.pad1 = 0;
+                    lds[threadIdx.x] = rec;
+                }
+            }
+            __syncthreads();
+            if (!blocked) {
+                const int n = (int)((a.T - base < kOccTile) ? a.T - base : kOccTile);
+                bool hit = false;
+                for (int j = lane; j < n; j += 64) {
+                    const OccRec rec = lds[j];
+                    const TriE tr{V3{rec.v0x, rec.v0y, rec.v0z}, V3{rec.e1x, rec.e1y, rec.e1z},
+                                  V3{rec.e2x, rec.e2y, rec.e2z}};
+#pragma unroll
+                    for (int s = 0; s <= K; ++s) {
+                        float t;
+                        const bool h = moller_trumbore(full[s], dir[s], tr, a.eps, t);
+                        hit = hit || (h && (t < a.thr) && rec.active);  // _utils.py:1469
+                    }
+                }
+                blocked = __any(hit);
+            }
+        }
+        __syncthreads();
+        if (have && lane == 0) {
+            if (DENSE) {
+                if (blocked) d_mask[flat] = 0;
+            } else if (!blocked) {
+                const unsigned long long slot = atomicAdd(v_count, 1ull);
+                if ((int64_t)slot < v_cap) valid[slot] = flat;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// emit: vertices / objects of the sorted valid keys
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void trace_emit_kernel(TraceArgs a, CandSrc cs,
+                                                         const long long *__restrict__ keys,
+                                                         int64_t num, float *__restrict__ vertices,
+                                                         int32_t *__restrict__ objects) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= num) return;
+    int64_t it, ir;
+    int32_t id[KA<K>::n];
+    V3 p[KA<K>::n], n[KA<K>::n], full[K + 2];
+    key_to_path<K>(a, cs, keys[i], it, ir, id, p, n, full);
+#pragma unroll
+    for (int j = 0; j < K + 2; ++j) st3(vertices + (i * (K + 2) + j) * 3, full[j]);
+    int32_t *ob = objects + i * (K + 2);
+    ob[0] = (int32_t)it;
+#pragma unroll
+    for (int j = 0; j < K; ++j) ob[1 + j] = id[j];
+    ob[K + 1] = (int32_t)ir;
+}
+
+// ------------------------------------------------------------------------------------------
+// VJP: cotangent of the (K+2) path vertices -> tx, rx and mesh-vertex gradients
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add3(float *p, V3 v) {
+    atomicAdd(p + 0, v.x);
+    atomicAdd(p + 1, v.y);
+    atomicAdd(p + 2, v.z);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void trace_vjp_kernel(
+    TraceArgs a, CandSrc cs, const float *__restrict__ mesh_vertices,
+    const int32_t *__restrict__ mesh_triangles, const long long *__restrict__ keys,
+    const float *__restrict__ cot, int64_t num, float *__restrict__ g_tx, float *__restrict__ g_rx,
+    float *__restrict__ g_vertices) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= num) return;
+    int64_t it, ir;
+    int32_t id[KA<K>::n];
+    V3 p[KA<K>::n], n[KA<K>::n], full[K + 2];
+    // padding rows and non-finite paths have constant (zeroed) vertices: no gradient (SV:696-699)
+    if (!key_to_path<K>(a, cs, keys[i], it, ir, id, p, n, full) || !path_finite<K>(full)) return;
+    const float *g = cot + i * (K + 2) * 3;
+    V3 tx_bar = ld3(g);                  // vertices[0] = tx
+    V3 rx_bar = ld3(g + 3 * (K + 1));    // vertices[K+1] = rx
+    if constexpr (K > 0) {
+        V3 gp[KA<K>::n], pb[KA<K>::n], nb[KA<K>::n], fb, tb;
+#pragma unroll
+        for (int j = 0; j < K; ++j) gp[j] = ld3(g + 3 * (j + 1));
+        image_chain_vjp<KA<K>::n>(full[0], full[K + 1], p, n, gp, fb, tb, pb, nb);
+        tx_bar = tx_bar + fb;
+        rx_bar = rx_bar + tb;
+        if (g_vertices) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                // mirror point = v0 of the triangle; normal = normalize((v1-v0) x (v2-v1))
+                const int64_t tri = id[j];
+                const int32_t i0 = mesh_triangles[3 * tri], i1 = mesh_triangles[3 * tri + 1],
+                              i2 = mesh_triangles[3 * tri + 2];
+                const V3 v0 = ld3(mesh_vertices + 3 * (int64_t)i0),
+                         v1 = ld3(mesh_vertices + 3 * (int64_t)i1),
+                         v2 = ld3(mesh_vertices + 3 * (int64_t)i2);
+                const V3 ea = v1 - v0, eb = v2 - v1;
+                const V3 c = cross(ea, eb);
+                const float len = __builtin_sqrtf(dot(c, c));
+                V3 cbar;
+                if (len == 0.0f) {
+                    cbar = nb[j];  // normalize divides by 1 for zero-length vectors
+                } else {
+                    const float inv = 1.0f / len;
+                    const float proj = dot(nb[j], c) * inv * inv * inv;
+                    cbar = nb[j] * inv - c * proj;
+                }
+                const V3 ea_bar = cross(eb, cbar);   // c = ea x eb
+                const V3 eb_bar = cross(cbar, ea);
+                atomic_add3(g_vertices + 3 * (int64_t)i0, pb[j] - ea_bar);
+                atomic_add3(g_vertices + 3 * (int64_t)i1, ea_bar - eb_bar);
+                atomic_add3(g_vertices + 3 * (int64_t)i2, eb_bar);
+            }
+        }
+    }
+    if (g_tx) atomic_add3(g_tx + 3 * it, tx_bar);
+    if (g_rx) atomic_add3(g_rx + 3 * ir, rx_bar);
+}
+
+// (a12) GPU-resident candidate table
+template <int K>
+__global__ __launch_bounds__(256) void candidates_fill_kernel(CandSrc cs, int32_t *__restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= cs.count) return;
+    int32_t id[KA<K>::n];
+    load_candidate<K>(cs, row, id);
+#pragma unroll
+    for (int j = 0; j < K; ++j) out[row * K + j] = id[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc *out) {
+    DRT_REQUIRE(c, "candidates is null");
+    DRT_REQUIRE(c->order >= 0 && c->order <= DRT_MAX_ORDER, "order %d out of range [0, %d]",
+                (int)c->order, DRT_MAX_ORDER);
+    DRT_REQUIRE(c->num_candidates >= 0, "negative candidate count");
+    CandSrc s{};
+    s.table = c->table;
+    s.count = c->num_candidates;
+    s.rank_lo = c->rank_lo;
+    s.num_nodes = c->num_nodes;
+    s.node_map = c->node_map;
+    s.id_scale = id_scale;
+    for (int j = 0; j < DRT_MAX_ORDER; ++j) s.pw[j] = 1;
+    if (!c->table && c->order > 0 && c->num_candidates > 0) {
+        DRT_REQUIRE(c->num_nodes >= 1 && c->rank_lo >= 0, "bad rank window");
+        // total = n * (n-1)^(order-1) must fit and contain the window
+        unsigned __int128 total = (unsigned __int128)c->num_nodes;
+        unsigned __int128 pw = 1;
+        for (int j = c->order - 1; j >= 0; --j) {
+            DRT_REQUIRE(pw < ((unsigned __int128)1 << 62), "candidate space too large for 64-bit ranks");
+            s.pw[j] = (int64_t)pw;
+            if (j > 0) pw *= (unsigned __int128)(c->num_nodes - 1);
+        }
+        total = (unsigned __int128)c->num_nodes * (unsigned __int128)s.pw[0];
+        DRT_REQUIRE((unsigned __int128)c->rank_lo + (unsigned __int128)c->num_candidates <= total,
+                    "rank window [%lld, %lld) exceeds the %s candidates",
+                    (long long)c->rank_lo, (long long)(c->rank_lo + c->num_candidates), "available");
+        for (int j = 0; j < c->order; ++j)
+            if (s.pw[j] == 0) s.pw[j] = 1;  // num_nodes == 1: only order 1 has a (single) candidate
+    }
+    *out = s;
+    return DRT_OK;
+}
+
+static TraceArgs make_args(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx, int64_t ntx,
+                           const float *rx, int64_t nrx) {
+    TraceArgs a{};
+    a.tri_verts = mesh->tri_verts;
+    a.normals = mesh->normals;
+    a.mask = mesh->has_mask ? mesh->mask : nullptr;
+    a.T = mesh->num_triangles;
+    a.tx = tx;
+    a.ntx = ntx;
+    a.rx = rx;
+    a.nrx = nrx;
+    if (pr) {
+        a.eps = pr->epsilon;
+        a.thr = 1.0f - pr->hit_tol;
+        a.min_len = pr->min_len;
+    }
+    return a;
+}
+
+struct Launch {
+    hipStream_t s;
+    TraceArgs a;
+    CandSrc cs;
+    bool quads;
+};
+
+static void filter_grid(const Launch &L, dim3 *grid, int64_t *tx_per_block) {
+    int64_t bx = ceil_div(L.cs.count, 256);
+    if (bx > 256 * 8) bx = 256 * 8;
+    if (bx < 1) bx = 1;
+    // few candidates but many transmitters: split the tx loop over blockIdx.y
+    int64_t by = 1;
+    if (bx < 1024 && L.a.ntx > 1) {
+        by = ceil_div(2048, bx);
+        if (by > L.a.ntx) by = L.a.ntx;
+        if (by > 65535) by = 65535;
+    }
+    *tx_per_block = ceil_div(L.a.ntx, by);
+    by = ceil_div(L.a.ntx, *tx_per_block);
+    *grid = dim3((unsigned)bx, (unsigned)by);
+}
+
+template <int K, bool QUADS, bool DENSE>
+static void launch_filter(const Launch &L, unsigned long long *qc, long long *q, int64_t qcap,
+                          float *dv, int32_t *dob, uint8_t *dm) {
+    dim3 grid;
+    int64_t tpb;
+    filter_grid(L, &grid, &tpb);
+    hipLaunchKernelGGL((trace_filter_kernel<K, QUADS, DENSE>), grid, dim3(256), 0, L.s, L.a, L.cs, qc,
+                       q, qcap, tpb, dv, dob, dm);
+}
+
+template <int K, bool DENSE>
+static void launch_occlusion(const Launch &L, const unsigned long long *qc, const long long *q,
+                             int64_t qcap, unsigned long long *vc, long long *v, int64_t vcap,
+                             uint8_t *dm) {
+    // persistent-style grid: the survivor count lives on the device
+    hipLaunchKernelGGL((trace_occlusion_kernel<K, DENSE>), dim3(256 * 4), dim3(256), 0, L.s, L.a, L.cs,
+                       qc, q, qcap, vc, v, vcap, dm);
+}
+
+#define DRT_ORDER_SWITCH(k, CALL)                                                     \
+    switch (k) {                                                                      \
+        case 0: CALL(0); break;                                                       \
+        case 1: CALL(1); break;                                                       \
+        case 2: CALL(2); break;                                                       \
+        case 3: CALL(3); break;                                                       \
+        case 4: CALL(4); break;                                                       \
+        case 5: CALL(5); break;                                                       \
+        case 6: CALL(6); break;                                                       \
+        case 7: CALL(7); break;                                                       \
+        case 8: CALL(8); break;                                                       \
+        default: return fail(DRT_E_UNSUPPORTED, "order %d not supported", (int)(k)); \
+    }
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static size_t sort_temp_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr,
+                                   (unsigned long long *)nullptr, (size_t)n, 0, 64, nullptr);
+    return bytes;
+}
+
+}  // namespace drt
+
+using namespace drt;
+
+extern "C" {
+
+int32_t drt_candidates_fill(int64_t num_nodes, int32_t order, int64_t rank_lo, int64_t rank_hi,
+                            const int32_t *node_map, int32_t id_scale, int32_t *out, void *stream) {
+    DRT_REQUIRE(rank_hi >= rank_lo, "rank_hi < rank_lo");
+    if (rank_hi == rank_lo || order == 0) return DRT_OK;
+    DRT_REQUIRE(out, "out is null");
+    drt_candidates c{};
+    c.table = nullptr;
+    c.num_candidates = rank_hi - rank_lo;
+    c.rank_lo = rank_lo;
+    c.num_nodes = num_nodes;
+    c.node_map = node_map;
+    c.order = order;
+    CandSrc cs;
+    int32_t rc = make_cand_src(&c, id_scale <= 0 ? 1 : id_scale, &cs);
+    if (rc != DRT_OK) return rc;
+    const dim3 grid((unsigned)ceil_div(cs.count, 256));
+#define CALL(K) hipLaunchKernelGGL(candidates_fill_kernel<K>, grid, dim3(256), 0, as_stream(stream), cs, out)
+    DRT_ORDER_SWITCH(order, CALL)
+#undef CALL
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+size_t drt_trace_dense_workspace_size(int64_t ntx, int64_t nrx, int64_t C) {
+    if (ntx <= 0 || nrx <= 0 || C <= 0) return 64;
+    return 64 + (size_t)ntx * (size_t)nrx * (size_t)C * 8;
+}
+
+int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx,
+                              int64_t ntx, const float *rx, int64_t nrx, const drt_candidates *cands,
+                              float *vertices, int32_t *objects, uint8_t *mask, void *ws,
+                              size_t ws_bytes, void *stream) {
+    DRT_REQUIRE(mesh && pr && cands, "null argument");
+    DRT_REQUIRE(ntx >= 0 && nrx >= 0, "negative size");
+    Launch L;
+    L.s = as_stream(stream);
+    L.quads = mesh->assume_quads != 0;
+    int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
+    if (rc != DRT_OK) return rc;
+    L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
+    const int64_t total = ntx * nrx * L.cs.count;
+    if (total == 0) return DRT_OK;  // SV:566-573
+    DRT_REQUIRE(tx && rx && vertices && objects && mask, "null pointer");
+    const size_t need = drt_trace_dense_workspace_size(ntx, nrx, L.cs.count);
+    if (!ws || ws_bytes < need) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", need);
+    auto *qc = reinterpret_cast<unsigned long long *>(ws);
+    auto *q = reinterpret_cast<long long *>(reinterpret_cast<char *>(ws) + 64);
+    DRT_HIP(hipMemsetAsync(qc, 0, 64, L.s));
+    const int k = cands->order;
+#define CALL(K)                                                                            \
+    do {                                                                                   \
+        if (L.quads)                                                                       \
+            launch_filter<K, true, true>(L, qc, q, total, vertices, objects, mask);        \
+        else                                                                               \
+            launch_filter<K, false, true>(L, qc, q, total, vertices, objects, mask);       \
+        launch_occlusion<K, true>(L, qc, q, total, nullptr, nullptr, 0, mask);             \
+    } while (0)
+    DRT_ORDER_SWITCH(k, CALL)
+#undef CALL
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+size_t drt_trace_compact_workspace_size(int64_t max_survivors, int64_t max_paths) {
+    if (max_survivors < 0) max_survivors = 0;
+    if (max_paths < 0) max_paths = 0;
+    return 64 + align_up((size_t)max_survivors * 8, 256) + align_up((size_t)max_paths * 8, 256) +
+           align_up(sort_temp_bytes(max_paths), 256) + 256;
+}
+
+int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx,
+                                int64_t ntx, const float *rx, int64_t nrx, const drt_candidates *cands,
+                                int64_t max_survivors, int64_t max_paths, int64_t *keys,
+                                float *vertices, int32_t *objects, int64_t *num_valid_host, void *ws,
+                                size_t ws_bytes, void *stream) {
+    DRT_REQUIRE(mesh && pr && cands && num_valid_host, "null argument");
+    DRT_REQUIRE(ntx >= 0 && nrx >= 0 && max_survivors >= 0 && max_paths >= 0, "negative size");
+    *num_valid_host = 0;
+    Launch L;
+    L.s = as_stream(stream);
+    L.quads = mesh->assume_quads != 0;
+    int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
+    if (rc != DRT_OK) return rc;
+    L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
+    const unsigned __int128 total = (unsigned __int128)ntx * (unsigned __int128)nrx *
+                                    (unsigned __int128)L.cs.count;
+    if (total == 0) return DRT_OK;
+    DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx*rx*candidates does not fit a 62-bit key");
+    DRT_REQUIRE(tx && rx, "null pointer");
+    const size_t need = drt_trace_compact_workspace_size(max_survivors, max_paths);
+    if (!ws || ws_bytes < need) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", need);
+    char *base = reinterpret_cast<char *>(ws);
+    auto *counters = reinterpret_cast<unsigned long long *>(base);  // [0] survivors, [1] valid
+    auto *q1 = reinterpret_cast<long long *>(base + 64);
+    auto *q2 = reinterpret_cast<long long *>(base + 64 + align_up((size_t)max_survivors * 8, 256));
+    char *sort_tmp = reinterpret_cast<char *>(q2) + align_up((size_t)max_paths * 8, 256);
+    DRT_HIP(hipMemsetAsync(counters, 0, 64, L.s));
+    const int k = cands->order;
+#define CALL(K)                                                                                   \
+    do {                                                                                          \
+        if (L.quads)                                                                              \
+            launch_filter<K, true, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+        else                                                                                      \
+            launch_filter<K, false, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+        launch_occlusion<K, false>(L, counters, q1, max_survivors, counters + 1, q2, max_paths,  \
+                                   nullptr);                                                      \
+    } while (0)
+    DRT_ORDER_SWITCH(k, CALL)
+#undef CALL
+    DRT_LAUNCH_CHECK();
+    unsigned long long host_counts[2] = {0, 0};
+    DRT_HIP(hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, L.s));
+    DRT_HIP(hipStreamSynchronize(L.s));
+    if ((int64_t)host_counts[0] > max_survivors) {
+        *num_valid_host = (int64_t)host_counts[0];
+        return fail(DRT_E_CAPACITY,
+                    "survivor queue overflow: %llu candidates passed the geometric checks, capacity %lld",
+                    host_counts[0], (long long)max_survivors);
+    }
+    const int64_t nv = (int64_t)host_counts[1];
+    *num_valid_host = nv;
+    if (nv > max_paths)
+        return fail(DRT_E_CAPACITY, "%lld valid paths, output capacity %lld", (long long)nv,
+                    (long long)max_paths);
+    if (nv == 0) return DRT_OK;
+    DRT_REQUIRE(keys && vertices && objects, "null output");
+    size_t tmp_bytes = sort_temp_bytes(nv);
+    DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tmp_bytes, reinterpret_cast<unsigned long long *>(q2),
+                                     reinterpret_cast<unsigned long long *>(keys), (size_t)nv, 0, 64,
+                                     L.s));
+#define CALL(K)                                                                                 \
+    hipLaunchKernelGGL(trace_emit_kernel<K>, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, L.s, L.a, \
+                       L.cs, reinterpret_cast<const long long *>(keys), nv, vertices, objects)
+    DRT_ORDER_SWITCH(k, CALL)
+#undef CALL
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t ntx, const float *rx,
+                            int64_t nrx, const drt_candidates *cands, const int64_t *keys,
+                            const float *cot, int64_t num, float *g_tx, float *g_rx,
+                            float *g_vertices, void *stream) {
+    DRT_REQUIRE(mesh && cands, "null argument");
+    DRT_REQUIRE(num >= 0, "negative size");
+    if (num == 0) return DRT_OK;
+    DRT_REQUIRE(tx && rx && keys && cot, "null pointer");
+    Launch L;
+    L.s = as_stream(stream);
+    L.quads = mesh->assume_quads != 0;
+    int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
+    if (rc != DRT_OK) return rc;
+    L.a = make_args(mesh, nullptr, tx, ntx, rx, nrx);
+    const int k = cands->order;
+#define CALL(K)                                                                                  \
+    hipLaunchKernelGGL(trace_vjp_kernel<K>, dim3((unsigned)ceil_div(num, 256)), dim3(256), 0, L.s, L.a, \
+                       L.cs, mesh->vertices, mesh->triangles, reinterpret_cast<const long long *>(keys), \
+                       cot, num, g_tx, g_rx, g_vertices)
+    DRT_ORDER_SWITCH(k, CALL)
+#undef CALL
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,16 @@
 """Host-side mirror of ``differt.geometry`` for the MI355X hot path (reference names kept)."""
 
+from ._graph import CompleteGraph, DiGraph
+from ._mesh import Mesh
+from ._paths import TracedPaths
+from ._scene import Scene
+from ._solver_image_method import (
+    consecutive_vertices_are_on_same_side_of_mirror,
+    image_method,
+    image_of_vertex_with_respect_to_mirror,
+    intersection_of_ray_with_plane,
+)
+from ._solvers import AbstractPathTracer, ExhaustivePathTracer
 from ._utils import (
     SizedIterator,
     assemble_path,
@@ -13,12 +24,23 @@ from ._utils import (
 )
 
 __all__ = [
+    "AbstractPathTracer",
+    "CompleteGraph",
+    "DiGraph",
+    "ExhaustivePathTracer",
+    "Mesh",
+    "Scene",
     "SizedIterator",
+    "TracedPaths",
     "assemble_path",
+    "consecutive_vertices_are_on_same_side_of_mirror",
     "first_triangle_hit_by_ray",
     "generate_all_path_candidates",
     "generate_all_path_candidates_chunks_iter",
     "generate_all_path_candidates_iter",
+    "image_method",
+    "image_of_vertex_with_respect_to_mirror",
+    "intersection_of_ray_with_plane",
     "normalize",
     "ray_intersect_any_triangle",
     "ray_intersect_triangle",

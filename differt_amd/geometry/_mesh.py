@@ -1,0 +1,243 @@
+"""``Mesh``: the part of the reference's triangle mesh that sits on the hot path.
+
+Mirrors the fields and the mesh-bound ray queries of ``differt/src/differt/geometry/_mesh.py``
+(fields :624-688, ``triangle_vertices`` :899-905, ``normals`` :950-956, ``box`` :2109-2217,
+``ray_intersect_any_triangle`` :3018-3094, ``first_triangle_hit_by_ray`` :3096-3162).  Scene
+authoring (sampling, editing, plotting, file IO) is out of scope.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field, replace
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._tensors import F32_EPS, as_f32, as_i32, device, ptr, stream
+from . import _utils
+
+__all__ = ["Mesh"]
+
+
+class _MeshHandle:
+    """Owns one ``drt_mesh_t`` (explicit replacement of the reference's ``_WARP_MESHES_CACHE``)."""
+
+    def __init__(self, vertices, triangles, mask, assume_quads: bool):
+        h = C.c_void_p()
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        _lib.call(
+            "drt_mesh_create", ptr(vertices), vertices.shape[0], ptr(triangles), triangles.shape[0],
+            ptr(m), int(assume_quads), stream(), C.byref(h),
+        )
+        self.h = h
+        self.num_triangles = triangles.shape[0]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                _lib.load().drt_mesh_destroy(self.h)
+            finally:
+                self.h = None
+
+    def triangle_vertices(self) -> torch.Tensor:
+        out = torch.empty((self.num_triangles, 3, 3), dtype=torch.float32, device=device())
+        _lib.call("drt_mesh_copy", self.h, ptr(out), None, stream())
+        return out
+
+    def normals(self) -> torch.Tensor:
+        out = torch.empty((self.num_triangles, 3), dtype=torch.float32, device=device())
+        _lib.call("drt_mesh_copy", self.h, None, ptr(out), stream())
+        return out
+
+
+class _FirstHitFn(torch.autograd.Function):
+    """``t`` of the first hit, differentiable in (vertices, origins, directions) like the
+    reference's custom VJP (_mesh.py:258-344): the backward pass re-evaluates Moller-Trumbore on the
+    hit face only; indices carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, vertices, origins, directions, triangles, mask, epsilon, batch_size):
+        R = origins.shape[0]
+        tv = vertices[triangles.long()].contiguous()
+        idx = torch.full((R,), -1, dtype=torch.int32, device=origins.device)
+        t = torch.full((R,), float("inf"), dtype=torch.float32, device=origins.device)
+        if R:
+            ws = torch.empty(R, dtype=torch.int64, device=origins.device)
+            m = None if mask is None else mask.to(torch.uint8).contiguous()
+            _lib.call(
+                "drt_first_triangle_hit_by_ray", ptr(origins), ptr(directions), R, ptr(tv),
+                tv.shape[0], 0, ptr(m), 0, epsilon, batch_size, ptr(idx), ptr(t), ptr(ws), R * 8,
+                stream(),
+            )
+        ctx.save_for_backward(vertices, origins, directions, triangles, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx, t
+
+    @staticmethod
+    def backward(ctx, _gidx, gt):
+        vertices, origins, directions, triangles, idx = ctx.saved_tensors
+        R = origins.shape[0]
+        gv = torch.zeros_like(vertices)
+        go, gd = torch.zeros_like(origins), torch.zeros_like(directions)
+        if R:
+            _lib.call(
+                "drt_first_hit_vjp", ptr(vertices), ptr(triangles), ptr(origins), ptr(directions),
+                ptr(idx), ptr(gt.contiguous()), R, ptr(gv), ptr(go), ptr(gd), stream(),
+            )
+        return gv, go, gd, None, None, None, None
+
+
+@dataclass
+class Mesh:
+    """Triangle mesh in HBM: ``vertices f32[Nv,3]``, ``triangles i32[T,3]``, optional
+    ``mask bool[T]`` (inactive triangles neither reflect nor occlude) and ``assume_quads``
+    (consecutive triangle pairs form planar quads, _mesh.py:851-886)."""
+
+    vertices: torch.Tensor
+    triangles: torch.Tensor
+    mask: torch.Tensor | None = None
+    assume_quads: bool = False
+    object_bounds: torch.Tensor | None = None
+    _handle: _MeshHandle | None = field(default=None, repr=False, compare=False)
+
+    def __post_init__(self):
+        dev = device()
+        self.vertices = as_f32(self.vertices, dev).reshape(-1, 3)
+        self.triangles = as_i32(self.triangles, dev).reshape(-1, 3).contiguous()
+        if self.mask is not None:
+            m = self.mask if isinstance(self.mask, torch.Tensor) else torch.as_tensor(np.asarray(self.mask))
+            self.mask = m.to(device=dev).bool().reshape(-1).contiguous()
+            if self.mask.shape[0] != self.triangles.shape[0]:
+                raise ValueError("mask must have one entry per triangle")
+        if self.assume_quads and self.triangles.shape[0] % 2 != 0:
+            raise ValueError("assume_quads requires an even number of triangles")  # _mesh.py:690-696
+
+    # ---- native handle (rebuilt when a field changes: dataclasses.replace makes a new object) ----
+    def handle(self) -> _MeshHandle:
+        if self._handle is None:
+            self._handle = _MeshHandle(
+                self.vertices.detach().contiguous(), self.triangles, self.mask, self.assume_quads
+            )
+        return self._handle
+
+    # ---- reference properties ----
+    @property
+    def num_triangles(self) -> int:
+        return self.triangles.shape[0]
+
+    @property
+    def num_quads(self) -> int:
+        if not self.assume_quads:
+            raise ValueError("Cannot access the number of quadrilaterals if 'assume_quads' is not set to 'True'.")
+        return self.triangles.shape[0] // 2
+
+    @property
+    def num_primitives(self) -> int:
+        """_mesh.py:879-886."""
+        return self.num_quads if self.assume_quads else self.num_triangles
+
+    @property
+    def is_empty(self) -> bool:
+        return self.triangles.shape[0] == 0
+
+    @property
+    def triangle_vertices(self) -> torch.Tensor:
+        """``[T,3,3]`` (_mesh.py:899-905); differentiable in ``vertices``."""
+        return self.vertices[self.triangles.long()]
+
+    @property
+    def normals(self) -> torch.Tensor:
+        """``[T,3]`` unit normals computed by the mesh kernel (_mesh.py:950-956)."""
+        return self.handle().normals()
+
+    def set_assume_quads(self, flag: bool = True) -> "Mesh":
+        return replace(self, assume_quads=flag, _handle=None)
+
+    def set_mask(self, mask) -> "Mesh":
+        return replace(self, mask=mask, _handle=None)
+
+    def with_vertices(self, vertices) -> "Mesh":
+        return replace(self, vertices=vertices, _handle=None)
+
+    def masked(self) -> "Mesh":
+        """Sub-mesh of the active triangles (_mesh.py ``masked``; used by mask==sub-mesh tests)."""
+        if self.mask is None:
+            return self
+        keep = self.mask
+        return replace(self, triangles=self.triangles[keep], mask=None, _handle=None,
+                       object_bounds=None)
+
+    def append(self, other: "Mesh") -> "Mesh":
+        """Concatenate two meshes (_mesh.py:1555-1734): indices of ``other`` are offset, masks are
+        concatenated (a missing mask counts as all-True), ``assume_quads`` = both."""
+        tri = torch.cat((self.triangles, other.triangles + self.vertices.shape[0]))
+        if self.mask is None and other.mask is None:
+            mask = None
+        else:
+            ma = self.mask if self.mask is not None else torch.ones(self.num_triangles, dtype=torch.bool, device=tri.device)
+            mb = other.mask if other.mask is not None else torch.ones(other.num_triangles, dtype=torch.bool, device=tri.device)
+            mask = torch.cat((ma, mb))
+        return Mesh(torch.cat((self.vertices, other.vertices)), tri, mask,
+                    self.assume_quads and other.assume_quads)
+
+    __add__ = append
+
+    def translate(self, t) -> "Mesh":
+        return replace(self, vertices=self.vertices + as_f32(t), _handle=None)
+
+    @classmethod
+    def empty(cls) -> "Mesh":
+        return cls(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32))
+
+    @classmethod
+    def box(cls, length=1.0, width=1.0, height=1.0, *, with_top: bool = False,
+            with_bottom: bool = True) -> "Mesh":
+        """Vertex/triangle tables of the reference (_mesh.py:2172-2217): 8 vertices, 10 triangles by
+        default, 12 with ``with_top``; consecutive triangles pair into quads."""
+        f = np.float32
+        dx = np.array([f(length) * f(0.5), 0, 0], dtype=f)
+        dy = np.array([0, f(width) * f(0.5), 0], dtype=f)
+        dz = np.array([0, 0, f(height) * f(0.5)], dtype=f)
+        vertices = np.stack((+dx + dy + dz, +dx + dy - dz, -dx + dy - dz, -dx + dy + dz,
+                             -dx - dy - dz, -dx - dy + dz, +dx - dy - dz, +dx - dy + dz)).astype(f)
+        tris = [[0, 1, 2], [0, 2, 3], [3, 2, 4], [3, 4, 5], [5, 4, 6], [5, 6, 7], [7, 6, 1], [7, 1, 0]]
+        if with_bottom:
+            tris += [[1, 4, 2], [1, 6, 4]]
+        if with_top:
+            tris += [[0, 3, 5], [0, 5, 7]]
+        tris = np.asarray(tris, dtype=np.int32)
+        idx = np.arange(0, tris.shape[0] + 1, 2)
+        return cls(vertices, tris, object_bounds=torch.as_tensor(np.column_stack((idx[:-1], idx[1:]))))
+
+    # ---- mesh-bound ray queries ----
+    def ray_intersect_any_triangle(self, ray_origins, ray_directions, *, hit_tol: float | None = None,
+                                   epsilon: float | None = None) -> torch.Tensor:
+        """Whether each ray is blocked by an active triangle (_mesh.py:3018-3094; non-differentiable
+        like the reference, :3087-3094).  The predicate is the pure-JAX operator's
+        (_utils.py:1469); the reference dispatches to a Warp BVH query here, see DESIGN.md."""
+        o, d = as_f32(ray_origins), as_f32(ray_directions)
+        batch = torch.broadcast_shapes(o.shape[:-1], d.shape[:-1])
+        if self.is_empty:  # _mesh.py:3053-3057
+            return torch.zeros(batch, dtype=torch.bool, device=o.device)
+        with torch.no_grad():
+            return _utils.ray_intersect_any_triangle(
+                o, d, self.handle().triangle_vertices(), self.mask, hit_tol=hit_tol, epsilon=epsilon
+            )
+
+    def first_triangle_hit_by_ray(self, ray_origins, ray_directions, *, epsilon: float | None = None,
+                                  batch_size: int | None = 512):
+        """Closest hit ``(index, t)``; ``t`` is differentiable w.r.t. origins, directions and mesh
+        vertices (_mesh.py:3096-3162, custom VJP :258-344).  Miss = ``(-1, inf)``."""
+        o, d = as_f32(ray_origins), as_f32(ray_directions)
+        batch = torch.broadcast_shapes(o.shape[:-1], d.shape[:-1])
+        if self.is_empty:  # _mesh.py:3129-3136
+            return (torch.full(batch, -1, dtype=torch.int32, device=o.device),
+                    torch.full(batch, float("inf"), dtype=torch.float32, device=o.device))
+        of = o.expand(*batch, 3).contiguous().reshape(-1, 3)
+        df = d.expand(*batch, 3).contiguous().reshape(-1, 3)
+        eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+        idx, t = _FirstHitFn.apply(self.vertices.contiguous(), of, df, self.triangles, self.mask, eps,
+                                   0 if batch_size is None else int(batch_size))
+        return idx.reshape(batch), t.reshape(batch)

@@ -1,0 +1,78 @@
+"""``TracedPaths``: the output container of the tracer (reference geometry/_paths.py:77-328)."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+
+import torch
+
+__all__ = ["TracedPaths"]
+
+
+@dataclass
+class TracedPaths:
+    """Ray paths with the layout of the reference (geometry/_paths.py:85-110):
+    ``vertices f32[*batch, path_length, 3]``, ``objects i32[*batch, path_length]``,
+    ``mask bool[*batch]``, ``interaction_types i32[*batch, order]``."""
+
+    vertices: torch.Tensor
+    objects: torch.Tensor
+    mask: torch.Tensor
+    interaction_types: torch.Tensor | None = None
+    confidence_threshold: float = 0.5
+    keys: torch.Tensor | None = None  # compact mode: flat [tx, rx, candidate] index of each path
+
+    @property
+    def shape(self) -> tuple[int, ...]:
+        return tuple(self.objects.shape[:-1])
+
+    @property
+    def path_length(self) -> int:
+        return self.objects.shape[-1]
+
+    @property
+    def order(self) -> int:
+        return self.path_length - 2
+
+    def _bool_mask(self) -> torch.Tensor:
+        m = self.mask
+        return m if m.dtype == torch.bool else (m >= self.confidence_threshold)
+
+    @property
+    def num_valid_paths(self) -> torch.Tensor:
+        """geometry/_paths.py:264-272."""
+        return self._bool_mask().sum()
+
+    @property
+    def masked_vertices(self) -> torch.Tensor:
+        """geometry/_paths.py:274-283: valid paths, batch flattened, row-major order."""
+        return self.vertices.reshape(-1, self.path_length, 3)[self._bool_mask().reshape(-1)]
+
+    @property
+    def masked_objects(self) -> torch.Tensor:
+        """geometry/_paths.py:285-297."""
+        return self.objects.reshape(-1, self.path_length)[self._bool_mask().reshape(-1)]
+
+    def reshape(self, *batch: int) -> "TracedPaths":
+        """geometry/_paths.py:123-150."""
+        it = self.interaction_types
+        return replace(
+            self,
+            vertices=self.vertices.reshape(*batch, self.path_length, 3),
+            objects=self.objects.reshape(*batch, self.path_length),
+            mask=self.mask.reshape(*batch),
+            interaction_types=None if it is None else it.reshape(*batch, self.order),
+        )
+
+    def masked(self) -> "TracedPaths":
+        """geometry/_paths.py:299-328: flattened, valid paths only."""
+        p = self.reshape(-1)
+        m = p._bool_mask()
+        it = p.interaction_types
+        return replace(
+            p,
+            vertices=p.vertices[m],
+            objects=p.objects[m],
+            mask=m[m],
+            interaction_types=None if it is None else it[m],
+        )

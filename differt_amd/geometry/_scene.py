@@ -1,0 +1,130 @@
+"""``Scene``: transmitters + receivers + mesh, and the ``trace_paths`` dispatch contract.
+
+Mirrors ``differt/src/differt/geometry/_scene.py`` (``Scene`` fields, ``trace_paths`` :650-764,
+grids :343-375).  Loaders, plotting, SBR launching and the MLM kernel are out of scope
+(SURVEY.md section 8).
+"""
+
+from __future__ import annotations
+
+from collections.abc import Iterator
+from dataclasses import dataclass, replace
+from typing import Any, Literal
+
+import numpy as np
+import torch
+
+from .._tensors import as_f32, as_i32
+from ._mesh import Mesh
+from ._paths import TracedPaths
+from ._solvers import AbstractPathTracer, ExhaustivePathTracer
+from ._utils import SizedIterator
+
+__all__ = ["Scene"]
+
+
+@dataclass
+class Scene:
+    transmitters: torch.Tensor
+    receivers: torch.Tensor
+    mesh: Mesh
+
+    def __post_init__(self):
+        self.transmitters = as_f32(self.transmitters)
+        self.receivers = as_f32(self.receivers)
+
+    @property
+    def num_transmitters(self) -> int:
+        return int(np.prod(self.transmitters.shape[:-1], dtype=np.int64))
+
+    @property
+    def num_receivers(self) -> int:
+        return int(np.prod(self.receivers.shape[:-1], dtype=np.int64))
+
+    def set_assume_quads(self, flag: bool = True) -> "Scene":
+        return replace(self, mesh=self.mesh.set_assume_quads(flag))
+
+    def with_mesh(self, mesh: Mesh) -> "Scene":
+        return replace(self, mesh=mesh)
+
+    def with_transmitters(self, tx) -> "Scene":
+        return replace(self, transmitters=tx)
+
+    def with_receivers(self, rx) -> "Scene":
+        return replace(self, receivers=rx)
+
+    def _grid(self, m: int, n: int | None, height: float) -> torch.Tensor:
+        """``[n, m, 3]`` grid over the mesh's horizontal bounding box (_scene.py:343-375)."""
+        n = m if n is None else n
+        v = self.mesh.vertices
+        lo, hi = v.min(dim=0).values, v.max(dim=0).values
+        x = torch.linspace(float(lo[0]), float(hi[0]), m, device=v.device)
+        y = torch.linspace(float(lo[1]), float(hi[1]), n, device=v.device)
+        xx, yy = torch.meshgrid(x, y, indexing="xy")
+        return torch.stack((xx, yy, torch.full_like(xx, height)), dim=-1)
+
+    def with_transmitters_grid(self, m: int = 50, n: int | None = 50, *, height: float = 1.5) -> "Scene":
+        return replace(self, transmitters=self._grid(m, n, height))
+
+    def with_receivers_grid(self, m: int = 50, n: int | None = 50, *, height: float = 1.5) -> "Scene":
+        return replace(self, receivers=self._grid(m, n, height))
+
+    def trace_paths(
+        self,
+        order: int | None = None,
+        *,
+        solver: AbstractPathTracer | Literal["exhaustive", "hybrid"] = "exhaustive",
+        path_candidates=None,
+        chunk_size: int | None = None,
+        compact: bool = False,
+        **solver_kwargs: Any,
+    ) -> TracedPaths | SizedIterator | Iterator[TracedPaths]:
+        """Trace ray paths between all transmitters and receivers (_scene.py:650-764).
+
+        Result batch shape: ``[*tx_batch, *rx_batch, num_candidates]`` (:762-764).  ``compact=True``
+        (MI355X extension) returns only the valid paths, flattened, without building the dense
+        arrays or the candidate table.
+        """
+        if (order is None) == (path_candidates is None):  # _scene.py:692-695
+            raise ValueError("You must specify one of 'order' or 'path_candidates', not both.")
+        if isinstance(solver, str):
+            if solver == "hybrid":
+                raise NotImplementedError(
+                    "the hybrid (visibility-pruned) tracer is a 'next' row (SURVEY.md section 8f)"
+                )
+            if solver != "exhaustive":
+                raise ValueError(f"Unknown solver '{solver}'.")
+            if chunk_size is not None:
+                solver_kwargs = {**solver_kwargs, "chunk_size": chunk_size}
+            solver = ExhaustivePathTracer(**solver_kwargs)
+        elif solver_kwargs:
+            raise ValueError("solver_kwargs are only valid when 'solver' is given by name")  # :708-719
+
+        tx_batch = tuple(self.transmitters.shape[:-1])
+        rx_batch = tuple(self.receivers.shape[:-1])
+
+        if compact:
+            if path_candidates is not None:
+                return solver.trace_path_candidates_compact(self, path_candidates)
+            return solver.trace_rank_range(self, order)
+
+        eff_chunk = chunk_size if chunk_size is not None else getattr(solver, "chunk_size", None)
+        if path_candidates is None and eff_chunk is not None:  # _scene.py:735-751
+            chunks = solver.generate_path_candidates_chunks_iter(self, order, chunk_size=eff_chunk)
+
+            def gen() -> Iterator[TracedPaths]:
+                for cands, types in chunks:
+                    p = solver.trace_path_candidates(self, cands, types)
+                    yield p.reshape(*tx_batch, *rx_batch, cands.shape[0])
+
+            return SizedIterator(gen(), size=chunks.__len__)
+
+        if path_candidates is None:
+            cands, types = solver.generate_path_candidates(self, order)
+        else:
+            cands = as_i32(path_candidates)
+            if cands.dim() != 2:
+                raise ValueError("path_candidates must have shape [num_candidates, order]")
+            types = None
+        paths = solver.trace_path_candidates(self, cands, types)
+        return paths.reshape(*tx_batch, *rx_batch, cands.shape[0])

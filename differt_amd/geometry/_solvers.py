@@ -1,0 +1,340 @@
+"""Path tracers with the reference's solver interface.
+
+Mirrors ``differt/src/differt/geometry/_solvers.py``: ``AbstractPathTracer`` (:53-247),
+``ExhaustivePathTracer`` (:778-957) and the fused ``_trace_path_candidates`` (:499-770), whose
+arithmetic runs in ``csrc/trace.hip`` behind ``drt_trace_paths_dense`` / ``_compact`` / ``_vjp``.
+Extension for MI355X: ``trace_rank_range`` traces a window of candidate RANKS that are enumerated
+on the GPU -- no candidate table is ever built -- and returns only the valid paths, compacted.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from collections.abc import Iterator, Sequence
+from dataclasses import dataclass
+from typing import TYPE_CHECKING, Any
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._tensors import F32_EPS, as_i32, device, ptr, stream
+from ._graph import CompleteGraph, DiGraph
+from ._paths import TracedPaths
+from ._utils import SizedIterator
+
+if TYPE_CHECKING:
+    from ._scene import Scene
+
+__all__ = ["AbstractPathTracer", "ExhaustivePathTracer"]
+
+
+def _params(epsilon, hit_tol, min_len) -> _lib.TraceParams:
+    return _lib.TraceParams(
+        10.0 * F32_EPS if epsilon is None else float(epsilon),   # _utils.py:1257-1259
+        100.0 * F32_EPS if hit_tol is None else float(hit_tol),  # _utils.py:1418-1420
+        10.0 * F32_EPS if min_len is None else float(min_len),   # _solvers.py:514-516
+        0,
+    )
+
+
+def _table_candidates(table: torch.Tensor) -> _lib.Candidates:
+    c = _lib.Candidates()
+    c.table = table.data_ptr() if table.numel() else None
+    c.num_candidates = table.shape[0]
+    c.rank_lo, c.num_nodes, c.node_map = 0, 0, None
+    c.order = table.shape[1]
+    return c
+
+
+def _rank_candidates(order: int, rank_lo: int, count: int, num_nodes: int,
+                     node_map: torch.Tensor | None) -> _lib.Candidates:
+    c = _lib.Candidates()
+    c.table = None
+    c.num_candidates = count
+    c.rank_lo = rank_lo
+    c.num_nodes = num_nodes
+    c.node_map = None if node_map is None else node_map.data_ptr()
+    c.order = order
+    return c
+
+
+class _TraceDenseFn(torch.autograd.Function):
+    """vertices/objects/mask for every (tx, rx, candidate); vertices differentiable in
+    (tx, rx, mesh vertices) through ``drt_trace_paths_vjp``."""
+
+    @staticmethod
+    def forward(ctx, tx, rx, mesh_vertices, mesh, table, params):
+        dev = tx.device
+        ntx, nrx, (Cn, k) = tx.shape[0], rx.shape[0], table.shape
+        verts = torch.zeros((ntx, nrx, Cn, k + 2, 3), dtype=torch.float32, device=dev)
+        objs = torch.zeros((ntx, nrx, Cn, k + 2), dtype=torch.int32, device=dev)
+        mask = torch.zeros((ntx, nrx, Cn), dtype=torch.uint8, device=dev)
+        if ntx * nrx * Cn:
+            lib = _lib.load()
+            nbytes = lib.drt_trace_dense_workspace_size(ntx, nrx, Cn)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            cands = _table_candidates(table)
+            _lib.call("drt_trace_paths_dense", mesh.handle().h, C.byref(params), ptr(tx), ntx, ptr(rx),
+                      nrx, C.byref(cands), ptr(verts), ptr(objs), ptr(mask), ptr(ws), nbytes, stream())
+        ctx.mesh, ctx.table = mesh, table
+        ctx.save_for_backward(tx, rx)
+        ctx.mark_non_differentiable(objs, mask)
+        return verts, objs, mask
+
+    @staticmethod
+    def backward(ctx, gv, _go, _gm):
+        tx, rx = ctx.saved_tensors
+        mesh, table = ctx.mesh, ctx.table
+        n = gv.numel() // (3 * (table.shape[1] + 2))
+        gtx, grx = torch.zeros_like(tx), torch.zeros_like(rx)
+        gmv = torch.zeros_like(mesh.vertices) if ctx.needs_input_grad[2] else None
+        if n:
+            keys = torch.arange(n, dtype=torch.int64, device=tx.device)
+            cands = _table_candidates(table)
+            _lib.call("drt_trace_paths_vjp", mesh.handle().h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+                      C.byref(cands), ptr(keys), ptr(gv.contiguous()), n, ptr(gtx), ptr(grx), ptr(gmv),
+                      stream())
+        return gtx, grx, gmv, None, None, None
+
+
+class _TraceCompactFn(torch.autograd.Function):
+    """Valid paths only (sorted like ``masked_vertices``); differentiable like the dense form."""
+
+    @staticmethod
+    def forward(ctx, tx, rx, mesh_vertices, mesh, cand_desc, params, max_survivors, max_paths):
+        dev = tx.device
+        order = cand_desc["order"]
+        lib = _lib.load()
+
+        def make_cands():
+            if cand_desc["table"] is not None:
+                return _table_candidates(cand_desc["table"])
+            return _rank_candidates(order, cand_desc["rank_lo"], cand_desc["count"],
+                                    cand_desc["num_nodes"], cand_desc["node_map"])
+
+        while True:
+            nbytes = lib.drt_trace_compact_workspace_size(max_survivors, max_paths)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            keys = torch.empty(max_paths, dtype=torch.int64, device=dev)
+            verts = torch.empty((max_paths, order + 2, 3), dtype=torch.float32, device=dev)
+            objs = torch.empty((max_paths, order + 2), dtype=torch.int32, device=dev)
+            nv = C.c_int64(0)
+            cands = make_cands()
+            try:
+                _lib.call("drt_trace_paths_compact", mesh.handle().h, C.byref(params), ptr(tx),
+                          tx.shape[0], ptr(rx), rx.shape[0], C.byref(cands), max_survivors, max_paths,
+                          ptr(keys), ptr(verts), ptr(objs), C.byref(nv), ptr(ws), nbytes, stream())
+                break
+            except _lib.CapacityError:
+                # the call reports what it needs; grow and retry (results never depend on capacities)
+                need = int(nv.value)
+                if need > max_survivors:
+                    max_survivors = max(2 * max_survivors, need)
+                else:
+                    max_paths = max(2 * max_paths, need)
+        n = int(nv.value)
+        ctx.mesh, ctx.make_cands = mesh, make_cands
+        keys = keys[:n].clone()
+        ctx.save_for_backward(tx, rx, keys)
+        objs = objs[:n].clone()
+        ctx.mark_non_differentiable(objs, keys)
+        return verts[:n].clone(), objs, keys
+
+    @staticmethod
+    def backward(ctx, gv, _go, _gk):
+        tx, rx, keys = ctx.saved_tensors
+        mesh = ctx.mesh
+        gtx, grx = torch.zeros_like(tx), torch.zeros_like(rx)
+        gmv = torch.zeros_like(mesh.vertices) if ctx.needs_input_grad[2] else None
+        n = keys.shape[0]
+        if n:
+            cands = ctx.make_cands()
+            _lib.call("drt_trace_paths_vjp", mesh.handle().h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+                      C.byref(cands), ptr(keys), ptr(gv.contiguous()), n, ptr(gtx), ptr(grx), ptr(gmv),
+                      stream())
+        return gtx, grx, gmv, None, None, None, None, None
+
+
+def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, interaction_types=None, *,
+                           epsilon, hit_tol, min_len, smoothing_factor, confidence_threshold,
+                           batch_size) -> TracedPaths:  # noqa: ARG001
+    """Reference ``_trace_path_candidates`` (_solvers.py:499-770), dense layout
+    ``[num_tx, num_rx, num_candidates, ...]``."""
+    if smoothing_factor is not None:
+        raise NotImplementedError("smoothed masks are not part of the MI355X hot path yet")
+    table = as_i32(path_candidates).contiguous()
+    if mesh.assume_quads:
+        table = table - table % 2  # user-supplied ids are rounded down to the even triangle (SC:756-757)
+    tx = tx_vertices.contiguous()
+    rx = rx_vertices.contiguous()
+    verts, objs, mask = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table,
+                                            _params(epsilon, hit_tol, min_len))
+    if interaction_types is None:  # _solvers.py:751-762
+        it = torch.zeros(objs.shape[:-1] + (table.shape[1],), dtype=torch.int32, device=objs.device)
+    else:
+        it = as_i32(interaction_types).expand(*objs.shape[:-1], table.shape[1])
+    return TracedPaths(verts, objs, mask.bool(), it, confidence_threshold)
+
+
+class AbstractPathTracer:
+    """Solver interface of the reference (_solvers.py:53-247): any object with these methods can be
+    passed as ``Scene.trace_paths(solver=...)``."""
+
+    epsilon: float | None = None
+    hit_tol: float | None = None
+
+    def generate_path_candidates(self, scene, order, specular_reflection=True, diffuse_scattering=False):
+        raise NotImplementedError
+
+    def trace_path_candidates(self, scene, path_candidates, interaction_types):
+        raise NotImplementedError
+
+    def generate_path_candidates_chunks_iter(self, scene, order, *args, chunk_size, pad_chunks=False,
+                                             **kwargs):
+        """Default of the reference (_solvers.py:93-174): slice the full table."""
+        cands, types = self.generate_path_candidates(scene, order, *args, **kwargs)
+        n = cands.shape[0]
+        nchunks = -(-n // chunk_size) if n else 0
+
+        def gen() -> Iterator:
+            for i in range(nchunks):
+                c, t = cands[i * chunk_size:(i + 1) * chunk_size], types[i * chunk_size:(i + 1) * chunk_size]
+                if pad_chunks and c.shape[0] < chunk_size:
+                    pad = chunk_size - c.shape[0]
+                    c = torch.cat((c, torch.full((pad, c.shape[1]), -1, dtype=c.dtype, device=c.device)))
+                    t = torch.cat((t, torch.zeros((pad, t.shape[1]), dtype=t.dtype, device=t.device)))
+                yield c, t
+
+        return SizedIterator(gen(), size=nchunks)
+
+
+@dataclass
+class ExhaustivePathTracer(AbstractPathTracer):
+    """Exhaustive image-method tracer (reference _solvers.py:778-957), same fields and defaults."""
+
+    epsilon: float | None = None
+    hit_tol: float | None = None
+    min_len: float | None = None
+    smoothing_factor: float | None = None
+    confidence_threshold: float = 0.5
+    batch_size: int | None = 512
+    disconnect_inactive_triangles: bool = False
+    chunk_size: int | None = None
+
+    # ---- candidate generation (host graph classes; lexicographic like graph.rs) ----
+    def _graph(self, scene):
+        mesh = scene.mesh
+        graph = CompleteGraph(mesh.num_primitives)
+        if self.disconnect_inactive_triangles and mesh.mask is not None:  # _solvers.py:820-827
+            mask = mesh.mask
+            if mesh.assume_quads:
+                mask = mask[0::2] & mask[1::2]
+            graph = DiGraph.from_complete_graph(graph)
+            from_, to = graph.insert_from_and_to_nodes()
+            graph.filter_by_mask(mask.cpu().numpy(), fast_mode=True)
+        else:
+            from_, to = graph.num_nodes, graph.num_nodes + 1
+        return graph, from_, to
+
+    def generate_path_candidates(self, scene, order, specular_reflection=True,  # noqa: ARG002
+                                 diffuse_scattering=False):  # noqa: ARG002
+        """``(candidates i32[C, order], interaction_types i32[C, order])`` (_solvers.py:803-848)."""
+        if isinstance(order, Sequence):
+            raise NotImplementedError("ExhaustivePathTracer does not support multiple orders yet.")
+        graph, from_, to = self._graph(scene)
+        arr = graph.all_paths_array(from_, to, order + 2, include_from_and_to=False)
+        cands = torch.as_tensor(arr.astype(np.int32).reshape(arr.shape[0], order), device=device())
+        if scene.mesh.assume_quads:
+            cands = 2 * cands  # _solvers.py:842-843
+        return cands, torch.zeros_like(cands)
+
+    def generate_path_candidates_chunks_iter(self, scene, order, *args, chunk_size=None,
+                                             pad_chunks=False, **kwargs):
+        """Native chunked generation (_solvers.py:850-934); the last chunk is padded with ``-1`` rows
+        when ``pad_chunks`` (:912-918)."""
+        eff = chunk_size or self.chunk_size
+        if eff is None:
+            return SizedIterator(iter([self.generate_path_candidates(scene, order, *args, **kwargs)]), size=1)
+        if isinstance(order, Sequence):
+            raise NotImplementedError("ExhaustivePathTracer does not support multiple orders yet.")
+        graph, from_, to = self._graph(scene)
+        it = graph.all_paths_array_chunks(from_, to, order + 2, include_from_and_to=False, chunk_size=eff)
+        quads = scene.mesh.assume_quads
+
+        def gen() -> Iterator:
+            for chunk in it:
+                arr = np.asarray(chunk).astype(np.int32)
+                arr = arr.reshape(arr.shape[0], order)
+                if pad_chunks and arr.shape[0] < eff:
+                    arr = np.pad(arr, ((0, eff - arr.shape[0]), (0, 0)), constant_values=-1)
+                c = torch.as_tensor(arr, device=device())
+                if quads:
+                    c = 2 * c
+                yield c, torch.zeros_like(c)
+
+        size: Any = it.__len__ if hasattr(it, "__len__") else -1
+        return SizedIterator(gen(), size=size)
+
+    # ---- tracing ----
+    def trace_path_candidates(self, scene, path_candidates, interaction_types=None) -> TracedPaths:
+        """_solvers.py:936-957."""
+        return _trace_path_candidates(
+            scene.mesh, scene.transmitters.reshape(-1, 3), scene.receivers.reshape(-1, 3),
+            path_candidates, interaction_types, epsilon=self.epsilon, hit_tol=self.hit_tol,
+            min_len=self.min_len, smoothing_factor=self.smoothing_factor,
+            confidence_threshold=self.confidence_threshold, batch_size=self.batch_size,
+        )
+
+    def num_path_candidates(self, scene, order: int) -> int:
+        """``n * (n-1)**(order-1)`` over the (active) primitives; 1 for order 0."""
+        n = self._num_nodes_and_map(scene)[0]
+        return 1 if order == 0 else n * (n - 1) ** (order - 1)
+
+    def _num_nodes_and_map(self, scene):
+        mesh = scene.mesh
+        if self.disconnect_inactive_triangles and mesh.mask is not None:
+            mask = mesh.mask
+            if mesh.assume_quads:
+                mask = mask[0::2] & mask[1::2]
+            node_map = torch.nonzero(mask).reshape(-1).to(torch.int32).contiguous()
+            return int(node_map.shape[0]), node_map
+        return mesh.num_primitives, None
+
+    def trace_rank_range(self, scene, order: int, rank_lo: int = 0, rank_hi: int | None = None, *,
+                         max_survivors: int = 1 << 20, max_paths: int = 1 << 16) -> TracedPaths:
+        """Trace candidates ``[rank_lo, rank_hi)`` of the lexicographic candidate order without
+        materialising them; returns the valid paths only, in ``masked_vertices`` order.
+        ``keys`` holds ``(tx*num_rx + rx) * (rank_hi - rank_lo) + (rank - rank_lo)``."""
+        if self.smoothing_factor is not None:
+            raise NotImplementedError("smoothed masks are not part of the MI355X hot path yet")
+        n, node_map = self._num_nodes_and_map(scene)
+        total = 1 if order == 0 else n * (n - 1) ** (order - 1)
+        hi = total if rank_hi is None else min(int(rank_hi), total)
+        lo = min(int(rank_lo), hi)
+        desc = {"table": None, "order": order, "rank_lo": lo, "count": hi - lo, "num_nodes": max(n, 1),
+                "node_map": node_map}
+        return self._trace_compact(scene, desc, max_survivors, max_paths)
+
+    def trace_path_candidates_compact(self, scene, path_candidates, *, max_survivors: int = 1 << 20,
+                                      max_paths: int = 1 << 16) -> TracedPaths:
+        """Compacted variant of :meth:`trace_path_candidates` for an explicit table."""
+        table = as_i32(path_candidates).contiguous()
+        if scene.mesh.assume_quads:
+            table = table - table % 2
+        desc = {"table": table, "order": table.shape[1]}
+        return self._trace_compact(scene, desc, max_survivors, max_paths)
+
+    def _trace_compact(self, scene, desc, max_survivors, max_paths) -> TracedPaths:
+        tx = scene.transmitters.reshape(-1, 3).contiguous()
+        rx = scene.receivers.reshape(-1, 3).contiguous()
+        verts, objs, keys = _TraceCompactFn.apply(
+            tx, rx, scene.mesh.vertices, scene.mesh, desc,
+            _params(self.epsilon, self.hit_tol, self.min_len), max_survivors, max_paths,
+        )
+        n, order = objs.shape[0], desc["order"]
+        return TracedPaths(
+            verts, objs, torch.ones(n, dtype=torch.bool, device=objs.device),
+            torch.zeros((n, order), dtype=torch.int32, device=objs.device),
+            self.confidence_threshold, keys,
+        )

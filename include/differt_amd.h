@@ -102,6 +102,12 @@ int32_t drt_first_hit_vjp(const float *vertices, const int32_t *triangles,
  * (a6-a10) image method -- reference: geometry/_solver_image_method.py:11-454.
  * Flat batches: from/to [B,3], mirrors [B,k,3] -> paths [B,k,3] (end points excluded).
  * ------------------------------------------------------------------------------------------- */
+/* element-wise helpers (_solver_image_method.py:11-79 and :82-135), flat batches [B,3] */
+int32_t drt_image_of_vertex(const float *vertices, const float *mirror_vertices,
+                            const float *mirror_normals, int64_t batch, float *out, void *stream);
+int32_t drt_intersection_of_ray_with_plane(const float *ray_origins, const float *ray_directions,
+                                           const float *plane_vertices, const float *plane_normals,
+                                           int64_t batch, float *out, void *stream);
 int32_t drt_image_method(const float *from_vertices, const float *to_vertices,
                          const float *mirror_vertices, const float *mirror_normals, int64_t batch,
                          int32_t num_mirrors, float *paths_out, void *stream);
@@ -129,6 +135,9 @@ int64_t drt_mesh_num_triangles(drt_mesh_t mesh);
 /* borrowed device pointers, valid until drt_mesh_destroy */
 const float *drt_mesh_triangle_vertices(drt_mesh_t mesh); /* [T,3,3] */
 const float *drt_mesh_normals(drt_mesh_t mesh);           /* [T,3]   */
+/* copies into caller-owned device buffers ([T,3,3] and [T,3]; either may be NULL) */
+int32_t drt_mesh_copy(drt_mesh_t mesh, float *triangle_vertices_out, float *normals_out,
+                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (a12-a14) path-candidate enumeration -- reference: differt-core/src/geometry/graph.rs

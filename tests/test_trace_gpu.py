@@ -1,0 +1,376 @@
+"""GPU parity of the image-method operators and the fused tracer (through the C ABI) vs the oracle.
+
+Bar (BASELINE.json north-star): valid-path masks and object indices bit-exact; path vertices
+<= 1e-5 rel (they are in fact bit-identical: same operation order, no FMA); gradients <= 1e-5 rel vs
+torch.autograd over the torch restatement of the reference (oracle/torch_ref.py).
+Mirrors differt/tests/geometry/test_image_method.py and test_scene.py:116-260, 334-364, 444-647.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from oracle import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def G():
+    import differt_amd.geometry as g
+
+    return g
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------ image method ----
+def test_image_operators_known_answers(G, goldens):
+    """test_image_method.py:19-29, 70-129."""
+    g = goldens["image_of_vertex"]
+    got = G.image_of_vertex_with_respect_to_mirror(g["vertices"], g["mirror_vertices"], g["mirror_normals"])
+    np.testing.assert_array_equal(_np(got), np.asarray(g["expected"], np.float32))
+    g = goldens["intersection_of_ray_with_plane"]
+    o = np.asarray(g["ray_origins"], np.float32)
+    d = np.asarray(g["ray_end"], np.float32)[None] - o
+    for case in g["cases"]:
+        got = _np(G.intersection_of_ray_with_plane(o, d, [case["plane_vertex"]], [case["plane_normal"]]))
+        exp = orc.intersection_of_ray_with_plane(o, d, [case["plane_vertex"]], [case["plane_normal"]])
+        np.testing.assert_array_equal(_bits(got), _bits(exp))
+        if case["expected"] == "inf":
+            assert np.isposinf(got).all()
+
+
+@pytest.mark.parametrize("batch", [(), (10,), (10, 20, 30)])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 8])
+def test_image_method_random_bit_exact(G, rng, batch, k):
+    """test_image_method.py:160-219 shapes; random mirrors, incl. inf propagation."""
+    a = rng.normal(size=(*batch, 3)).astype(np.float32)
+    b = rng.normal(size=(*batch, 3)).astype(np.float32)
+    mv = rng.normal(size=(*batch, k, 3)).astype(np.float32)
+    mn, _ = orc.normalize(rng.normal(size=(*batch, k, 3)).astype(np.float32))
+    exp = orc.image_method(a, b, mv, mn)
+    got = G.image_method(a, b, mv, mn)
+    assert tuple(got.shape) == (*batch, k, 3)
+    np.testing.assert_array_equal(_bits(_np(got)), _bits(exp))
+    full = orc.assemble_path(a, exp, b)
+    ss = G.consecutive_vertices_are_on_same_side_of_mirror(full, mv, mn)
+    np.testing.assert_array_equal(_np(ss), orc.consecutive_vertices_are_on_same_side_of_mirror(full, mv, mn))
+
+
+def test_image_method_corridor_and_empty(G, goldens):
+    """fixtures.py:82-117 golden corridor; k == 0 -> empty (IM:349-358); TypeError (IM:422-424)."""
+    g = goldens["planar_mirrors_setup"]
+    got = G.image_method(g["from_vertex"], g["to_vertex"], g["mirror_vertices"], g["mirror_normals"])
+    np.testing.assert_allclose(_np(got), np.asarray(g["paths"], np.float32), atol=1e-7)
+    e = G.image_method(np.zeros((4, 3), np.float32), np.ones((4, 3), np.float32),
+                       np.zeros((4, 0, 3), np.float32), np.zeros((4, 0, 3), np.float32))
+    assert tuple(e.shape) == (4, 0, 3)
+    with pytest.raises(TypeError):
+        G.consecutive_vertices_are_on_same_side_of_mirror(np.zeros((3, 3)), np.zeros((2, 3)), np.zeros((2, 3)))
+
+
+def test_image_method_parallel_inf_no_nan(G):
+    """IM:123-135, 165-181 + test_image_method.py:109-117: inf outputs, NaN-free gradients."""
+    a = np.array([[0.0, 0.0, 1.0]], np.float32)
+    b = np.array([[1.0, 0.0, -1.0]], np.float32)  # image(image(a)) - b is parallel to mirror 2
+    mv = np.array([[[5.0, 0, 0], [0, 0, 0.0]]], np.float32)
+    mn = np.array([[[1.0, 0, 0], [0, 0, 1.0]]], np.float32)
+    exp = orc.image_method(a, b, mv, mn)
+    ta = torch.tensor(a, device="cuda", requires_grad=True)
+    tb = torch.tensor(b, device="cuda", requires_grad=True)
+    tmv = torch.tensor(mv, device="cuda", requires_grad=True)
+    tmn = torch.tensor(mn, device="cuda", requires_grad=True)
+    got = G.image_method(ta, tb, tmv, tmn)
+    np.testing.assert_array_equal(_bits(_np(got)), _bits(exp))
+    assert np.isinf(exp).all()  # parallel at mirror 2 -> inf, propagated to mirror 1
+    torch.where(torch.isfinite(got), got, torch.zeros_like(got)).sum().backward()
+    for t in (ta, tb, tmv, tmn):
+        assert not torch.isnan(t.grad).any()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5])
+def test_image_method_vjp_vs_autograd(G, rng, k):
+    """Hand-written VJP kernel vs torch.autograd over the torch restatement of the reference.
+
+    Truth = float64 autograd.  Random mirror chains contain a few near-parallel (ill-conditioned)
+    samples where ANY float32 evaluation is off by cond*eps, so the bar is per sample:
+    error <= 1e-5 relative, or no worse than 4x the error of plain float32 autograd (the
+    reference's own precision); and as many samples as float32 autograd must meet 1e-5 outright."""
+    B = 257
+    a = rng.normal(size=(B, 3)) * 3
+    b = rng.normal(size=(B, 3)) * 3
+    mv = rng.normal(size=(B, k, 3))
+    mn = rng.normal(size=(B, k, 3))
+    mn /= np.linalg.norm(mn, axis=-1, keepdims=True)
+    w = rng.normal(size=(B, k, 3))
+    a, b, mv, mn, w = (x.astype(np.float32) for x in (a, b, mv, mn, w))
+
+    def grads(dtype, device, fn):
+        ins = [torch.tensor(x, dtype=dtype, device=device, requires_grad=True) for x in (a, b, mv, mn)]
+        (fn(*ins) * torch.tensor(w, dtype=dtype, device=device)).sum().backward()
+        return [t.grad.detach().cpu().double().numpy().reshape(B, -1) for t in ins]
+
+    g64 = grads(torch.float64, "cpu", torch_ref.image_method)
+    g32 = grads(torch.float32, "cpu", torch_ref.image_method)
+    ggpu = grads(torch.float32, "cuda", G.image_method)
+    for got, ref32, truth, name in zip(ggpu, g32, g64, ("from", "to", "mirror_vertices", "mirror_normals")):
+        scale = np.abs(truth).max(axis=1) + 1e-30
+        err_gpu = np.abs(got - truth).max(axis=1) / scale
+        err_ref = np.abs(ref32 - truth).max(axis=1) / scale
+        assert np.isfinite(got).all(), name
+        assert (err_gpu <= np.maximum(RTOL, 4 * err_ref)).all(), (name, err_gpu.max(), err_ref.max())
+        # as many samples within 1e-5 as plain float32 autograd manages (long random chains are
+        # ill-conditioned more often)
+        assert (err_gpu <= RTOL).mean() >= (err_ref <= RTOL).mean() - 0.05, (
+            name, (err_gpu <= RTOL).mean(), (err_ref <= RTOL).mean())
+
+
+# ------------------------------------------------------------------ fused trace ----
+def _scene(G, tb, tx, rx, assume_quads=False, mask=None):
+    mesh = G.Mesh(tb["vertices"], tb["triangles"], mask=mask, assume_quads=assume_quads)
+    return G.Scene(np.asarray(tx, np.float32), np.asarray(rx, np.float32), mesh)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("assume_quads", [False, True])
+@pytest.mark.parametrize("mesh_mask", [False, True])
+def test_two_buildings_goldens(G, goldens, two_buildings, order, assume_quads, mesh_mask):
+    """differt/tests/geometry/test_scene.py:116-260 (exhaustive rows) through Scene.trace_paths,
+    plus bit parity of every dense output with the oracle, plus dense == compact."""
+    g = goldens["advanced_path_tracing_example"]
+    exp = g["orders"][str(order)]
+    if order == 4 and not assume_quads:
+        pytest.skip("292k candidates x dense layout: covered by the compact test below")
+    mask = np.ones(two_buildings["triangles"].shape[0], bool) if mesh_mask else None
+    scene = _scene(G, two_buildings, g["tx"], g["rx"], assume_quads, mask)
+    got = scene.trace_paths(order)
+    C = got.mask.shape[-1]
+    assert tuple(got.vertices.shape) == (C, order + 2, 3) and tuple(got.objects.shape) == (C, order + 2)
+    exp_objects = np.asarray(exp["objects"], np.int32)
+    if assume_quads:
+        exp_objects = exp_objects - exp_objects % 2
+    exp_vertices = orc.assemble_path(np.asarray(g["tx"], np.float32),
+                                     np.asarray(exp["path_vertices"], np.float32).reshape(1, order, 3),
+                                     np.asarray(g["rx"], np.float32))
+    np.testing.assert_array_equal(_np(got.masked_objects), exp_objects)
+    np.testing.assert_allclose(_np(got.masked_vertices), exp_vertices, rtol=g["rtol"])
+    assert int(got.num_valid_paths) == 1
+    # oracle, every candidate
+    n_prim = scene.mesh.num_primitives
+    cand = orc.generate_all_path_candidates(n_prim, order).astype(np.int32) * (2 if assume_quads else 1)
+    o = orc.trace_path_candidates(two_buildings["vertices"], two_buildings["triangles"], g["tx"], g["rx"],
+                                  cand, mask=mask, assume_quads=assume_quads)
+    np.testing.assert_array_equal(_np(got.mask).reshape(-1), o["mask"].reshape(-1))
+    np.testing.assert_array_equal(_np(got.objects).reshape(-1), o["objects"].reshape(-1))
+    np.testing.assert_array_equal(_bits(_np(got.vertices)).reshape(-1), _bits(o["vertices"]).reshape(-1))
+    # compact == masked dense
+    cp = scene.trace_paths(order, compact=True)
+    np.testing.assert_array_equal(_np(cp.objects), _np(got.masked_objects))
+    np.testing.assert_array_equal(_bits(_np(cp.vertices)), _bits(_np(got.masked_vertices)))
+
+
+def test_two_buildings_order4_compact(G, goldens, two_buildings):
+    """test_scene.py:146-160 order 4 without assume_quads: 292 008 candidates, GPU-unranked."""
+    g = goldens["advanced_path_tracing_example"]
+    exp = g["orders"]["4"]
+    scene = _scene(G, two_buildings, g["tx"], g["rx"])
+    cp = scene.trace_paths(4, compact=True)
+    np.testing.assert_array_equal(_np(cp.objects), np.asarray(exp["objects"], np.int32))
+    exp_vertices = orc.assemble_path(np.asarray(g["tx"], np.float32),
+                                     np.asarray(exp["path_vertices"], np.float32).reshape(1, 4, 3),
+                                     np.asarray(g["rx"], np.float32))
+    np.testing.assert_allclose(_np(cp.vertices), exp_vertices, rtol=g["rtol"])
+    cand = orc.generate_all_path_candidates(24, 4).astype(np.int32)
+    o = orc.trace_path_candidates(two_buildings["vertices"], two_buildings["triangles"], g["tx"], g["rx"], cand)
+    np.testing.assert_array_equal(_np(cp.keys), np.flatnonzero(o["mask"].reshape(-1)))
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("assume_quads", [False, True])
+def test_canyon_multi_tx_rx(G, rng, order, assume_quads):
+    """3 TX x 5 RX in a masked street canyon (tests/conftest.py): dense outputs bit-identical to the
+    oracle, compact output = masked dense in masked_vertices order (geometry/_paths.py:274-297)."""
+    from conftest import canyon_case
+
+    V, Tr, mask, tx, rx, cand = canyon_case(rng, order, assume_quads)
+    o = orc.trace_path_candidates(V, Tr, tx, rx, cand, mask=mask, assume_quads=assume_quads)
+    scene = G.Scene(tx, rx, G.Mesh(V, Tr, mask=mask, assume_quads=assume_quads))
+    got = scene.trace_paths(path_candidates=cand)
+    assert tuple(got.mask.shape) == (3, 5, cand.shape[0])
+    np.testing.assert_array_equal(_np(got.mask), o["mask"])
+    np.testing.assert_array_equal(_np(got.objects), o["objects"])
+    np.testing.assert_array_equal(_bits(_np(got.vertices)), _bits(o["vertices"]))
+    assert o["mask"].sum() >= 40, "test scene produced too few valid paths: not a meaningful parity case"
+    cp = scene.trace_paths(path_candidates=cand, compact=True)
+    np.testing.assert_array_equal(_np(cp.keys), np.flatnonzero(o["mask"].reshape(-1)))
+    np.testing.assert_array_equal(_np(cp.objects), o["objects"].reshape(-1, order + 2)[o["mask"].reshape(-1)])
+    np.testing.assert_array_equal(_bits(_np(cp.vertices)),
+                                  _bits(o["vertices"].reshape(-1, order + 2, 3)[o["mask"].reshape(-1)]))
+
+
+def test_rank_window_and_disconnect(G, goldens, two_buildings):
+    """GPU unranking over rank windows == table; disconnect_inactive_triangles == mask
+    (test_scene.py:585-724)."""
+    g = goldens["advanced_path_tracing_example"]
+    rng = np.random.default_rng(5)
+    mask = rng.random(24) > 0.3
+    mask[[8, 9, 22]] = True
+    scene = _scene(G, two_buildings, g["tx"], g["rx"], mask=mask)
+    full = G.ExhaustivePathTracer().trace_rank_range(scene, 2)
+    a = G.ExhaustivePathTracer().trace_rank_range(scene, 2, 0, 200)
+    b = G.ExhaustivePathTracer().trace_rank_range(scene, 2, 200, None)
+    keys = np.concatenate([_np(a.keys), _np(b.keys) + 200])
+    np.testing.assert_array_equal(keys, _np(full.keys))
+    np.testing.assert_array_equal(np.concatenate([_np(a.objects), _np(b.objects)]), _np(full.objects))
+    dis = G.ExhaustivePathTracer(disconnect_inactive_triangles=True)
+    d = dis.trace_rank_range(scene, 2)
+    np.testing.assert_array_equal(_np(d.objects), _np(full.objects))
+    np.testing.assert_array_equal(_bits(_np(d.vertices)), _bits(_np(full.vertices)))
+    # candidate tables: GPU fill == host unranking == oracle odometer
+    cands, types = dis.generate_path_candidates(scene, 2)
+    act = np.flatnonzero(mask)
+    np.testing.assert_array_equal(_np(cands), act[orc.generate_all_path_candidates(len(act), 2)])
+    assert (_np(types) == 0).all()
+    sub = scene.with_mesh(scene.mesh.masked())
+    s = sub.trace_paths(2, compact=True)
+    np.testing.assert_array_equal(_bits(_np(s.vertices)), _bits(_np(full.vertices)))
+
+
+def test_chunks_padding_empty(G, goldens, two_buildings):
+    """chunk iteration (SC:735-751), -1 padded rows (SV:912-918), no candidates (SV:566-573),
+    empty mesh (test_scene.py:444-534)."""
+    g = goldens["advanced_path_tracing_example"]
+    scene = _scene(G, two_buildings, g["tx"], g["rx"])
+    whole = scene.trace_paths(2)
+    chunks = list(scene.trace_paths(2, chunk_size=100))
+    assert len(chunks) == -(-552 // 100)
+    np.testing.assert_array_equal(np.concatenate([_np(c.mask) for c in chunks], axis=-1), _np(whole.mask))
+    tracer = G.ExhaustivePathTracer()
+    padded = list(tracer.generate_path_candidates_chunks_iter(scene, 2, chunk_size=100, pad_chunks=True))
+    assert all(c.shape == (100, 2) for c, _ in padded) and (_np(padded[-1][0])[-1] == -1).all()
+    last = tracer.trace_path_candidates(scene, *padded[-1])
+    assert not _np(last.mask)[..., 52:].any() and (_np(last.vertices)[..., 52:, :, :] == 0).all()
+    none = scene.trace_paths(path_candidates=np.zeros((0, 3), np.int32))
+    assert tuple(none.vertices.shape) == (0, 5, 3)
+    empty = G.Scene(g["tx"], g["rx"], G.Mesh.empty())
+    los = empty.trace_paths(0)
+    assert _np(los.mask).tolist() == [True] and _np(los.objects).tolist() == [[0, 0]]
+    assert tuple(empty.trace_paths(2).vertices.shape) == (0, 4, 3)
+    with pytest.raises(ValueError):
+        scene.trace_paths()
+
+
+def test_tx_rx_grids_shape(G, two_buildings):
+    """test_scene.py:536-562."""
+    scene = _scene(G, two_buildings, [0, 0, 1], [1, 1, 1]).with_transmitters_grid(3, 2).with_receivers_grid(4, 5)
+    assert tuple(scene.transmitters.shape) == (2, 3, 3) and tuple(scene.receivers.shape) == (5, 4, 3)
+    p = scene.trace_paths(1)
+    assert tuple(p.mask.shape) == (2, 3, 5, 4, 24)
+    assert tuple(p.vertices.shape) == (2, 3, 5, 4, 24, 3, 3)
+
+
+def test_config1_box(G):
+    """BASELINE configs[0]: 1 TX, 1 RX, 12-triangle box, order 1."""
+    V, Tr = orc.box_mesh(with_top=True)
+    tx, rx = [0.1, -0.2, 0.05], [-0.3, 0.25, -0.1]
+    cand = orc.generate_all_path_candidates(12, 1).astype(np.int32)
+    o = orc.trace_path_candidates(V, Tr, tx, rx, cand)
+    scene = G.Scene(tx, rx, G.Mesh.box(with_top=True))
+    np.testing.assert_array_equal(_np(scene.mesh.vertices), V)
+    np.testing.assert_array_equal(_np(scene.mesh.triangles), Tr)
+    np.testing.assert_array_equal(_bits(_np(scene.mesh.normals)), _bits(orc.mesh_normals(orc.triangle_vertices(V, Tr))))
+    got = scene.trace_paths(1)
+    np.testing.assert_array_equal(_np(got.mask), o["mask"].reshape(-1))
+    np.testing.assert_array_equal(_bits(_np(got.vertices)), _bits(o["vertices"].reshape(-1, 3, 3)))
+    q = scene.set_assume_quads().trace_paths(1)
+    assert int(q.num_valid_paths) == 6
+
+
+# ------------------------------------------------------------------ gradients ----
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("compact", [False, True])
+def test_trace_grad_vs_autograd(G, goldens, two_buildings, order, compact):
+    """d(sum of valid path lengths)/d(tx, rx, mesh vertices): HIP VJP vs torch.autograd over the
+    torch restatement, <= 1e-5 relative (BASELINE north-star)."""
+    g = goldens["advanced_path_tracing_example"]
+    rng = np.random.default_rng(11)
+    tx = (np.asarray(g["tx"], np.float32) + rng.normal(size=(3, 3)).astype(np.float32) * 0.3)
+    rx = (np.asarray(g["rx"], np.float32) + rng.normal(size=(2, 3)).astype(np.float32) * 0.3)
+    V, Tr = two_buildings["vertices"], two_buildings["triangles"]
+    cand = orc.generate_all_path_candidates(24, order).astype(np.int32)
+    o = orc.trace_path_candidates(V, Tr, tx, rx, cand)
+    valid = o["mask"].reshape(-1)
+    assert valid.sum() > 0
+
+    def length(v):
+        return torch.sqrt((torch.diff(v, dim=-2) ** 2).sum(-1)).sum()
+
+    vt = torch.tensor(V, dtype=torch.float64, requires_grad=True)
+    txt = torch.tensor(tx, dtype=torch.float64, requires_grad=True)
+    rxt = torch.tensor(rx, dtype=torch.float64, requires_grad=True)
+    full = torch_ref.trace_vertices(vt, torch.tensor(Tr, dtype=torch.long), txt, rxt, torch.tensor(cand, dtype=torch.long))
+    length(full.reshape(-1, order + 2, 3)[torch.tensor(valid)]).backward()
+
+    txg = torch.tensor(tx, device="cuda", requires_grad=True)
+    rxg = torch.tensor(rx, device="cuda", requires_grad=True)
+    vg = torch.tensor(V, device="cuda", requires_grad=True)
+    scene = G.Scene(txg, rxg, G.Mesh(vg, Tr))
+    paths = scene.trace_paths(order, compact=compact)
+    got_v = paths.vertices if compact else paths.masked_vertices
+    assert got_v.shape[0] == valid.sum()
+    length(got_v).backward()
+    for got, exp, name in ((txg, txt, "tx"), (rxg, rxt, "rx"), (vg, vt, "vertices")):
+        e = exp.grad.numpy()
+        scale = np.abs(e).max()
+        np.testing.assert_allclose(_np(got.grad), e, rtol=RTOL, atol=RTOL * scale, err_msg=name)
+
+
+def test_first_hit_box_and_jacobians(G, goldens):
+    """differt/tests/geometry/test_mesh.py:1984-2073: mesh-bound queries == free functions on
+    Mesh.box(2,2,2); Jacobians of t w.r.t. origins, directions, vertices at 1e-5."""
+    g = goldens["first_hit_box"]
+    mesh = G.Mesh.box(*g["box"])
+    rng = np.random.default_rng(3)
+    o = rng.uniform(-5, 5, (10, 3)).astype(np.float32)
+    d = rng.uniform(-1, 1, (10, 3)).astype(np.float32)
+    tv = _np(mesh.triangle_vertices)
+    np.testing.assert_array_equal(_np(mesh.ray_intersect_any_triangle(o, d)), orc.ray_intersect_any_triangle(o, d, tv))
+    ei, et = orc.first_triangle_hit_by_ray(o, d, tv)
+    gi, gt = mesh.first_triangle_hit_by_ray(o, d)
+    np.testing.assert_array_equal(_np(gi), ei)
+    np.testing.assert_array_equal(_np(gt), et)
+
+    o = np.asarray(g["ray_origins"], np.float32)
+    d = np.asarray(g["ray_directions"], np.float32)
+    V, Tr = _np(mesh.vertices), _np(mesh.triangles)
+    faces, _ = orc.first_triangle_hit_by_ray(o, d, tv)
+    assert (faces >= 0).all()
+    vt = torch.tensor(V, dtype=torch.float64, requires_grad=True)
+    ot = torch.tensor(o, dtype=torch.float64, requires_grad=True)
+    dt = torch.tensor(d, dtype=torch.float64, requires_grad=True)
+    jac_ref = torch.autograd.functional.jacobian(
+        lambda oo, dd, vv: torch_ref.differentiable_distance(vv, torch.tensor(Tr, dtype=torch.long), oo, dd,
+                                                             torch.tensor(faces, dtype=torch.long)),
+        (ot, dt, vt))
+    og = torch.tensor(o, device="cuda", requires_grad=True)
+    dg = torch.tensor(d, device="cuda", requires_grad=True)
+    vg = torch.tensor(V, device="cuda", requires_grad=True)
+
+    def fun(oo, dd, vv):
+        return G.Mesh(vv, Tr).first_triangle_hit_by_ray(oo, dd)[1]
+
+    jac_got = torch.autograd.functional.jacobian(fun, (og, dg, vg))
+    for jg, jr in zip(jac_got, jac_ref):
+        np.testing.assert_allclose(_np(jg), jr.numpy(), rtol=1e-5, atol=1e-5)
