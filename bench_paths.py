@@ -1,0 +1,108 @@
+"""Image-method tracing benchmark (BASELINE configs[2]): 16 TX x 64 RX, 10k-triangle synthetic
+Manhattan mesh, reflection order 2, forward + gradient w.r.t. the TX positions.
+
+Used by bench.py (the "paths" object of its JSON line) and runnable on its own:
+
+    python bench_paths.py [--ranks N] [--order 2]
+
+One step = candidate ranks [0, N) of the n*(n-1) order-2 candidates, unranked on the GPU, for every
+(tx, rx) pair: filter kernel -> occlusion kernel -> sort -> emit, then loss = sum of valid path
+lengths and its backward through the VJP kernel.  Reports path-candidates/s and valid paths/s.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import time
+
+import numpy as np
+
+
+def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16, num_rx: int = 64,
+        num_boxes: int = 1000, steps: int = 2, cpu_sample: bool = True) -> dict:
+    import torch
+
+    import differt_amd.geometry as G
+    import synthetic_scenes as S
+
+    V, Tr, centres, heights = S.manhattan(num_boxes)
+    tx, rx = S.manhattan_tx_rx(centres, heights, num_tx, num_rx)
+    mesh = G.Mesh(V, Tr)
+    n = mesh.num_primitives
+    total = n * (n - 1) ** (order - 1)
+    count = total if num_ranks is None else min(num_ranks, total)
+    tracer = G.ExhaustivePathTracer()
+
+    def step():
+        txg = torch.tensor(tx, device="cuda", requires_grad=True)
+        scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
+        paths = tracer.trace_rank_range(scene, order, 0, count, max_survivors=1 << 24, max_paths=1 << 20)
+        loss = torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum()
+        loss.backward()
+        return paths, txg.grad
+
+    paths, grad = step()  # warm-up (also sizes the queues)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        paths, grad = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nvalid = int(paths.objects.shape[0])
+    pairs = num_tx * num_rx
+    out = {
+        "workload": f"configs[2]: {num_tx} TX x {num_rx} RX, {Tr.shape[0]}-triangle synthetic Manhattan mesh, "
+                    f"order {order}, fwd + grad(TX); candidate ranks [0, {count}) of {total} per pair",
+        "path_candidates_per_step": pairs * count,
+        "valid_paths": nvalid,
+        "s_per_step": dt,
+        "path_candidates_per_s": pairs * count / dt,
+        "valid_paths_per_s": nvalid / dt,
+        "grad_tx_finite": bool(torch.isfinite(grad).all().item()),
+        "grad_tx_absmax": float(grad.abs().max().item()),
+    }
+    if cpu_sample:
+        out["cpu_baseline"] = cpu_sample_rate(V, Tr, tx, rx, order, n)
+    return out
+
+
+def cpu_sample_rate(V, Tr, tx, rx, order, n, budget_s: float = 10.0) -> dict:
+    """The CPU oracle (dense reference algorithm incl. brute-force occlusion of every candidate) on a
+    bounded sample: 1 TX x 1 RX x the first `m` candidates."""
+    import os
+
+    import oracle as orc
+
+    m = 2000
+    cand = orc.CompleteGraphIter(n, n, n + 1, order + 2, False).collect_array(m).astype(np.int32)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.trace_path_candidates(V, Tr, tx[:1], rx[:1], cand)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 50:
+            break
+    return {
+        "value": m * reps / el,
+        "unit": "path-candidates/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"{reps} passes of 1 TX x 1 RX x first {m} order-{order} candidates, dense reference "
+                  f"algorithm (every candidate's {order + 1} segments tested against all {Tr.shape[0]} triangles), {el:.1f} s",
+    }
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--order", type=int, default=2)
+    ap.add_argument("--ranks", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--boxes", type=int, default=1000)
+    ap.add_argument("--tx", type=int, default=16)
+    ap.add_argument("--rx", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(run(order=a.order, num_ranks=a.ranks, steps=a.steps, num_boxes=a.boxes, num_tx=a.tx,
+                         num_rx=a.rx, cpu_sample=not a.no_cpu)))

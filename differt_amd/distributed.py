@@ -1,0 +1,97 @@
+"""Multi-GPU execution of the hot path: one process per GPU (``torch.distributed``; backend
+``nccl`` = RCCL over xGMI on MI355X, ``gloo`` in the CPU tests).
+
+The path shards naturally: the lexicographic candidate-rank space
+``[0, C)`` (or the ray axis of a stand-alone ray query) is cut into one contiguous block per rank,
+the mesh (a few MB) is replicated, and NO collective runs during compute.  The epilogue is
+
+* ``gather_paths``      -- one ``all_gather`` of per-rank counts, then one of padded records, then a
+                           sort of the (few) valid paths by their global flat key: the result is the
+                           single-GPU order of ``TracedPaths.masked_vertices`` on every rank;
+* ``allreduce_grads``   -- one SUM all-reduce of the [N_tx,3] (+[N_rx,3], +[N_v,3]) gradients;
+* ``reduce_first_hit``  -- triangle-block sharding (BASELINE configs[4]): every rank holds a block
+                           of triangles and produces packed ``(t, tie)`` 64-bit keys for the same
+                           rays; a MIN all-reduce picks the global first hit with the reference's
+                           tile tie-break, independent of the partition.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["allreduce_grads", "gather_paths", "globalize_keys", "reduce_first_hit", "shard_interval"]
+
+
+def shard_interval(total: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous block ``[lo, hi)`` of ``range(total)`` owned by ``rank`` (sizes differ by <= 1)."""
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError("bad world_size / rank")
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _world(group) -> tuple[int, int]:
+    if not dist.is_available() or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def gather_paths(keys: torch.Tensor, vertices: torch.Tensor, objects: torch.Tensor,
+                 key_offset: int = 0, group=None):
+    """All-gather the valid paths of every rank; returns ``(keys, vertices, objects)`` identical on
+    all ranks, sorted by global flat key ``(tx*num_rx + rx) * C + candidate_rank`` (the order of
+    ``masked_vertices``).  ``keys`` must already be global (see ``globalize_keys``); ``key_offset``
+    is a convenience for the single-pair case."""
+    world, _ = _world(group)
+    keys = keys + key_offset
+    if world == 1:
+        return keys, vertices, objects
+    n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=keys.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+
+    def pad(t: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros((cap, *t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[: t.shape[0]] = t
+        return out
+
+    outs = []
+    for t in (keys, vertices, objects):
+        bufs = [torch.zeros((cap, *t.shape[1:]), dtype=t.dtype, device=t.device) for _ in range(world)]
+        dist.all_gather(bufs, pad(t.contiguous()), group=group)
+        outs.append(torch.cat([b[:c] for b, c in zip(bufs, counts)]))
+    perm = torch.argsort(outs[0], stable=True)
+    return tuple(o[perm] for o in outs)
+
+
+def globalize_keys(local_keys: torch.Tensor, local_count: int, rank_lo: int, total: int) -> torch.Tensor:
+    """Keys of a rank-window trace ``pair * local_count + (rank - rank_lo)`` -> global flat keys
+    ``pair * total + rank``."""
+    pair = torch.div(local_keys, local_count, rounding_mode="floor")
+    return pair * total + rank_lo + (local_keys - pair * local_count)
+
+
+def allreduce_grads(*grads: torch.Tensor, group=None) -> None:
+    """In-place SUM all-reduce of gradient tensors (one flat bucket, one collective)."""
+    world, _ = _world(group)
+    if world == 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off: off + g.numel()].reshape(g.shape))
+        off += g.numel()
+
+
+def reduce_first_hit(packed_keys: torch.Tensor, group=None) -> torch.Tensor:
+    """MIN all-reduce of packed first-hit keys ``(ordered(t) << 32) | tie`` held as int64 with the
+    sign bit flipped (so that signed MIN == unsigned MIN; RCCL has no uint64 MIN on every build)."""
+    world, _ = _world(group)
+    if world > 1:
+        dist.all_reduce(packed_keys, op=dist.ReduceOp.MIN, group=group)
+    return packed_keys

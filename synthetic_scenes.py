@@ -1,0 +1,62 @@
+"""Synthetic inputs of the BASELINE configs, NumPy `default_rng` seeded.
+
+Shared by bench.py / bench_paths.py and the tests so that CPU oracle and GPU see identical bytes.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+_BOX_TRIS_TOP_NO_BOTTOM = np.array(
+    # Mesh.box(with_top=True, with_bottom=False): reference _mesh.py:2186-2208 triangle table
+    [[0, 1, 2], [0, 2, 3], [3, 2, 4], [3, 4, 5], [5, 4, 6], [5, 6, 7], [7, 6, 1], [7, 1, 0],
+     [0, 3, 5], [0, 5, 7]],
+    dtype=np.int32,
+)
+
+
+def _box_vertices(length, width, height):
+    f = np.float32
+    dx = np.array([f(length) * f(0.5), 0, 0], dtype=f)
+    dy = np.array([0, f(width) * f(0.5), 0], dtype=f)
+    dz = np.array([0, 0, f(height) * f(0.5)], dtype=f)
+    return np.stack((+dx + dy + dz, +dx + dy - dz, -dx + dy - dz, -dx + dy + dz,
+                     -dx - dy - dz, -dx - dy + dz, +dx - dy - dz, +dx - dy + dz)).astype(f)
+
+
+def manhattan(num_boxes: int = 1000, pitch: float = 40.0, seed: int = 1234):
+    """cfg3/cfg4 (num_boxes=1000 -> 10 000 triangles) and cfg5 (num_boxes=20000 -> 200 000):
+    boxes on a `pitch`-metre grid, footprint U(10,30) m, height U(10,80) m, 10 triangles each
+    (walls + roof, no floor), quads = consecutive triangle pairs."""
+    rng = np.random.default_rng(seed)
+    nx = int(np.ceil(np.sqrt(num_boxes)))
+    verts = np.empty((num_boxes, 8, 3), np.float32)
+    tris = np.empty((num_boxes, 10, 3), np.int32)
+    heights = np.empty(num_boxes, np.float32)
+    centres = np.empty((num_boxes, 2), np.float32)
+    for b in range(num_boxes):
+        ix, iy = b % nx, b // nx
+        l, w = rng.uniform(10, 30, 2)
+        h = rng.uniform(10, 80)
+        cx, cy = (ix - nx / 2 + 0.5) * pitch, (iy - nx / 2 + 0.5) * pitch
+        verts[b] = _box_vertices(l, w, h) + np.array([cx, cy, h / 2], np.float32)
+        tris[b] = _BOX_TRIS_TOP_NO_BOTTOM + 8 * b
+        heights[b] = h
+        centres[b] = (cx, cy)
+    return verts.reshape(-1, 3), tris.reshape(-1, 3), centres, heights
+
+
+def manhattan_tx_rx(centres, heights, num_tx: int, num_rx: int, pitch: float = 40.0, seed: int = 99):
+    """TX 5 m above randomly chosen roofs, RX at 1.5 m on street crossings (between boxes)."""
+    rng = np.random.default_rng(seed)
+    sel = rng.choice(len(heights), num_tx, replace=False)
+    tx = np.column_stack((centres[sel], heights[sel] + 5.0)).astype(np.float32)
+    lo, hi = centres.min(axis=0), centres.max(axis=0)
+    nx = int(round((hi[0] - lo[0]) / pitch))
+    ny = int(round((hi[1] - lo[1]) / pitch))
+    gx = rng.integers(0, max(nx, 1), num_rx)
+    gy = rng.integers(0, max(ny, 1), num_rx)
+    jitter = rng.uniform(-3, 3, (num_rx, 2))
+    rx = np.column_stack((lo[0] + (gx + 0.5) * pitch + jitter[:, 0], lo[1] + (gy + 0.5) * pitch + jitter[:, 1],
+                          np.full(num_rx, 1.5))).astype(np.float32)
+    return tx, rx

@@ -1,0 +1,75 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/differt_amd.h declares;
+host-only entry points work; device entry points fail LOUDLY (status code, no abort, no CPU
+fallback) when there is no GPU.  CPU only."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from differt_amd import _lib
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    L = _lib.load()
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 35
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    unbound = [s for s in declared if s not in _lib._SIGNATURES]
+    assert not unbound, f"declared in the header but no ctypes signature: {unbound}"
+    stale = [s for s in _lib._SIGNATURES if s not in declared]
+    assert not stale, f"ctypes signature without a declaration in the header: {stale}"
+    assert L.drt_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # drt_trace_params: 3 floats + int32; drt_candidates: ptr, 3 x i64, ptr, 2 x i32
+    assert C.sizeof(_lib.TraceParams) == 16
+    assert C.sizeof(_lib.Candidates) == 48
+    assert _lib.Candidates.order.offset == 40
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_fails_loudly_not_silently():
+    L = _lib.load()
+    assert L.drt_device_check() == _lib.DRT_E_NO_DEVICE
+    assert b"no HIP device" in L.drt_last_error()
+    with pytest.raises(_lib.DrtError):
+        _lib.require_device()
+    import differt_amd.geometry as G
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G.ray_intersect_triangle(np.zeros(3), np.ones(3), np.zeros((3, 3)))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G.Mesh.box()
+
+
+def test_argument_validation_returns_status_codes():
+    L = _lib.load()
+    # invalid arguments are rejected before any device work
+    rc = L.drt_ray_intersect_triangle_dense(None, None, -1, None, 5, 0.0, None, None, None)
+    assert rc == _lib.DRT_E_INVALID and b"negative" in L.drt_last_error()
+    with pytest.raises(ValueError):
+        _lib.call("drt_complete_graph_fill_host", 3, 3, 4, 4, 0, 5, 2, None)
+    c, o = C.c_uint64(), C.c_int32()
+    _lib.call("drt_complete_graph_count", 10000, 10000, 10001, 4, C.byref(c), C.byref(o))
+    assert c.value == 10000 * 9999 and o.value == 0
+    assert L.drt_first_triangle_hit_by_ray_workspace_size(1000) == 8000
+    assert L.drt_trace_dense_workspace_size(2, 3, 10) == 64 + 2 * 3 * 10 * 8
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under differt_amd/ may reference it."""
+    import pathlib
+
+    root = pathlib.Path(_lib.__file__).resolve().parent
+    offenders = []
+    for p in list(root.rglob("*.py")) + list(root.rglob("*.hip")) + list(root.rglob("*.hpp")) + list(root.rglob("*.cpp")):
+        text = p.read_text()
+        if "import oracle" in text or "from oracle" in text or "differt_oracle" in text:
+            offenders.append(str(p))
+    assert not offenders, offenders
