@@ -242,7 +242,7 @@ def main() -> None:
         try:
             import bench_paths
 
-            result["paths"] = bench_paths.run(dev)
+            result["paths"] = bench_paths.run(dev, cpu_sample=not args.no_cpu_baseline)
         except ImportError:
             pass
         except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
