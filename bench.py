@@ -195,7 +195,7 @@ def main() -> None:
                 "outputs": "t f32[R,T] + hit u8[R,T]",
             },
             "roofline": {
-                "kernel": "drt::mt_dense_kernel<true>",
+                "kernel": "drt::mt_dense_kernel<4, true>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -25,28 +25,31 @@ namespace drt {
 // (a1) dense
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kDenseThreads = 256;
-constexpr int kTriPerLane = 4;
-constexpr int kTriPerBlock = kDenseThreads * kTriPerLane;  // 1024
 
-template <bool VEC>
+// TPL = triangles per lane (4 or 8).  Measured on MI355X (scratch/write_bw.hip): a CU retires one
+// wave-store in max(~50 cycles, bytes / ~10 B/clk), so the [R,T] f32 + u8 output pattern alone costs
+// 0.79 ms per 3.28 GB launch (4.2 TB/s) whatever the tile shape, and hiding it behind the ~0.7 ms of
+// VALU work needs all 8 waves/SIMD: TPL = 8 (124 VGPRs, 4 waves/SIMD, half as many `hit` stores)
+// measured 1.9 ms vs 0.97 ms for TPL = 4 (56 VGPRs), so the launcher always picks 4.
+template <int TPL, bool VEC>
 __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
     const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
     const float *__restrict__ tv, int64_t T, float eps, float *__restrict__ t_out,
     uint8_t *__restrict__ hit_out, int rays_per_block) {
-    const int64_t j0 = ((int64_t)blockIdx.y * kDenseThreads + threadIdx.x) * kTriPerLane;
+    const int64_t j0 = ((int64_t)blockIdx.y * kDenseThreads + threadIdx.x) * TPL;
     if (j0 >= T) return;
     const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
     const int64_t r1 = (r0 + rays_per_block < R) ? r0 + rays_per_block : R;
 
-    TriE tri[kTriPerLane];
+    TriE tri[TPL];
 #pragma unroll
-    for (int q = 0; q < kTriPerLane; ++q) {
+    for (int q = 0; q < TPL; ++q) {
         // lanes past the end re-read the last triangle; their results are never stored
         const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
         tri[q] = load_tri(tv + 9 * j);
-        // keep the edges live in VGPRs: without this the compiler re-derives e1/e2 from the
-        // vertices on every ray (6 extra VALU ops per test) to save registers
+        // keep the edges live in VGPRs (otherwise they may be re-derived from the vertices per ray)
         asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z),
                           "+v"(tri[q].e2.x), "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
     }
@@ -54,20 +57,28 @@ __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
     for (int64_t r = r0; r < r1; ++r) {
         const V3 o = ld3(ro + 3 * r);  // wave-uniform -> scalar loads
         const V3 d = ld3(rd + 3 * r);
-        float t[kTriPerLane];
-        bool h[kTriPerLane];
-#pragma unroll
-        for (int q = 0; q < kTriPerLane; ++q) h[q] = moller_trumbore(o, d, tri[q], eps, t[q]);
+        float t[TPL];
+        bool h[TPL];
+        moller_trumbore_n<TPL>(o, d, tri, eps, t, h);
         const int64_t base = r * T + j0;
         if (VEC) {
-            f32x4 tt = {t[0], t[1], t[2], t[3]};
-            uint32_t hh = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) |
-                          ((uint32_t)h[3] << 24);
-            __builtin_nontemporal_store(tt, reinterpret_cast<f32x4 *>(t_out + base));
-            __builtin_nontemporal_store(hh, reinterpret_cast<uint32_t *>(hit_out + base));
+            uint32_t hh[TPL / 4];
+#pragma unroll
+            for (int g = 0; g < TPL / 4; ++g) {
+                f32x4 tt = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+                __builtin_nontemporal_store(tt, reinterpret_cast<f32x4 *>(t_out + base + 4 * g));
+                hh[g] = (uint32_t)h[4 * g] | ((uint32_t)h[4 * g + 1] << 8) |
+                        ((uint32_t)h[4 * g + 2] << 16) | ((uint32_t)h[4 * g + 3] << 24);
+            }
+            if (TPL == 8) {
+                u32x2 h2 = {hh[0], hh[TPL / 4 - 1]};
+                __builtin_nontemporal_store(h2, reinterpret_cast<u32x2 *>(hit_out + base));
+            } else {
+                __builtin_nontemporal_store(hh[0], reinterpret_cast<uint32_t *>(hit_out + base));
+            }
         } else {
 #pragma unroll
-            for (int q = 0; q < kTriPerLane; ++q)
+            for (int q = 0; q < TPL; ++q)
                 if (j0 + q < T) {
                     t_out[base + q] = t[q];
                     hit_out[base + q] = (uint8_t)h[q];
@@ -360,7 +371,14 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
     if (R == 0 || T == 0) return DRT_OK;
     DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
-    const int64_t cols = ceil_div(T, kTriPerBlock);
+    // 8 triangles per lane when rows are 8-aligned and there is enough work to fill the chip
+    const bool al8 = (T % 8 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(hit_out) & 7) == 0);
+    const bool al4 = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(hit_out) & 3) == 0);
+    const int tpl = 4;  // see the note above mt_dense_kernel: occupancy beats fewer stores
+    (void)al8;
+    const int64_t cols = ceil_div(T, (int64_t)kDenseThreads * tpl);
     DRT_REQUIRE(cols <= 65535, "too many triangles for one launch (%lld)", (long long)T);
     // rays per block: as many as possible (amortises the triangle loads) while keeping >= ~4096 blocks
     int64_t rpb = (R * cols) / 4096;
@@ -368,15 +386,17 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     if (rpb > 64) rpb = 64;
     const int64_t rows = ceil_div(R, rpb);
     DRT_REQUIRE(rows < (1ll << 31), "too many rays for one launch");
-    const bool vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(hit_out) & 3) == 0);
     dim3 grid((unsigned)rows, (unsigned)cols);
-    if (vec)
-        hipLaunchKernelGGL(mt_dense_kernel<true>, grid, dim3(kDenseThreads), 0, as_stream(stream),
-                           ro, rd, R, tv, T, eps, t_out, hit_out, (int)rpb);
+    hipStream_t s = as_stream(stream);
+    if (tpl == 8)
+        hipLaunchKernelGGL((mt_dense_kernel<8, true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
+                           eps, t_out, hit_out, (int)rpb);
+    else if (al4)
+        hipLaunchKernelGGL((mt_dense_kernel<4, true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
+                           eps, t_out, hit_out, (int)rpb);
     else
-        hipLaunchKernelGGL(mt_dense_kernel<false>, grid, dim3(kDenseThreads), 0, as_stream(stream),
-                           ro, rd, R, tv, T, eps, t_out, hit_out, (int)rpb);
+        hipLaunchKernelGGL((mt_dense_kernel<4, false>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
+                           eps, t_out, hit_out, (int)rpb);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }
