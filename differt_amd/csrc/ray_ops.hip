@@ -61,6 +61,9 @@ __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
         bool h[TPL];
         moller_trumbore_n<TPL>(o, d, tri, eps, t, h);
         const int64_t base = r * T + j0;
+#ifdef DRT_EXPERIMENT_NO_STORE  // roofline study only: arithmetic without stores
+        if (t[0] + t[1] + t[2] + t[3] != 12345.678f) continue;
+#endif
         if (VEC) {
             uint32_t hh[TPL / 4];
 #pragma unroll
