@@ -85,6 +85,9 @@ _SIGNATURES = {
         [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     ),
     "drt_consecutive_vertices_same_side": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "drt_viewing_frustum": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "drt_fibonacci_lattice": (_i32, [_i64, _vp, _vp, _vp]),
+    "drt_triangles_visible_from_vertex": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp]),
     "drt_mesh_create": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, C.POINTER(_vp)]),
     "drt_mesh_destroy": (_i32, [_vp]),
     "drt_mesh_num_triangles": (_i64, [_vp]),

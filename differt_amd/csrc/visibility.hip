@@ -1,0 +1,218 @@
+// visibility.hip -- triangles visible from a vertex by ray launching ("next" row f2 of SURVEY.md 8f):
+//   viewing_frustum              reference geometry/_utils.py:639-927
+//   fibonacci_lattice            reference geometry/_utils.py:369-490 (split-modulus frac, :426-462)
+//   triangles_visible_from_vertex reference geometry/_utils.py:1540-1772, Mesh method _mesh.py:3164-3253
+// The lattice is never materialised: each lane derives its ray from (i, frustum), finds the first
+// triangle it hits over LDS-staged tiles (same arithmetic and tie rule as first_triangle_hit_by_ray
+// with batch_size=None: lowest index among equal t) and marks it visible (benign race, like the
+// reference's Warp kernel, _mesh.py:364-366).
+#include "common.hpp"
+#include "geom.hpp"
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+constexpr float kPi = 3.14159274101257324f;      // float32(pi)
+constexpr float kTwoPi = 6.28318548202514648f;   // float32(2*pi)
+
+struct Frustum {
+    float r_min, p_min, a_min, r_max, p_max, a_max;
+};
+
+// one block per viewing vertex; world vertices = triangle vertices + triangle centres
+// (geometry/_utils.py:1669-1673), active per triangle.
+__global__ __launch_bounds__(256) void frustum_kernel(const float *__restrict__ view, int64_t B,
+                                                      const float *__restrict__ tv, int64_t T,
+                                                      const uint8_t *__restrict__ active,
+                                                      float *__restrict__ out) {
+    const int64_t b = blockIdx.x;
+    const V3 vv = ld3(view + 3 * b);
+    float r_min = kInf, r_max = 0.0f, p_min = kPi, p_max = 0.0f;
+    float a_min = kPi, a_max = -kPi, a0_min = kTwoPi, a0_max = 0.0f;
+    for (int64_t t = threadIdx.x; t < T; t += 256) {
+        if (active && !active[t]) continue;
+        const V3 v0 = ld3(tv + 9 * t), v1 = ld3(tv + 9 * t + 3), v2 = ld3(tv + 9 * t + 6);
+        const V3 s = (v0 + v1) + v2;
+        const V3 w[4] = {v0, v1, v2, V3{s.x / 3.0f, s.y / 3.0f, s.z / 3.0f}};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const V3 x = w[k] - vv;
+            float r = __builtin_sqrtf(dot(x, x));  // cartesian_to_spherical, :952-956
+            r = (r == 0.0f) ? 1.0f : r;
+            const float p = acosf(x.z / r);
+            const float a = atan2f(x.y, x.x);
+            const float a0 = fmodf(a + kTwoPi, kTwoPi);
+            r_min = fminf(r_min, r); r_max = fmaxf(r_max, r);
+            p_min = fminf(p_min, p); p_max = fmaxf(p_max, p);
+            a_min = fminf(a_min, a); a_max = fmaxf(a_max, a);
+            a0_min = fminf(a0_min, a0); a0_max = fmaxf(a0_max, a0);
+        }
+    }
+    __shared__ float red[8][256];
+    float vals[8] = {r_min, -r_max, p_min, -p_max, a_min, -a_max, a0_min, -a0_max};  // all as minima
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = vals[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        r_min = red[0][0]; r_max = -red[1][0]; p_min = red[2][0]; p_max = -red[3][0];
+        a_min = red[4][0]; a_max = -red[5][0]; a0_min = red[6][0]; a0_max = -red[7][0];
+        // azimuth: keep the narrower of the [-pi,pi) and [0,2pi) domains (:850-877), full circle
+        // when both exceed 270 degrees (:879-890)
+        const float a_width = a_max - a_min, a0_width = a0_max - a0_min;
+        if (a_width > a0_width) { a_min = a0_min; a_max = a0_max; }
+        if (fminf(a_width, a0_width) > 1.5f * kPi) { a_min = -kPi; a_max = kPi; }
+        // degenerate polar band (:892-915)
+        float p0_min = p_min, p0_max = p_max;
+        if (p_min == p_max) { p_min = 0.0f; p0_max = kPi; }
+        if ((p_max - p_min) > (p0_max - p0_min)) { p_min = p0_min; p_max = p0_max; }
+        float *o = out + 6 * b;
+        o[0] = r_min; o[1] = p_min; o[2] = a_min; o[3] = r_max; o[4] = p_max; o[5] = a_max;
+    }
+}
+
+// direction of lattice point i of n inside the frustum (or on the full sphere when fr == nullptr)
+__device__ __forceinline__ V3 lattice_direction(int64_t i_int, int64_t n, const float *fr) {
+    const float i = (float)i_int;
+    const float inv_phi = 0.6180339887498949f;
+    const float m1 = 262144.0f, m2 = 512.0f;
+    const float inv_phi_m1 = (float)(0.6180339887498949 * 262144.0 - 162013.0);  // (inv_phi*m1) % 1
+    const float inv_phi_m2 = (float)(0.6180339887498949 * 512.0 - 316.0);        // (inv_phi*m2) % 1
+    const float q1 = floorf(i / m1);
+    const float rem = i - q1 * m1;
+    const float q2 = floorf(rem / m2);
+    const float r = rem - q2 * m2;
+    const float frac = fmodf((q1 * inv_phi_m1 + q2 * inv_phi_m2) + r * inv_phi, 1.0f);
+    float lat, lon;
+    if (fr) {
+        const float p_min = fr[1], a_min = fr[2], p_max = fr[4], a_max = fr[5];
+        const float c0 = cosf(p_min), c1 = cosf(p_max);
+        const float denom = (n > 1) ? (float)(n - 1) : 1.0f;
+        lat = acosf(c0 - (c0 - c1) * (i / denom));
+        lon = a_min + (a_max - a_min) * frac;
+    } else {
+        lat = acosf(1.0f - (2.0f * i) / (float)n);
+        lon = kTwoPi * frac;
+    }
+    const float sp = sinf(lat), cp = cosf(lat);
+    return V3{sp * cosf(lon), sp * sinf(lon), cp};
+}
+
+__global__ __launch_bounds__(256) void lattice_kernel(int64_t n, const float *__restrict__ fr,
+                                                      float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    st3(out + 3 * i, lattice_direction(i, n, fr));
+}
+
+constexpr int kVisTile = 256;
+struct __attribute__((aligned(16))) VisRec {
+    float v0x, v0y, v0z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z;
+    uint32_t active;
+    uint32_t pad0, pad1;
+};
+
+// grid (ceil(num_rays / 256), B); lane = lattice ray
+__global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict__ view,
+                                                         const float *__restrict__ frusta,
+                                                         int64_t num_rays,
+                                                         const float *__restrict__ tv, int64_t T,
+                                                         const uint8_t *__restrict__ active, float eps,
+                                                         uint8_t *__restrict__ visible) {
+    __shared__ VisRec lds[kVisTile];
+    const int64_t b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < num_rays;
+    const V3 o = ld3(view + 3 * b);
+    const V3 d = lattice_direction(valid ? i : 0, num_rays, frusta + 6 * b);
+    float best_t = kInf;
+    int64_t best_j = -1;
+    for (int64_t base = 0; base < T; base += kVisTile) {
+        __syncthreads();
+        {
+            const int64_t j = base + threadIdx.x;
+            if (j < T) {
+                const TriE tr = load_tri(tv + 9 * j);
+                VisRec rec;
+                rec.v0x = tr.v0.x; rec.v0y = tr.v0.y; rec.v0z = tr.v0.z;
+                rec.e1x = tr.e1.x; rec.e1y = tr.e1.y; rec.e1z = tr.e1.z;
+                rec.e2x = tr.e2.x; rec.e2y = tr.e2.y; rec.e2z = tr.e2.z;
+                rec.active = active ? (uint32_t)active[j] : 1u;
+                rec.pad0 = rec.pad1 = 0;
+                lds[threadIdx.x] = rec;
+            }
+        }
+        __syncthreads();
+        const int n = (int)((T - base < kVisTile) ? T - base : kVisTile);
+        for (int j = 0; j < n; ++j) {
+            const VisRec rec = lds[j];
+            const TriE tr{V3{rec.v0x, rec.v0y, rec.v0z}, V3{rec.e1x, rec.e1y, rec.e1z},
+                          V3{rec.e2x, rec.e2y, rec.e2z}};
+            float t;
+            const bool h = moller_trumbore(o, d, tr, eps, t);
+            if (h && rec.active && t < best_t) {  // strict <: the lowest index wins ties (argmin)
+                best_t = t;
+                best_j = base + j;
+            }
+        }
+    }
+    if (valid && best_j >= 0 && is_finite(best_t)) visible[b * T + best_j] = 1;
+}
+
+}  // namespace drt
+
+using namespace drt;
+
+extern "C" {
+
+int32_t drt_viewing_frustum(const float *viewing_vertices, int64_t B, const float *tv, int64_t T,
+                            const uint8_t *active, float *frustum_out, void *stream) {
+    DRT_REQUIRE(B >= 0 && T >= 0, "negative size");
+    if (B == 0) return DRT_OK;
+    DRT_REQUIRE(viewing_vertices && frustum_out && (T == 0 || tv), "null pointer");
+    hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream),
+                       viewing_vertices, B, tv, T, active, frustum_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_fibonacci_lattice(int64_t n, const float *frustum, float *out, void *stream) {
+    DRT_REQUIRE(n > 0, "Invalid size %lld, must be strictly positive.", (long long)n);
+    DRT_REQUIRE(out, "null output");
+    hipLaunchKernelGGL(lattice_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       as_stream(stream), n, frustum, out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_triangles_visible_from_vertex(const float *vertices, int64_t B, const float *tv, int64_t T,
+                                          const uint8_t *active, int64_t num_rays, float epsilon,
+                                          uint8_t *visible_out, float *frustum_workspace,
+                                          void *stream) {
+    DRT_REQUIRE(B >= 0 && T >= 0, "negative size");
+    DRT_REQUIRE(num_rays > 0, "num_rays must be strictly positive");
+    if (B == 0 || T == 0) return DRT_OK;
+    DRT_REQUIRE(vertices && tv && visible_out && frustum_workspace, "null pointer");
+    DRT_REQUIRE(B <= 65535, "at most 65535 viewing vertices per call");
+    hipStream_t s = as_stream(stream);
+    DRT_HIP(hipMemsetAsync(visible_out, 0, (size_t)B * (size_t)T, s));
+    hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)B), dim3(256), 0, s, vertices, B, tv, T, active,
+                       frustum_workspace);
+    DRT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(visibility_kernel, dim3((unsigned)ceil_div(num_rays, 256), (unsigned)B),
+                       dim3(256), 0, s, vertices, frustum_workspace, num_rays, tv, T, active, epsilon,
+                       visible_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+}  // extern "C"

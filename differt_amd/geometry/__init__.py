@@ -10,10 +10,12 @@ from ._solver_image_method import (
     image_of_vertex_with_respect_to_mirror,
     intersection_of_ray_with_plane,
 )
-from ._solvers import AbstractPathTracer, ExhaustivePathTracer
+from ._solvers import AbstractPathTracer, ExhaustivePathTracer, HybridPathTracer
 from ._utils import (
     SizedIterator,
     assemble_path,
+    cartesian_to_spherical,
+    fibonacci_lattice,
     first_triangle_hit_by_ray,
     generate_all_path_candidates,
     generate_all_path_candidates_chunks_iter,
@@ -21,6 +23,9 @@ from ._utils import (
     normalize,
     ray_intersect_any_triangle,
     ray_intersect_triangle,
+    spherical_to_cartesian,
+    triangles_visible_from_vertex,
+    viewing_frustum,
 )
 
 __all__ = [
@@ -28,11 +33,17 @@ __all__ = [
     "CompleteGraph",
     "DiGraph",
     "ExhaustivePathTracer",
+    "HybridPathTracer",
     "Mesh",
     "Scene",
     "SizedIterator",
     "TracedPaths",
     "assemble_path",
+    "cartesian_to_spherical",
+    "fibonacci_lattice",
+    "spherical_to_cartesian",
+    "triangles_visible_from_vertex",
+    "viewing_frustum",
     "consecutive_vertices_are_on_same_side_of_mirror",
     "first_triangle_hit_by_ray",
     "generate_all_path_candidates",

@@ -226,6 +226,16 @@ class Mesh:
                 o, d, self.handle().triangle_vertices(), self.mask, hit_tol=hit_tol, epsilon=epsilon
             )
 
+    def triangles_visible_from_vertex(self, vertex, num_rays: int = int(1e6)) -> torch.Tensor:
+        """``bool[*batch, T]``: triangles visible from each vertex (_mesh.py:3164-3253); masked
+        triangles are never visible and do not occlude."""
+        v = as_f32(vertex)
+        if self.is_empty:
+            return torch.zeros((*v.shape[:-1], 0), dtype=torch.bool, device=v.device)
+        with torch.no_grad():
+            return _utils.triangles_visible_from_vertex(v, self.handle().triangle_vertices(), self.mask,
+                                                        num_rays=num_rays)
+
     def first_triangle_hit_by_ray(self, ray_origins, ray_directions, *, epsilon: float | None = None,
                                   batch_size: int | None = 512):
         """Closest hit ``(index, t)``; ``t`` is differentiable w.r.t. origins, directions and mesh

@@ -17,7 +17,7 @@ import torch
 from .._tensors import as_f32, as_i32
 from ._mesh import Mesh
 from ._paths import TracedPaths
-from ._solvers import AbstractPathTracer, ExhaustivePathTracer
+from ._solvers import AbstractPathTracer, ExhaustivePathTracer, HybridPathTracer
 from ._utils import SizedIterator
 
 __all__ = ["Scene"]
@@ -88,15 +88,12 @@ class Scene:
         if (order is None) == (path_candidates is None):  # _scene.py:692-695
             raise ValueError("You must specify one of 'order' or 'path_candidates', not both.")
         if isinstance(solver, str):
-            if solver == "hybrid":
-                raise NotImplementedError(
-                    "the hybrid (visibility-pruned) tracer is a 'next' row (SURVEY.md section 8f)"
-                )
-            if solver != "exhaustive":
+            if solver not in ("exhaustive", "hybrid"):
                 raise ValueError(f"Unknown solver '{solver}'.")
             if chunk_size is not None:
                 solver_kwargs = {**solver_kwargs, "chunk_size": chunk_size}
-            solver = ExhaustivePathTracer(**solver_kwargs)
+            cls = ExhaustivePathTracer if solver == "exhaustive" else HybridPathTracer
+            solver = cls(**solver_kwargs)
         elif solver_kwargs:
             raise ValueError("solver_kwargs are only valid when 'solver' is given by name")  # :708-719
 
@@ -106,6 +103,9 @@ class Scene:
         if compact:
             if path_candidates is not None:
                 return solver.trace_path_candidates_compact(self, path_candidates)
+            if isinstance(solver, HybridPathTracer):
+                cands, _ = solver.generate_path_candidates(self, order)
+                return solver.trace_path_candidates_compact(self, cands)
             return solver.trace_rank_range(self, order)
 
         eff_chunk = chunk_size if chunk_size is not None else getattr(solver, "chunk_size", None)

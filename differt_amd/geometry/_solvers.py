@@ -26,7 +26,7 @@ from ._utils import SizedIterator
 if TYPE_CHECKING:
     from ._scene import Scene
 
-__all__ = ["AbstractPathTracer", "ExhaustivePathTracer"]
+__all__ = ["AbstractPathTracer", "ExhaustivePathTracer", "HybridPathTracer"]
 
 
 def _params(epsilon, hit_tol, min_len) -> _lib.TraceParams:
@@ -338,3 +338,37 @@ class ExhaustivePathTracer(AbstractPathTracer):
             torch.zeros((n, order), dtype=torch.int32, device=objs.device),
             self.confidence_threshold, keys,
         )
+
+
+@dataclass
+class HybridPathTracer(ExhaustivePathTracer):
+    """Visibility-pruned exhaustive tracer (reference _solvers.py:960-1176): ray launching estimates
+    which primitives are visible from the transmitters / receivers, the first (last) interaction of
+    a candidate is restricted to them, then candidates are traced exhaustively.
+
+    Visibility is merged over all transmitters (receivers), as in the reference (:969-973)."""
+
+    num_rays: int = int(1e6)
+
+    def _graph(self, scene):
+        mesh = scene.mesh
+        tx = scene.transmitters.reshape(-1, 3)
+        rx = scene.receivers.reshape(-1, 3)
+        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays).any(dim=0)
+        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays).any(dim=0)
+        if mesh.assume_quads:  # _solvers.py:1024-1031
+            vis_tx = vis_tx.reshape(-1, 2).any(dim=-1)
+            vis_rx = vis_rx.reshape(-1, 2).any(dim=-1)
+        graph = DiGraph.from_complete_graph(CompleteGraph(mesh.num_primitives))
+        from_, to = graph.insert_from_and_to_nodes(
+            from_adjacency=vis_tx.cpu().numpy(), to_adjacency=vis_rx.cpu().numpy()
+        )
+        if mesh.mask is not None:  # _solvers.py:1038-1042
+            mask = mesh.mask
+            if mesh.assume_quads:
+                mask = mask[0::2] & mask[1::2]
+            graph.filter_by_mask(mask.cpu().numpy(), fast_mode=True)
+        return graph, from_, to
+
+    def trace_rank_range(self, *args, **kwargs):  # noqa: ARG002
+        raise NotImplementedError("rank windows address the complete graph; the hybrid tracer prunes it")

@@ -19,6 +19,11 @@ from .._tensors import F32_EPS, as_f32, as_u8, device, ptr, stream
 __all__ = [
     "SizedIterator",
     "assemble_path",
+    "cartesian_to_spherical",
+    "fibonacci_lattice",
+    "spherical_to_cartesian",
+    "triangles_visible_from_vertex",
+    "viewing_frustum",
     "first_triangle_hit_by_ray",
     "generate_all_path_candidates",
     "generate_all_path_candidates_chunks_iter",
@@ -213,6 +218,95 @@ def first_triangle_hit_by_ray(
             0 if batch_size is None else int(batch_size), ptr(idx), ptr(t), ptr(ws), R * 8, stream(),
         )
     return idx.reshape(batch), t.reshape(batch)
+
+
+# ------------------------------------------------------------------------------------------
+# visibility by ray launching (reference _utils.py:369-490, 639-993, 1540-1772)
+# ------------------------------------------------------------------------------------------
+def cartesian_to_spherical(xyz):
+    """Reference ``cartesian_to_spherical`` (_utils.py:930-958): ``(r, polar, azimuth)``.
+    Generic element-wise helper (not on the hot path): torch ops."""
+    x = as_f32(xyz)
+    r = torch.sqrt((x * x).sum(-1))
+    r = torch.where(r == 0.0, torch.ones_like(r), r)
+    return torch.stack((r, torch.acos(x[..., 2] / r), torch.atan2(x[..., 1], x[..., 0])), dim=-1)
+
+
+def spherical_to_cartesian(rpa):
+    """Reference ``spherical_to_cartesian`` (_utils.py:961-993); radius 1 when missing."""
+    v = as_f32(rpa)
+    p, a = v[..., -2], v[..., -1]
+    xyz = torch.stack((torch.sin(p) * torch.cos(a), torch.sin(p) * torch.sin(a), torch.cos(p)), dim=-1)
+    return xyz * v[..., 0, None] if v.shape[-1] == 3 else xyz
+
+
+def fibonacci_lattice(n: int, dtype=None, *, frustum=None):  # noqa: ARG001
+    """``n`` directions on the unit sphere, or inside ``frustum [2, 2|3]`` (_utils.py:369-490,
+    including the split-modulus evaluation of ``frac(i / phi)`` for large ``n``, :426-462)."""
+    if n <= 0:
+        raise ValueError(f"Invalid size {n!r}, must be strictly positive.")
+    dev = device()
+    out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    fr = None
+    if frustum is not None:
+        f = as_f32(frustum, dev)
+        fr = torch.zeros((2, 3), dtype=torch.float32, device=dev)
+        fr[:, 3 - f.shape[-1]:] = f.reshape(2, -1)
+    _lib.call("drt_fibonacci_lattice", n, ptr(fr), ptr(out), stream())
+    return out
+
+
+def _triangle_world(triangle_vertices, active_triangles):
+    dev = device()
+    tv = as_f32(triangle_vertices, dev)
+    if tv.dim() != 3:
+        raise NotImplementedError("batched triangle sets are not supported by the visibility kernels")
+    act = None if active_triangles is None else as_u8(active_triangles, dev).reshape(-1).contiguous()
+    return dev, tv.contiguous(), act
+
+
+def viewing_frustum(viewing_vertex, world_vertices, *, active_vertices=None, reduce: bool = False):
+    """Spherical bounding region ``[*batch, 2, 3]`` of the world seen from a vertex
+    (_utils.py:639-927).  The kernel consumes triangles (vertices + centres are derived inside, as
+    ``triangles_visible_from_vertex`` does, :1669-1673): ``world_vertices`` must be ``[T, 3, 3]``
+    triangle vertices and ``active_vertices`` a per-triangle mask."""
+    if reduce:
+        raise NotImplementedError("reduce=True is not needed on the hot path")
+    dev, tv, act = _triangle_world(world_vertices, active_vertices)
+    v = as_f32(viewing_vertex, dev)
+    batch = v.shape[:-1]
+    vf = v.reshape(-1, 3).contiguous()
+    out = torch.empty((vf.shape[0], 2, 3), dtype=torch.float32, device=dev)
+    _lib.call("drt_viewing_frustum", ptr(vf), vf.shape[0], ptr(tv), tv.shape[0], ptr(act), ptr(out),
+              stream())
+    return out.reshape(*batch, 2, 3)
+
+
+def triangles_visible_from_vertex(
+    vertex,
+    triangle_vertices,
+    active_triangles=None,
+    num_rays: int = int(1e6),
+    batch_size: int | None = 512,  # noqa: ARG001 - rays are generated on the fly, nothing to batch
+    **kwargs: Any,
+):
+    """Which triangles receive the first hit of at least one of ``num_rays`` lattice rays launched
+    inside the viewing frustum (_utils.py:1540-1772).  ``bool[*batch, T]``."""
+    epsilon = kwargs.pop("epsilon", None)
+    if kwargs:
+        raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
+    dev, tv, act = _triangle_world(triangle_vertices, active_triangles)
+    v = as_f32(vertex, dev)
+    batch = v.shape[:-1]
+    vf = v.reshape(-1, 3).contiguous()
+    B, T = vf.shape[0], tv.shape[0]
+    vis = torch.zeros((B, T), dtype=torch.uint8, device=dev)
+    if B and T:
+        eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+        ws = torch.empty((B, 6), dtype=torch.float32, device=dev)
+        _lib.call("drt_triangles_visible_from_vertex", ptr(vf), B, ptr(tv), T, ptr(act), int(num_rays),
+                  eps, ptr(vis), ptr(ws), stream())
+    return vis.bool().reshape(*batch, T)
 
 
 # ------------------------------------------------------------------------------------------

@@ -140,6 +140,25 @@ int32_t drt_mesh_copy(drt_mesh_t mesh, float *triangle_vertices_out, float *norm
                       void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (f2, "next" row) visibility by ray launching -- reference: geometry/_utils.py:369-490
+ * (fibonacci_lattice), :639-927 (viewing_frustum), :1540-1772 (triangles_visible_from_vertex) and the
+ * Mesh method geometry/_mesh.py:3164-3253.  World vertices of the frustum are the triangle vertices
+ * plus the triangle centres (_utils.py:1669-1673).  frustum layout: [B,2,3] =
+ * [[r_min, polar_min, azim_min], [r_max, polar_max, azim_max]].
+ * ------------------------------------------------------------------------------------------- */
+int32_t drt_viewing_frustum(const float *viewing_vertices, int64_t num_vertices,
+                            const float *triangle_vertices, int64_t num_triangles,
+                            const uint8_t *active_triangles, float *frustum_out, void *stream);
+/* n lattice directions [n,3]; frustum = device [2,3] or NULL (full sphere) */
+int32_t drt_fibonacci_lattice(int64_t n, const float *frustum, float *out, void *stream);
+/* visible_out u8 [B,T]; frustum_workspace: device float [B,6] */
+int32_t drt_triangles_visible_from_vertex(const float *vertices, int64_t num_vertices,
+                                          const float *triangle_vertices, int64_t num_triangles,
+                                          const uint8_t *active_triangles, int64_t num_rays,
+                                          float epsilon, uint8_t *visible_out,
+                                          float *frustum_workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (a12-a14) path-candidate enumeration -- reference: differt-core/src/geometry/graph.rs
  * (CompleteGraph :127-277, iterator :286-491, count :314-377) and geometry/_utils.py:1047-1132.
  * Host-side (no GPU needed): exact count and lexicographic unranking of "no two equal neighbours"

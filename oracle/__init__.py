@@ -549,3 +549,115 @@ def differentiable_distance(tv, o, d, faces):
     if f.shape[0]:
         lib().orc_differentiable_distance(_p(tv), _p(o), _p(d), _p(f), f.shape[0], _p(out))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# visibility by ray launching ("next" row f2): UT:369-490, 639-993, 1540-1772 (NumPy float32)
+# Transcendentals (cos/sin/arccos/arctan2) are NumPy's float32 routines: XLA's may differ in the
+# last ulp, so lattice directions are pinned at ~1e-7 relative, visible SETS by the reference's
+# known-answer tests (test_utils.py:717-827).
+# --------------------------------------------------------------------------------------
+def cartesian_to_spherical(xyz):
+    """UT:930-958."""
+    xyz = _f32(xyz)
+    r = np.sqrt((xyz * xyz).sum(-1, dtype=np.float32)).astype(np.float32)
+    r = np.where(r == 0.0, np.float32(1.0), r).astype(np.float32)
+    p = np.arccos((xyz[..., 2] / r).astype(np.float32)).astype(np.float32)
+    a = np.arctan2(xyz[..., 1], xyz[..., 0]).astype(np.float32)
+    return np.stack((r, p, a), axis=-1)
+
+
+def spherical_to_cartesian(rpa):
+    """UT:961-993."""
+    rpa = _f32(rpa)
+    p, a = rpa[..., -2], rpa[..., -1]
+    cp, sp, ca, sa = np.cos(p), np.sin(p), np.cos(a), np.sin(a)
+    xyz = np.stack((sp * ca, sp * sa, cp), axis=-1).astype(np.float32)
+    if rpa.shape[-1] == 3:
+        xyz = xyz * rpa[..., 0, None]
+    return xyz.astype(np.float32)
+
+
+def viewing_frustum(viewing_vertex, world_vertices, *, active_vertices=None):
+    """UT:639-927 (reduce=False): [*batch, 2, 3] = [[r_min, p_min, a_min], [r_max, p_max, a_max]]."""
+    f = np.float32
+    wv, vv = _f32(world_vertices), _f32(viewing_vertex)
+    rpa = cartesian_to_spherical(wv - vv[..., None, :])
+    r, p, a = rpa[..., 0], rpa[..., 1], rpa[..., 2]
+    act = None if active_vertices is None else np.broadcast_to(np.asarray(active_vertices, bool), r.shape)
+
+    def red(fn, x, init):
+        if act is None:
+            return fn(np.concatenate((x, np.full((*x.shape[:-1], 1), init, f)), -1), axis=-1).astype(f)
+        return fn(np.where(act, x, f(init)), axis=-1, initial=f(init)).astype(f)
+
+    pi, two_pi = f(np.pi), f(2 * np.pi)
+    r_min, r_max = red(np.min, r, np.inf), red(np.max, r, 0)
+    p_min, p_max = red(np.min, p, pi), red(np.max, p, 0)
+    a_min, a_max = red(np.min, a, pi), red(np.max, a, -pi)
+    a_0 = np.mod(a + two_pi, two_pi).astype(f)
+    a_0_min, a_0_max = red(np.min, a_0, two_pi), red(np.max, a_0, 0)
+    a_width, a_0_width = a_max - a_min, a_0_max - a_0_min
+    swap = a_width > a_0_width
+    a_min, a_max = np.where(swap, a_0_min, a_min), np.where(swap, a_0_max, a_max)
+    full = np.minimum(a_width, a_0_width) > f(1.5) * pi
+    a_min, a_max = np.where(full, -pi, a_min), np.where(full, pi, a_max)
+    p_0_min, p_0_max = p_min, p_max
+    deg = p_min == p_max
+    p_min = np.where(deg, f(0.0), p_min)
+    p_0_max = np.where(deg, pi, p_0_max)
+    sw = (p_max - p_min) > (p_0_max - p_0_min)
+    p_min, p_max = np.where(sw, p_0_min, p_min), np.where(sw, p_0_max, p_max)
+    out = np.stack((r_min, p_min, a_min, r_max, p_max, a_max), axis=-1).astype(f)
+    return out.reshape(*r.shape[:-1], 2, 3)
+
+
+def fibonacci_lattice(n: int, frustum=None):
+    """UT:369-490 (float32), incl. the split-modulus evaluation of frac(i / phi) (:426-462)."""
+    if n <= 0:
+        raise ValueError(f"Invalid size {n!r}, must be strictly positive.")
+    f = np.float32
+    i = np.arange(0.0, n, dtype=f)
+    inv_phi, m1, m2 = 0.6180339887498949, 262144.0, 512.0
+    inv_phi_m1, inv_phi_m2 = f((inv_phi * m1) % 1.0), f((inv_phi * m2) % 1.0)
+    q1 = np.floor(i / f(m1)).astype(f)
+    rem = (i - q1 * f(m1)).astype(f)
+    q2 = np.floor(rem / f(m2)).astype(f)
+    r = (rem - q2 * f(m2)).astype(f)
+    frac = np.mod(((q1 * inv_phi_m1).astype(f) + (q2 * inv_phi_m2).astype(f)).astype(f) + (r * f(inv_phi)).astype(f), f(1.0)).astype(f)
+    if frustum is not None:
+        fr = _f32(frustum)
+        p_min, a_min, p_max, a_max = fr[0, -2], fr[0, -1], fr[1, -2], fr[1, -1]
+        cos_p_min, cos_p_max = np.cos(p_min), np.cos(p_max)
+        denom = f(n - 1) if n > 1 else f(1.0)
+        cos_lat = (cos_p_min - ((cos_p_min - cos_p_max) * (i / denom).astype(f)).astype(f)).astype(f)
+        lat = np.arccos(cos_lat).astype(f)
+        lon = (a_min + ((a_max - a_min) * frac).astype(f)).astype(f)
+    else:
+        lat = np.arccos((f(1) - (f(2) * i).astype(f) / f(n)).astype(f)).astype(f)
+        lon = ((f(2) * f(np.pi)) * frac).astype(f)
+    return spherical_to_cartesian(np.stack((lat, lon), axis=-1))
+
+
+def triangles_visible_from_vertex(vertex, triangle_vertices_, active_triangles=None, num_rays=int(1e6),
+                                  *, epsilon=None):
+    """UT:1540-1772: frustum -> Fibonacci lattice rays -> first hit (one tile) -> scatter."""
+    v = _f32(vertex)
+    tv = _f32(triangle_vertices_)
+    T = tv.shape[0]
+    batch = v.shape[:-1]
+    vf = v.reshape(-1, 3)
+    out = np.zeros((vf.shape[0], T), dtype=bool)
+    if T == 0:
+        return out.reshape(*batch, T)
+    centers = tv.mean(axis=-2, keepdims=True, dtype=np.float32)
+    world = np.concatenate((tv, centers), axis=-2).reshape(-1, 3)
+    act = None if active_triangles is None else np.asarray(active_triangles, bool)
+    actv = None if act is None else np.repeat(act, 4, axis=-1)
+    for b in range(vf.shape[0]):
+        fr = viewing_frustum(vf[b], world, active_vertices=actv)
+        dirs = fibonacci_lattice(num_rays, frustum=fr)
+        idx, _ = first_triangle_hit_by_ray(np.broadcast_to(vf[b], dirs.shape), dirs, tv, act,
+                                           batch_size=None, epsilon=epsilon)
+        out[b, idx[idx >= 0]] = True
+    return out.reshape(*batch, T)
