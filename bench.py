@@ -248,6 +248,14 @@ def main() -> None:
         except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
             result["paths"] = {"error": repr(exc)}
 
+    if rank == 0 and not args.no_paths:
+        try:
+            import bench_queries
+
+            result["queries"] = bench_queries.run(dev)
+        except Exception as exc:  # noqa: BLE001
+            result["queries"] = {"error": repr(exc)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(T)
 

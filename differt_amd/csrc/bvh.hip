@@ -1,0 +1,428 @@
+// bvh.hip -- own LBVH over a drt_mesh_t and ray queries that use it ("next" row f1 of SURVEY.md 8f).
+//
+// The reference's mesh-bound queries (geometry/_mesh.py:142-223, 3018-3162) run on NVIDIA Warp's BVH
+// (warp-lang, not under /root/reference, no ROCm support).  This is an independent implementation:
+//   build   : Morton codes of triangle centroids -> radix sort (rocPRIM) -> Karras' parallel radix
+//             tree (2012) -> bottom-up AABB refit with atomic arrival flags.  64-byte nodes hold BOTH
+//             children's boxes so that one node visit is one 64-B load and two slab tests.
+//   any-hit : lane = ray, depth-first traversal with a private stack, leaf test = the SAME
+//             Moller-Trumbore as the brute-force operators (geom.hpp), predicate of _utils.py:1469.
+//   first-hit: same traversal ordered near child first, packed (t, tie) key as in ray_ops.hip, boxes
+//             with entry distance <= best t are still visited so that ties resolve exactly like the
+//             brute-force kernel (lowest index in a tile, later tile wins).
+// Boxes are padded and the slab test is widened by a few ulps: a triangle test is skipped only if the
+// ray misses the padded box.  For non-degenerate rays the result equals the brute-force kernels bit
+// for bit (tests/test_bvh_gpu.py); for rays grazing a triangle's plane within ~1e-7 rad the
+// brute-force outcome itself is rounding noise and the two may differ -- the brute-force operators
+// remain the normative ones.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+#include "geom.hpp"
+#include "mesh.hpp"
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+struct __attribute__((aligned(16))) BvhNode {
+    float llo[3];
+    int32_t left;   // >= 0: internal node index;  < 0: leaf, triangle id = ~left
+    float lhi[3];
+    int32_t right;
+    float rlo[3];
+    uint32_t pad0;
+    float rhi[3];
+    uint32_t pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
+
+struct Box {
+    float lo[3], hi[3];
+};
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// per-triangle padded boxes + scene bounds (atomic min/max on ordered uints)
+__global__ __launch_bounds__(256) void tri_boxes_kernel(const float *__restrict__ tv, int64_t T,
+                                                        Box *__restrict__ boxes,
+                                                        uint32_t *__restrict__ scene /*[6]*/) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const V3 a = ld3(tv + 9 * t), b = ld3(tv + 9 * t + 3), c = ld3(tv + 9 * t + 6);
+    Box bx;
+    bx.lo[0] = fminf(a.x, fminf(b.x, c.x)); bx.hi[0] = fmaxf(a.x, fmaxf(b.x, c.x));
+    bx.lo[1] = fminf(a.y, fminf(b.y, c.y)); bx.hi[1] = fmaxf(a.y, fmaxf(b.y, c.y));
+    bx.lo[2] = fminf(a.z, fminf(b.z, c.z)); bx.hi[2] = fmaxf(a.z, fmaxf(b.z, c.z));
+    boxes[t] = bx;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (is_finite(bx.lo[k])) atomicMin(scene + k, float_to_ordered(bx.lo[k]));
+        if (is_finite(bx.hi[k])) atomicMax(scene + 3 + k, float_to_ordered(bx.hi[k]));
+    }
+}
+
+__global__ __launch_bounds__(256) void pad_and_morton_kernel(Box *__restrict__ boxes, int64_t T,
+                                                             const uint32_t *__restrict__ scene,
+                                                             uint64_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ ids) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float slo[3], shi[3], ext = 0.0f, mag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        slo[k] = ordered_to_float(scene[k]);
+        shi[k] = ordered_to_float(scene[3 + k]);
+        ext = fmaxf(ext, shi[k] - slo[k]);
+        mag = fmaxf(mag, fmaxf(fabsf(slo[k]), fabsf(shi[k])));
+    }
+    // padding: far above the rounding of any coordinate in the scene (2^-14 of its magnitude)
+    const float pad = fmaxf(mag, ext) * 0x1p-14f + 1e-30f;
+    Box bx = boxes[t];
+    uint32_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float cen = 0.5f * (bx.lo[k] + bx.hi[k]);
+        float u = (ext > 0.0f) ? (cen - slo[k]) / ext : 0.0f;
+        u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+        code |= expand_bits((uint32_t)u) << (2 - k);
+        bx.lo[k] -= pad;
+        bx.hi[k] += pad;
+    }
+    boxes[t] = bx;
+    keys[t] = ((uint64_t)code << 32) | (uint32_t)t;  // index in the low bits: all keys distinct
+    ids[t] = (uint32_t)t;
+}
+
+__device__ __forceinline__ int delta(const uint64_t *keys, int64_t n, int64_t i, int64_t j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));  // keys are distinct -> xor != 0
+}
+
+// Karras 2012, one thread per internal node
+__global__ __launch_bounds__(256) void radix_tree_kernel(const uint64_t *__restrict__ keys, int64_t n,
+                                                         BvhNode *__restrict__ nodes,
+                                                         int32_t *__restrict__ parent_internal,
+                                                         int32_t *__restrict__ parent_leaf) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int64_t lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int64_t l = 0;
+    for (int64_t t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int64_t j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int64_t s = 0;
+    for (int64_t t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    const bool left_leaf = (lo == gamma), right_leaf = (hi == gamma + 1);
+    nodes[i].left = left_leaf ? ~(int32_t)gamma : (int32_t)gamma;
+    nodes[i].right = right_leaf ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
+    if (left_leaf) parent_leaf[gamma] = (int32_t)i; else parent_internal[gamma] = (int32_t)i;
+    if (right_leaf) parent_leaf[gamma + 1] = (int32_t)i; else parent_internal[gamma + 1] = (int32_t)i;
+    if (i == 0) parent_internal[0] = -1;
+}
+
+__device__ __forceinline__ void box_union(const Box &a, const Box &b, Box &o) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o.lo[k] = fminf(a.lo[k], b.lo[k]);
+        o.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+    }
+}
+
+// one thread per leaf walks up; the second arrival at a node owns it
+__global__ __launch_bounds__(256) void refit_kernel(int64_t n, const uint32_t *__restrict__ sorted_ids,
+                                                    const Box *__restrict__ tri_boxes,
+                                                    BvhNode *__restrict__ nodes,
+                                                    const int32_t *__restrict__ parent_internal,
+                                                    const int32_t *__restrict__ parent_leaf,
+                                                    Box *__restrict__ node_boxes,
+                                                    uint32_t *__restrict__ flags) {
+    const int64_t leaf = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (leaf >= n) return;
+    int32_t p = parent_leaf[leaf];
+    while (p >= 0) {
+        __threadfence();
+        if (atomicAdd(flags + p, 1u) == 0u) return;  // first arrival: the sibling will finish
+        __threadfence();
+        BvhNode nd = nodes[p];
+        Box lb, rb;
+        if (nd.left < 0) { lb = tri_boxes[sorted_ids[~nd.left]]; } else { lb = node_boxes[nd.left]; }
+        if (nd.right < 0) { rb = tri_boxes[sorted_ids[~nd.right]]; } else { rb = node_boxes[nd.right]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            nd.llo[k] = lb.lo[k]; nd.lhi[k] = lb.hi[k];
+            nd.rlo[k] = rb.lo[k]; nd.rhi[k] = rb.hi[k];
+        }
+        // leaves are stored as triangle ids from now on
+        if (nd.left < 0) nd.left = ~(int32_t)sorted_ids[~nd.left];
+        if (nd.right < 0) nd.right = ~(int32_t)sorted_ids[~nd.right];
+        nodes[p] = nd;
+        Box u;
+        box_union(lb, rb, u);
+        node_boxes[p] = u;
+        p = parent_internal[p];
+    }
+}
+
+// ---- traversal ---------------------------------------------------------------------------------
+struct RayPrep {
+    V3 o, d, inv;
+};
+
+__device__ __forceinline__ RayPrep prep_ray(V3 o, V3 d) {
+    return RayPrep{o, d, V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z}};
+}
+
+// entry / exit parameters of the ray through a box, widened by a few ulps; NaNs (0 * inf) are
+// ignored by fminf/fmaxf
+__device__ __forceinline__ void slab(const RayPrep &r, const float *lo, const float *hi, float &t0,
+                                     float &t1) {
+    const float ax = (lo[0] - r.o.x) * r.inv.x, bx = (hi[0] - r.o.x) * r.inv.x;
+    const float ay = (lo[1] - r.o.y) * r.inv.y, by = (hi[1] - r.o.y) * r.inv.y;
+    const float az = (lo[2] - r.o.z) * r.inv.z, bz = (hi[2] - r.o.z) * r.inv.z;
+    t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    t0 = t0 - fabsf(t0) * 0x1p-20f - 1e-30f;
+    t1 = t1 + fabsf(t1) * 0x1p-20f + 1e-30f;
+}
+
+struct TileTieB {
+    int64_t bs, nb, ntiles;
+};
+__device__ __forceinline__ uint64_t first_hit_key_b(float t, int64_t j, const TileTieB &tt) {
+    const int64_t tile = (j < tt.nb * tt.bs) ? j / tt.bs : tt.nb;
+    const int64_t in_tile = j - tile * tt.bs;
+    return ((uint64_t)float_to_ordered(t) << 32) | (uint64_t)((tt.ntiles - 1 - tile) * tt.bs + in_tile);
+}
+
+constexpr int kStack = 64;
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void bvh_query_kernel(
+    const BvhNode *__restrict__ nodes, int64_t T, const float *__restrict__ tv,
+    const uint8_t *__restrict__ mask, const float *__restrict__ ro, const float *__restrict__ rd,
+    int64_t R, float eps, float thr, TileTieB tt, uint8_t *__restrict__ any_out,
+    int32_t *__restrict__ idx_out, float *__restrict__ t_out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const RayPrep ray = prep_ray(ld3(ro + 3 * r), ld3(rd + 3 * r));
+    bool any = false;
+    uint64_t best = ~0ull;
+    float best_t = FIRST ? kInf : thr;  // boxes entered after this parameter cannot matter
+    int32_t stack[kStack];
+    int sp = 0;
+    int32_t node = 0;
+    // T == 1: the single triangle is tested directly
+    if (T == 1) node = ~0;
+    for (;;) {
+        if (node < 0) {
+            const int64_t j = ~node;
+            float t;
+            const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) &&
+                           (!mask || mask[j]);
+            if (FIRST) {
+                if (h && is_finite(t)) {
+                    const uint64_t k = first_hit_key_b(t, j, tt);
+                    if (k < best) { best = k; best_t = t; }
+                }
+            } else if (h && (t < thr)) {
+                any = true;
+                break;
+            }
+        } else {
+            const BvhNode nd = nodes[node];
+            float l0, l1, r0, r1;
+            slab(ray, nd.llo, nd.lhi, l0, l1);
+            slab(ray, nd.rlo, nd.rhi, r0, r1);
+            const bool hl = (l0 <= l1) && (l1 >= 0.0f) && (l0 <= best_t);
+            const bool hr = (r0 <= r1) && (r1 >= 0.0f) && (r0 <= best_t);
+            if (hl && hr) {
+                const bool left_first = l0 <= r0;
+                const int32_t nearc = left_first ? nd.left : nd.right;
+                const int32_t farc = left_first ? nd.right : nd.left;
+                if (sp < kStack) stack[sp++] = farc;
+                node = nearc;
+                continue;
+            }
+            if (hl) { node = nd.left; continue; }
+            if (hr) { node = nd.right; continue; }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+    if (FIRST) {
+        if (best == ~0ull) {
+            idx_out[r] = -1;
+            t_out[r] = kInf;
+        } else {
+            const uint64_t tie = best & 0xffffffffull;
+            const int64_t tile = tt.ntiles - 1 - (int64_t)(tie / (uint64_t)tt.bs);
+            idx_out[r] = (int32_t)(tile * tt.bs + (int64_t)(tie % (uint64_t)tt.bs));
+            t_out[r] = ordered_to_float((uint32_t)(best >> 32));
+        }
+    } else {
+        any_out[r] = (uint8_t)any;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_miss_kernel(int64_t R, int32_t *__restrict__ idx,
+                                                        float *__restrict__ t) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    idx[r] = -1;
+    t[r] = kInf;
+}
+
+}  // namespace drt
+
+using namespace drt;
+
+extern "C" {
+
+int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
+    DRT_REQUIRE(m, "mesh is null");
+    if (m->bvh_nodes) return DRT_OK;
+    const int64_t T = m->num_triangles;
+    if (T == 0) return DRT_OK;
+    hipStream_t s = as_stream(stream);
+    const size_t nn = (size_t)(T > 1 ? T - 1 : 1);
+    BvhNode *nodes = nullptr;
+    Box *tri_boxes = nullptr, *node_boxes = nullptr;
+    uint64_t *keys = nullptr, *keys_sorted = nullptr;
+    uint32_t *ids = nullptr, *ids_sorted = nullptr, *scene = nullptr, *flags = nullptr;
+    int32_t *par_int = nullptr, *par_leaf = nullptr;
+    void *tmp = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(tri_boxes); (void)hipFree(node_boxes); (void)hipFree(keys);
+        (void)hipFree(keys_sorted); (void)hipFree(ids); (void)hipFree(ids_sorted); (void)hipFree(scene);
+        (void)hipFree(flags); (void)hipFree(par_int); (void)hipFree(par_leaf); (void)hipFree(tmp);
+    };
+#define TRY_HIP(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            cleanup();                                                                   \
+            (void)hipFree(nodes);                                                        \
+            return fail(DRT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
+        }                                                                                \
+    } while (0)
+    TRY_HIP(hipMalloc(&nodes, nn * sizeof(BvhNode)));
+    TRY_HIP(hipMalloc(&tri_boxes, (size_t)T * sizeof(Box)));
+    TRY_HIP(hipMalloc(&node_boxes, nn * sizeof(Box)));
+    TRY_HIP(hipMalloc(&keys, (size_t)T * 8));
+    TRY_HIP(hipMalloc(&keys_sorted, (size_t)T * 8));
+    TRY_HIP(hipMalloc(&ids, (size_t)T * 4));
+    TRY_HIP(hipMalloc(&ids_sorted, (size_t)T * 4));
+    TRY_HIP(hipMalloc(&scene, 24));
+    TRY_HIP(hipMalloc(&flags, nn * 4));
+    TRY_HIP(hipMalloc(&par_int, nn * 4));
+    TRY_HIP(hipMalloc(&par_leaf, (size_t)T * 4));
+    // scene bounds as ordered uints: min slots start at +max, max slots at 0
+    TRY_HIP(hipMemsetAsync(scene, 0xff, 12, s));
+    TRY_HIP(hipMemsetAsync(scene + 3, 0, 12, s));
+    TRY_HIP(hipMemsetAsync(flags, 0, nn * 4, s));
+    TRY_HIP(hipMemsetAsync(nodes, 0, nn * sizeof(BvhNode), s));
+    const dim3 gt((unsigned)ceil_div(T, 256));
+    hipLaunchKernelGGL(tri_boxes_kernel, gt, dim3(256), 0, s, m->tri_verts, T, tri_boxes, scene);
+    hipLaunchKernelGGL(pad_and_morton_kernel, gt, dim3(256), 0, s, tri_boxes, T, scene, keys, ids);
+    TRY_HIP(hipGetLastError());
+    if (T > 1) {
+        size_t tmp_bytes = 0;
+        TRY_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_sorted, ids, ids_sorted,
+                                          (size_t)T, 0, 64, s));
+        TRY_HIP(hipMalloc(&tmp, tmp_bytes));
+        TRY_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_sorted, ids, ids_sorted, (size_t)T,
+                                          0, 64, s));
+        hipLaunchKernelGGL(radix_tree_kernel, dim3((unsigned)ceil_div(T - 1, 256)), dim3(256), 0, s,
+                           keys_sorted, T, nodes, par_int, par_leaf);
+        hipLaunchKernelGGL(refit_kernel, gt, dim3(256), 0, s, T, ids_sorted, tri_boxes, nodes, par_int,
+                           par_leaf, node_boxes, flags);
+        TRY_HIP(hipGetLastError());
+    }
+    TRY_HIP(hipStreamSynchronize(s));
+#undef TRY_HIP
+    cleanup();
+    m->bvh_nodes = nodes;
+    return DRT_OK;
+}
+
+int32_t drt_mesh_has_bvh(drt_mesh_t m) { return (m && m->bvh_nodes) ? 1 : 0; }
+
+static TileTieB make_tie_b(int64_t T, int64_t batch_size) {
+    int64_t bs = batch_size <= 0 ? T : batch_size;
+    if (bs > T) bs = T;
+    if (bs < 1) bs = 1;
+    TileTieB tt;
+    tt.bs = bs;
+    tt.nb = T / bs;
+    tt.ntiles = tt.nb + ((T % bs) ? 1 : 0);
+    return tt;
+}
+
+int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t m, const float *ro, const float *rd, int64_t R,
+                                            float epsilon, float hit_tol, uint8_t *out, void *stream) {
+    DRT_REQUIRE(m, "mesh is null");
+    DRT_REQUIRE(R >= 0, "negative size");
+    if (R == 0) return DRT_OK;
+    DRT_REQUIRE(out, "null output");
+    hipStream_t s = as_stream(stream);
+    if (m->num_triangles == 0) {  // _mesh.py:3053-3057
+        DRT_HIP(hipMemsetAsync(out, 0, (size_t)R, s));
+        return DRT_OK;
+    }
+    DRT_REQUIRE(ro && rd, "null pointer");
+    int32_t rc = drt_mesh_build_bvh(m, stream);
+    if (rc != DRT_OK) return rc;
+    const TileTieB tt = make_tie_b(m->num_triangles, 0);
+    hipLaunchKernelGGL(bvh_query_kernel<false>, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->num_triangles, m->tri_verts,
+                       m->has_mask ? m->mask : nullptr, ro, rd, R, epsilon, 1.0f - hit_tol, tt, out,
+                       (int32_t *)nullptr, (float *)nullptr);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_mesh_first_triangle_hit_by_ray(drt_mesh_t m, const float *ro, const float *rd, int64_t R,
+                                           float epsilon, int64_t batch_size, int32_t *idx, float *t,
+                                           void *stream) {
+    DRT_REQUIRE(m, "mesh is null");
+    DRT_REQUIRE(R >= 0, "negative size");
+    if (R == 0) return DRT_OK;
+    DRT_REQUIRE(idx && t, "null output");
+    hipStream_t s = as_stream(stream);
+    if (m->num_triangles == 0) {  // _mesh.py:3129-3136
+        hipLaunchKernelGGL(fill_miss_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s, R, idx, t);
+        DRT_LAUNCH_CHECK();
+        return DRT_OK;
+    }
+    DRT_REQUIRE(ro && rd, "null pointer");
+    int32_t rc = drt_mesh_build_bvh(m, stream);
+    if (rc != DRT_OK) return rc;
+    const TileTieB tt = make_tie_b(m->num_triangles, batch_size);
+    hipLaunchKernelGGL(bvh_query_kernel<true>, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->num_triangles, m->tri_verts,
+                       m->has_mask ? m->mask : nullptr, ro, rd, R, epsilon, 0.0f, tt,
+                       (uint8_t *)nullptr, idx, t);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+}  // extern "C"

@@ -50,6 +50,7 @@ int32_t drt_mesh_destroy(drt_mesh_t m) {
     (void)hipFree(m->tri_verts);
     (void)hipFree(m->normals);
     (void)hipFree(m->mask);
+    (void)hipFree(m->bvh_nodes);
     delete m;
     return DRT_OK;
 }

@@ -14,4 +14,5 @@ struct drt_mesh {
     float *tri_verts = nullptr;    // [T,3,3]  gathered triangle vertices (reference Mesh.triangle_vertices)
     float *normals = nullptr;      // [T,3]    reference Mesh.normals
     uint8_t *mask = nullptr;       // [T] or nullptr (all active)
+    void *bvh_nodes = nullptr;     // LBVH (csrc/bvh.hip), built lazily by drt_mesh_build_bvh
 };

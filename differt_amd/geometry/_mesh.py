@@ -58,12 +58,15 @@ class _FirstHitFn(torch.autograd.Function):
     hit face only; indices carry no gradient."""
 
     @staticmethod
-    def forward(ctx, vertices, origins, directions, triangles, mask, epsilon, batch_size):
+    def forward(ctx, vertices, origins, directions, triangles, mask, epsilon, batch_size, bvh_handle=None):
         R = origins.shape[0]
-        tv = vertices[triangles.long()].contiguous()
         idx = torch.full((R,), -1, dtype=torch.int32, device=origins.device)
         t = torch.full((R,), float("inf"), dtype=torch.float32, device=origins.device)
-        if R:
+        if R and bvh_handle is not None:
+            _lib.call("drt_mesh_first_triangle_hit_by_ray", bvh_handle.h, ptr(origins), ptr(directions), R,
+                      epsilon, batch_size, ptr(idx), ptr(t), stream())
+        elif R:
+            tv = vertices[triangles.long()].contiguous()
             ws = torch.empty(R, dtype=torch.int64, device=origins.device)
             m = None if mask is None else mask.to(torch.uint8).contiguous()
             _lib.call(
@@ -86,7 +89,7 @@ class _FirstHitFn(torch.autograd.Function):
                 "drt_first_hit_vjp", ptr(vertices), ptr(triangles), ptr(origins), ptr(directions),
                 ptr(idx), ptr(gt.contiguous()), R, ptr(gv), ptr(go), ptr(gd), stream(),
             )
-        return gv, go, gd, None, None, None, None
+        return gv, go, gd, None, None, None, None, None
 
 
 @dataclass
@@ -213,7 +216,7 @@ class Mesh:
 
     # ---- mesh-bound ray queries ----
     def ray_intersect_any_triangle(self, ray_origins, ray_directions, *, hit_tol: float | None = None,
-                                   epsilon: float | None = None) -> torch.Tensor:
+                                   epsilon: float | None = None, accel: str | None = None) -> torch.Tensor:
         """Whether each ray is blocked by an active triangle (_mesh.py:3018-3094; non-differentiable
         like the reference, :3087-3094).  The predicate is the pure-JAX operator's
         (_utils.py:1469); the reference dispatches to a Warp BVH query here, see DESIGN.md."""
@@ -221,6 +224,16 @@ class Mesh:
         batch = torch.broadcast_shapes(o.shape[:-1], d.shape[:-1])
         if self.is_empty:  # _mesh.py:3053-3057
             return torch.zeros(batch, dtype=torch.bool, device=o.device)
+        if accel == "bvh":  # own LBVH, the counterpart of the reference's Warp BVH (csrc/bvh.hip)
+            of = o.detach().expand(*batch, 3).contiguous().reshape(-1, 3)
+            df = d.detach().expand(*batch, 3).contiguous().reshape(-1, 3)
+            out = torch.empty(of.shape[0], dtype=torch.uint8, device=o.device)
+            _lib.call("drt_mesh_ray_intersect_any_triangle", self.handle().h, ptr(of), ptr(df),
+                      of.shape[0], 10.0 * F32_EPS if epsilon is None else float(epsilon),
+                      100.0 * F32_EPS if hit_tol is None else float(hit_tol), ptr(out), stream())
+            return out.bool().reshape(batch)
+        if accel is not None:
+            raise ValueError(f"unknown accel {accel!r}")
         with torch.no_grad():
             return _utils.ray_intersect_any_triangle(
                 o, d, self.handle().triangle_vertices(), self.mask, hit_tol=hit_tol, epsilon=epsilon
@@ -237,7 +250,7 @@ class Mesh:
                                                         num_rays=num_rays)
 
     def first_triangle_hit_by_ray(self, ray_origins, ray_directions, *, epsilon: float | None = None,
-                                  batch_size: int | None = 512):
+                                  batch_size: int | None = 512, accel: str | None = None):
         """Closest hit ``(index, t)``; ``t`` is differentiable w.r.t. origins, directions and mesh
         vertices (_mesh.py:3096-3162, custom VJP :258-344).  Miss = ``(-1, inf)``."""
         o, d = as_f32(ray_origins), as_f32(ray_directions)
@@ -248,6 +261,9 @@ class Mesh:
         of = o.expand(*batch, 3).contiguous().reshape(-1, 3)
         df = d.expand(*batch, 3).contiguous().reshape(-1, 3)
         eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+        if accel not in (None, "bvh"):
+            raise ValueError(f"unknown accel {accel!r}")
         idx, t = _FirstHitFn.apply(self.vertices.contiguous(), of, df, self.triangles, self.mask, eps,
-                                   0 if batch_size is None else int(batch_size))
+                                   0 if batch_size is None else int(batch_size),
+                                   self.handle() if accel == "bvh" else None)
         return idx.reshape(batch), t.reshape(batch)

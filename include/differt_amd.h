@@ -140,6 +140,22 @@ int32_t drt_mesh_copy(drt_mesh_t mesh, float *triangle_vertices_out, float *norm
                       void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (f1, "next" row) BVH-accelerated mesh queries -- the counterpart of the reference's Warp-backed
+ * Mesh.ray_intersect_any_triangle / Mesh.first_triangle_hit_by_ray (geometry/_mesh.py:142-223,
+ * 3018-3162).  Own LBVH (Morton sort + Karras radix tree), built lazily and cached in the handle.
+ * Same predicate, epsilon, mask and tie-break as the brute-force entry points above.
+ * ------------------------------------------------------------------------------------------- */
+int32_t drt_mesh_build_bvh(drt_mesh_t mesh, void *stream);
+int32_t drt_mesh_has_bvh(drt_mesh_t mesh);
+int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t mesh, const float *ray_origins,
+                                            const float *ray_directions, int64_t num_rays,
+                                            float epsilon, float hit_tol, uint8_t *out, void *stream);
+int32_t drt_mesh_first_triangle_hit_by_ray(drt_mesh_t mesh, const float *ray_origins,
+                                           const float *ray_directions, int64_t num_rays,
+                                           float epsilon, int64_t batch_size, int32_t *index_out,
+                                           float *t_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (f2, "next" row) visibility by ray launching -- reference: geometry/_utils.py:369-490
  * (fibonacci_lattice), :639-927 (viewing_frustum), :1540-1772 (triangles_visible_from_vertex) and the
  * Mesh method geometry/_mesh.py:3164-3253.  World vertices of the frustum are the triangle vertices

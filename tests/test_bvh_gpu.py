@@ -1,0 +1,147 @@
+"""BVH-accelerated mesh queries ("next" row f1) vs the brute-force HIP operators and the oracle.
+
+The BVH only decides WHICH triangles are tested; the test itself is the shared Moller-Trumbore, so
+results must be bit-identical (indices with the reference tie-break, t, any-hit flags) whenever no
+triangle test is culled wrongly.  Scenes: random soup, street canyon, 10k / 200k Manhattan, masks,
+duplicated triangles (ties), axis-aligned and vertex/edge-grazing rays, single-triangle and empty
+meshes.  Mirrors differt/tests/geometry/test_mesh.py:1984-2073 (Warp == pure operators).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+import synthetic_scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import differt_amd.geometry as g
+
+    return g
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _check(G, mesh, o, d, batch_size=512, oracle_rows=0):
+    bi, bt = mesh.first_triangle_hit_by_ray(o, d, batch_size=batch_size)
+    ai, at = mesh.first_triangle_hit_by_ray(o, d, batch_size=batch_size, accel="bvh")
+    assert torch.equal(ai, bi), int((ai != bi).sum())
+    assert torch.equal(at.view(torch.int32), bt.view(torch.int32))
+    ba = mesh.ray_intersect_any_triangle(o, d)
+    aa = mesh.ray_intersect_any_triangle(o, d, accel="bvh")
+    assert torch.equal(aa, ba), int((aa != ba).sum())
+    if oracle_rows:
+        tv = _np(mesh.triangle_vertices)
+        m = None if mesh.mask is None else _np(mesh.mask)
+        on, dn = (np.asarray(x, np.float32) if not isinstance(x, torch.Tensor) else _np(x) for x in (o, d))
+        sel = np.random.default_rng(0).choice(len(on), oracle_rows, replace=False)
+        ei, et = orc.first_triangle_hit_by_ray(on[sel], dn[sel], tv, m, batch_size=batch_size)
+        np.testing.assert_array_equal(_np(ai)[sel], ei)
+        np.testing.assert_array_equal(_np(at)[sel], et)
+    return int((bi >= 0).sum()), int(ba.sum())
+
+
+def test_random_soup(G, rng):
+    T, R = 5000, 200_000
+    tv = (rng.uniform(-50, 50, (T, 1, 3)) + rng.normal(size=(T, 3, 3)) * 2).astype(np.float32)
+    V, Tr = tv.reshape(-1, 3), np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+    mask = rng.random(T) > 0.2
+    o = rng.uniform(-60, 60, (R, 3)).astype(np.float32)
+    d = (rng.uniform(-60, 60, (R, 3)).astype(np.float32) - o)
+    for m in (None, mask):
+        nh, na = _check(G, G.Mesh(V, Tr, mask=m), o, d, oracle_rows=64)
+        assert nh > 1000 and na > 1000
+
+
+@pytest.mark.parametrize("batch_size", [512, 11, None])
+def test_canyon_and_ties(G, rng, batch_size):
+    from conftest import canyon_scene
+
+    V, Tr = canyon_scene(rng, nextra=8)
+    # duplicate a few triangles far apart in index -> exact ties across 512-tiles / BVH leaves
+    Tr = np.concatenate((Tr, Tr[[0, 16, 34, 35]], Tr, Tr[[1, 17]])).astype(np.int32)
+    mesh = G.Mesh(V, Tr)
+    R = 100_000
+    o = np.stack([rng.uniform(-25, 25, R), rng.uniform(-5, 5, R), rng.uniform(0.5, 18, R)], -1).astype(np.float32)
+    d = rng.normal(size=(R, 3)).astype(np.float32) * 30
+    nh, na = _check(G, mesh, o, d, batch_size=batch_size, oracle_rows=48)
+    assert nh > 0.5 * R  # inside a canyon most rays hit something
+
+
+def test_axis_aligned_and_grazing_rays(G):
+    """Rays parallel to box faces (a == 0 exactly), through box vertices and along edges."""
+    V, Tr, _, _ = S.manhattan(64)
+    mesh = G.Mesh(V, Tr)
+    corners = V.reshape(64, 8, 3)
+    o, d = [], []
+    for b in range(64):
+        for c in range(8):
+            p = corners[b, c]
+            for dirv in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [1, 1, 0], [1, 1, 1]):
+                dv = np.asarray(dirv, np.float32) * 500
+                o.append(p - dv * 0.5)          # passes exactly through the corner
+                d.append(dv)
+                o.append(p + np.float32(1e-3))  # starts next to the corner
+                d.append(dv)
+    o, d = np.asarray(o, np.float32), np.asarray(d, np.float32)
+    _check(G, mesh, o, d, oracle_rows=64)
+    # rays between box corners (edge-aligned segments, un-normalised, like TX->RX segments)
+    rng = np.random.default_rng(9)
+    a = V[rng.integers(0, len(V), 50_000)]
+    b = V[rng.integers(0, len(V), 50_000)]
+    _check(G, mesh, a, (b - a).astype(np.float32), oracle_rows=64)
+
+
+@pytest.mark.parametrize("boxes", [1000, 20000])
+def test_manhattan(G, boxes):
+    """10k and 200k triangles (configs[2] / configs[4] meshes): 1e6 rays."""
+    V, Tr, centres, heights = S.manhattan(boxes)
+    mesh = G.Mesh(V, Tr)
+    rng = np.random.default_rng(boxes)
+    R = 1_000_000 if boxes == 1000 else 200_000
+    ext = np.abs(V[:, :2]).max()
+    o = np.stack([rng.uniform(-ext, ext, R), rng.uniform(-ext, ext, R), rng.uniform(1, 120, R)], -1).astype(np.float32)
+    tgt = np.stack([rng.uniform(-ext, ext, R), rng.uniform(-ext, ext, R), rng.uniform(1, 60, R)], -1).astype(np.float32)
+    nh, na = _check(G, mesh, o, (tgt - o).astype(np.float32), oracle_rows=24)
+    assert nh > 0.3 * R
+
+
+def test_tiny_meshes(G):
+    o = np.array([[0.25, 0.25, 1.0], [5, 5, 1.0]], np.float32)
+    d = np.array([[0, 0, -2.0], [0, 0, -2.0]], np.float32)
+    one = G.Mesh(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32))
+    _check(G, one, o, d)
+    i, t = one.first_triangle_hit_by_ray(o, d, accel="bvh")
+    assert _np(i).tolist() == [0, -1] and _np(t)[0] == 0.5
+    two = G.Mesh(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, -1], [1, 0, -1], [0, 1, -1]], np.float32),
+                 np.array([[0, 1, 2], [3, 4, 5]], np.int32))
+    _check(G, two, o, d)
+    e = G.Mesh.empty()
+    i, t = e.first_triangle_hit_by_ray(o, d, accel="bvh")
+    assert (_np(i) == -1).all() and np.isinf(_np(t)).all()
+    assert not _np(e.ray_intersect_any_triangle(o, d, accel="bvh")).any()
+
+
+def test_bvh_first_hit_gradients(G):
+    """The BVH path keeps the custom VJP (test_mesh.py:2028-2072)."""
+    mesh0 = G.Mesh.box(2.0, 2.0, 2.0)
+    o = torch.tensor([[0.0, 0.0, 3.0], [0.0, 3.0, 0.0], [3.0, 0.0, 0.0]], device="cuda", requires_grad=True)
+    d = torch.tensor([[0.0, 0.0, -1.0], [0.0, -1.0, 0.0], [-1.0, 0.0, 0.0]], device="cuda", requires_grad=True)
+    v = mesh0.vertices.clone().requires_grad_(True)
+    grads = []
+    for accel in (None, "bvh"):
+        for x in (o, d, v):
+            x.grad = None
+        _, t = G.Mesh(v, mesh0.triangles).first_triangle_hit_by_ray(o, d, accel=accel)
+        t.sum().backward()
+        grads.append([x.grad.clone() for x in (o, d, v)])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
