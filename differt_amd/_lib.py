@@ -42,8 +42,11 @@ class TraceParams(C.Structure):
         ("epsilon", C.c_float),
         ("hit_tol", C.c_float),
         ("min_len", C.c_float),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
+
+
+DRT_TRACE_USE_BVH = 1
 
 
 class Candidates(C.Structure):

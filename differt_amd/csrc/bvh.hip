@@ -23,22 +23,11 @@
 #include "common.hpp"
 #include "geom.hpp"
 #include "mesh.hpp"
+#include "bvh.hpp"
 
 #pragma clang fp contract(off)
 
 namespace drt {
-
-struct __attribute__((aligned(16))) BvhNode {
-    float llo[3];
-    int32_t left;   // >= 0: internal node index;  < 0: leaf, triangle id = ~left
-    float lhi[3];
-    int32_t right;
-    float rlo[3];
-    uint32_t pad0;
-    float rhi[3];
-    uint32_t pad1;
-};
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
 
 struct Box {
     float lo[3], hi[3];
@@ -180,28 +169,6 @@ __global__ __launch_bounds__(256) void refit_kernel(int64_t n, const uint32_t *_
         node_boxes[p] = u;
         p = parent_internal[p];
     }
-}
-
-// ---- traversal ---------------------------------------------------------------------------------
-struct RayPrep {
-    V3 o, d, inv;
-};
-
-__device__ __forceinline__ RayPrep prep_ray(V3 o, V3 d) {
-    return RayPrep{o, d, V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z}};
-}
-
-// entry / exit parameters of the ray through a box, widened by a few ulps; NaNs (0 * inf) are
-// ignored by fminf/fmaxf
-__device__ __forceinline__ void slab(const RayPrep &r, const float *lo, const float *hi, float &t0,
-                                     float &t1) {
-    const float ax = (lo[0] - r.o.x) * r.inv.x, bx = (hi[0] - r.o.x) * r.inv.x;
-    const float ay = (lo[1] - r.o.y) * r.inv.y, by = (hi[1] - r.o.y) * r.inv.y;
-    const float az = (lo[2] - r.o.z) * r.inv.z, bz = (hi[2] - r.o.z) * r.inv.z;
-    t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    t0 = t0 - fabsf(t0) * 0x1p-20f - 1e-30f;
-    t1 = t1 + fabsf(t1) * 0x1p-20f + 1e-30f;
 }
 
 struct TileTieB {

@@ -1,0 +1,85 @@
+// bvh.hpp -- node layout and traversal primitives of the LBVH (built in bvh.hip), shared with the
+// occlusion stage of the tracer (trace.hip).
+#pragma once
+
+#include "geom.hpp"
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+struct __attribute__((aligned(16))) BvhNode {
+    float llo[3];
+    int32_t left;   // >= 0: internal node index;  < 0: leaf, triangle id = ~left
+    float lhi[3];
+    int32_t right;
+    float rlo[3];
+    uint32_t pad0;
+    float rhi[3];
+    uint32_t pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
+
+// ---- traversal ---------------------------------------------------------------------------------
+struct RayPrep {
+    V3 o, d, inv;
+};
+
+__device__ __forceinline__ RayPrep prep_ray(V3 o, V3 d) {
+    return RayPrep{o, d, V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z}};
+}
+
+// entry / exit parameters of the ray through a box, widened by a few ulps; NaNs (0 * inf) are
+// ignored by fminf/fmaxf
+__device__ __forceinline__ void slab(const RayPrep &r, const float *lo, const float *hi, float &t0,
+                                     float &t1) {
+    const float ax = (lo[0] - r.o.x) * r.inv.x, bx = (hi[0] - r.o.x) * r.inv.x;
+    const float ay = (lo[1] - r.o.y) * r.inv.y, by = (hi[1] - r.o.y) * r.inv.y;
+    const float az = (lo[2] - r.o.z) * r.inv.z, bz = (hi[2] - r.o.z) * r.inv.z;
+    t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    t0 = t0 - fabsf(t0) * 0x1p-20f - 1e-30f;
+    t1 = t1 + fabsf(t1) * 0x1p-20f + 1e-30f;
+}
+
+
+constexpr int kBvhStack = 64;
+
+// any-hit with the predicate of reference geometry/_utils.py:1469: exists an active triangle with
+// hit && t < thr.  Leaf test = the shared Moller-Trumbore.
+__device__ __forceinline__ bool bvh_any_hit(const BvhNode *__restrict__ nodes, int64_t T,
+                                            const float *__restrict__ tv,
+                                            const uint8_t *__restrict__ mask, V3 o, V3 d, float eps,
+                                            float thr) {
+    const RayPrep ray = prep_ray(o, d);
+    int32_t stack[kBvhStack];
+    int sp = 0;
+    int32_t node = (T == 1) ? ~0 : 0;
+    for (;;) {
+        if (node < 0) {
+            const int64_t j = ~node;
+            float t;
+            const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) &&
+                           (!mask || mask[j]);
+            if (h && (t < thr)) return true;
+        } else {
+            const BvhNode nd = nodes[node];
+            float l0, l1, r0, r1;
+            slab(ray, nd.llo, nd.lhi, l0, l1);
+            slab(ray, nd.rlo, nd.rhi, r0, r1);
+            const bool hl = (l0 <= l1) && (l1 >= 0.0f) && (l0 <= thr);
+            const bool hr = (r0 <= r1) && (r1 >= 0.0f) && (r0 <= thr);
+            if (hl && hr) {
+                if (sp < kBvhStack) stack[sp++] = nd.right;
+                node = nd.left;
+                continue;
+            }
+            if (hl) { node = nd.left; continue; }
+            if (hr) { node = nd.right; continue; }
+        }
+        if (sp == 0) return false;
+        node = stack[--sp];
+    }
+}
+
+}  // namespace drt

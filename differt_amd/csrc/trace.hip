@@ -27,6 +27,7 @@
 #include "geom.hpp"
 #include "image_chain.hpp"
 #include "mesh.hpp"
+#include "bvh.hpp"
 
 #pragma clang fp contract(off)
 
@@ -355,6 +356,37 @@ __global__ __launch_bounds__(256) void trace_occlusion_kernel(
     }
 }
 
+// stage B, BVH flavour (opt-in, drt_trace_params.flags & DRT_TRACE_USE_BVH): one LANE per surviving
+// candidate walks the mesh LBVH for each of its order+1 segments.  O(log T) per segment instead of
+// O(T): the choice for very large meshes (configs[4], 200k triangles).
+template <int K, bool DENSE>
+__global__ __launch_bounds__(256) void trace_occlusion_bvh_kernel(
+    TraceArgs a, CandSrc cs, const BvhNode *__restrict__ nodes,
+    const unsigned long long *__restrict__ q_count, const long long *__restrict__ queue, int64_t q_cap,
+    unsigned long long *__restrict__ v_count, long long *__restrict__ valid, int64_t v_cap,
+    uint8_t *__restrict__ d_mask) {
+    int64_t count = (int64_t)*q_count;
+    if (count > q_cap) count = q_cap;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) {
+        const int64_t flat = queue[e];
+        int64_t it, ir;
+        int32_t id[KA<K>::n];
+        V3 p[KA<K>::n], n[KA<K>::n], full[K + 2];
+        key_to_path<K>(a, cs, flat, it, ir, id, p, n, full);
+        bool blocked = false;
+#pragma unroll 1
+        for (int s = 0; s <= K && !blocked; ++s)
+            blocked = bvh_any_hit(nodes, a.T, a.tri_verts, a.mask, full[s], full[s + 1] - full[s], a.eps,
+                                  a.thr);
+        if (DENSE) {
+            if (blocked) d_mask[flat] = 0;
+        } else if (!blocked) {
+            const unsigned long long slot = atomicAdd(v_count, 1ull);
+            if ((int64_t)slot < v_cap) valid[slot] = flat;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // emit: vertices / objects of the sorted valid keys
 // ------------------------------------------------------------------------------------------
@@ -515,6 +547,7 @@ struct Launch {
     TraceArgs a;
     CandSrc cs;
     bool quads;
+    const BvhNode *bvh = nullptr;  // non-null: stage B walks the LBVH
 };
 
 static void filter_grid(const Launch &L, dim3 *grid, int64_t *tx_per_block) {
@@ -548,8 +581,12 @@ static void launch_occlusion(const Launch &L, const unsigned long long *qc, cons
                              int64_t qcap, unsigned long long *vc, long long *v, int64_t vcap,
                              uint8_t *dm) {
     // persistent-style grid: the survivor count lives on the device
-    hipLaunchKernelGGL((trace_occlusion_kernel<K, DENSE>), dim3(256 * 4), dim3(256), 0, L.s, L.a, L.cs,
-                       qc, q, qcap, vc, v, vcap, dm);
+    if (L.bvh && L.a.T > 0)
+        hipLaunchKernelGGL((trace_occlusion_bvh_kernel<K, DENSE>), dim3(256 * 8), dim3(256), 0, L.s, L.a,
+                           L.cs, L.bvh, qc, q, qcap, vc, v, vcap, dm);
+    else
+        hipLaunchKernelGGL((trace_occlusion_kernel<K, DENSE>), dim3(256 * 4), dim3(256), 0, L.s, L.a,
+                           L.cs, qc, q, qcap, vc, v, vcap, dm);
 }
 
 #define DRT_ORDER_SWITCH(k, CALL)                                                     \
@@ -622,6 +659,11 @@ int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *pr, const
     int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
     if (rc != DRT_OK) return rc;
     L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
+    if ((pr->flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0) {
+        rc = drt_mesh_build_bvh(mesh, stream);
+        if (rc != DRT_OK) return rc;
+        L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
+    }
     const int64_t total = ntx * nrx * L.cs.count;
     if (total == 0) return DRT_OK;  // SV:566-573
     DRT_REQUIRE(tx && rx && vertices && objects && mask, "null pointer");
@@ -666,6 +708,11 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
     int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
     if (rc != DRT_OK) return rc;
     L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
+    if ((pr->flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0) {
+        rc = drt_mesh_build_bvh(mesh, stream);
+        if (rc != DRT_OK) return rc;
+        L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
+    }
     const unsigned __int128 total = (unsigned __int128)ntx * (unsigned __int128)nrx *
                                     (unsigned __int128)L.cs.count;
     if (total == 0) return DRT_OK;

@@ -29,12 +29,14 @@ if TYPE_CHECKING:
 __all__ = ["AbstractPathTracer", "ExhaustivePathTracer", "HybridPathTracer"]
 
 
-def _params(epsilon, hit_tol, min_len) -> _lib.TraceParams:
+def _params(epsilon, hit_tol, min_len, accel=None) -> _lib.TraceParams:
+    if accel not in (None, "bvh"):
+        raise ValueError(f"unknown accel {accel!r}")
     return _lib.TraceParams(
         10.0 * F32_EPS if epsilon is None else float(epsilon),   # _utils.py:1257-1259
         100.0 * F32_EPS if hit_tol is None else float(hit_tol),  # _utils.py:1418-1420
         10.0 * F32_EPS if min_len is None else float(min_len),   # _solvers.py:514-516
-        0,
+        _lib.DRT_TRACE_USE_BVH if accel == "bvh" else 0,
     )
 
 
@@ -158,7 +160,7 @@ class _TraceCompactFn(torch.autograd.Function):
 
 def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, interaction_types=None, *,
                            epsilon, hit_tol, min_len, smoothing_factor, confidence_threshold,
-                           batch_size) -> TracedPaths:  # noqa: ARG001
+                           batch_size, accel=None) -> TracedPaths:  # noqa: ARG001
     """Reference ``_trace_path_candidates`` (_solvers.py:499-770), dense layout
     ``[num_tx, num_rx, num_candidates, ...]``."""
     if smoothing_factor is not None:
@@ -169,7 +171,7 @@ def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, inte
     tx = tx_vertices.contiguous()
     rx = rx_vertices.contiguous()
     verts, objs, mask = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table,
-                                            _params(epsilon, hit_tol, min_len))
+                                            _params(epsilon, hit_tol, min_len, accel))
     if interaction_types is None:  # _solvers.py:751-762
         it = torch.zeros(objs.shape[:-1] + (table.shape[1],), dtype=torch.int32, device=objs.device)
     else:
@@ -221,6 +223,9 @@ class ExhaustivePathTracer(AbstractPathTracer):
     batch_size: int | None = 512
     disconnect_inactive_triangles: bool = False
     chunk_size: int | None = None
+    accel: str | None = None
+    """MI355X extension: ``"bvh"`` makes the occlusion stage walk the mesh LBVH (O(log T) per segment,
+    like the reference's Warp path) instead of testing every triangle."""
 
     # ---- candidate generation (host graph classes; lexicographic like graph.rs) ----
     def _graph(self, scene):
@@ -284,6 +289,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
             path_candidates, interaction_types, epsilon=self.epsilon, hit_tol=self.hit_tol,
             min_len=self.min_len, smoothing_factor=self.smoothing_factor,
             confidence_threshold=self.confidence_threshold, batch_size=self.batch_size,
+            accel=self.accel,
         )
 
     def num_path_candidates(self, scene, order: int) -> int:
@@ -330,7 +336,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
         rx = scene.receivers.reshape(-1, 3).contiguous()
         verts, objs, keys = _TraceCompactFn.apply(
             tx, rx, scene.mesh.vertices, scene.mesh, desc,
-            _params(self.epsilon, self.hit_tol, self.min_len), max_survivors, max_paths,
+            _params(self.epsilon, self.hit_tol, self.min_len, self.accel), max_survivors, max_paths,
         )
         n, order = objs.shape[0], desc["order"]
         return TracedPaths(

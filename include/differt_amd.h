@@ -233,8 +233,9 @@ typedef struct drt_trace_params {
     float epsilon;          /* MT epsilon; reference default 10*eps (_utils.py:1257-1259) */
     float hit_tol;          /* occlusion tolerance; default 100*eps (_utils.py:1418-1420) */
     float min_len;          /* squared-length threshold; default 10*eps (_solvers.py:514-516) */
-    int32_t reserved;
+    int32_t flags;          /* DRT_TRACE_* bits */
 } drt_trace_params;
+#define DRT_TRACE_USE_BVH 1 /* occlusion stage walks the mesh LBVH instead of testing every triangle */
 
 typedef struct drt_candidates {
     const int32_t *table;   /* device [num_candidates, order] or NULL */

@@ -145,3 +145,35 @@ def test_bvh_first_hit_gradients(G):
         grads.append([x.grad.clone() for x in (o, d, v)])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+@pytest.mark.parametrize("assume_quads", [False, True])
+def test_trace_with_bvh_occlusion_equals_brute_force(G, rng, order, assume_quads):
+    """Tracer with `accel="bvh"` (occlusion stage on the LBVH): dense mask and compact output identical
+    to the default brute-force stage and to the oracle."""
+    from conftest import canyon_case
+
+    if order == 0:
+        V, Tr, mask, tx, rx, _ = canyon_case(rng, 1, assume_quads)
+        cand = np.zeros((1, 0), np.int32)
+    else:
+        V, Tr, mask, tx, rx, cand = canyon_case(rng, order, assume_quads)
+    scene = G.Scene(tx, rx, G.Mesh(V, Tr, mask=mask, assume_quads=assume_quads))
+    o = orc.trace_path_candidates(V, Tr, tx, rx, cand, mask=mask, assume_quads=assume_quads)
+    fast = scene.trace_paths(path_candidates=cand, solver=G.ExhaustivePathTracer(accel="bvh"))
+    np.testing.assert_array_equal(_np(fast.mask), o["mask"])
+    np.testing.assert_array_equal(_np(fast.vertices).view(np.uint32), o["vertices"].view(np.uint32))
+    cp = scene.trace_paths(path_candidates=cand, solver=G.ExhaustivePathTracer(accel="bvh"), compact=True)
+    np.testing.assert_array_equal(_np(cp.keys), np.flatnonzero(o["mask"].reshape(-1)))
+
+
+def test_cfg3_window_bvh_vs_brute(G):
+    """configs[2] scene, 5e6 ranks x 1024 pairs: identical valid keys with either occlusion stage."""
+    V, Tr, centres, heights = S.manhattan(1000)
+    tx, rx = S.manhattan_tx_rx(centres, heights, 16, 64)
+    scene = G.Scene(tx, rx, G.Mesh(V, Tr))
+    lo, hi = 40_000_000, 45_000_000
+    a = G.ExhaustivePathTracer().trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
+    b = G.ExhaustivePathTracer(accel="bvh").trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
+    assert torch.equal(a.keys, b.keys) and torch.equal(a.vertices, b.vertices)
