@@ -24,6 +24,7 @@
 #include "geom.hpp"
 #include "mesh.hpp"
 #include "bvh.hpp"
+#include "lattice.hpp"
 
 #pragma clang fp contract(off)
 
@@ -250,6 +251,53 @@ __global__ __launch_bounds__(256) void bvh_query_kernel(
     }
 }
 
+// visibility (reference geometry/_mesh.py:3164-3253): lane = lattice ray, closest hit through the BVH
+// with the tie rule of first_triangle_hit_by_ray(batch_size=None): lowest index among equal t.
+__global__ __launch_bounds__(256) void bvh_visibility_kernel(
+    const BvhNode *__restrict__ nodes, int64_t T, const float *__restrict__ tv,
+    const uint8_t *__restrict__ mask, const float *__restrict__ view,
+    const float *__restrict__ frusta, int64_t num_rays, float eps, uint8_t *__restrict__ visible) {
+    const int64_t b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_rays) return;
+    const RayPrep ray = prep_ray(ld3(view + 3 * b), lattice_direction(i, num_rays, frusta + 6 * b));
+    float best_t = kInf;
+    int64_t best_j = -1;
+    int32_t stack[kStack];
+    int sp = 0;
+    int32_t node = (T == 1) ? ~0 : 0;
+    for (;;) {
+        if (node < 0) {
+            const int64_t j = ~node;
+            float t;
+            const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) &&
+                           (!mask || mask[j]);
+            if (h && is_finite(t) && (t < best_t || (t == best_t && j < best_j))) {
+                best_t = t;
+                best_j = j;
+            }
+        } else {
+            const BvhNode nd = nodes[node];
+            float l0, l1, r0, r1;
+            slab(ray, nd.llo, nd.lhi, l0, l1);
+            slab(ray, nd.rlo, nd.rhi, r0, r1);
+            const bool hl = (l0 <= l1) && (l1 >= 0.0f) && (l0 <= best_t);
+            const bool hr = (r0 <= r1) && (r1 >= 0.0f) && (r0 <= best_t);
+            if (hl && hr) {
+                const bool left_first = l0 <= r0;
+                if (sp < kStack) stack[sp++] = left_first ? nd.right : nd.left;
+                node = left_first ? nd.left : nd.right;
+                continue;
+            }
+            if (hl) { node = nd.left; continue; }
+            if (hr) { node = nd.right; continue; }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+    if (best_j >= 0) visible[b * T + best_j] = 1;
+}
+
 __global__ __launch_bounds__(256) void fill_miss_kernel(int64_t R, int32_t *__restrict__ idx,
                                                         float *__restrict__ t) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -363,6 +411,30 @@ int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t m, const float *ro, const
                        reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->num_triangles, m->tri_verts,
                        m->has_mask ? m->mask : nullptr, ro, rd, R, epsilon, 1.0f - hit_tol, tt, out,
                        (int32_t *)nullptr, (float *)nullptr);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_mesh_triangles_visible_from_vertex(drt_mesh_t m, const float *vertices, int64_t B,
+                                               int64_t num_rays, float epsilon, uint8_t *visible_out,
+                                               float *frustum_workspace, void *stream) {
+    DRT_REQUIRE(m, "mesh is null");
+    DRT_REQUIRE(B >= 0, "negative size");
+    DRT_REQUIRE(num_rays > 0, "num_rays must be strictly positive");
+    const int64_t T = m->num_triangles;
+    if (B == 0 || T == 0) return DRT_OK;
+    DRT_REQUIRE(vertices && visible_out && frustum_workspace, "null pointer");
+    DRT_REQUIRE(B <= 65535, "at most 65535 viewing vertices per call");
+    int32_t rc = drt_mesh_build_bvh(m, stream);
+    if (rc != DRT_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    const uint8_t *mask = m->has_mask ? m->mask : nullptr;
+    DRT_HIP(hipMemsetAsync(visible_out, 0, (size_t)B * (size_t)T, s));
+    launch_frustum_kernel(vertices, B, m->tri_verts, T, mask, frustum_workspace, s);
+    DRT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bvh_visibility_kernel, dim3((unsigned)ceil_div(num_rays, 256), (unsigned)B),
+                       dim3(256), 0, s, reinterpret_cast<const BvhNode *>(m->bvh_nodes), T, m->tri_verts,
+                       mask, vertices, frustum_workspace, num_rays, epsilon, visible_out);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

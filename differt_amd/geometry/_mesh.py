@@ -239,12 +239,24 @@ class Mesh:
                 o, d, self.handle().triangle_vertices(), self.mask, hit_tol=hit_tol, epsilon=epsilon
             )
 
-    def triangles_visible_from_vertex(self, vertex, num_rays: int = int(1e6)) -> torch.Tensor:
+    def triangles_visible_from_vertex(self, vertex, num_rays: int = int(1e6), *,
+                                      accel: str | None = None) -> torch.Tensor:
         """``bool[*batch, T]``: triangles visible from each vertex (_mesh.py:3164-3253); masked
         triangles are never visible and do not occlude."""
         v = as_f32(vertex)
         if self.is_empty:
             return torch.zeros((*v.shape[:-1], 0), dtype=torch.bool, device=v.device)
+        if accel == "bvh":
+            vf = v.detach().reshape(-1, 3).contiguous()
+            B, T = vf.shape[0], self.num_triangles
+            vis = torch.zeros((B, T), dtype=torch.uint8, device=v.device)
+            ws = torch.empty((max(B, 1), 6), dtype=torch.float32, device=v.device)
+            if B:
+                _lib.call("drt_mesh_triangles_visible_from_vertex", self.handle().h, ptr(vf), B, int(num_rays),
+                          10.0 * F32_EPS, ptr(vis), ptr(ws), stream())
+            return vis.bool().reshape(*v.shape[:-1], T)
+        if accel is not None:
+            raise ValueError(f"unknown accel {accel!r}")
         with torch.no_grad():
             return _utils.triangles_visible_from_vertex(v, self.handle().triangle_vertices(), self.mask,
                                                         num_rays=num_rays)

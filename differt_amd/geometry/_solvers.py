@@ -360,8 +360,8 @@ class HybridPathTracer(ExhaustivePathTracer):
         mesh = scene.mesh
         tx = scene.transmitters.reshape(-1, 3)
         rx = scene.receivers.reshape(-1, 3)
-        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays).any(dim=0)
-        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays).any(dim=0)
+        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
+        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
         if mesh.assume_quads:  # _solvers.py:1024-1031
             vis_tx = vis_tx.reshape(-1, 2).any(dim=-1)
             vis_rx = vis_rx.reshape(-1, 2).any(dim=-1)

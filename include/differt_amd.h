@@ -150,6 +150,11 @@ int32_t drt_mesh_has_bvh(drt_mesh_t mesh);
 int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t mesh, const float *ray_origins,
                                             const float *ray_directions, int64_t num_rays,
                                             float epsilon, float hit_tol, uint8_t *out, void *stream);
+/* BVH flavour of drt_triangles_visible_from_vertex (geometry/_mesh.py:3164-3253) */
+int32_t drt_mesh_triangles_visible_from_vertex(drt_mesh_t mesh, const float *vertices,
+                                               int64_t num_vertices, int64_t num_rays, float epsilon,
+                                               uint8_t *visible_out, float *frustum_workspace,
+                                               void *stream);
 int32_t drt_mesh_first_triangle_hit_by_ray(drt_mesh_t mesh, const float *ray_origins,
                                            const float *ray_directions, int64_t num_rays,
                                            float epsilon, int64_t batch_size, int32_t *index_out,

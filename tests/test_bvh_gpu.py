@@ -177,3 +177,23 @@ def test_cfg3_window_bvh_vs_brute(G):
     a = G.ExhaustivePathTracer().trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
     b = G.ExhaustivePathTracer(accel="bvh").trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
     assert torch.equal(a.keys, b.keys) and torch.equal(a.vertices, b.vertices)
+
+
+def test_bvh_visibility_equals_brute_force(G):
+    """Mesh.triangles_visible_from_vertex(accel="bvh") == the LDS-tiled kernel (same lattice, same
+    first-hit rule) on cube / masked box-in-box / Manhattan."""
+    Vc, Tc = orc.box_mesh(with_top=True)
+    cube = G.Mesh(Vc, Tc)
+    for p in ([2.0, 0, 0], [2.0, 2.0, 0], [2.0, 2.0, 2.0]):
+        a = cube.triangles_visible_from_vertex(np.asarray(p, np.float32), num_rays=10_000)
+        b = cube.triangles_visible_from_vertex(np.asarray(p, np.float32), num_rays=10_000, accel="bvh")
+        assert torch.equal(a, b)
+    V, Tr, centres, heights = S.manhattan(1000)
+    tx, rx = S.manhattan_tx_rx(centres, heights, 2, 3)
+    mask = np.random.default_rng(0).random(Tr.shape[0]) > 0.1
+    for m in (None, mask):
+        mesh = G.Mesh(V, Tr, mask=m)
+        pts = np.concatenate((tx, rx))
+        a = mesh.triangles_visible_from_vertex(pts, num_rays=200_000)
+        b = mesh.triangles_visible_from_vertex(pts, num_rays=200_000, accel="bvh")
+        assert torch.equal(a, b) and int(a.sum()) > 50
