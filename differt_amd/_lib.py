@@ -94,6 +94,8 @@ _SIGNATURES = {
     "drt_mesh_first_triangle_hit_by_ray": (_i32, [_vp, _vp, _vp, _i64, _f32, _i64, _vp, _vp, _vp]),
     "drt_mesh_triangles_visible_from_vertex": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "drt_viewing_frustum": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "drt_viewing_frustum_points": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "drt_launch_paths": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _i64, _f32, _vp, _vp, _vp, _vp]),
     "drt_fibonacci_lattice": (_i32, [_i64, _vp, _vp, _vp]),
     "drt_triangles_visible_from_vertex": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp]),
     "drt_mesh_create": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, C.POINTER(_vp)]),

@@ -172,15 +172,6 @@ __global__ __launch_bounds__(256) void refit_kernel(int64_t n, const uint32_t *_
     }
 }
 
-struct TileTieB {
-    int64_t bs, nb, ntiles;
-};
-__device__ __forceinline__ uint64_t first_hit_key_b(float t, int64_t j, const TileTieB &tt) {
-    const int64_t tile = (j < tt.nb * tt.bs) ? j / tt.bs : tt.nb;
-    const int64_t in_tile = j - tile * tt.bs;
-    return ((uint64_t)float_to_ordered(t) << 32) | (uint64_t)((tt.ntiles - 1 - tile) * tt.bs + in_tile);
-}
-
 constexpr int kStack = 64;
 
 template <bool FIRST>
@@ -380,17 +371,6 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
 }
 
 int32_t drt_mesh_has_bvh(drt_mesh_t m) { return (m && m->bvh_nodes) ? 1 : 0; }
-
-static TileTieB make_tie_b(int64_t T, int64_t batch_size) {
-    int64_t bs = batch_size <= 0 ? T : batch_size;
-    if (bs > T) bs = T;
-    if (bs < 1) bs = 1;
-    TileTieB tt;
-    tt.bs = bs;
-    tt.nb = T / bs;
-    tt.ntiles = tt.nb + ((T % bs) ? 1 : 0);
-    return tt;
-}
 
 int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t m, const float *ro, const float *rd, int64_t R,
                                             float epsilon, float hit_tol, uint8_t *out, void *stream) {

@@ -139,6 +139,53 @@ __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict
     if (valid && best_j >= 0 && is_finite(best_t)) visible[b * T + best_j] = 1;
 }
 
+// frustum over an arbitrary list of world points (SBR: triangle vertices + receivers,
+// geometry/_solvers.py:1213-1219)
+__global__ __launch_bounds__(256) void frustum_points_kernel(const float *__restrict__ view,
+                                                             const float *__restrict__ pts, int64_t N,
+                                                             float *__restrict__ out) {
+    const int64_t b = blockIdx.x;
+    const V3 vv = ld3(view + 3 * b);
+    float r_min = kInf, r_max = 0.0f, p_min = kPi, p_max = 0.0f;
+    float a_min = kPi, a_max = -kPi, a0_min = kTwoPi, a0_max = 0.0f;
+    for (int64_t k = threadIdx.x; k < N; k += 256) {
+        const V3 x = ld3(pts + 3 * k) - vv;
+        float r = __builtin_sqrtf(dot(x, x));
+        r = (r == 0.0f) ? 1.0f : r;
+        const float p = acosf(x.z / r);
+        const float a = atan2f(x.y, x.x);
+        const float a0 = fmodf(a + kTwoPi, kTwoPi);
+        r_min = fminf(r_min, r); r_max = fmaxf(r_max, r);
+        p_min = fminf(p_min, p); p_max = fmaxf(p_max, p);
+        a_min = fminf(a_min, a); a_max = fmaxf(a_max, a);
+        a0_min = fminf(a0_min, a0); a0_max = fmaxf(a0_max, a0);
+    }
+    __shared__ float red[8][256];
+    float vals[8] = {r_min, -r_max, p_min, -p_max, a_min, -a_max, a0_min, -a0_max};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = vals[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        r_min = red[0][0]; r_max = -red[1][0]; p_min = red[2][0]; p_max = -red[3][0];
+        a_min = red[4][0]; a_max = -red[5][0]; a0_min = red[6][0]; a0_max = -red[7][0];
+        const float a_width = a_max - a_min, a0_width = a0_max - a0_min;
+        if (a_width > a0_width) { a_min = a0_min; a_max = a0_max; }
+        if (fminf(a_width, a0_width) > 1.5f * kPi) { a_min = -kPi; a_max = kPi; }
+        float p0_min = p_min, p0_max = p_max;
+        if (p_min == p_max) { p_min = 0.0f; p0_max = kPi; }
+        if ((p_max - p_min) > (p0_max - p0_min)) { p_min = p0_min; p_max = p0_max; }
+        float *o = out + 6 * b;
+        o[0] = r_min; o[1] = p_min; o[2] = a_min; o[3] = r_max; o[4] = p_max; o[5] = a_max;
+    }
+}
+
 void launch_frustum_kernel(const float *view, int64_t B, const float *tv, int64_t T,
                            const uint8_t *active, float *out, hipStream_t s) {
     hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)B), dim3(256), 0, s, view, B, tv, T, active, out);
@@ -157,6 +204,17 @@ int32_t drt_viewing_frustum(const float *viewing_vertices, int64_t B, const floa
     DRT_REQUIRE(viewing_vertices && frustum_out && (T == 0 || tv), "null pointer");
     hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream),
                        viewing_vertices, B, tv, T, active, frustum_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_viewing_frustum_points(const float *viewing_vertices, int64_t B, const float *points,
+                                   int64_t N, float *frustum_out, void *stream) {
+    DRT_REQUIRE(B >= 0 && N >= 0, "negative size");
+    if (B == 0) return DRT_OK;
+    DRT_REQUIRE(viewing_vertices && frustum_out && (N == 0 || points), "null pointer");
+    hipLaunchKernelGGL(frustum_points_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream),
+                       viewing_vertices, points, N, frustum_out);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

@@ -2,7 +2,7 @@
 
 from ._graph import CompleteGraph, DiGraph
 from ._mesh import Mesh
-from ._paths import TracedPaths
+from ._paths import LaunchedPaths, TracedPaths
 from ._scene import Scene
 from ._solver_image_method import (
     consecutive_vertices_are_on_same_side_of_mirror,
@@ -10,7 +10,13 @@ from ._solver_image_method import (
     image_of_vertex_with_respect_to_mirror,
     intersection_of_ray_with_plane,
 )
-from ._solvers import AbstractPathTracer, ExhaustivePathTracer, HybridPathTracer
+from ._solvers import (
+    AbstractPathLauncher,
+    AbstractPathTracer,
+    ExhaustivePathTracer,
+    HybridPathTracer,
+    SBRPathLauncher,
+)
 from ._utils import (
     SizedIterator,
     assemble_path,
@@ -29,12 +35,15 @@ from ._utils import (
 )
 
 __all__ = [
+    "AbstractPathLauncher",
     "AbstractPathTracer",
     "CompleteGraph",
     "DiGraph",
     "ExhaustivePathTracer",
     "HybridPathTracer",
+    "LaunchedPaths",
     "Mesh",
+    "SBRPathLauncher",
     "Scene",
     "SizedIterator",
     "TracedPaths",

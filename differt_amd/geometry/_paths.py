@@ -6,7 +6,7 @@ from dataclasses import dataclass, replace
 
 import torch
 
-__all__ = ["TracedPaths"]
+__all__ = ["LaunchedPaths", "TracedPaths"]
 
 
 @dataclass
@@ -76,3 +76,51 @@ class TracedPaths:
             mask=m[m],
             interaction_types=None if it is None else it[m],
         )
+
+
+@dataclass
+class LaunchedPaths:
+    """Paths produced by ray launching (reference geometry/_paths.py:513-): one mask per path order
+    (``masks[..., k]`` = the order-k path of that ray reaches the receiver), lower orders included."""
+
+    vertices: torch.Tensor           # [*batch, order+2, 3]
+    objects: torch.Tensor            # [*batch, order+2]
+    masks: torch.Tensor              # [*batch, order+1]
+    interaction_types: torch.Tensor | None = None
+    confidence_threshold: float = 0.5
+
+    @property
+    def shape(self) -> tuple[int, ...]:
+        return tuple(self.vertices.shape[:-2])
+
+    @property
+    def path_length(self) -> int:
+        return self.objects.shape[-1]
+
+    @property
+    def order(self) -> int:
+        return self.path_length - 2
+
+    @property
+    def mask(self) -> torch.Tensor:
+        """Highest-order mask (geometry/_paths.py ``LaunchedPaths.mask``)."""
+        return self.masks[..., -1]
+
+    def get_paths(self, order: int) -> TracedPaths:
+        """``TracedPaths`` of the given order (first ``order`` bounces + receiver)."""
+        if order < 0 or order > self.order:
+            raise ValueError(
+                f"Paths order must be strictly between 0 and {self.order} (incl.), but you provided {order}."
+            )
+        v = torch.cat((self.vertices[..., : order + 1, :], self.vertices[..., -1:, :]), dim=-2)
+        o = torch.cat((self.objects[..., : order + 1], self.objects[..., -1:]), dim=-1)
+        it = None if self.interaction_types is None else self.interaction_types[..., :order]
+        return TracedPaths(v, o, self.masks[..., order], it, self.confidence_threshold)
+
+    @property
+    def masked_vertices(self) -> torch.Tensor:
+        return self.get_paths(self.order).masked_vertices
+
+    @property
+    def masked_objects(self) -> torch.Tensor:
+        return self.get_paths(self.order).masked_objects

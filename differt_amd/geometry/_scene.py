@@ -16,8 +16,14 @@ import torch
 
 from .._tensors import as_f32, as_i32
 from ._mesh import Mesh
-from ._paths import TracedPaths
-from ._solvers import AbstractPathTracer, ExhaustivePathTracer, HybridPathTracer
+from ._paths import LaunchedPaths, TracedPaths
+from ._solvers import (
+    AbstractPathLauncher,
+    AbstractPathTracer,
+    ExhaustivePathTracer,
+    HybridPathTracer,
+    SBRPathLauncher,
+)
 from ._utils import SizedIterator
 
 __all__ = ["Scene"]
@@ -68,6 +74,24 @@ class Scene:
 
     def with_receivers_grid(self, m: int = 50, n: int | None = 50, *, height: float = 1.5) -> "Scene":
         return replace(self, receivers=self._grid(m, n, height))
+
+    def launch_paths(self, order: int, *, solver: AbstractPathLauncher | Literal["sbr"] = "sbr",
+                     **solver_kwargs: Any) -> LaunchedPaths:
+        """Launch rays and bounce them ``order`` times (_scene.py:783-835); batch shape
+        ``[*tx_batch, *rx_batch, num_rays]``."""
+        if isinstance(solver, str):
+            if solver != "sbr":
+                raise ValueError(f"Unknown solver '{solver}'.")
+            solver = SBRPathLauncher(**solver_kwargs)
+        elif solver_kwargs:
+            raise ValueError("solver_kwargs are only valid when 'solver' is given by name")
+        p = solver.launch_paths(self, order)
+        batch = (*self.transmitters.shape[:-1], *self.receivers.shape[:-1], p.vertices.shape[2])
+        return LaunchedPaths(
+            p.vertices.reshape(*batch, order + 2, 3), p.objects.reshape(*batch, order + 2),
+            p.masks.reshape(*batch, order + 1), p.interaction_types.reshape(*batch, order),
+            p.confidence_threshold,
+        )
 
     def trace_paths(
         self,

@@ -20,13 +20,19 @@ import torch
 from .. import _lib
 from .._tensors import F32_EPS, as_i32, device, ptr, stream
 from ._graph import CompleteGraph, DiGraph
-from ._paths import TracedPaths
+from ._paths import LaunchedPaths, TracedPaths
 from ._utils import SizedIterator
 
 if TYPE_CHECKING:
     from ._scene import Scene
 
-__all__ = ["AbstractPathTracer", "ExhaustivePathTracer", "HybridPathTracer"]
+__all__ = [
+    "AbstractPathLauncher",
+    "AbstractPathTracer",
+    "ExhaustivePathTracer",
+    "HybridPathTracer",
+    "SBRPathLauncher",
+]
 
 
 def _params(epsilon, hit_tol, min_len, accel=None) -> _lib.TraceParams:
@@ -378,3 +384,62 @@ class HybridPathTracer(ExhaustivePathTracer):
 
     def trace_rank_range(self, *args, **kwargs):  # noqa: ARG002
         raise NotImplementedError("rank windows address the complete graph; the hybrid tracer prunes it")
+
+
+class AbstractPathLauncher:
+    """Ray-launching solver interface of the reference (_solvers.py:250-491): subclasses provide
+    ``launch_rays``; ``launch_paths`` runs first-hit / ``filter_rays`` / ``bounce_rays`` for
+    ``order + 1`` bounces -- here one fused HIP kernel (csrc/launch.hip) over the mesh LBVH."""
+
+    max_dist: float = 1e-3
+    epsilon: float | None = None
+
+    def launch_rays(self, scene):
+        raise NotImplementedError
+
+    def launch_paths(self, scene, order: int) -> LaunchedPaths:
+        tx = scene.transmitters.reshape(-1, 3).contiguous()
+        rx = scene.receivers.reshape(-1, 3).contiguous()
+        ro, rd = self.launch_rays(scene)
+        ro, rd = ro.contiguous(), rd.contiguous()
+        ntx, nrx, R = tx.shape[0], rx.shape[0], ro.shape[1]
+        dev = tx.device
+        tris = torch.empty((ntx, R, order), dtype=torch.int32, device=dev)
+        verts = torch.empty((ntx, R, order, 3), dtype=torch.float32, device=dev)
+        masks = torch.zeros((ntx, nrx, R, order + 1), dtype=torch.uint8, device=dev)
+        eps = 10.0 * F32_EPS if self.epsilon is None else float(self.epsilon)
+        _lib.call("drt_launch_paths", scene.mesh.handle().h, ptr(ro), ptr(rd), ntx, R, ptr(rx), nrx,
+                  order, eps, 512, float(self.max_dist), ptr(tris), ptr(verts), ptr(masks), stream())
+        # reference layout [num_tx, num_rx, num_rays, ...] (_solvers.py:446-490): broadcast views
+        inner = verts[:, None].expand(ntx, nrx, R, order, 3)
+        vertices = torch.cat((tx[:, None, None, None, :].expand(ntx, nrx, R, 1, 3), inner,
+                              rx[None, :, None, None, :].expand(ntx, nrx, R, 1, 3)), dim=-2)
+        ar_tx = torch.arange(ntx, dtype=torch.int32, device=dev)[:, None, None, None].expand(ntx, nrx, R, 1)
+        ar_rx = torch.arange(nrx, dtype=torch.int32, device=dev)[None, :, None, None].expand(ntx, nrx, R, 1)
+        objects = torch.cat((ar_tx, tris[:, None].expand(ntx, nrx, R, order), ar_rx), dim=-1)
+        it = torch.zeros((ntx, nrx, R, order), dtype=torch.int32, device=dev)
+        return LaunchedPaths(vertices, objects, masks.bool(), it)
+
+
+@dataclass
+class SBRPathLauncher(AbstractPathLauncher):
+    """Shooting-and-bouncing rays (reference _solvers.py:1179-1226), same fields and defaults."""
+
+    num_rays: int = int(1e6)
+    epsilon: float | None = None
+    hit_tol: float | None = None
+    max_dist: float = 1e-3
+
+    def launch_rays(self, scene):
+        """A Fibonacci lattice inside the frustum that contains the mesh and the receivers, per
+        transmitter (_solvers.py:1202-1226)."""
+        tx = scene.transmitters.reshape(-1, 3).contiguous()
+        rx = scene.receivers.reshape(-1, 3)
+        world = torch.cat((scene.mesh.triangle_vertices.detach().reshape(-1, 3), rx)).contiguous()
+        ntx = tx.shape[0]
+        fr = torch.empty((ntx, 2, 3), dtype=torch.float32, device=tx.device)
+        _lib.call("drt_viewing_frustum_points", ptr(tx), ntx, ptr(world), world.shape[0], ptr(fr), stream())
+        dirs = torch.empty((ntx, self.num_rays, 3), dtype=torch.float32, device=tx.device)
+        for i in range(ntx):
+            _lib.call("drt_fibonacci_lattice", self.num_rays, ptr(fr[i]), ptr(dirs[i]), stream())
+        return tx[:, None, :].expand(ntx, self.num_rays, 3).contiguous(), dirs

@@ -170,6 +170,10 @@ int32_t drt_mesh_first_triangle_hit_by_ray(drt_mesh_t mesh, const float *ray_ori
 int32_t drt_viewing_frustum(const float *viewing_vertices, int64_t num_vertices,
                             const float *triangle_vertices, int64_t num_triangles,
                             const uint8_t *active_triangles, float *frustum_out, void *stream);
+/* same over an explicit list of world points [N,3] (no centres, no mask) */
+int32_t drt_viewing_frustum_points(const float *viewing_vertices, int64_t num_vertices,
+                                   const float *points, int64_t num_points, float *frustum_out,
+                                   void *stream);
 /* n lattice directions [n,3]; frustum = device [2,3] or NULL (full sphere) */
 int32_t drt_fibonacci_lattice(int64_t n, const float *frustum, float *out, void *stream);
 /* visible_out u8 [B,T]; frustum_workspace: device float [B,6] */
@@ -178,6 +182,18 @@ int32_t drt_triangles_visible_from_vertex(const float *vertices, int64_t num_ver
                                           const uint8_t *active_triangles, int64_t num_rays,
                                           float epsilon, uint8_t *visible_out,
                                           float *frustum_workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (f3, "next" row) shooting-and-bouncing rays -- reference: AbstractPathLauncher.launch_paths
+ * geometry/_solvers.py:358-491 (first hit + filter_rays :320-356 + bounce_rays :279-318 per bounce).
+ * rays [Ntx, num_rays, 3] are given (launch_rays is the reference's extension point).  Outputs, NOT
+ * broadcast over receivers: triangles [Ntx, num_rays, order] i32 (-1 = left the scene),
+ * vertices [Ntx, num_rays, order, 3] (bounce points), masks [Ntx, Nrx, num_rays, order+1] u8.
+ * ------------------------------------------------------------------------------------------- */
+int32_t drt_launch_paths(drt_mesh_t mesh, const float *ray_origins, const float *ray_directions,
+                         int64_t num_tx, int64_t num_rays, const float *rx, int64_t num_rx,
+                         int32_t order, float epsilon, int64_t batch_size, float max_dist,
+                         int32_t *triangles_out, float *vertices_out, uint8_t *masks_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (a12-a14) path-candidate enumeration -- reference: differt-core/src/geometry/graph.rs

@@ -661,3 +661,66 @@ def triangles_visible_from_vertex(vertex, triangle_vertices_, active_triangles=N
                                            batch_size=None, epsilon=epsilon)
         out[b, idx[idx >= 0]] = True
     return out.reshape(*batch, T)
+
+
+# --------------------------------------------------------------------------------------
+# shooting-and-bouncing rays ("next" row f3): SV:279-491, 1179-1226 (NumPy float32 + C first-hit)
+# --------------------------------------------------------------------------------------
+def _dot32(a, b):
+    p = (a * b).astype(np.float32)
+    return ((p[..., 0] + p[..., 1]).astype(np.float32) + p[..., 2]).astype(np.float32)
+
+
+def _cross32(a, b):
+    f = np.float32
+    x = ((a[..., 1] * b[..., 2]).astype(f) - (a[..., 2] * b[..., 1]).astype(f)).astype(f)
+    y = ((a[..., 2] * b[..., 0]).astype(f) - (a[..., 0] * b[..., 2]).astype(f)).astype(f)
+    z = ((a[..., 0] * b[..., 1]).astype(f) - (a[..., 1] * b[..., 0]).astype(f)).astype(f)
+    return np.stack((x, y, z), axis=-1)
+
+
+def sbr_launch_rays(vertices, triangles, tx, rx, num_rays):
+    """SBRPathLauncher.launch_rays SV:1202-1226: frustum over triangle vertices + receivers, lattice."""
+    tv = triangle_vertices(vertices, triangles)
+    txa, rxa = _f32(tx).reshape(-1, 3), _f32(rx).reshape(-1, 3)
+    world = np.concatenate((tv.reshape(-1, 3), rxa), axis=0)
+    dirs = np.stack([fibonacci_lattice(num_rays, frustum=viewing_frustum(t, world)) for t in txa])
+    return np.broadcast_to(txa[:, None, :], dirs.shape).copy(), dirs
+
+
+def launch_paths(vertices, triangles, ray_origins, ray_directions, rx, order, *, mask=None,
+                 max_dist=1e-3, epsilon=None, batch_size=512):
+    """AbstractPathLauncher.launch_paths SV:358-491 for given rays [Ntx, R, 3] (first hit = the pure
+    operator UT:1775-1960; the reference dispatches to Warp here).  Returns dict(triangles
+    [Ntx,R,order], vertices [Ntx,R,order,3], masks [Ntx,Nrx,R,order+1])."""
+    f = np.float32
+    tv = triangle_vertices(vertices, triangles)
+    nrm = mesh_normals(tv)
+    o, d = _f32(ray_origins).copy(), _f32(ray_directions).copy()
+    rxa = _f32(rx).reshape(-1, 3)
+    ntx, R = o.shape[0], o.shape[1]
+    valid = np.ones((ntx, R), bool)
+    tris, verts, masks = [], [], []
+    md = f(max_dist)
+    for _ in range(order + 1):
+        idx, t_hit = first_triangle_hit_by_ray(o, d, tv, mask, batch_size=batch_size, epsilon=epsilon)
+        v = (rxa[None, :, None, :] - o[:, None, :, :]).astype(f)          # SV:340-342
+        c = _cross32(np.broadcast_to(d[:, None], v.shape), v)
+        dist2 = (((c[..., 0] * c[..., 0]).astype(f) + (c[..., 1] * c[..., 1]).astype(f)).astype(f)
+                 + (c[..., 2] * c[..., 2]).astype(f)).astype(f)            # SV:343-345
+        t_rx = _dot32(np.broadcast_to(d[:, None], v.shape), v)            # SV:346-348
+        masks.append((t_rx > 0) & (t_rx < t_hit[:, None, :]) & valid[:, None, :] & (dist2 < md))
+        inside = np.isfinite(t_hit)                                        # SV:300-303
+        valid = valid & inside
+        t = np.where(inside, t_hit, f(0)).astype(f)
+        o = (o + (t[..., None] * d).astype(f)).astype(f)                   # SV:305
+        n = nrm[np.where(idx >= 0, idx, len(nrm) - 1)] if len(nrm) else np.zeros_like(d)
+        c2 = (f(2.0) * _dot32(d, n)).astype(f)
+        d = (d - (c2[..., None] * n).astype(f)).astype(f)                  # SV:307-312
+        tris.append(idx)
+        verts.append(o.copy())
+    return {
+        "triangles": np.stack(tris[:-1], axis=-1) if order else np.zeros((ntx, R, 0), np.int32),
+        "vertices": np.stack(verts[:-1], axis=-2) if order else np.zeros((ntx, R, 0, 3), f),
+        "masks": np.stack(masks, axis=-1),
+    }
