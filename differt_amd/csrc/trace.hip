@@ -145,7 +145,8 @@ __device__ __forceinline__ bool inside_one(const Mirrors<K, QUADS> &m, const V3 
 // ------------------------------------------------------------------------------------------
 template <int K, bool QUADS, bool DENSE>
 __global__ __launch_bounds__(256) void trace_filter_kernel(
-    TraceArgs a, CandSrc cs, unsigned long long *__restrict__ q_count,
+    TraceArgs a, const float *__restrict__ txp, const float *__restrict__ rxp, CandSrc cs,
+    unsigned long long *__restrict__ q_count,
     long long *__restrict__ queue, int64_t q_cap, int64_t tx_per_block,
     float *__restrict__ d_vertices, int32_t *__restrict__ d_objects, uint8_t *__restrict__ d_mask) {
     const int lane = threadIdx.x & 63;
@@ -161,7 +162,10 @@ __global__ __launch_bounds__(256) void trace_filter_kernel(
         const bool cand_ok = in_range && m.ok;
 
         for (int64_t it = it0; it < it1; ++it) {
-            const V3 tx = ld3(a.tx + 3 * it);
+            // txp / rxp are separate `const __restrict__` kernel arguments so that these wave-uniform
+            // reads become scalar loads (through the by-value TraceArgs they were per-lane global loads
+            // with a vmcnt(0) stall in every iteration)
+            const V3 tx = ld3(txp + 3 * it);
             V3 img[KA<K>::n];
             {
                 V3 prev = tx;  // forward scan, IM:191-195
@@ -172,15 +176,31 @@ __global__ __launch_bounds__(256) void trace_filter_kernel(
                 }
             }
             for (int64_t ir = 0; ir < a.nrx; ++ir) {
-                const V3 rx = ld3(a.rx + 3 * ir);
+                const V3 rx = ld3(rxp + 3 * ir);
                 V3 full[K + 2];
                 full[0] = tx;
                 full[K + 1] = rx;
                 {
-                    V3 cur = rx;  // reverse scan, IM:196-201
+                    // reverse scan, IM:196-201.  Fast path per mirror when NO lane of the wave needs
+                    // the reference's where-guards (parallel ray IM:123-135, infinite previous point
+                    // IM:165-181): the plain t = vn / un; x = o + d * t, which is exactly what the
+                    // guarded form computes in that case.  Otherwise the whole wave runs the guarded
+                    // form (bit-identical for the untroubled lanes).
+                    V3 cur = rx;
 #pragma unroll
                     for (int j = K - 1; j >= 0; --j) {
-                        cur = backward_step(cur, img[j], m.p[j], m.n[j]);
+                        const V3 dir = img[j] - cur;
+                        const V3 v = m.p[j] - cur;
+                        const float un = dot(dir, m.n[j]);
+                        const float vn = dot(v, m.n[j]);
+                        const bool trouble = (un == 0.0f) || !(is_finite(cur.x) && is_finite(cur.y) &&
+                                                               is_finite(cur.z));
+                        if (__builtin_expect(__any(trouble), 0)) {
+                            cur = backward_step(cur, img[j], m.p[j], m.n[j]);
+                        } else {
+                            const float t = vn / un;
+                            cur = V3{cur.x + dir.x * t, cur.y + dir.y * t, cur.z + dir.z * t};
+                        }
                         full[j + 1] = cur;
                     }
                 }
@@ -572,8 +592,8 @@ static void launch_filter(const Launch &L, unsigned long long *qc, long long *q,
     dim3 grid;
     int64_t tpb;
     filter_grid(L, &grid, &tpb);
-    hipLaunchKernelGGL((trace_filter_kernel<K, QUADS, DENSE>), grid, dim3(256), 0, L.s, L.a, L.cs, qc,
-                       q, qcap, tpb, dv, dob, dm);
+    hipLaunchKernelGGL((trace_filter_kernel<K, QUADS, DENSE>), grid, dim3(256), 0, L.s, L.a, L.a.tx,
+                       L.a.rx, L.cs, qc, q, qcap, tpb, dv, dob, dm);
 }
 
 template <int K, bool DENSE>

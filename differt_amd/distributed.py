@@ -20,7 +20,14 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-__all__ = ["allreduce_grads", "gather_paths", "globalize_keys", "reduce_first_hit", "shard_interval"]
+__all__ = [
+    "allreduce_grads",
+    "gather_paths",
+    "globalize_keys",
+    "reduce_first_hit",
+    "shard_interval",
+    "trace_rank_range_sharded",
+]
 
 
 def shard_interval(total: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -95,3 +102,24 @@ def reduce_first_hit(packed_keys: torch.Tensor, group=None) -> torch.Tensor:
     if world > 1:
         dist.all_reduce(packed_keys, op=dist.ReduceOp.MIN, group=group)
     return packed_keys
+
+
+def trace_rank_range_sharded(tracer, scene, order: int, rank_lo: int = 0, rank_hi: int | None = None,
+                             group=None, gather: bool = True, **kwargs):
+    """Candidate-rank sharding of ``ExhaustivePathTracer.trace_rank_range``:
+    every rank traces one contiguous block of ``[rank_lo, rank_hi)`` against its replica of the mesh,
+    no collective during compute.  Returns ``(keys, vertices, objects)`` with GLOBAL keys
+    ``(tx*num_rx + rx) * (rank_hi - rank_lo) + (rank - rank_lo)``; gathered (and sorted = the
+    single-GPU ``masked_vertices`` order) on every rank when ``gather``, else this rank's part.
+    ``vertices`` of the local part stay attached to autograd; call ``allreduce_grads`` on the
+    transmitter / receiver gradients after ``backward``."""
+    world, rank = _world(group)
+    total = tracer.num_path_candidates(scene, order)
+    hi = total if rank_hi is None else min(int(rank_hi), total)
+    lo = min(int(rank_lo), hi)
+    a, b = shard_interval(hi - lo, world, rank)
+    local = tracer.trace_rank_range(scene, order, lo + a, lo + b, **kwargs)
+    keys = globalize_keys(local.keys, b - a, a, hi - lo)
+    if not gather or world == 1:
+        return keys, local.vertices, local.objects
+    return gather_paths(keys, local.vertices.detach(), local.objects, group=group)

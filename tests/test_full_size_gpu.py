@@ -251,3 +251,26 @@ def test_cfg5_200k_triangles(G):
     lo = 123456 * (n - 1)
     w = G.ExhaustivePathTracer().trace_rank_range(scene, 2, lo, lo + 3 * (n - 1), max_survivors=1 << 22)
     _oracle_revalidate(V, Tr, tx, rx[:64], w, 3 * (n - 1), 2, n)
+
+
+def test_sharded_driver_single_process(G, manhattan):
+    """differt_amd.distributed.trace_rank_range_sharded with world_size 1 == trace_rank_range, and a
+    manual 3-way emulation of the sharding (what N ranks would each compute) == the whole."""
+    from differt_amd.distributed import gather_paths, globalize_keys, shard_interval, trace_rank_range_sharded
+
+    V, Tr, tx, rx = manhattan
+    scene = G.Scene(tx[:2], rx[:4], G.Mesh(V, Tr))
+    tracer = G.ExhaustivePathTracer()
+    lo, hi = 30_000_000, 60_000_000
+    keys, verts, objs = trace_rank_range_sharded(tracer, scene, 2, lo, hi, max_survivors=1 << 22)
+    whole = tracer.trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
+    assert torch.equal(keys, whole.keys) and torch.equal(verts, whole.vertices) and torch.equal(objs, whole.objects)
+    parts = []
+    for r in range(3):
+        a, b = shard_interval(hi - lo, 3, r)
+        p = tracer.trace_rank_range(scene, 2, lo + a, lo + b, max_survivors=1 << 22)
+        parts.append((globalize_keys(p.keys, b - a, a, hi - lo), p.vertices, p.objects))
+    k = torch.cat([p[0] for p in parts])
+    perm = torch.argsort(k, stable=True)
+    assert torch.equal(k[perm], whole.keys)
+    assert torch.equal(torch.cat([p[1] for p in parts])[perm], whole.vertices)
