@@ -59,6 +59,9 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         "s_per_step": dt,
         "path_candidates_per_s": pairs * count / dt,
         "valid_paths_per_s": nvalid / dt,
+        # 113k + 8 FLOP per candidate before occlusion (234 at k=2, 347 at k=3), vs the
+        # 157.3 TFLOP/s FP32 vector peak (which counts an FMA as 2: one-rounding-per-op code tops at 50 %)
+        "valu_frac_of_157TF": (113 * order + 8) * pairs * count / dt / 157.3e12,
         "grad_tx_finite": bool(torch.isfinite(grad).all().item()),
         "grad_tx_absmax": float(grad.abs().max().item()),
     }

@@ -253,6 +253,18 @@ class ExhaustivePathTracer(AbstractPathTracer):
         """``(candidates i32[C, order], interaction_types i32[C, order])`` (_solvers.py:803-848)."""
         if isinstance(order, Sequence):
             raise NotImplementedError("ExhaustivePathTracer does not support multiple orders yet.")
+        if type(self) is ExhaustivePathTracer and order >= 1:
+            # complete graph (optionally over the active primitives only): the table is unranked on
+            # the GPU, no host enumeration and no host->device copy (reference: _solvers.py:817-843)
+            n, node_map = self._num_nodes_and_map(scene)
+            total = n * (n - 1) ** (order - 1) if n > 0 else 0
+            if total >= 2**31:
+                raise MemoryError(f"{total} candidates: use trace_rank_range / chunk_size instead of a table")
+            cands = torch.empty((total, order), dtype=torch.int32, device=device())
+            if total:
+                _lib.call("drt_candidates_fill", max(n, 1), order, 0, total, ptr(node_map),
+                          2 if scene.mesh.assume_quads else 1, ptr(cands), stream())
+            return cands, torch.zeros_like(cands)
         graph, from_, to = self._graph(scene)
         arr = graph.all_paths_array(from_, to, order + 2, include_from_and_to=False)
         cands = torch.as_tensor(arr.astype(np.int32).reshape(arr.shape[0], order), device=device())

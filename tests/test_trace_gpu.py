@@ -374,3 +374,30 @@ def test_first_hit_box_and_jacobians(G, goldens):
     jac_got = torch.autograd.functional.jacobian(fun, (og, dg, vg))
     for jg, jr in zip(jac_got, jac_ref):
         np.testing.assert_allclose(_np(jg), jr.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("assume_quads", [False, True])
+@pytest.mark.parametrize("disconnect", [False, True])
+def test_generate_path_candidates_gpu_fill(G, two_buildings, goldens, assume_quads, disconnect):
+    """ExhaustivePathTracer.generate_path_candidates (GPU unranking) == the host enumerator == the
+    oracle's odometer (test_scene.py:334-364 candidates round trip; _solvers.py:803-848)."""
+    g = goldens["advanced_path_tracing_example"]
+    rng = np.random.default_rng(4)
+    mask = rng.random(24) > 0.3
+    if assume_quads:
+        mask[1::2] = mask[0::2]
+    scene = _scene(G, two_buildings, g["tx"], g["rx"], assume_quads, mask)
+    tracer = G.ExhaustivePathTracer(disconnect_inactive_triangles=disconnect)
+    for order in (0, 1, 2, 3):
+        cands, types = tracer.generate_path_candidates(scene, order)
+        prim_mask = (mask[0::2] & mask[1::2]) if assume_quads else mask
+        nodes = np.flatnonzero(prim_mask) if disconnect else np.arange(len(prim_mask))
+        exp = nodes[orc.generate_all_path_candidates(len(nodes), order)] if order else np.zeros((1, 0), np.int64)
+        exp = exp * (2 if assume_quads else 1)
+        assert tuple(cands.shape) == exp.shape and cands.dtype == torch.int32
+        np.testing.assert_array_equal(_np(cands), exp)
+        assert (_np(types) == 0).all()
+        # tracing the generated table == tracing the rank range
+        a = tracer.trace_path_candidates_compact(scene, cands)
+        b = tracer.trace_rank_range(scene, order)
+        assert torch.equal(a.objects, b.objects) and torch.equal(a.vertices, b.vertices)
