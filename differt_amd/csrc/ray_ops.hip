@@ -383,8 +383,10 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     (void)al8;
     const int64_t cols = ceil_div(T, (int64_t)kDenseThreads * tpl);
     DRT_REQUIRE(cols <= 65535, "too many triangles for one launch (%lld)", (long long)T);
-    // rays per block: as many as possible (amortises the triangle loads) while keeping >= ~4096 blocks
-    int64_t rpb = (R * cols) / 4096;
+    // rays per block: as many as possible (amortises the 144-B/lane triangle loads) while keeping
+    // >= ~640 blocks; measured on the literal configs[1] launch (256 rays): 17.2 us at 1 ray/block,
+    // 10.5 us at 4
+    int64_t rpb = (R * cols) / 640;
     if (rpb < 1) rpb = 1;
     if (rpb > 64) rpb = 64;
     const int64_t rows = ceil_div(R, rpb);
