@@ -77,7 +77,7 @@ def cpu_sample_rate(V, Tr, tx, rx, order, n, budget_s: float = 10.0) -> dict:
 
     import oracle as orc
 
-    m = 2000
+    m = 20000
     cand = orc.CompleteGraphIter(n, n, n + 1, order + 2, False).collect_array(m).astype(np.int32)
     t0 = time.perf_counter()
     reps = 0
@@ -85,7 +85,7 @@ def cpu_sample_rate(V, Tr, tx, rx, order, n, budget_s: float = 10.0) -> dict:
         orc.trace_path_candidates(V, Tr, tx[:1], rx[:1], cand)
         reps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or reps >= 50:
+        if el > budget_s or reps >= 500:
             break
     return {
         "value": m * reps / el,
