@@ -238,15 +238,19 @@ def main() -> None:
             "hbm_frac": (5 * Rl * T + 24 * Rl + 36 * T) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
         }
 
-    if rank == 0 and not args.no_paths:
+    if not args.no_paths:  # every rank takes part: the candidate-rank space is sharded over the GPUs
+        paths = None
         try:
             import bench_paths
 
-            result["paths"] = bench_paths.run(dev, cpu_sample=not args.no_cpu_baseline)
+            paths = bench_paths.run(dev, cpu_sample=not args.no_cpu_baseline, rank=rank, world=world,
+                                    dist=dist)
         except ImportError:
             pass
         except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
-            result["paths"] = {"error": repr(exc)}
+            paths = {"error": repr(exc)}
+        if rank == 0 and paths is not None:
+            result["paths"] = paths
 
     if rank == 0 and not args.no_paths:
         try:

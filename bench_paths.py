@@ -20,7 +20,12 @@ import numpy as np
 
 
 def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16, num_rx: int = 64,
-        num_boxes: int = 1000, steps: int = 2, cpu_sample: bool = True) -> dict:
+        num_boxes: int = 1000, steps: int = 2, cpu_sample: bool = True, rank: int = 0, world: int = 1,
+        dist=None) -> dict:
+    """With world > 1 the candidate-rank space is cut in one contiguous block per rank
+    (differt_amd.distributed.shard_interval): no collective during compute.  Time = max over ranks,
+    valid paths = sum over ranks (the gather / gradient all-reduce epilogue of
+    differt_amd.distributed is exercised by tests/test_distributed_cpu.py, not timed here)."""
     import torch
 
     import differt_amd.geometry as G
@@ -33,27 +38,51 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
     total = n * (n - 1) ** (order - 1)
     count = total if num_ranks is None else min(num_ranks, total)
     tracer = G.ExhaustivePathTracer()
+    from differt_amd.distributed import shard_interval
+
+    lo, hi = shard_interval(count, world, rank)
 
     def step():
         txg = torch.tensor(tx, device="cuda", requires_grad=True)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
-        paths = tracer.trace_rank_range(scene, order, 0, count, max_survivors=1 << 24, max_paths=1 << 20)
+        paths = tracer.trace_rank_range(scene, order, lo, hi, max_survivors=1 << 24, max_paths=1 << 20)
         loss = torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum()
         loss.backward()
-        return paths, txg.grad
+        return paths.objects.shape[0], txg.grad
 
-    paths, grad = step()  # warm-up (also sizes the queues)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        paths, grad = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    nvalid = int(paths.objects.shape[0])
+    # The timed region is collective-free (each rank works on its own block); ONE all-reduce at the
+    # end combines {max time, sum of valid paths, sum of |grad|, failure flag}, and every rank reaches
+    # it even if its own leg raised -- a failing rank cannot dead-lock the others.
+    nvalid, grad, dt, err = 0, None, 0.0, None
+    try:
+        nvalid, grad = step()  # warm-up (also sizes the queues)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nvalid, grad = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    except Exception as exc:  # noqa: BLE001
+        err = repr(exc)
+    if dist is not None and world > 1:
+        gsum = float(grad.abs().sum().item()) if grad is not None else 0.0
+        vmax = torch.tensor([dt, 1.0 if err else 0.0], dtype=torch.float64, device="cuda")
+        vsum = torch.tensor([float(nvalid), gsum], dtype=torch.float64, device="cuda")
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+        dt, failed = float(vmax[0].item()), bool(vmax[1].item() > 0)
+        nvalid = int(vsum[0].item())
+        if failed and err is None:
+            err = "another rank failed"
+    if err is not None:
+        return {"error": err}
+    nvalid = int(nvalid)
     pairs = num_tx * num_rx
     out = {
         "workload": f"configs[2]: {num_tx} TX x {num_rx} RX, {Tr.shape[0]}-triangle synthetic Manhattan mesh, "
-                    f"order {order}, fwd + grad(TX); candidate ranks [0, {count}) of {total} per pair",
+                    f"order {order}, fwd + grad(TX); candidate ranks [0, {count}) of {total} per pair"
+                    + (f", rank space sharded over {world} GPUs (strong scaling)" if world > 1 else ""),
+        "n_gpus": world,
         "path_candidates_per_step": pairs * count,
         "valid_paths": nvalid,
         "s_per_step": dt,
@@ -65,7 +94,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         "grad_tx_finite": bool(torch.isfinite(grad).all().item()),
         "grad_tx_absmax": float(grad.abs().max().item()),
     }
-    if cpu_sample:
+    if cpu_sample and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_sample_rate(V, Tr, tx, rx, order, n)
     return out
 
