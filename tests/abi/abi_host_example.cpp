@@ -1,0 +1,111 @@
+// A torch-free, Python-free caller of the C ABI: what a host application (or an XLA FFI handler)
+// does.  Build: hipcc -O2 -I include tests/abi/abi_host_example.cpp -L differt_amd/lib -ldiffert_amd
+// Prints "OK <hits> <first_index> <valid_paths>" and exits 0 when every call succeeds.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "differt_amd.h"
+
+#define CHECK(x)                                                                 \
+    do {                                                                         \
+        int32_t rc_ = (x);                                                       \
+        if (rc_ != DRT_OK) {                                                     \
+            std::fprintf(stderr, "%s -> %d: %s\n", #x, rc_, drt_last_error());   \
+            return 1;                                                            \
+        }                                                                        \
+    } while (0)
+#define HIPCHECK(x)                                                                          \
+    do {                                                                                     \
+        if ((x) != hipSuccess) { std::fprintf(stderr, "hip error at %s\n", #x); return 1; }  \
+    } while (0)
+
+template <typename T>
+static T *to_device(const std::vector<T> &h) {
+    T *d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(T) + 16) != hipSuccess) std::abort();
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) std::abort();
+    return d;
+}
+
+int main() {
+    if (drt_abi_version() != DRT_ABI_VERSION) return 2;
+    CHECK(drt_device_check());
+    // a unit cube (reference Mesh.box(with_top=True): 8 vertices, 12 triangles)
+    std::vector<float> V = {.5f, .5f, .5f, .5f, .5f, -.5f, -.5f, .5f, -.5f, -.5f, .5f, .5f,
+                            -.5f, -.5f, -.5f, -.5f, -.5f, .5f, .5f, -.5f, -.5f, .5f, -.5f, .5f};
+    std::vector<int32_t> Tr = {0, 1, 2, 0, 2, 3, 3, 2, 4, 3, 4, 5, 5, 4, 6, 5, 6, 7, 7, 6, 1, 7, 1, 0,
+                               1, 4, 2, 1, 6, 4, 0, 3, 5, 0, 5, 7};
+    float *dV = to_device(V);
+    int32_t *dT = to_device(Tr);
+    hipStream_t stream;
+    HIPCHECK(hipStreamCreate(&stream));
+    drt_mesh_t mesh = nullptr;
+    CHECK(drt_mesh_create(dV, 8, dT, 12, nullptr, 0, stream, &mesh));
+
+    // 1. dense Moller-Trumbore: 2 rays x 12 triangles
+    std::vector<float> o = {0, 0, 3, 3, 0.1f, 0.2f}, d = {0, 0, -1, -1, 0, 0};
+    float *dO = to_device(o), *dD = to_device(d);
+    float *dt;
+    uint8_t *dh;
+    HIPCHECK(hipMalloc(&dt, 24 * 4));
+    HIPCHECK(hipMalloc(&dh, 24));
+    const float eps = 10.0f * 1.1920929e-7f;
+    CHECK(drt_ray_intersect_triangle_dense(dO, dD, 2, drt_mesh_triangle_vertices(mesh), 12, eps, dt, dh, stream));
+    std::vector<uint8_t> hit(24);
+    HIPCHECK(hipMemcpyAsync(hit.data(), dh, 24, hipMemcpyDeviceToHost, stream));
+    // 2. first hit (brute force + BVH must agree)
+    int32_t *di, *di2;
+    float *dft, *dft2;
+    void *ws;
+    HIPCHECK(hipMalloc(&di, 8)); HIPCHECK(hipMalloc(&di2, 8)); HIPCHECK(hipMalloc(&dft, 8)); HIPCHECK(hipMalloc(&dft2, 8));
+    HIPCHECK(hipMalloc(&ws, drt_first_triangle_hit_by_ray_workspace_size(2)));
+    CHECK(drt_first_triangle_hit_by_ray(dO, dD, 2, drt_mesh_triangle_vertices(mesh), 12, 0, nullptr, 0, eps, 512,
+                                        di, dft, ws, 16, stream));
+    CHECK(drt_mesh_first_triangle_hit_by_ray(mesh, dO, dD, 2, eps, 512, di2, dft2, stream));
+    int32_t idx[2], idx2[2];
+    float tt[2], tt2[2];
+    HIPCHECK(hipMemcpyAsync(idx, di, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(idx2, di2, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(tt, dft, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(tt2, dft2, 8, hipMemcpyDeviceToHost, stream));
+    // 3. image-method trace inside the cube: order 1, every candidate rank unranked on the GPU
+    std::vector<float> tx = {0.1f, -0.2f, 0.05f}, rx = {-0.3f, 0.25f, -0.1f};
+    float *dtx = to_device(tx), *drx = to_device(rx);
+    drt_trace_params pr = {eps, 100.0f * 1.1920929e-7f, eps, 0};
+    drt_candidates cand = {nullptr, 12, 0, 12, nullptr, 1, 0};
+    const int64_t cap = 64;
+    size_t wbytes = drt_trace_compact_workspace_size(cap, cap);
+    void *tws;
+    int64_t *keys;
+    float *pv;
+    int32_t *po;
+    HIPCHECK(hipMalloc(&tws, wbytes)); HIPCHECK(hipMalloc(&keys, cap * 8));
+    HIPCHECK(hipMalloc(&pv, cap * 3 * 3 * 4)); HIPCHECK(hipMalloc(&po, cap * 3 * 4));
+    int64_t nvalid = -1;
+    CHECK(drt_trace_paths_compact(mesh, &pr, dtx, 1, drx, 1, &cand, cap, cap, keys, pv, po, &nvalid, tws, wbytes, stream));
+    // 4. gradient of the traced vertices w.r.t. tx (cotangent = ones)
+    std::vector<float> cot((size_t)nvalid * 9, 1.0f);
+    float *dcot = to_device(cot), *gtx;
+    HIPCHECK(hipMalloc(&gtx, 12));
+    HIPCHECK(hipMemsetAsync(gtx, 0, 12, stream));
+    CHECK(drt_trace_paths_vjp(mesh, dtx, 1, drx, 1, &cand, keys, dcot, nvalid, gtx, nullptr, nullptr, stream));
+    float g[3];
+    HIPCHECK(hipMemcpyAsync(g, gtx, 12, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    // 5. host-side candidate count (no GPU involved)
+    uint64_t count = 0;
+    int32_t ovf = 0;
+    CHECK(drt_complete_graph_count(10000, 10000, 10001, 4, &count, &ovf));
+    int nhit = 0;
+    for (uint8_t h : hit) nhit += h;
+    const bool ok = nhit >= 2 && idx[0] == idx2[0] && idx[1] == idx2[1] && tt[0] == tt2[0] && idx[0] >= 0 &&
+                    std::fabs(tt[0] - 2.5f) < 1e-6f && nvalid >= 6 && std::isfinite(g[0]) &&
+                    count == 10000ull * 9999ull && !ovf;
+    std::printf("%s %d %d %lld\n", ok ? "OK" : "MISMATCH", nhit, idx[0], (long long)nvalid);
+    CHECK(drt_mesh_destroy(mesh));
+    return ok ? 0 : 3;
+}
