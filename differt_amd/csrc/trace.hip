@@ -118,8 +118,6 @@ __device__ __forceinline__ void load_mirrors(const TraceArgs &a, const int32_t (
     }
 }
 
-enum : uint32_t { F_INSIDE = 1, F_SAME = 2, F_LEN = 4, F_FINITE = 8, F_ALL = 15 };
-
 template <int K>
 __device__ __forceinline__ bool path_finite(const V3 (&full)[K + 2]) {
     bool fin = true;

@@ -7,6 +7,7 @@ grids :343-375).  Loaders, plotting, SBR launching and the MLM kernel are out of
 
 from __future__ import annotations
 
+import warnings
 from collections.abc import Iterator
 from dataclasses import dataclass, replace
 from typing import Any, Literal
@@ -74,6 +75,34 @@ class Scene:
 
     def with_receivers_grid(self, m: int = 50, n: int | None = 50, *, height: float = 1.5) -> "Scene":
         return replace(self, receivers=self._grid(m, n, height))
+
+    def compute_paths(self, order: int | None = None, *, method: Literal["exhaustive", "sbr", "hybrid"] = "exhaustive",
+                      chunk_size: int | None = None, num_rays: int = int(1e6), path_candidates=None,
+                      epsilon=None, hit_tol=None, min_len=None, max_dist: float = 1e-3,
+                      smoothing_factor=None, confidence_threshold: float = 0.5,
+                      batch_size: int | None = 512, disconnect_inactive_triangles: bool = False):
+        """Deprecated front end of the reference (_scene.py:1046-1248): dispatches to
+        :meth:`trace_paths` / :meth:`launch_paths`."""
+        warnings.warn("compute_paths is deprecated. Use trace_paths() or launch_paths() instead.",
+                      DeprecationWarning, stacklevel=2)
+        if method == "sbr":
+            if order is None:
+                raise ValueError("Argument 'order' is required.")
+            return self.launch_paths(order, solver=SBRPathLauncher(num_rays=num_rays, max_dist=max_dist))
+        if method == "hybrid":
+            solver = HybridPathTracer(num_rays=num_rays, epsilon=epsilon, hit_tol=hit_tol, min_len=min_len,
+                                      smoothing_factor=smoothing_factor,
+                                      confidence_threshold=confidence_threshold, batch_size=batch_size,
+                                      chunk_size=chunk_size)
+        elif method == "exhaustive":
+            solver = ExhaustivePathTracer(epsilon=epsilon, hit_tol=hit_tol, min_len=min_len,
+                                          smoothing_factor=smoothing_factor,
+                                          confidence_threshold=confidence_threshold, batch_size=batch_size,
+                                          disconnect_inactive_triangles=disconnect_inactive_triangles,
+                                          chunk_size=chunk_size)
+        else:
+            raise ValueError(f"Unknown method '{method}'.")
+        return self.trace_paths(order, solver=solver, path_candidates=path_candidates)
 
     def launch_paths(self, order: int, *, solver: AbstractPathLauncher | Literal["sbr"] = "sbr",
                      **solver_kwargs: Any) -> LaunchedPaths:

@@ -401,3 +401,23 @@ def test_generate_path_candidates_gpu_fill(G, two_buildings, goldens, assume_qua
         a = tracer.trace_path_candidates_compact(scene, cands)
         b = tracer.trace_rank_range(scene, order)
         assert torch.equal(a.objects, b.objects) and torch.equal(a.vertices, b.vertices)
+
+
+def test_compute_paths_deprecated_front_end(G, goldens, two_buildings):
+    """_scene.py:1046-1248: deprecated dispatcher (DeprecationWarning, same results, ValueError)."""
+    g = goldens["advanced_path_tracing_example"]
+    scene = _scene(G, two_buildings, g["tx"], g["rx"])
+    ref = scene.trace_paths(2)
+    with pytest.warns(DeprecationWarning):
+        a = scene.compute_paths(2)
+    with pytest.warns(DeprecationWarning):
+        b = scene.compute_paths(2, method="hybrid", num_rays=100_000)
+    with pytest.warns(DeprecationWarning):
+        c = scene.compute_paths(1, method="sbr", num_rays=50_000, max_dist=1e-1)
+    assert torch.equal(a.mask, ref.mask) and torch.equal(a.vertices, ref.vertices)
+    assert torch.equal(b.masked_objects, ref.masked_objects)
+    assert isinstance(c, G.LaunchedPaths) and bool(c.mask.any())
+    with pytest.warns(DeprecationWarning), pytest.raises(ValueError):
+        scene.compute_paths(method="sbr")
+    with pytest.warns(DeprecationWarning), pytest.raises(ValueError):
+        scene.compute_paths()
