@@ -16,6 +16,7 @@
 //                ballot / shuffle reduction.
 #include "common.hpp"
 #include "geom.hpp"
+#include "tri_tile.hpp"
 
 #pragma clang fp contract(off)
 
@@ -108,37 +109,6 @@ __global__ __launch_bounds__(256) void mt_paired_kernel(const float *__restrict_
 // LDS triangle tile shared by the any-hit / first-hit kernels
 // ------------------------------------------------------------------------------------------
 constexpr int kQueryThreads = 256;
-constexpr int kTile = 256;  // triangles per LDS tile: 256 * 48 B = 12 KiB
-
-struct __attribute__((aligned(16))) TriRec {
-    float v0x, v0y, v0z, e1x;
-    float e1y, e1z, e2x, e2y;
-    float e2z;
-    uint32_t active;
-    uint32_t pad0, pad1;
-};
-static_assert(sizeof(TriRec) == 48, "TriRec must be 3 x 16 B");
-
-__device__ __forceinline__ void stage_tile(TriRec *lds, const float *__restrict__ tv,
-                                           const uint8_t *__restrict__ active, int64_t base,
-                                           int64_t end) {
-    const int64_t j = base + threadIdx.x;
-    if (threadIdx.x < kTile && j < end) {
-        TriE tr = load_tri(tv + 9 * j);
-        TriRec rec;
-        rec.v0x = tr.v0.x; rec.v0y = tr.v0.y; rec.v0z = tr.v0.z;
-        rec.e1x = tr.e1.x; rec.e1y = tr.e1.y; rec.e1z = tr.e1.z;
-        rec.e2x = tr.e2.x; rec.e2y = tr.e2.y; rec.e2z = tr.e2.z;
-        rec.active = active ? (uint32_t)active[j] : 1u;
-        rec.pad0 = rec.pad1 = 0;
-        lds[threadIdx.x] = rec;
-    }
-}
-
-__device__ __forceinline__ TriE rec_tri(const TriRec &r) {
-    return TriE{V3{r.v0x, r.v0y, r.v0z}, V3{r.e1x, r.e1y, r.e1z}, V3{r.e2x, r.e2y, r.e2z}};
-}
-
 // (a2) shared triangle set, lane = ray.  out must be zero-initialised.
 __global__ __launch_bounds__(kQueryThreads) void any_hit_shared_kernel(
     const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,

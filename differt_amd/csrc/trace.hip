@@ -27,6 +27,7 @@
 #include "geom.hpp"
 #include "image_chain.hpp"
 #include "mesh.hpp"
+#include "tri_tile.hpp"
 #include "bvh.hpp"
 
 #pragma clang fp contract(off)
@@ -289,22 +290,12 @@ __device__ __forceinline__ bool key_to_path(const TraceArgs &a, const CandSrc &c
 // ------------------------------------------------------------------------------------------
 // stage B: one wavefront per surviving candidate
 // ------------------------------------------------------------------------------------------
-constexpr int kOccTile = 256;
-
-struct __attribute__((aligned(16))) OccRec {
-    float v0x, v0y, v0z, e1x;
-    float e1y, e1z, e2x, e2y;
-    float e2z;
-    uint32_t active;
-    uint32_t pad0, pad1;
-};
-
 template <int K, bool DENSE>
 __global__ __launch_bounds__(256) void trace_occlusion_kernel(
     TraceArgs a, CandSrc cs, const unsigned long long *__restrict__ q_count,
     const long long *__restrict__ queue, int64_t q_cap, unsigned long long *__restrict__ v_count,
     long long *__restrict__ valid, int64_t v_cap, uint8_t *__restrict__ d_mask) {
-    __shared__ OccRec lds[kOccTile];
+    __shared__ TriRec lds[kTile];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     int64_t count = (int64_t)*q_count;
@@ -328,30 +319,17 @@ __global__ __launch_bounds__(256) void trace_occlusion_kernel(
 #pragma unroll
         for (int s = 0; s <= K; ++s) dir[s] = full[s + 1] - full[s];
         bool blocked = !have;  // idle waves count as done
-        for (int64_t base = 0; base < a.T; base += kOccTile) {
+        for (int64_t base = 0; base < a.T; base += kTile) {
             // block-wide early exit (also the barrier that protects the previous tile's readers)
             if (__syncthreads_and(blocked ? 1 : 0)) break;
-            {
-                const int64_t j = base + threadIdx.x;
-                if (j < a.T) {
-                    const TriE tr = load_tri(a.tri_verts + 9 * j);
-                    OccRec rec;
-                    rec.v0x = tr.v0.x; rec.v0y = tr.v0.y; rec.v0z = tr.v0.z;
-                    rec.e1x = tr.e1.x; rec.e1y = tr.e1.y; rec.e1z = tr.e1.z;
-                    rec.e2x = tr.e2.x; rec.e2y = tr.e2.y; rec.e2z = tr.e2.z;
-                    rec.active = a.mask ? (uint32_t)a.mask[j] : 1u;
-                    rec.pad0 = rec.pad1 = 0;
-                    lds[threadIdx.x] = rec;
-                }
-            }
+            stage_tile(lds, a.tri_verts, a.mask, base, a.T);
             __syncthreads();
             if (!blocked) {
-                const int n = (int)((a.T - base < kOccTile) ? a.T - base : kOccTile);
+                const int n = (int)((a.T - base < kTile) ? a.T - base : kTile);
                 bool hit = false;
                 for (int j = lane; j < n; j += 64) {
-                    const OccRec rec = lds[j];
-                    const TriE tr{V3{rec.v0x, rec.v0y, rec.v0z}, V3{rec.e1x, rec.e1y, rec.e1z},
-                                  V3{rec.e2x, rec.e2y, rec.e2z}};
+                    const TriRec rec = lds[j];
+                    const TriE tr = rec_tri(rec);
 #pragma unroll
                     for (int s = 0; s <= K; ++s) {
                         float t;

@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "geom.hpp"
 #include "lattice.hpp"
+#include "tri_tile.hpp"
 
 #pragma clang fp contract(off)
 
@@ -83,15 +84,6 @@ __global__ __launch_bounds__(256) void lattice_kernel(int64_t n, const float *__
     st3(out + 3 * i, lattice_direction(i, n, fr));
 }
 
-constexpr int kVisTile = 256;
-struct __attribute__((aligned(16))) VisRec {
-    float v0x, v0y, v0z, e1x;
-    float e1y, e1z, e2x, e2y;
-    float e2z;
-    uint32_t active;
-    uint32_t pad0, pad1;
-};
-
 // grid (ceil(num_rays / 256), B); lane = lattice ray
 __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict__ view,
                                                          const float *__restrict__ frusta,
@@ -99,7 +91,7 @@ __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict
                                                          const float *__restrict__ tv, int64_t T,
                                                          const uint8_t *__restrict__ active, float eps,
                                                          uint8_t *__restrict__ visible) {
-    __shared__ VisRec lds[kVisTile];
+    __shared__ TriRec lds[kTile];
     const int64_t b = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < num_rays;
@@ -107,27 +99,14 @@ __global__ __launch_bounds__(256) void visibility_kernel(const float *__restrict
     const V3 d = lattice_direction(valid ? i : 0, num_rays, frusta + 6 * b);
     float best_t = kInf;
     int64_t best_j = -1;
-    for (int64_t base = 0; base < T; base += kVisTile) {
+    for (int64_t base = 0; base < T; base += kTile) {
         __syncthreads();
-        {
-            const int64_t j = base + threadIdx.x;
-            if (j < T) {
-                const TriE tr = load_tri(tv + 9 * j);
-                VisRec rec;
-                rec.v0x = tr.v0.x; rec.v0y = tr.v0.y; rec.v0z = tr.v0.z;
-                rec.e1x = tr.e1.x; rec.e1y = tr.e1.y; rec.e1z = tr.e1.z;
-                rec.e2x = tr.e2.x; rec.e2y = tr.e2.y; rec.e2z = tr.e2.z;
-                rec.active = active ? (uint32_t)active[j] : 1u;
-                rec.pad0 = rec.pad1 = 0;
-                lds[threadIdx.x] = rec;
-            }
-        }
+        stage_tile(lds, tv, active, base, T);
         __syncthreads();
-        const int n = (int)((T - base < kVisTile) ? T - base : kVisTile);
+        const int n = (int)((T - base < kTile) ? T - base : kTile);
         for (int j = 0; j < n; ++j) {
-            const VisRec rec = lds[j];
-            const TriE tr{V3{rec.v0x, rec.v0y, rec.v0z}, V3{rec.e1x, rec.e1y, rec.e1z},
-                          V3{rec.e2x, rec.e2y, rec.e2z}};
+            const TriRec rec = lds[j];
+            const TriE tr = rec_tri(rec);
             float t;
             const bool h = moller_trumbore(o, d, tr, eps, t);
             if (h && rec.active && t < best_t) {  // strict <: the lowest index wins ties (argmin)
