@@ -160,7 +160,10 @@ class _DiGraphIter:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            _lib.load().drt_digraph_iter_destroy(self._h)
+            try:
+                _lib.load().drt_digraph_iter_destroy(self._h)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
             self._h = None
 
     def __iter__(self):
@@ -188,7 +191,10 @@ class DiGraph:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            _lib.load().drt_digraph_destroy(self._h)
+            try:
+                _lib.load().drt_digraph_destroy(self._h)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
             self._h = None
 
     @classmethod

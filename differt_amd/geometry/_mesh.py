@@ -38,8 +38,9 @@ class _MeshHandle:
         if getattr(self, "h", None):
             try:
                 _lib.load().drt_mesh_destroy(self.h)
-            finally:
-                self.h = None
+            except Exception:  # noqa: BLE001 - interpreter shutdown: modules may already be torn down
+                pass
+            self.h = None
 
     def triangle_vertices(self) -> torch.Tensor:
         out = torch.empty((self.num_triangles, 3, 3), dtype=torch.float32, device=device())
