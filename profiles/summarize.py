@@ -35,6 +35,15 @@ def main() -> None:
             key += f" [grid={r.get('Grid_Size_X', r.get('Grid_Size', '?'))}x{r.get('Grid_Size_Y', '')}]"
         groups[key].append(dur)
     lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
+             "Commands (on the MI355X box, `cd /tmp && export TMPDIR=/tmp` first):", "",
+             "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o " + tag +
+             " -- python bench.py --steps 10 --no-cpu-baseline",
+             "    rocprofv3 --pmc FETCH_SIZE --output-format csv ... -- python bench.py --steps 3 --warmup 1 "
+             "--no-cpu-baseline --no-paths",
+             "    rocprofv3 --pmc WRITE_SIZE --output-format csv ... -- python bench.py --steps 3 --warmup 1 "
+             "--no-cpu-baseline --no-paths", "",
+             "`mt_dense_kernel<4, true> [grid=262144x10]` are the timed launches of `bench.py` "
+             "(65 536 rays x 10 000 triangles); `[grid=16384x10]` the literal 256-ray configs[1] launches.", "",
              "| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
     for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"| `{k}` | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | "
