@@ -80,6 +80,7 @@ _SIGNATURES = {
         [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp],
     ),
     "drt_first_hit_vjp": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "drt_normalize": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "drt_image_of_vertex": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "drt_intersection_of_ray_with_plane": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "drt_image_method": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),

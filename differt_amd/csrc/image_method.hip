@@ -90,6 +90,19 @@ __global__ __launch_bounds__(256) void ray_plane_kernel(const float *__restrict_
     st3(out + 3 * b, ray_plane(ld3(o + 3 * b), ld3(d + 3 * b), ld3(p + 3 * b), ld3(n + 3 * b)));
 }
 
+// geometry/_utils.py:66-72 normalize: v / where(|v| == 0, 1, |v|), lengths returned too
+__global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ v, int64_t B,
+                                                        float *__restrict__ out,
+                                                        float *__restrict__ len_out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const V3 x = ld3(v + 3 * b);
+    const float len = __builtin_sqrtf(dot(x, x));
+    const float den = (len == 0.0f) ? 1.0f : len;
+    st3(out + 3 * b, V3{x.x / den, x.y / den, x.z / den});
+    if (len_out) len_out[b] = len;
+}
+
 template <int K>
 static void launch_fwd(const float *from, const float *to, const float *mv, const float *mn,
                        int64_t B, float *out, hipStream_t s) {
@@ -124,6 +137,16 @@ using namespace drt;
     }
 
 extern "C" {
+
+int32_t drt_normalize(const float *vectors, int64_t B, float *out, float *lengths_out, void *stream) {
+    DRT_REQUIRE(B >= 0, "negative size");
+    if (B == 0) return DRT_OK;
+    DRT_REQUIRE(vectors && out, "null pointer");
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+                       as_stream(stream), vectors, B, out, lengths_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
 
 int32_t drt_image_of_vertex(const float *x, const float *p, const float *n, int64_t B, float *out,
                             void *stream) {

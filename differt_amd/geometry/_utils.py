@@ -43,11 +43,17 @@ def _no_smoothing(smoothing_factor) -> None:
 
 
 def normalize(vectors, keepdims: bool = False):
-    """Reference ``normalize`` (_utils.py:29-72): zero-length vectors are divided by one."""
-    v = as_f32(vectors)
-    lengths = torch.sqrt((v * v).sum(dim=-1, keepdim=True))
-    safe = torch.where(lengths == 0.0, torch.ones_like(lengths), lengths)
-    return v / safe, (lengths if keepdims else lengths.squeeze(-1))
+    """Reference ``normalize`` (_utils.py:29-72): zero-length vectors are divided by one.
+    Returns ``(unit vectors, lengths)``."""
+    dev = device()
+    v = as_f32(vectors, dev).contiguous()
+    batch = v.shape[:-1]
+    B = int(np.prod(batch, dtype=np.int64))
+    out = torch.empty_like(v)
+    lengths = torch.empty(batch, dtype=torch.float32, device=dev)
+    if B:
+        _lib.call("drt_normalize", ptr(v.reshape(B, 3)), B, ptr(out), ptr(lengths), stream())
+    return out, (lengths[..., None] if keepdims else lengths)
 
 
 def assemble_path(from_vertex, intermediate_vertices, to_vertex=None):

@@ -102,6 +102,9 @@ int32_t drt_first_hit_vjp(const float *vertices, const int32_t *triangles,
  * (a6-a10) image method -- reference: geometry/_solver_image_method.py:11-454.
  * Flat batches: from/to [B,3], mirrors [B,k,3] -> paths [B,k,3] (end points excluded).
  * ------------------------------------------------------------------------------------------- */
+/* normalize (geometry/_utils.py:29-72): out = v / where(|v| == 0, 1, |v|); lengths_out [B] or NULL */
+int32_t drt_normalize(const float *vectors, int64_t batch, float *out, float *lengths_out,
+                      void *stream);
 /* element-wise helpers (_solver_image_method.py:11-79 and :82-135), flat batches [B,3] */
 int32_t drt_image_of_vertex(const float *vertices, const float *mirror_vertices,
                             const float *mirror_normals, int64_t batch, float *out, void *stream);

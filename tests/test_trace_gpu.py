@@ -421,3 +421,18 @@ def test_compute_paths_deprecated_front_end(G, goldens, two_buildings):
         scene.compute_paths(method="sbr")
     with pytest.warns(DeprecationWarning), pytest.raises(ValueError):
         scene.compute_paths()
+
+
+def test_normalize_and_assemble_path(G, rng):
+    """_utils.py:29-72 (zero vectors -> 0, length 0) and :514-565, bit-exact vs the oracle."""
+    v = rng.normal(size=(7, 5, 3)).astype(np.float32) * 10
+    v[0, 0] = 0
+    got, lens = G.normalize(v)
+    exp, elens = orc.normalize(v)
+    np.testing.assert_array_equal(_bits(_np(got)), _bits(exp))
+    np.testing.assert_array_equal(_bits(_np(lens)), _bits(elens))
+    assert (_np(got)[0, 0] == 0).all() and _np(lens)[0, 0] == 0
+    assert tuple(G.normalize(v, keepdims=True)[1].shape) == (7, 5, 1)
+    a, m, b = rng.normal(size=(4, 1, 3)), rng.normal(size=(1, 6, 2, 3)), rng.normal(size=(3,))
+    np.testing.assert_array_equal(_np(G.assemble_path(a, m, b)), orc.assemble_path(a, m, b))
+    assert tuple(G.assemble_path(a[:, 0], b).shape) == (4, 2, 3)
