@@ -79,6 +79,8 @@ _SIGNATURES = {
         _i32,
         [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp],
     ),
+    "drt_first_hit_keys": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _f32, _i64, _vp, _i32, _vp]),
+    "drt_first_hit_finalize": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "drt_first_hit_vjp": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "drt_normalize": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "drt_image_of_vertex": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),

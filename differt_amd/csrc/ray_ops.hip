@@ -153,7 +153,7 @@ __device__ __forceinline__ uint64_t first_hit_key(float t, int64_t j, const Tile
 __global__ __launch_bounds__(kQueryThreads) void first_hit_shared_kernel(
     const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
     const float *__restrict__ tv, int64_t T, const uint8_t *__restrict__ active, float eps,
-    TileTie tt, unsigned long long *__restrict__ keys, int64_t tri_per_split) {
+    TileTie tt, unsigned long long *__restrict__ keys, int64_t tri_per_split, int64_t index_offset) {
     __shared__ TriRec lds[kTile];
     const int64_t r = (int64_t)blockIdx.x * kQueryThreads + threadIdx.x;
     const bool valid = r < R;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kQueryThreads) void first_hit_shared_kernel(
             bool h = moller_trumbore(o, d, rec_tri(rec), eps, t);
             // a hit with t == +inf is treated as a miss by the reference (isinf/isfinite fix-ups)
             if (h && rec.active && is_finite(t)) {
-                uint64_t k = first_hit_key(t, base + j, tt);
+                uint64_t k = first_hit_key(t, index_offset + base + j, tt);
                 best = (k < best) ? k : best;
             }
         }
@@ -448,7 +448,7 @@ int32_t drt_first_triangle_hit_by_ray(const float *ro, const float *rd, int64_t 
             const int64_t tps = choose_split(ray_blocks, T, &nsplit);
             hipLaunchKernelGGL(first_hit_shared_kernel,
                                dim3((unsigned)ray_blocks, (unsigned)nsplit), dim3(kQueryThreads), 0,
-                               s, ro, rd, R, tv, T, active, eps, tt, keys, tps);
+                               s, ro, rd, R, tv, T, active, eps, tt, keys, tps, (int64_t)0);
             DRT_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(first_hit_finalize_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256),
@@ -459,6 +459,43 @@ int32_t drt_first_triangle_hit_by_ray(const float *ro, const float *rd, int64_t 
                            s, ro, rd, R, tv, T, tv_ray_stride, active, active_ray_stride, eps, 0.0f,
                            tt, (uint8_t *)nullptr, idx, t_out);
     }
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_first_hit_keys(const float *ro, const float *rd, int64_t R, const float *tv_block,
+                           int64_t T_block, int64_t index_offset, int64_t total_triangles,
+                           const uint8_t *active_block, float eps, int64_t batch_size,
+                           uint64_t *keys, int32_t init, void *stream) {
+    DRT_REQUIRE(R >= 0 && T_block >= 0 && index_offset >= 0, "negative size");
+    DRT_REQUIRE(index_offset + T_block <= total_triangles, "block exceeds the mesh");
+    DRT_REQUIRE(total_triangles < (1ll << 31), "too many triangles");
+    if (R == 0) return DRT_OK;
+    DRT_REQUIRE(keys, "null keys");
+    hipStream_t s = as_stream(stream);
+    if (init) DRT_HIP(hipMemsetAsync(keys, 0xff, (size_t)R * 8, s));
+    if (T_block == 0) return DRT_OK;
+    DRT_REQUIRE(ro && rd && tv_block, "null pointer");
+    const TileTie tt = make_tie(total_triangles, batch_size);
+    const int64_t ray_blocks = ceil_div(R, kQueryThreads);
+    int64_t nsplit;
+    const int64_t tps = choose_split(ray_blocks, T_block, &nsplit);
+    hipLaunchKernelGGL(first_hit_shared_kernel, dim3((unsigned)ray_blocks, (unsigned)nsplit),
+                       dim3(kQueryThreads), 0, s, ro, rd, R, tv_block, T_block, active_block, eps, tt,
+                       reinterpret_cast<unsigned long long *>(keys), tps, index_offset);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_first_hit_finalize(const uint64_t *keys, int64_t R, int64_t total_triangles,
+                               int64_t batch_size, int32_t *idx, float *t_out, void *stream) {
+    DRT_REQUIRE(R >= 0, "negative size");
+    if (R == 0) return DRT_OK;
+    DRT_REQUIRE(keys && idx && t_out, "null pointer");
+    const TileTie tt = make_tie(total_triangles > 0 ? total_triangles : 1, batch_size);
+    hipLaunchKernelGGL(first_hit_finalize_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0,
+                       as_stream(stream), reinterpret_cast<const unsigned long long *>(keys), R, tt, idx,
+                       t_out);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

@@ -22,6 +22,7 @@ import torch.distributed as dist
 
 __all__ = [
     "allreduce_grads",
+    "first_triangle_hit_by_ray_sharded",
     "gather_paths",
     "globalize_keys",
     "reduce_first_hit",
@@ -123,3 +124,38 @@ def trace_rank_range_sharded(tracer, scene, order: int, rank_lo: int = 0, rank_h
     if not gather or world == 1:
         return keys, local.vertices, local.objects
     return gather_paths(keys, local.vertices.detach(), local.objects, group=group)
+
+
+def first_triangle_hit_by_ray_sharded(ray_origins, ray_directions, triangle_vertices_block,
+                                      index_offset: int, total_triangles: int, active_block=None, *,
+                                      epsilon: float | None = None, batch_size: int | None = 512,
+                                      group=None):
+    """Triangle-block sharding of ``first_triangle_hit_by_ray`` (BASELINE configs[4]): this rank holds
+    triangles ``[index_offset, index_offset + T_block)`` of a mesh of ``total_triangles``; all ranks
+    pass the same rays.  Local packed keys -> one MIN all-reduce (8 B per ray) -> decode.  The result
+    (GLOBAL indices, t) equals the single-GPU operator bit for bit, ties included."""
+    import ctypes as C  # noqa: F401
+
+    from . import _lib
+    from ._tensors import F32_EPS, as_f32, as_u8, device, ptr, stream
+
+    dev = device()
+    o = as_f32(ray_origins, dev).reshape(-1, 3).contiguous()
+    d = as_f32(ray_directions, dev).reshape(-1, 3).contiguous()
+    tv = as_f32(triangle_vertices_block, dev).reshape(-1, 3, 3).contiguous()
+    act = None if active_block is None else as_u8(active_block, dev).reshape(-1).contiguous()
+    R = o.shape[0]
+    eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+    bs = 0 if batch_size is None else int(batch_size)
+    keys = torch.empty(R, dtype=torch.int64, device=dev)
+    _lib.call("drt_first_hit_keys", ptr(o), ptr(d), R, ptr(tv), tv.shape[0], int(index_offset),
+              int(total_triangles), ptr(act), eps, bs, ptr(keys), 1, stream())
+    # unsigned MIN as a signed MIN: flip the sign bit, reduce, flip back
+    flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=dev)
+    packed = torch.bitwise_xor(keys, flip)
+    reduce_first_hit(packed, group=group)
+    keys = torch.bitwise_xor(packed, flip).contiguous()
+    idx = torch.empty(R, dtype=torch.int32, device=dev)
+    t = torch.empty(R, dtype=torch.float32, device=dev)
+    _lib.call("drt_first_hit_finalize", ptr(keys), R, int(total_triangles), bs, ptr(idx), ptr(t), stream())
+    return idx, t, keys

@@ -89,6 +89,19 @@ int32_t drt_first_triangle_hit_by_ray(const float *ray_origins, const float *ray
                                       float *t_out, void *workspace, size_t workspace_bytes,
                                       void *stream);
 
+/* Triangle-block sharding (BASELINE configs[4]): every GPU holds a block
+ * [index_offset, index_offset + T_block) of the mesh and computes, for the SAME rays, packed 64-bit
+ * keys (ordered(t) << 32) | tie with GLOBAL tile ids -- so the MIN over blocks (one RCCL all-reduce of
+ * 8 B per ray) is the single-GPU first hit including the reference tie-break, whatever the
+ * partition.  keys are in/out (init != 0 resets them to "miss"); finalize decodes them. */
+int32_t drt_first_hit_keys(const float *ray_origins, const float *ray_directions, int64_t num_rays,
+                           const float *triangle_vertices_block, int64_t block_triangles,
+                           int64_t index_offset, int64_t total_triangles,
+                           const uint8_t *active_block, float epsilon, int64_t batch_size,
+                           uint64_t *keys, int32_t init, void *stream);
+int32_t drt_first_hit_finalize(const uint64_t *keys, int64_t num_rays, int64_t total_triangles,
+                               int64_t batch_size, int32_t *index_out, float *t_out, void *stream);
+
 /* (a5) backward of the first-hit distance -- reference: geometry/_mesh.py:226-344: the cotangent of
  * t flows through Moller-Trumbore on the hit face only.  Gradients are ACCUMULATED (atomic adds)
  * into grad_vertices [Nv,3] (may be NULL); grad_origins / grad_directions [R,3] are written. */

@@ -230,21 +230,43 @@ def test_cfg5_200k_triangles(G):
     np.testing.assert_array_equal(_np(idx)[sel], ei)
     np.testing.assert_array_equal(_np(t)[sel], et)
     np.testing.assert_array_equal(_np(blocked)[sel], orc.ray_intersect_any_triangle(o[sel], d[sel], tv))
-    # triangle-block sharding (8 blocks of 25 000 triangles) + MIN of packed keys == unsharded, via
-    # the single-GPU kernel on each block
-    best_t = torch.full((len(rx),), float("inf"), device="cuda")
-    best_i = torch.full((len(rx),), -1, dtype=torch.int32, device="cuda")
+    # triangle-block sharding (configs[4]: 8 blocks of 25 000 triangles): per-block packed keys with
+    # GLOBAL tile ids, MIN-combined (what the RCCL all-reduce does), decoded == the unsharded operator,
+    # indices included, for tiles that straddle block boundaries (25 000 % 512 != 0) and with ties
+    from differt_amd.distributed import first_triangle_hit_by_ray_sharded
+
     ttv = torch.as_tensor(tv, device="cuda")
+    ttv[[24999, 25000, 150000]] = ttv[12345].clone()  # exact duplicates in different blocks
+    ref_i, ref_t = G.first_triangle_hit_by_ray(o, d, ttv)
+    flip = torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
+    combined = None
     for b in range(8):
-        bi, bt = G.first_triangle_hit_by_ray(o, d, ttv[b * 25000:(b + 1) * 25000])
-        # later block wins ties only if it is a later 512-tile: blocks are multiples of 512? 25000 is
-        # not, so compare on t and resolve equal t with the reference rule on global tile ids
-        gi = torch.where(bi >= 0, bi + b * 25000, bi)
-        better = (bt < best_t) | ((bt == best_t) & (gi >= 0) & ((gi // 512 > best_i // 512) |
-                                                              ((gi // 512 == best_i // 512) & (gi < best_i))))
-        best_t = torch.where(better, bt, best_t)
-        best_i = torch.where(better, gi, best_i)
-    assert torch.equal(best_t, t)
+        _, _, keys = first_triangle_hit_by_ray_sharded(o, d, ttv[b * 25000:(b + 1) * 25000], b * 25000, 200000)
+        signed = torch.bitwise_xor(keys, flip)
+        combined = signed if combined is None else torch.minimum(combined, signed)
+    from differt_amd import _lib
+    from differt_amd._tensors import ptr, stream
+
+    keys = torch.bitwise_xor(combined, flip).contiguous()
+    si = torch.empty(len(rx), dtype=torch.int32, device="cuda")
+    st = torch.empty(len(rx), dtype=torch.float32, device="cuda")
+    _lib.call("drt_first_hit_finalize", ptr(keys), len(rx), 200000, 512, ptr(si), ptr(st), stream())
+    assert torch.equal(si, ref_i) and torch.equal(st, ref_t)
+    # a ray aimed at the duplicated triangle: the later 512-tile wins (index 150000)
+    cen = ttv[12345].mean(dim=0)
+    oo = (cen + torch.tensor([0.0, 0.0, 500.0], device="cuda"))[None]
+    dd = (cen - oo[0])[None] * 2
+    ti, _ = G.first_triangle_hit_by_ray(oo, dd, ttv)
+    combined = None
+    for b in range(8):
+        _, _, k = first_triangle_hit_by_ray_sharded(oo, dd, ttv[b * 25000:(b + 1) * 25000], b * 25000, 200000)
+        sk = torch.bitwise_xor(k, flip)
+        combined = sk if combined is None else torch.minimum(combined, sk)
+    k = torch.bitwise_xor(combined, flip).contiguous()
+    i1 = torch.empty(1, dtype=torch.int32, device="cuda")
+    t1 = torch.empty(1, dtype=torch.float32, device="cuda")
+    _lib.call("drt_first_hit_finalize", ptr(k), 1, 200000, 512, ptr(i1), ptr(t1), stream())
+    assert int(i1) == int(ti)
     # a rank window of the order-2 tracer on the big mesh, re-validated by the oracle
     scene = G.Scene(tx, rx[:64], mesh)
     n = 200000
