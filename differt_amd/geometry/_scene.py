@@ -153,6 +153,13 @@ class Scene:
         tx_batch = tuple(self.transmitters.shape[:-1])
         rx_batch = tuple(self.receivers.shape[:-1])
 
+        if path_candidates is not None:
+            path_candidates = as_i32(path_candidates)
+            if path_candidates.dim() != 2:
+                raise ValueError("path_candidates must have shape [num_candidates, order]")
+            if self.mesh.assume_quads:  # user-supplied ids are rounded down to the even triangle
+                path_candidates = path_candidates - path_candidates % 2  # _scene.py:756-757
+
         if compact:
             if path_candidates is not None:
                 return solver.trace_path_candidates_compact(self, path_candidates)
@@ -175,9 +182,7 @@ class Scene:
         if path_candidates is None:
             cands, types = solver.generate_path_candidates(self, order)
         else:
-            cands = as_i32(path_candidates)
-            if cands.dim() != 2:
-                raise ValueError("path_candidates must have shape [num_candidates, order]")
+            cands = path_candidates
             types = None
         paths = solver.trace_path_candidates(self, cands, types)
         return paths.reshape(*tx_batch, *rx_batch, cands.shape[0])

@@ -172,8 +172,6 @@ def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, inte
     if smoothing_factor is not None:
         raise NotImplementedError("smoothed masks are not part of the MI355X hot path yet")
     table = as_i32(path_candidates).contiguous()
-    if mesh.assume_quads:
-        table = table - table % 2  # user-supplied ids are rounded down to the even triangle (SC:756-757)
     tx = tx_vertices.contiguous()
     rx = rx_vertices.contiguous()
     verts, objs, mask = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table,
@@ -344,8 +342,6 @@ class ExhaustivePathTracer(AbstractPathTracer):
                                       max_paths: int = 1 << 16) -> TracedPaths:
         """Compacted variant of :meth:`trace_path_candidates` for an explicit table."""
         table = as_i32(path_candidates).contiguous()
-        if scene.mesh.assume_quads:
-            table = table - table % 2
         desc = {"table": table, "order": table.shape[1]}
         return self._trace_compact(scene, desc, max_survivors, max_paths)
 

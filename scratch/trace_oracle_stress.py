@@ -1,0 +1,58 @@
+"""Fused tracer (dense + compact) vs the CPU oracle over random scenes: masks, objects and vertices
+bit for bit.  python scratch/trace_oracle_stress.py [seconds]"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import differt_amd.geometry as G  # noqa: E402
+import oracle as orc  # noqa: E402
+import synthetic_scenes as S  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(31)
+st = {"cases": 0, "candidate_evals": 0, "valid_paths": 0, "mask_mismatch": 0, "vertex_mismatch": 0,
+      "object_mismatch": 0, "compact_mismatch": 0}
+t0 = time.time()
+while time.time() - t0 < budget:
+    boxes = int(rng.integers(2, 40))
+    pitch = float(rng.uniform(20, 45))
+    V, Tr, c, h = S.manhattan(boxes, pitch=pitch, seed=int(rng.integers(1 << 30)))
+    if rng.random() < 0.5:  # add a ground quad under the city
+        ext = float(np.abs(V[:, :2]).max()) + 10
+        gv = np.array([[-ext, -ext, 0], [ext, -ext, 0], [ext, ext, 0], [-ext, ext, 0]], np.float32)
+        Tr = np.concatenate((Tr, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V)))
+        V = np.concatenate((V, gv))
+    ntx, nrx = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    tx, rx = S.manhattan_tx_rx(c, h, min(ntx, boxes), nrx, seed=int(rng.integers(1 << 30)), pitch=pitch)
+    tx[:, 2] = rng.uniform(2, 40, len(tx))
+    quads = bool(rng.random() < 0.3)
+    mask = (rng.random(Tr.shape[0]) > 0.1) if rng.random() < 0.4 else None
+    if mask is not None and quads:
+        mask[1::2] = mask[0::2]
+    order = int(rng.choice([0, 1, 2, 2, 3]))
+    n = Tr.shape[0] // 2 if quads else Tr.shape[0]
+    full = orc.generate_all_path_candidates(n, order)
+    if full.shape[0] > 20000:
+        full = full[np.sort(rng.choice(full.shape[0], 20000, replace=False))]
+    cand = (full * (2 if quads else 1)).astype(np.int32)
+    if rng.random() < 0.1 and order:
+        cand[rng.integers(0, len(cand))] = -1  # a padding row
+    ocand = cand - cand % 2 if quads else cand  # Scene.trace_paths rounds user-supplied ids (SC:756-757)
+    o = orc.trace_path_candidates(V, Tr, tx, rx, ocand, mask=mask, assume_quads=quads)
+    scene = G.Scene(tx, rx, G.Mesh(V, Tr, mask=mask, assume_quads=quads))
+    got = scene.trace_paths(path_candidates=cand)
+    cp = scene.trace_paths(path_candidates=cand, compact=True)
+    m = got.mask.cpu().numpy()
+    st["cases"] += 1
+    st["candidate_evals"] += m.size
+    st["valid_paths"] += int(o["mask"].sum())
+    st["mask_mismatch"] += int((m != o["mask"]).sum())
+    st["vertex_mismatch"] += int((got.vertices.cpu().numpy().view(np.uint32) != o["vertices"].view(np.uint32)).sum())
+    st["object_mismatch"] += int((got.objects.cpu().numpy() != o["objects"]).sum())
+    st["compact_mismatch"] += int(not np.array_equal(cp.keys.cpu().numpy(), np.flatnonzero(o["mask"].reshape(-1))))
+st["seconds"] = time.time() - t0
+print(json.dumps(st))
