@@ -108,12 +108,14 @@ class Scene:
                      **solver_kwargs: Any) -> LaunchedPaths:
         """Launch rays and bounce them ``order`` times (_scene.py:783-835); batch shape
         ``[*tx_batch, *rx_batch, num_rays]``."""
+        if order is None:  # _scene.py:815-817
+            raise ValueError("Argument 'order' is required.")
         if isinstance(solver, str):
             if solver != "sbr":
-                raise ValueError(f"Unknown solver '{solver}'.")
+                raise ValueError(f"Unknown solver: {solver}")  # :823
             solver = SBRPathLauncher(**solver_kwargs)
         elif solver_kwargs:
-            raise ValueError("solver_kwargs are only valid when 'solver' is given by name")
+            raise ValueError("solver_kwargs cannot be used when a solver instance is provided.")  # :826
         p = solver.launch_paths(self, order)
         batch = (*self.transmitters.shape[:-1], *self.receivers.shape[:-1], p.vertices.shape[2])
         return LaunchedPaths(
@@ -139,16 +141,28 @@ class Scene:
         arrays or the candidate table.
         """
         if (order is None) == (path_candidates is None):  # _scene.py:692-695
-            raise ValueError("You must specify one of 'order' or 'path_candidates', not both.")
+            raise ValueError("You must specify one of 'order' or `path_candidates`, not both.")
         if isinstance(solver, str):
             if solver not in ("exhaustive", "hybrid"):
-                raise ValueError(f"Unknown solver '{solver}'.")
+                raise ValueError(f"Unknown solver: {solver}")  # :702
             if chunk_size is not None:
                 solver_kwargs = {**solver_kwargs, "chunk_size": chunk_size}
             cls = ExhaustivePathTracer if solver == "exhaustive" else HybridPathTracer
             solver = cls(**solver_kwargs)
-        elif solver_kwargs:
-            raise ValueError("solver_kwargs are only valid when 'solver' is given by name")  # :708-719
+        elif solver_kwargs or chunk_size is not None:
+            raise ValueError("solver_kwargs cannot be used when a solver instance is provided.")  # :705
+
+        hybrid = isinstance(solver, HybridPathTracer)
+        if hybrid and getattr(solver, "smoothing_factor", None) is not None:  # :708-716
+            warnings.warn("Argument 'smoothing' is currently ignored when using HybridPathTracer.",
+                          UserWarning, stacklevel=2)
+            solver = replace(solver, smoothing_factor=None)
+        if hybrid and order is None:  # :717-719
+            raise ValueError("Argument 'order' is required when using HybridPathTracer.")
+        if path_candidates is not None and getattr(solver, "chunk_size", None) is not None:  # :720-728
+            warnings.warn("Argument 'chunk_size' is ignored when 'path_candidates' is provided.",
+                          UserWarning, stacklevel=2)
+            solver = replace(solver, chunk_size=None)
 
         tx_batch = tuple(self.transmitters.shape[:-1])
         rx_batch = tuple(self.receivers.shape[:-1])
@@ -168,7 +182,7 @@ class Scene:
                 return solver.trace_path_candidates_compact(self, cands)
             return solver.trace_rank_range(self, order)
 
-        eff_chunk = chunk_size if chunk_size is not None else getattr(solver, "chunk_size", None)
+        eff_chunk = getattr(solver, "chunk_size", None)
         if path_candidates is None and eff_chunk is not None:  # _scene.py:735-751
             chunks = solver.generate_path_candidates_chunks_iter(self, order, chunk_size=eff_chunk)
 
@@ -177,6 +191,8 @@ class Scene:
                     p = solver.trace_path_candidates(self, cands, types)
                     yield p.reshape(*tx_batch, *rx_batch, cands.shape[0])
 
+            if chunks.__len__() < 0:  # DiGraph chunk iterators do not know their length (size -1, SV:929-932)
+                return gen()
             return SizedIterator(gen(), size=chunks.__len__)
 
         if path_candidates is None:

@@ -214,6 +214,16 @@ class AbstractPathTracer:
 
         return SizedIterator(gen(), size=nchunks)
 
+    def trace_paths(self, scene, order, chunk_size: int | None = None, pad_chunks: bool = False):
+        """Generate then trace (_solvers.py:214-247): one :class:`TracedPaths`, or an iterator of
+        them (one per chunk) when ``chunk_size`` is given.  Layout ``[num_tx, num_rx, C, ...]``."""
+        if chunk_size is not None:
+            return (self.trace_path_candidates(scene, c, t)
+                    for c, t in self.generate_path_candidates_chunks_iter(
+                        scene, order, chunk_size=chunk_size, pad_chunks=pad_chunks))
+        cands, types = self.generate_path_candidates(scene, order)
+        return self.trace_path_candidates(scene, cands, types)
+
 
 @dataclass
 class ExhaustivePathTracer(AbstractPathTracer):
