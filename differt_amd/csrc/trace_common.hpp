@@ -1,0 +1,244 @@
+// trace_common.hpp -- pieces shared by the hard-mask tracer (trace.hip) and the smoothed tracer
+// (smooth.hip): candidate sources (table or GPU unranking), mirror gathers, path reconstruction
+// from a flat (tx, rx, candidate) index, and the host-side argument builders.
+// Reference: geometry/_solvers.py:499-586 (`_trace_path_candidates`, gathers + image method).
+#pragma once
+
+#include "common.hpp"
+#include "geom.hpp"
+#include "image_chain.hpp"
+#include "mesh.hpp"
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+template <int K>
+struct KA {
+    static constexpr int n = K > 0 ? K : 1;  // array extent that is legal for K == 0
+};
+
+struct CandSrc {
+    const int32_t *table;
+    int64_t count;    // number of candidate rows
+    int64_t rank_lo;
+    int64_t num_nodes;
+    const int32_t *node_map;
+    int32_t id_scale;
+    int64_t pw[DRT_MAX_ORDER];  // pw[j] = (num_nodes-1)^(K-1-j)
+};
+
+struct TraceArgs {
+    const float *tri_verts;  // [T,3,3]
+    const float *normals;    // [T,3]
+    const uint8_t *mask;     // [T] or null
+    int64_t T;
+    const float *tx;
+    int64_t ntx;
+    const float *rx;
+    int64_t nrx;
+    float eps, thr, min_len;
+};
+
+// candidate row -> K primitive ids (table value or GPU unranking of rank_lo + row):
+// c_0 = r / (n-1)^(K-1);  d_j = (r / (n-1)^(K-1-j)) mod (n-1);  c_j = d_j + (d_j >= c_{j-1})
+// which enumerates "no two equal neighbours" tuples in lexicographic order (graph.rs:400-470).
+template <int K>
+__device__ __forceinline__ void load_candidate(const CandSrc &s, int64_t row,
+                                               int32_t (&id)[KA<K>::n]) {
+    if (K == 0) return;
+    if (s.table) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) id[j] = s.table[row * K + j];
+    } else {
+        uint64_t r = (uint64_t)(s.rank_lo + row);
+        int64_t prev = -1;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint64_t q = r / (uint64_t)s.pw[j];
+            r -= q * (uint64_t)s.pw[j];
+            int64_t c = (int64_t)q;
+            if (j > 0) c += (c >= prev) ? 1 : 0;
+            prev = c;
+            int32_t v = (int32_t)c;
+            if (s.node_map) v = s.node_map[c];
+            id[j] = v * s.id_scale;
+        }
+    }
+}
+
+template <int K, bool QUADS>
+struct Mirrors {
+    V3 p[KA<K>::n], n[KA<K>::n];
+    TriE tri[KA<K>::n];
+    TriE tri2[QUADS ? KA<K>::n : 1];
+    bool ok;      // ids in range (negative / out-of-range ids = padding rows: invalid)
+    bool active;  // every touched triangle unmasked
+};
+
+template <int K, bool QUADS>
+__device__ __forceinline__ void load_mirrors(const TraceArgs &a, const int32_t (&id)[KA<K>::n],
+                                             Mirrors<K, QUADS> &m) {
+    m.ok = true;
+    m.active = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int64_t i = id[j];
+        const bool ok = (i >= 0) && (i + (QUADS ? 1 : 0) < a.T);
+        m.ok = m.ok && ok;
+        const int64_t s = ok ? i : 0;
+        m.tri[j] = load_tri(a.tri_verts + 9 * s);
+        m.p[j] = m.tri[j].v0;                 // SV:552-557: first vertex of the (even) triangle
+        m.n[j] = ld3(a.normals + 3 * s);      // SV:560-562
+        if (QUADS) m.tri2[j] = load_tri(a.tri_verts + 9 * (s + 1));
+        if (a.mask) {
+            m.active = m.active && (a.mask[s] != 0);
+            if (QUADS) m.active = m.active && (a.mask[s + 1] != 0);
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ bool path_finite(const V3 (&full)[K + 2]) {
+    bool fin = true;
+#pragma unroll
+    for (int j = 0; j < K + 2; ++j)
+        fin = fin && is_finite(full[j].x) && is_finite(full[j].y) && is_finite(full[j].z);
+    return fin;
+}
+
+template <int K>
+__device__ __forceinline__ bool key_to_path(const TraceArgs &a, const CandSrc &cs, int64_t flat,
+                                            int64_t &it, int64_t &ir, int32_t (&id)[KA<K>::n],
+                                            V3 (&p)[KA<K>::n], V3 (&n)[KA<K>::n], V3 (&full)[K + 2]) {
+    const int64_t pair = flat / cs.count;
+    const int64_t row = flat - pair * cs.count;
+    it = pair / a.nrx;
+    ir = pair - it * a.nrx;
+    load_candidate<K>(cs, row, id);
+    bool ok = (flat >= 0) && (it < a.ntx);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool in = (id[j] >= 0) && ((int64_t)id[j] < a.T);
+        ok = ok && in;
+        const int64_t s = in ? id[j] : 0;
+        p[j] = ld3(a.tri_verts + 9 * s);
+        n[j] = ld3(a.normals + 3 * s);
+    }
+    if (!ok) it = 0;
+    full[0] = ld3(a.tx + 3 * it);
+    full[K + 1] = ld3(a.rx + 3 * ir);
+    if constexpr (K > 0) {
+        V3 path[KA<K>::n];
+        image_chain<KA<K>::n>(full[0], full[K + 1], p, n, path);
+#pragma unroll
+        for (int j = 0; j < K; ++j) full[j + 1] = path[j];
+    }
+    return ok;
+}
+
+__device__ __forceinline__ void atomic_add3(float *p, V3 v) {
+    atomicAdd(p + 0, v.x);
+    atomicAdd(p + 1, v.y);
+    atomicAdd(p + 2, v.z);
+}
+
+// Reverse of "mirror point = v0 of triangle `tri`, mirror normal = normalize((v1-v0) x (v2-v1))"
+// (_mesh.py:950-956): scatters the cotangents (p_bar, n_bar) of one mirror into the mesh vertices.
+__device__ __forceinline__ void mirror_vjp_to_mesh(const float *__restrict__ mesh_vertices,
+                                                   const int32_t *__restrict__ mesh_triangles,
+                                                   int64_t tri, V3 p_bar, V3 n_bar,
+                                                   float *__restrict__ g_vertices) {
+    const int32_t i0 = mesh_triangles[3 * tri], i1 = mesh_triangles[3 * tri + 1],
+                  i2 = mesh_triangles[3 * tri + 2];
+    const V3 v0 = ld3(mesh_vertices + 3 * (int64_t)i0), v1 = ld3(mesh_vertices + 3 * (int64_t)i1),
+             v2 = ld3(mesh_vertices + 3 * (int64_t)i2);
+    const V3 ea = v1 - v0, eb = v2 - v1;
+    const V3 c = cross(ea, eb);
+    const float len = __builtin_sqrtf(dot(c, c));
+    V3 cbar;
+    if (len == 0.0f) {
+        cbar = n_bar;  // normalize divides by 1 for zero-length vectors
+    } else {
+        const float inv = 1.0f / len;
+        const float proj = dot(n_bar, c) * inv * inv * inv;
+        cbar = n_bar * inv - c * proj;
+    }
+    const V3 ea_bar = cross(eb, cbar);  // c = ea x eb
+    const V3 eb_bar = cross(cbar, ea);
+    atomic_add3(g_vertices + 3 * (int64_t)i0, p_bar - ea_bar);
+    atomic_add3(g_vertices + 3 * (int64_t)i1, ea_bar - eb_bar);
+    atomic_add3(g_vertices + 3 * (int64_t)i2, eb_bar);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc *out) {
+    DRT_REQUIRE(c, "candidates is null");
+    DRT_REQUIRE(c->order >= 0 && c->order <= DRT_MAX_ORDER, "order %d out of range [0, %d]",
+                (int)c->order, DRT_MAX_ORDER);
+    DRT_REQUIRE(c->num_candidates >= 0, "negative candidate count");
+    CandSrc s{};
+    s.table = c->table;
+    s.count = c->num_candidates;
+    s.rank_lo = c->rank_lo;
+    s.num_nodes = c->num_nodes;
+    s.node_map = c->node_map;
+    s.id_scale = id_scale;
+    for (int j = 0; j < DRT_MAX_ORDER; ++j) s.pw[j] = 1;
+    if (!c->table && c->order > 0 && c->num_candidates > 0) {
+        DRT_REQUIRE(c->num_nodes >= 1 && c->rank_lo >= 0, "bad rank window");
+        // total = n * (n-1)^(order-1) must fit and contain the window
+        unsigned __int128 total = (unsigned __int128)c->num_nodes;
+        unsigned __int128 pw = 1;
+        for (int j = c->order - 1; j >= 0; --j) {
+            DRT_REQUIRE(pw < ((unsigned __int128)1 << 62), "candidate space too large for 64-bit ranks");
+            s.pw[j] = (int64_t)pw;
+            if (j > 0) pw *= (unsigned __int128)(c->num_nodes - 1);
+        }
+        total = (unsigned __int128)c->num_nodes * (unsigned __int128)s.pw[0];
+        DRT_REQUIRE((unsigned __int128)c->rank_lo + (unsigned __int128)c->num_candidates <= total,
+                    "rank window [%lld, %lld) exceeds the %s candidates",
+                    (long long)c->rank_lo, (long long)(c->rank_lo + c->num_candidates), "available");
+        for (int j = 0; j < c->order; ++j)
+            if (s.pw[j] == 0) s.pw[j] = 1;  // num_nodes == 1: only order 1 has a (single) candidate
+    }
+    *out = s;
+    return DRT_OK;
+}
+
+static TraceArgs make_args(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx, int64_t ntx,
+                           const float *rx, int64_t nrx) {
+    TraceArgs a{};
+    a.tri_verts = mesh->tri_verts;
+    a.normals = mesh->normals;
+    a.mask = mesh->has_mask ? mesh->mask : nullptr;
+    a.T = mesh->num_triangles;
+    a.tx = tx;
+    a.ntx = ntx;
+    a.rx = rx;
+    a.nrx = nrx;
+    if (pr) {
+        a.eps = pr->epsilon;
+        a.thr = 1.0f - pr->hit_tol;
+        a.min_len = pr->min_len;
+    }
+    return a;
+}
+
+#define DRT_ORDER_SWITCH(k, CALL)                                                     \
+    switch (k) {                                                                      \
+        case 0: CALL(0); break;                                                       \
+        case 1: CALL(1); break;                                                       \
+        case 2: CALL(2); break;                                                       \
+        case 3: CALL(3); break;                                                       \
+        case 4: CALL(4); break;                                                       \
+        case 5: CALL(5); break;                                                       \
+        case 6: CALL(6); break;                                                       \
+        case 7: CALL(7); break;                                                       \
+        case 8: CALL(8); break;                                                       \
+        default: return fail(DRT_E_UNSUPPORTED, "order %d not supported", (int)(k)); \
+    }
+
+}  // namespace drt
