@@ -140,6 +140,20 @@ _SIGNATURES = {
         _i32,
         [_vp, _vp, _i64, _vp, _i64, C.POINTER(Candidates), _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     ),
+    "drt_ray_intersect_triangle_smooth": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),
+    "drt_ray_intersect_triangle_smooth_vjp": (
+        _i32, [_vp, _vp, _i64, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "drt_ray_intersect_any_triangle_smooth": (
+        _i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _f32, _f32, _i64, _vp, _vp]),
+    "drt_ray_intersect_any_triangle_smooth_vjp": (
+        _i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "drt_consecutive_vertices_same_side_smooth": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp]),
+    "drt_trace_paths_dense_smooth": (
+        _i32, [_vp, C.POINTER(TraceParams), _f32, _i64, _vp, _i64, _vp, _i64, C.POINTER(Candidates),
+               _vp, _vp, _vp, _vp]),
+    "drt_trace_paths_dense_smooth_vjp": (
+        _i32, [_vp, C.POINTER(TraceParams), _f32, _i64, _vp, _i64, _vp, _i64, C.POINTER(Candidates),
+               _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 # functions whose int32 result is NOT a status code

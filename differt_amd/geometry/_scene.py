@@ -155,8 +155,7 @@ class Scene:
         hybrid = isinstance(solver, HybridPathTracer)
         if hybrid and getattr(solver, "smoothing_factor", None) is not None:  # :708-716
             warnings.warn("Argument 'smoothing' is currently ignored when using HybridPathTracer.",
-                          UserWarning, stacklevel=2)
-            solver = replace(solver, smoothing_factor=None)
+                          UserWarning, stacklevel=2)  # the reference warns and still forwards it (SV:1173)
         if hybrid and order is None:  # :717-719
             raise ValueError("Argument 'order' is required when using HybridPathTracer.")
         if path_candidates is not None and getattr(solver, "chunk_size", None) is not None:  # :720-728

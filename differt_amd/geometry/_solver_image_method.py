@@ -100,9 +100,9 @@ def intersection_of_ray_with_plane(ray_origin, ray_direction, plane_vertex, plan
 def consecutive_vertices_are_on_same_side_of_mirror(
     vertices, mirror_vertices, mirror_normals, *, smoothing_factor=None
 ):
-    """_solver_image_method.py:386-454 (hard mode); needs ``num_vertices == num_mirrors + 2``."""
-    if smoothing_factor is not None:
-        raise NotImplementedError("smoothed masks are not part of the MI355X hot path yet")
+    """_solver_image_method.py:386-454; needs ``num_vertices == num_mirrors + 2``.  With
+    ``smoothing_factor`` the result is ``sigmoid(alpha * sign(dot_prev) * sign(dot_next))`` (:450-453),
+    a float whose gradient is zero everywhere (``sign`` is piecewise constant)."""
     dev = device()
     v, mv, mn = as_f32(vertices, dev), as_f32(mirror_vertices, dev), as_f32(mirror_normals, dev)
     k = mv.shape[-2]
@@ -110,6 +110,13 @@ def consecutive_vertices_are_on_same_side_of_mirror(
         raise TypeError(f"expected vertices with {k + 2} points on axis -2, got {v.shape[-2]}")
     batch = torch.broadcast_shapes(v.shape[:-2], mv.shape[:-2], mn.shape[:-2])
     B = int(np.prod(batch, dtype=np.int64))
+    if smoothing_factor is not None:
+        out = torch.empty((*batch, k), dtype=torch.float32, device=dev)
+        if k and B:
+            v, mv, mn = _bcast(batch, (v.detach(), (k + 2, 3)), (mv.detach(), (k, 3)), (mn.detach(), (k, 3)))
+            _lib.call("drt_consecutive_vertices_same_side_smooth", ptr(v), ptr(mv), ptr(mn), B, k,
+                      float(smoothing_factor), ptr(out), stream())
+        return out
     out = torch.empty((*batch, k), dtype=torch.uint8, device=dev)
     if k and B:
         v, mv, mn = _bcast(batch, (v, (k + 2, 3)), (mv, (k, 3)), (mn, (k, 3)))

@@ -164,23 +164,63 @@ class _TraceCompactFn(torch.autograd.Function):
         return gtx, grx, gmv, None, None, None, None, None
 
 
+class _TraceSmoothFn(torch.autograd.Function):
+    """Smoothed tracer (_solvers.py:499-770 with ``smoothing_factor``): vertices AND the float mask are
+    differentiable in (tx, rx, mesh vertices) through ``drt_trace_paths_dense_smooth_vjp``."""
+
+    @staticmethod
+    def forward(ctx, tx, rx, mesh_vertices, mesh, table, params, alpha, batch_size):
+        dev = tx.device
+        ntx, nrx, (Cn, k) = tx.shape[0], rx.shape[0], table.shape
+        verts = torch.zeros((ntx, nrx, Cn, k + 2, 3), dtype=torch.float32, device=dev)
+        objs = torch.zeros((ntx, nrx, Cn, k + 2), dtype=torch.int32, device=dev)
+        mask = torch.zeros((ntx, nrx, Cn), dtype=torch.float32, device=dev)
+        if ntx * nrx * Cn:
+            cands = _table_candidates(table)
+            _lib.call("drt_trace_paths_dense_smooth", mesh.handle().h, C.byref(params), alpha, batch_size,
+                      ptr(tx), ntx, ptr(rx), nrx, C.byref(cands), ptr(verts), ptr(objs), ptr(mask), stream())
+        ctx.mesh, ctx.table, ctx.cfg = mesh, table, (params, alpha, batch_size)
+        ctx.save_for_backward(tx, rx)
+        ctx.mark_non_differentiable(objs)
+        return verts, objs, mask
+
+    @staticmethod
+    def backward(ctx, gv, _go, gm):
+        tx, rx = ctx.saved_tensors
+        mesh, table = ctx.mesh, ctx.table
+        params, alpha, batch_size = ctx.cfg
+        gtx, grx = torch.zeros_like(tx), torch.zeros_like(rx)
+        gmv = torch.zeros_like(mesh.vertices) if ctx.needs_input_grad[2] else None
+        if gv.numel() // (3 * (table.shape[1] + 2)):
+            cands = _table_candidates(table)
+            _lib.call("drt_trace_paths_dense_smooth_vjp", mesh.handle().h, C.byref(params), alpha, batch_size,
+                      ptr(tx), tx.shape[0], ptr(rx), rx.shape[0], C.byref(cands), ptr(gv.contiguous()),
+                      ptr(gm.contiguous()), ptr(gtx), ptr(grx), ptr(gmv), stream())
+        return gtx, grx, gmv, None, None, None, None, None
+
+
 def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, interaction_types=None, *,
                            epsilon, hit_tol, min_len, smoothing_factor, confidence_threshold,
-                           batch_size, accel=None) -> TracedPaths:  # noqa: ARG001
+                           batch_size, accel=None) -> TracedPaths:
     """Reference ``_trace_path_candidates`` (_solvers.py:499-770), dense layout
-    ``[num_tx, num_rx, num_candidates, ...]``."""
-    if smoothing_factor is not None:
-        raise NotImplementedError("smoothed masks are not part of the MI355X hot path yet")
+    ``[num_tx, num_rx, num_candidates, ...]``; ``smoothing_factor`` switches to the float-mask mode
+    (:599-713), whose blocked term uses the pure operator with ``batch_size`` tiles (:665-674)."""
     table = as_i32(path_candidates).contiguous()
     tx = tx_vertices.contiguous()
     rx = rx_vertices.contiguous()
-    verts, objs, mask = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table,
-                                            _params(epsilon, hit_tol, min_len, accel))
+    if smoothing_factor is not None:
+        verts, objs, mask = _TraceSmoothFn.apply(
+            tx, rx, mesh.vertices, mesh, table, _params(epsilon, hit_tol, min_len, None),
+            float(smoothing_factor), 0 if batch_size is None else int(batch_size))
+    else:
+        verts, objs, mask = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table,
+                                                _params(epsilon, hit_tol, min_len, accel))
     if interaction_types is None:  # _solvers.py:751-762
         it = torch.zeros(objs.shape[:-1] + (table.shape[1],), dtype=torch.int32, device=objs.device)
     else:
         it = as_i32(interaction_types).expand(*objs.shape[:-1], table.shape[1])
-    return TracedPaths(verts, objs, mask.bool(), it, confidence_threshold)
+    return TracedPaths(verts, objs, mask if smoothing_factor is not None else mask.bool(), it,
+                       confidence_threshold)
 
 
 class AbstractPathTracer:
@@ -339,7 +379,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
         materialising them; returns the valid paths only, in ``masked_vertices`` order.
         ``keys`` holds ``(tx*num_rx + rx) * (rank_hi - rank_lo) + (rank - rank_lo)``."""
         if self.smoothing_factor is not None:
-            raise NotImplementedError("smoothed masks are not part of the MI355X hot path yet")
+            raise NotImplementedError("the smoothed mode is dense by nature (every candidate gets a confidence): "
+                                      "use trace_path_candidates / Scene.trace_paths without compact")
         n, node_map = self._num_nodes_and_map(scene)
         total = 1 if order == 0 else n * (n - 1) ** (order - 1)
         hi = total if rank_hi is None else min(int(rank_hi), total)

@@ -37,9 +37,66 @@ __all__ = [
 def _no_smoothing(smoothing_factor) -> None:
     if smoothing_factor is not None:
         raise NotImplementedError(
-            "smoothing_factor (soft masks, reference _utils.py:1279-1320) is not part of the "
-            "MI355X hot path yet: only the hard-mask operators are implemented"
+            "smoothing_factor is not defined for this operator (the reference only smooths "
+            "ray_intersect_triangle / ray_intersect_any_triangle / the tracer)"
         )
+
+
+class _MtSmoothFn(torch.autograd.Function):
+    """Smoothed Moller-Trumbore (_utils.py:1279-1320) on flat buffers: rays ``[R,3]``, triangles
+    ``[T,3,3]``; ``dense`` -> ``[R,T]`` outputs, else paired ``[R]``.  Differentiable in all three."""
+
+    @staticmethod
+    def forward(ctx, o, d, tv, eps, alpha, dense):
+        R, T = o.shape[0], tv.shape[0]
+        shape = (R, T) if dense else (R,)
+        t = torch.empty(shape, dtype=torch.float32, device=o.device)
+        hit = torch.empty(shape, dtype=torch.float32, device=o.device)
+        if t.numel():
+            _lib.call("drt_ray_intersect_triangle_smooth", ptr(o), ptr(d), R, ptr(tv), T, int(dense), eps,
+                      alpha, ptr(t), ptr(hit), stream())
+        ctx.save_for_backward(o, d, tv)
+        ctx.cfg = (eps, alpha, dense)
+        return t, hit
+
+    @staticmethod
+    def backward(ctx, gt, gh):
+        o, d, tv = ctx.saved_tensors
+        eps, alpha, dense = ctx.cfg
+        go, gd, gtv = torch.zeros_like(o), torch.zeros_like(d), torch.zeros_like(tv)
+        if o.numel() and tv.numel():
+            _lib.call("drt_ray_intersect_triangle_smooth_vjp", ptr(o), ptr(d), o.shape[0], ptr(tv),
+                      tv.shape[0], int(dense), eps, alpha,
+                      ptr(None if gt is None else gt.contiguous()),
+                      ptr(None if gh is None else gh.contiguous()), ptr(go), ptr(gd), ptr(gtv), stream())
+        return go, gd, gtv, None, None, None
+
+
+class _AnySmoothFn(torch.autograd.Function):
+    """Smoothed any-triangle confidence (_utils.py:1436-1537) on the flat layout of
+    :func:`_flatten_query`; differentiable in the rays and the triangle vertices."""
+
+    @staticmethod
+    def forward(ctx, o, d, tv, act, cfg):
+        R, T, tvs, acts, eps, tol, alpha, bs = cfg
+        out = torch.zeros(R, dtype=torch.float32, device=o.device)
+        if R:
+            _lib.call("drt_ray_intersect_any_triangle_smooth", ptr(o), ptr(d), R, ptr(tv), T, tvs, ptr(act),
+                      acts, eps, tol, alpha, bs, ptr(out), stream())
+        ctx.save_for_backward(o, d, tv)
+        ctx.act, ctx.cfg = act, cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        o, d, tv = ctx.saved_tensors
+        R, T, tvs, acts, eps, tol, alpha, bs = ctx.cfg
+        go, gd, gtv = torch.zeros_like(o), torch.zeros_like(d), torch.zeros_like(tv)
+        if R and T:
+            _lib.call("drt_ray_intersect_any_triangle_smooth_vjp", ptr(o), ptr(d), R, ptr(tv), T, tvs,
+                      ptr(ctx.act), acts, eps, tol, alpha, bs, ptr(gout.contiguous()), ptr(go), ptr(gd),
+                      ptr(gtv), stream())
+        return go, gd, gtv, None, None
 
 
 def normalize(vectors, keepdims: bool = False):
@@ -92,15 +149,11 @@ def ray_intersect_triangle(
     :1257-1259; ``t`` is returned for misses too).  The ``o[..., None, :]`` x ``tv[T,3,3]`` outer
     form runs the dense kernel (no input materialisation); any other broadcast runs paired.
     """
-    _no_smoothing(smoothing_factor)
     dev = device()
     o, d, tv = as_f32(ray_origins, dev), as_f32(ray_directions, dev), as_f32(triangle_vertices, dev)
     eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
     batch = torch.broadcast_shapes(o.shape[:-1], d.shape[:-1], tv.shape[:-2])
-    t = torch.empty(batch, dtype=torch.float32, device=dev)
-    hit = torch.empty(batch, dtype=torch.uint8, device=dev)
-    if t.numel() == 0:
-        return t, hit.bool()
+    sf = None if smoothing_factor is None else float(smoothing_factor)
     # outer-product form: rays [..., 1, 3] against one shared triangle list [T, 3, 3]
     nb = len(batch)
     tvb = (1,) * (nb - (tv.dim() - 2)) + tuple(tv.shape[:-2])
@@ -112,6 +165,23 @@ def ray_intersect_triangle(
         and ob[-1] == 1
         and db[-1] == 1
     )
+    if sf is not None:  # _utils.py:1279-1320: hit is a float confidence; differentiable (autograd)
+        if dense:
+            T, rb = batch[-1], batch[:-1]
+            of = o.reshape(ob[:-1] + (3,)).expand(*rb, 3).contiguous().reshape(-1, 3)
+            df = d.reshape(db[:-1] + (3,)).expand(*rb, 3).contiguous().reshape(-1, 3)
+            t, hit = _MtSmoothFn.apply(of, df, tv.reshape(T, 3, 3).contiguous(), eps, sf, True)
+        else:
+            n = int(np.prod(batch, dtype=np.int64))
+            of = o.expand(*batch, 3).contiguous().reshape(n, 3)
+            df = d.expand(*batch, 3).contiguous().reshape(n, 3)
+            tvf = tv.expand(*batch, 3, 3).contiguous().reshape(n, 3, 3)
+            t, hit = _MtSmoothFn.apply(of, df, tvf, eps, sf, False)
+        return t.reshape(batch), hit.reshape(batch)
+    t = torch.empty(batch, dtype=torch.float32, device=dev)
+    hit = torch.empty(batch, dtype=torch.uint8, device=dev)
+    if t.numel() == 0:
+        return t, hit.bool()
     if dense:
         T = batch[-1]
         rb = batch[:-1]
@@ -165,7 +235,7 @@ def ray_intersect_any_triangle(
     *,
     hit_tol: float | None = None,
     smoothing_factor=None,
-    batch_size: int | None = 512,  # noqa: ARG001 - tiling does not change an OR
+    batch_size: int | None = 512,  # tiling does not change an OR; it does order the smoothed sums
     **kwargs: Any,
 ):
     """Whether each ray hits any triangle before ``t = 1 - hit_tol``.
@@ -174,7 +244,6 @@ def ray_intersect_any_triangle(
     :1418-1420, ``T == 0 -> False`` :1441-1450, ``active_triangles`` :1468-1469).  ``epsilon`` is
     forwarded to Moller-Trumbore through ``**kwargs`` like in the reference.
     """
-    _no_smoothing(smoothing_factor)
     epsilon = kwargs.pop("epsilon", None)
     if kwargs:
         raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
@@ -183,6 +252,9 @@ def ray_intersect_any_triangle(
     )
     eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
     tol = 100.0 * F32_EPS if hit_tol is None else float(hit_tol)
+    if smoothing_factor is not None:  # float confidence, :1465-1476 (tiles matter: clipped sums)
+        cfg = (R, T, tvs, acts, eps, tol, float(smoothing_factor), 0 if batch_size is None else int(batch_size))
+        return _AnySmoothFn.apply(o, d, tv, act, cfg).reshape(batch)
     out = torch.zeros(R, dtype=torch.uint8, device=dev)
     if R:
         _lib.call(

@@ -319,6 +319,68 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
                             const float *vertices_cotangent, int64_t num_paths, float *grad_tx,
                             float *grad_rx, float *grad_vertices, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (f4) smoothed ("soft mask") mode -- reference: differt/src/differt/utils.py:70-89
+ * (smoothing_function = sigmoid(x * alpha)); every bool of the hard mode becomes a float32
+ * confidence in [0,1], differentiable in rays / end points / mesh vertices.
+ *   Moller-Trumbore           geometry/_utils.py:1279-1320   (min of the six sigmoids)
+ *   any triangle              geometry/_utils.py:1436-1537   (per tile of `batch_size` triangles: sum
+ *                             of min(hit, sigmoid((1-hit_tol-t) alpha)) over the active triangles,
+ *                             tiles folded with clip(left+right, max=1); batch_size <= 0 = None)
+ *   same side                 geometry/_solver_image_method.py:450-453
+ *   tracer                    geometry/_solvers.py:499-770, smoothed branches :599-713;
+ *                             mask = min(inside, same_side, 1-blocked, 1-too_small, finite) * active
+ * `dense` != 0: rays [R,3] x triangles [T,3,3] -> [R,T]; 0: paired, num_triangles == num_rays.
+ * All *_vjp entry points ACCUMULATE (atomic adds) into zero-initialised gradient buffers, any of
+ * which may be NULL; the min / max route cotangents to the first extremal term.
+ * ------------------------------------------------------------------------------------------- */
+int32_t drt_ray_intersect_triangle_smooth(const float *ray_origins, const float *ray_directions,
+                                          int64_t num_rays, const float *triangle_vertices,
+                                          int64_t num_triangles, int32_t dense, float epsilon,
+                                          float smoothing_factor, float *t_out, float *hit_out,
+                                          void *stream);
+int32_t drt_ray_intersect_triangle_smooth_vjp(const float *ray_origins, const float *ray_directions,
+                                              int64_t num_rays, const float *triangle_vertices,
+                                              int64_t num_triangles, int32_t dense, float epsilon,
+                                              float smoothing_factor, const float *t_cotangent,
+                                              const float *hit_cotangent, float *grad_origins,
+                                              float *grad_directions, float *grad_triangle_vertices,
+                                              void *stream);
+int32_t drt_ray_intersect_any_triangle_smooth(const float *ray_origins, const float *ray_directions,
+                                              int64_t num_rays, const float *triangle_vertices,
+                                              int64_t num_triangles, int64_t tv_ray_stride,
+                                              const uint8_t *active, int64_t active_ray_stride,
+                                              float epsilon, float hit_tol, float smoothing_factor,
+                                              int64_t batch_size, float *out, void *stream);
+/* grad_origins / grad_directions [R,3] are WRITTEN for rays with a non-zero cotangent (pass zeroed
+ * buffers); grad_triangle_vertices has the layout of triangle_vertices (shared or per ray). */
+int32_t drt_ray_intersect_any_triangle_smooth_vjp(const float *ray_origins, const float *ray_directions,
+                                                  int64_t num_rays, const float *triangle_vertices,
+                                                  int64_t num_triangles, int64_t tv_ray_stride,
+                                                  const uint8_t *active, int64_t active_ray_stride,
+                                                  float epsilon, float hit_tol, float smoothing_factor,
+                                                  int64_t batch_size, const float *out_cotangent,
+                                                  float *grad_origins, float *grad_directions,
+                                                  float *grad_triangle_vertices, void *stream);
+int32_t drt_consecutive_vertices_same_side_smooth(const float *vertices, const float *mirror_vertices,
+                                                  const float *mirror_normals, int64_t batch,
+                                                  int32_t num_mirrors, float smoothing_factor,
+                                                  float *out, void *stream);
+/* Dense layout of drt_trace_paths_dense with a float32 mask [Ntx,Nrx,C]; no workspace. */
+int32_t drt_trace_paths_dense_smooth(drt_mesh_t mesh, const drt_trace_params *params,
+                                     float smoothing_factor, int64_t batch_size, const float *tx,
+                                     int64_t num_tx, const float *rx, int64_t num_rx,
+                                     const drt_candidates *cands, float *vertices, int32_t *objects,
+                                     float *mask, void *stream);
+/* Cotangents of the dense outputs (vertices [Ntx,Nrx,C,order+2,3] and/or mask [Ntx,Nrx,C], either may
+ * be NULL) -> grad_tx [Ntx,3], grad_rx [Nrx,3], grad_vertices [Nv,3]. */
+int32_t drt_trace_paths_dense_smooth_vjp(drt_mesh_t mesh, const drt_trace_params *params,
+                                         float smoothing_factor, int64_t batch_size, const float *tx,
+                                         int64_t num_tx, const float *rx, int64_t num_rx,
+                                         const drt_candidates *cands, const float *vertices_cotangent,
+                                         const float *mask_cotangent, float *grad_tx, float *grad_rx,
+                                         float *grad_vertices, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

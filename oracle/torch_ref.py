@@ -17,13 +17,13 @@ import torch
 
 def image_of_vertex(x, p, n):
     inc = x - p
-    return x - 2.0 * (inc * n).sum(-1, keepdim=True) * n  # IM:73-79
+    return x - 2.0 * _dot3(inc, n)[..., None] * n  # IM:73-79
 
 
 def intersection_of_ray_with_plane(o, d, p, n):
     v = p - o
-    un = (d * n).sum(-1, keepdim=True)
-    vn = (v * n).sum(-1, keepdim=True)
+    un = _dot3(d, n)[..., None]
+    vn = _dot3(v, n)[..., None]
     parallel = un == 0.0
     un = torch.where(parallel, torch.ones_like(un), un)  # IM:123-124
     t = vn / un
@@ -105,10 +105,25 @@ def _cross3(a, b):
                         a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]), dim=-1)
 
 
+class _Logistic(torch.autograd.Function):
+    """`lax.logistic`: value 1/(1+exp(-y)) the way XLA expands it, derivative s(1-s) (JAX's own JVP
+    rule, which stays finite where exp(-y) overflows)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        s = 1.0 / (1.0 + torch.exp(-y))
+        ctx.save_for_backward(s)
+        return s
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        return g * (s * (1.0 - s))
+
+
 def smoothing_function(x, smoothing_factor=1.0):
-    """utils.py:70-89: sigmoid(x * alpha), written the way XLA expands `logistic`: 1/(1+exp(-y))."""
-    y = x * smoothing_factor
-    return 1.0 / (1.0 + torch.exp(-y))
+    """utils.py:70-89: sigmoid(x * alpha)."""
+    return _Logistic.apply(x * smoothing_factor)
 
 
 def _min_with_one(*terms):
