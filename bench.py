@@ -112,12 +112,21 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    # Test hook: DRT_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, so that the N > 1 code path
+    # (sharding, barriers, the MAX / SUM all-reduces, rank-0 JSON) can be exercised on a 1-GPU box.
+    # Numbers from such a run are meaningless and are tagged in the JSON.
+    share_gpu = os.environ.get("DRT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     lib.require_device()
     dev = torch.device("cuda", local_rank)
 
@@ -185,7 +194,7 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (TEST HOOK: all ranks share cuda:0 over gloo, numbers invalid)" if share_gpu else ""),
             "config": {
                 "workload": "BASELINE configs[1] (cfg2): rays x 10k random triangles, dense "
                 "ray_intersect_triangle fwd; ray axis extended from 256 to --rays (same seeded "
