@@ -49,6 +49,16 @@ class TraceParams(C.Structure):
 DRT_TRACE_USE_BVH = 1
 
 
+class EmParams(C.Structure):
+    _fields_ = [
+        ("frequency", C.c_double),
+        ("tx_polarization", C.c_int32),
+        ("tx_vector", C.c_float * 3),
+        ("rx_polarization", C.c_int32),
+        ("rx_vector", C.c_float * 3),
+    ]
+
+
 class Candidates(C.Structure):
     _fields_ = [
         ("table", C.c_void_p),
@@ -154,6 +164,14 @@ _SIGNATURES = {
     "drt_trace_paths_dense_smooth_vjp": (
         _i32, [_vp, C.POINTER(TraceParams), _f32, _i64, _vp, _i64, _vp, _i64, C.POINTER(Candidates),
                _vp, _vp, _vp, _vp, _vp, _vp]),
+    "drt_path_length": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "drt_sp_directions": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "drt_sp_rotation_matrix": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "drt_fresnel_coefficients": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "drt_complex_refractive_index": (_i32, [_vp, _vp, _i64, C.c_double, _vp]),
+    "drt_paths_channel": (
+        _i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, C.POINTER(EmParams),
+               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 # functions whose int32 result is NOT a status code

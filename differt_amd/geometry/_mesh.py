@@ -104,6 +104,9 @@ class Mesh:
     mask: torch.Tensor | None = None
     assume_quads: bool = False
     object_bounds: torch.Tensor | None = None
+    face_materials: torch.Tensor | None = None
+    """``i32[T]`` index into ``material_names`` (reference fields _mesh.py:661-673)."""
+    material_names: tuple[str, ...] = ()
     _handle: _MeshHandle | None = field(default=None, repr=False, compare=False)
 
     def __post_init__(self):
@@ -161,6 +164,24 @@ class Mesh:
 
     def set_mask(self, mask) -> "Mesh":
         return replace(self, mask=mask, _handle=None)
+
+    def set_face_materials(self, materials) -> "Mesh":
+        """_mesh.py:1977-2003: one index for all triangles or one per triangle (no bounds check)."""
+        fm = as_i32(materials).reshape(-1)
+        return replace(self, face_materials=fm.expand(self.num_triangles).contiguous())
+
+    def set_materials(self, *names: str) -> "Mesh":
+        """_mesh.py:1930-1975: one name for all triangles, one per triangle, or one per quad."""
+        if len(names) not in {1, self.num_triangles, self.num_primitives}:
+            if self.assume_quads:
+                raise ValueError(f"Expected either 1, {self.num_triangles}, or {self.num_primitives} names, "
+                                 f"got {len(names)}.")
+            raise ValueError(f"Expected either 1, or {self.num_triangles} names, got {len(names)}.")
+        table = {name: i for i, name in enumerate(dict.fromkeys((*self.material_names, *names)))}
+        idx = np.array([table[name] for name in names], dtype=np.int32)
+        if self.assume_quads and len(names) == self.num_quads and len(names) != 1:
+            idx = np.repeat(idx, 2)
+        return replace(self, material_names=tuple(table)).set_face_materials(idx)
 
     def with_vertices(self, vertices) -> "Mesh":
         return replace(self, vertices=vertices, _handle=None)

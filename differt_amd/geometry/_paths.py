@@ -56,10 +56,12 @@ class TracedPaths:
     def reshape(self, *batch: int) -> "TracedPaths":
         """geometry/_paths.py:123-150."""
         it = self.interaction_types
+        objects = self.objects.reshape(*batch, self.path_length)
+        batch = tuple(objects.shape[:-1])  # resolves a -1 (ambiguous for the empty order-0 arrays)
         return replace(
             self,
             vertices=self.vertices.reshape(*batch, self.path_length, 3),
-            objects=self.objects.reshape(*batch, self.path_length),
+            objects=objects,
             mask=self.mask.reshape(*batch),
             interaction_types=None if it is None else it.reshape(*batch, self.order),
         )

@@ -381,6 +381,45 @@ int32_t drt_trace_paths_dense_smooth_vjp(drt_mesh_t mesh, const drt_trace_params
                                          const float *mask_cotangent, float *grad_tx, float *grad_rx,
                                          float *grad_vertices, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (f4, second half) EM post-processing of traced paths.  Complex numbers are interleaved float32
+ * pairs (re, im).  Reference: geometry/_utils.py:150-181 (path_length), em/_utils.py:84-303
+ * (sp_directions, sp_rotation_matrix), em/_fresnel.py:47-214 (fresnel_coefficients),
+ * plugins/deepmimo.py:334-404, 480-482, 533-711 (per-path channel coefficient as exported to DeepMIMO:
+ * isotropic antennas, far field, all interactions specular reflections on half spaces
+ * (thickness < 0) or slabs (thickness >= 0)).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct drt_em_params {
+    double frequency;        /* Hz */
+    int32_t tx_polarization; /* 0 = "V", 1 = "H", 2 = tx_vector (plugins/deepmimo.py:568-589) */
+    float tx_vector[3];
+    int32_t rx_polarization; /* same encoding (plugins/deepmimo.py:645-662) */
+    float rx_vector[3];
+} drt_em_params;
+
+int32_t drt_path_length(const float *paths, int64_t batch, int32_t path_length, float *out, void *stream);
+int32_t drt_sp_directions(const float *k_i, const float *k_r, const float *normals, int64_t batch,
+                          float *e_i_s, float *e_i_p, float *e_r_s, float *e_r_p, void *stream);
+/* out [batch,2,2] = [[<b_s,a_s>, <b_s,a_p>], [<b_p,a_s>, <b_p,a_p>]] */
+int32_t drt_sp_rotation_matrix(const float *e_a_s, const float *e_a_p, const float *e_b_s,
+                               const float *e_b_p, int64_t batch, float *out, void *stream);
+/* n_r complex [batch,2], cos_theta_i [batch] -> r_s, r_p, t_s, t_p complex [batch,2] */
+int32_t drt_fresnel_coefficients(const float *n_r, const float *cos_theta_i, int64_t batch, float *r_s,
+                                 float *r_p, float *t_s, float *t_p, void *stream);
+/* HOST pointers: sqrt(eta_r - j sigma / (omega eps0)) per material, complex [M,2]. */
+int32_t drt_complex_refractive_index(const float *eta_r, const float *conductivity,
+                                     int64_t num_materials, double frequency, float *n_complex_out);
+/* vertices [N,order+2,3], objects [N,order+2] (triangle ids in columns 1..order), mesh normals [T,3],
+ * face_materials i32[T] -> material index, n_complex [M,2], thickness [M] (negative = half space).
+ * Outputs per path: a complex [N,2] (incl. the lambda/4pi factor), power [dBW], phase [deg],
+ * length [m], delay [s], angles of arrival / departure [deg] (azimuth, elevation = polar angle). */
+int32_t drt_paths_channel(const float *vertices, const int32_t *objects, int64_t num_paths, int32_t order,
+                          const float *normals, const int32_t *face_materials, int64_t num_triangles,
+                          const float *n_complex, const float *thickness, int64_t num_materials,
+                          const drt_em_params *params, float *a, float *power, float *phase,
+                          float *length, float *delay, float *aoa_az, float *aoa_el, float *aod_az,
+                          float *aod_el, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
