@@ -2,7 +2,7 @@
 
 from ._graph import CompleteGraph, DiGraph
 from ._mesh import Mesh
-from ._paths import LaunchedPaths, TracedPaths
+from ._paths import LaunchedPaths, TracedPaths, merge_cell_ids
 from ._scene import Scene
 from ._solver_image_method import (
     consecutive_vertices_are_on_same_side_of_mirror,
@@ -59,6 +59,7 @@ __all__ = [
     "generate_all_path_candidates_chunks_iter",
     "generate_all_path_candidates_iter",
     "image_method",
+    "merge_cell_ids",
     "image_of_vertex_with_respect_to_mirror",
     "intersection_of_ray_with_plane",
     "normalize",

@@ -420,6 +420,16 @@ int32_t drt_paths_channel(const float *vertices, const int32_t *objects, int64_t
                           float *length, float *delay, float *aoa_az, float *aoa_el, float *aod_az,
                           float *aod_el, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (a15) cell ids of equal rows -- reference: geometry/_paths.py:21-38 (`_cell_ids`), behind
+ * TracedPaths.group_by_objects :378-421, multipath_cells :331-376, merge_cell_ids :41-74 and the
+ * "first occurrence" of mask_duplicate_objects :196-252.
+ *   ids_out[r] = min { i : rows[i,:] == rows[r,:] }      rows: i32[num_rows, width], row-major
+ * ------------------------------------------------------------------------------------------- */
+size_t drt_row_cell_ids_workspace_size(int64_t num_rows);
+int32_t drt_row_cell_ids(const int32_t *rows, int64_t num_rows, int32_t width, int32_t *ids_out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -724,3 +724,20 @@ def launch_paths(vertices, triangles, ray_origins, ray_directions, rx, order, *,
         "vertices": np.stack(verts[:-1], axis=-2) if order else np.zeros((ntx, R, 0, 3), f),
         "masks": np.stack(masks, axis=-1),
     }
+
+
+# --------------------------------------------------------------------------------------
+# cell ids of equal rows (PA:21-38 `_cell_ids`: a reverse scan comparing every row with every other)
+# --------------------------------------------------------------------------------------
+def cell_ids(rows) -> np.ndarray:
+    """``out[r]`` = smallest ``i`` with ``rows[i] == rows[r]`` (the reverse scan of PA:24-38 leaves,
+    for every row, the LAST index written = the smallest matching one)."""
+    rows = np.asarray(rows)
+    n = rows.shape[0]
+    if n <= 2048:  # literal restatement
+        out = np.empty(n, dtype=np.int32)
+        for index in range(n - 1, -1, -1):
+            out[(rows == rows[index]).all(axis=-1)] = index
+        return out
+    _, first, inverse = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+    return first[inverse.reshape(-1)].astype(np.int32)
