@@ -43,6 +43,20 @@ template <int MODE> __global__ __launch_bounds__(256) void fill_parts(float *t, 
         if (MODE == 2 || MODE == 3) { if ((threadIdx.x & 3) == 0 && j0 + 16 <= T) __builtin_nontemporal_store(hv, (u4 *)(h + r * T + j0)); }
     }
 }
+// XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2); here the
+// column blocks of one chunk of rows all land on the SAME XCD so that its L2 sees whole rows
+template <bool NT> __global__ __launch_bounds__(256) void fill_rows_xcd(float *t, uint8_t *h, int64_t R, int64_t T, int rpb, int ncol) {
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid & 7, q = bid >> 3;
+    const int64_t col = q % ncol, rc = (q / ncol) * 8 + xcd;
+    int64_t j0 = (col * 256 + threadIdx.x) * 4; if (j0 >= T) return;
+    int64_t r0 = rc * rpb;
+    f4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (int64_t r = r0; r < r0 + rpb && r < R; ++r) {
+        if (NT) { __builtin_nontemporal_store(v, (f4 *)(t + r * T + j0)); __builtin_nontemporal_store(0x01000100u, (uint32_t *)(h + r * T + j0)); }
+        else { *(f4 *)(t + r * T + j0) = v; *(uint32_t *)(h + r * T + j0) = 0x01000100u; }
+    }
+}
 template <int THREADS> __global__ __launch_bounds__(THREADS) void fill_rows_bs(float *t, uint8_t *h, int64_t R, int64_t T, int rpb) {
     int64_t j0 = ((int64_t)blockIdx.x * THREADS + threadIdx.x) * 4; if (j0 >= T) return;
     int64_t r0 = (int64_t)blockIdx.y * rpb;
@@ -76,6 +90,13 @@ int main() {
     time("block 1024 rpb=16", [&] { fill_rows_bs<1024><<<dim3(3, R / 16), 1024>>>(t, h, R, T, 16); });
     time("block 1024 rpb=4", [&] { fill_rows_bs<1024><<<dim3(3, R / 4), 1024>>>(t, h, R, T, 4); });
     time("block 1024 rpb=64", [&] { fill_rows_bs<1024><<<dim3(3, R / 64), 1024>>>(t, h, R, T, 64); });
+    for (int rpb : {4, 16, 64}) {
+        char name[64];
+        snprintf(name, 64, "xcd-aware plain rpb=%d", rpb);
+        time(name, [&] { fill_rows_xcd<false><<<dim3(10 * (R / rpb)), 256>>>(t, h, R, T, rpb, 10); });
+        snprintf(name, 64, "xcd-aware nt    rpb=%d", rpb);
+        time(name, [&] { fill_rows_xcd<true><<<dim3(10 * (R / rpb)), 256>>>(t, h, R, T, rpb, 10); });
+    }
     for (int rpb : {16}) {
         char name[64];
         snprintf(name, 64, "xcol plain rpb=%d", rpb);
