@@ -96,7 +96,56 @@ int main() {
     float g[3];
     HIPCHECK(hipMemcpyAsync(g, gtx, 12, hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));
-    // 5. host-side candidate count (no GPU involved)
+    // 5. smoothed (soft mask) tracer, dense layout: confidences in [0,1] and their gradient w.r.t. tx
+    drt_candidates cand2 = {nullptr, 12, 0, 12, nullptr, 1, 0};
+    std::vector<int32_t> table(12);
+    for (int i = 0; i < 12; ++i) table[i] = i;
+    int32_t *dtab = to_device(table);
+    cand2.table = dtab;
+    float *sv, *sm, *gtx2;
+    int32_t *so;
+    HIPCHECK(hipMalloc(&sv, 12 * 3 * 3 * 4)); HIPCHECK(hipMalloc(&so, 12 * 3 * 4)); HIPCHECK(hipMalloc(&sm, 12 * 4));
+    HIPCHECK(hipMalloc(&gtx2, 12));
+    HIPCHECK(hipMemsetAsync(gtx2, 0, 12, stream));
+    const float alpha = 20.0f;
+    CHECK(drt_trace_paths_dense_smooth(mesh, &pr, alpha, 512, dtx, 1, drx, 1, &cand2, sv, so, sm, stream));
+    std::vector<float> mcot(12, 1.0f);
+    float *dmcot = to_device(mcot);
+    CHECK(drt_trace_paths_dense_smooth_vjp(mesh, &pr, alpha, 512, dtx, 1, drx, 1, &cand2, nullptr, dmcot, gtx2, nullptr,
+                                           nullptr, stream));
+    float conf[12], g2[3];
+    HIPCHECK(hipMemcpyAsync(conf, sm, 48, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(g2, gtx2, 12, hipMemcpyDeviceToHost, stream));
+    // 6. EM post-processing of those 12 paths: complex channel coefficient, power, delay, angles
+    std::vector<int32_t> fmat(12, 0);
+    int32_t *dfm = to_device(fmat);
+    const float eta_r = 5.24f, sigma = 0.09f;
+    float n_host[2];
+    CHECK(drt_complex_refractive_index(&eta_r, &sigma, 1, 2.4e9, n_host));
+    std::vector<float> nc = {n_host[0], n_host[1]}, thick = {-1.0f};
+    float *dnc = to_device(nc), *dth = to_device(thick), *em_out;
+    HIPCHECK(hipMalloc(&em_out, 12 * 10 * 4));
+    drt_em_params ep = {2.4e9, 0, {0, 0, 0}, 0, {0, 0, 0}};
+    CHECK(drt_paths_channel(sv, so, 12, 1, drt_mesh_normals(mesh), dfm, 12, dnc, dth, 1, &ep, em_out, em_out + 24,
+                            em_out + 36, em_out + 48, em_out + 60, em_out + 72, em_out + 84, em_out + 96, em_out + 108,
+                            stream));
+    float delay[12], power[12];
+    HIPCHECK(hipMemcpyAsync(power, em_out + 24, 48, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(delay, em_out + 60, 48, hipMemcpyDeviceToHost, stream));
+    // 7. cell ids of equal rows (TracedPaths.group_by_objects)
+    std::vector<int32_t> rows = {4, 1, 0, 3, 2, 7, 0, 3, 4, 1};
+    int32_t *drows = to_device(rows), *dids;
+    void *gws;
+    const size_t gbytes = drt_row_cell_ids_workspace_size(5);
+    HIPCHECK(hipMalloc(&dids, 20)); HIPCHECK(hipMalloc(&gws, gbytes));
+    CHECK(drt_row_cell_ids(drows, 5, 2, dids, gws, gbytes, stream));
+    int32_t ids[5];
+    HIPCHECK(hipMemcpyAsync(ids, dids, 20, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    bool ok2 = std::isfinite(g2[0]) && ids[0] == 0 && ids[1] == 1 && ids[2] == 2 && ids[3] == 1 && ids[4] == 0;
+    for (int i = 0; i < 12; ++i)
+        ok2 = ok2 && conf[i] >= 0.0f && conf[i] <= 1.0f && delay[i] > 0.0f && delay[i] < 1e-7f && power[i] < 0.0f;
+    // 8. host-side candidate count (no GPU involved)
     uint64_t count = 0;
     int32_t ovf = 0;
     CHECK(drt_complete_graph_count(10000, 10000, 10001, 4, &count, &ovf));
@@ -104,7 +153,7 @@ int main() {
     for (uint8_t h : hit) nhit += h;
     const bool ok = nhit >= 2 && idx[0] == idx2[0] && idx[1] == idx2[1] && tt[0] == tt2[0] && idx[0] >= 0 &&
                     std::fabs(tt[0] - 2.5f) < 1e-6f && nvalid >= 6 && std::isfinite(g[0]) &&
-                    count == 10000ull * 9999ull && !ovf;
+                    count == 10000ull * 9999ull && !ovf && ok2;
     std::printf("%s %d %d %lld\n", ok ? "OK" : "MISMATCH", nhit, idx[0], (long long)nvalid);
     CHECK(drt_mesh_destroy(mesh));
     return ok ? 0 : 3;
