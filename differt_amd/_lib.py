@@ -165,6 +165,9 @@ _SIGNATURES = {
         _i32, [_vp, C.POINTER(TraceParams), _f32, _i64, _vp, _i64, _vp, _i64, C.POINTER(Candidates),
                _vp, _vp, _vp, _vp, _vp, _vp]),
     "drt_path_length": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "drt_length_to_delay": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "drt_fspl": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "drt_refractive_index": (_i32, [_vp, _i64, _vp, _vp]),
     "drt_sp_directions": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "drt_sp_rotation_matrix": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "drt_fresnel_coefficients": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

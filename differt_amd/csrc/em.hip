@@ -311,6 +311,35 @@ __global__ __launch_bounds__(256) void fresnel_kernel(const float *__restrict__ 
     t_p[2 * i] = f.t_p.re, t_p[2 * i + 1] = f.t_p.im;
 }
 
+// em/_utils.py:14-44 (length / speed), :345-367 (free-space path loss), em/_fresnel.py:10-44 (sqrt)
+__global__ __launch_bounds__(256) void length_to_delay_kernel(const float *__restrict__ len,
+                                                              const float *__restrict__ speed, int64_t B,
+                                                              float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < B) out[i] = len[i] / speed[i];
+}
+
+__global__ __launch_bounds__(256) void fspl_kernel(const float *__restrict__ d, const float *__restrict__ f,
+                                                   int64_t B, int db, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    if (db) {
+        out[i] = (20.0f * log10f(d[i]) + 20.0f * log10f(f[i])) - 147.55221677811662f;
+    } else {
+        const float x = ((12.566370614359172f * d[i]) * f[i]) / 299792458.0f;
+        out[i] = x * x;
+    }
+}
+
+__global__ __launch_bounds__(256) void csqrt_kernel(const float *__restrict__ z, int64_t B,
+                                                    float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const Cf r = csqrt_f(Cf{z[2 * i], z[2 * i + 1]});
+    out[2 * i] = r.re;
+    out[2 * i + 1] = r.im;
+}
+
 }  // namespace drt
 
 using namespace drt;
@@ -356,6 +385,36 @@ int32_t drt_fresnel_coefficients(const float *n_r, const float *cos_theta_i, int
     DRT_REQUIRE(n_r && cos_theta_i && r_s && r_p && t_s && t_p, "null pointer");
     hipLaunchKernelGGL(fresnel_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, as_stream(stream), n_r,
                        cos_theta_i, batch, r_s, r_p, t_s, t_p);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_length_to_delay(const float *length, const float *speed, int64_t batch, float *out, void *stream) {
+    DRT_REQUIRE(batch >= 0, "negative size");
+    if (batch == 0) return DRT_OK;
+    DRT_REQUIRE(length && speed && out, "null pointer");
+    hipLaunchKernelGGL(length_to_delay_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, as_stream(stream),
+                       length, speed, batch, out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_fspl(const float *d, const float *f, int64_t batch, int32_t db, float *out, void *stream) {
+    DRT_REQUIRE(batch >= 0, "negative size");
+    if (batch == 0) return DRT_OK;
+    DRT_REQUIRE(d && f && out, "null pointer");
+    hipLaunchKernelGGL(fspl_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, as_stream(stream), d, f, batch,
+                       (int)db, out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_refractive_index(const float *epsilon_r, int64_t batch, float *out, void *stream) {
+    DRT_REQUIRE(batch >= 0, "negative size");
+    if (batch == 0) return DRT_OK;
+    DRT_REQUIRE(epsilon_r && out, "null pointer");
+    hipLaunchKernelGGL(csqrt_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, as_stream(stream), epsilon_r,
+                       batch, out);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

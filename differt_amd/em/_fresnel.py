@@ -18,12 +18,20 @@ def _as_c64(x, dev):
 
 
 def refractive_index(epsilon_r, mu_r=None):
-    """em/_fresnel.py:10-44: ``sqrt(epsilon_r * mu_r)`` (one square root; no kernel)."""
+    """em/_fresnel.py:10-44: ``sqrt(epsilon_r * mu_r)``; real for real non-negative inputs, complex64
+    otherwise (``mu_r`` multiplies on the host side of the call: it is a scalar material constant)."""
     dev = device()
-    e = epsilon_r if isinstance(epsilon_r, torch.Tensor) else torch.as_tensor(np.asarray(epsilon_r), device=dev)
+    e = _as_c64(epsilon_r, dev)
+    real_in = not (torch.is_complex(epsilon_r) if isinstance(epsilon_r, torch.Tensor) else np.iscomplexobj(epsilon_r))
     if mu_r is not None:
-        e = e * (mu_r if isinstance(mu_r, torch.Tensor) else torch.as_tensor(np.asarray(mu_r), device=dev))
-    return torch.sqrt(e)
+        e = e * _as_c64(mu_r, dev)
+        real_in = real_in and not (torch.is_complex(mu_r) if isinstance(mu_r, torch.Tensor) else np.iscomplexobj(mu_r))
+    z = torch.view_as_real(e.contiguous()).contiguous()
+    out = torch.empty_like(z)
+    if e.numel():
+        _lib.call("drt_refractive_index", ptr(z), e.numel(), ptr(out), stream())
+    n = torch.view_as_complex(out).reshape(e.shape)
+    return n.real.contiguous() if real_in and bool((e.real >= 0).all()) else n
 
 
 def fresnel_coefficients(n_r, cos_theta_i):

@@ -2,8 +2,6 @@
 
 from __future__ import annotations
 
-import math
-
 import numpy as np
 import torch
 
@@ -14,10 +12,20 @@ from ._constants import c
 __all__ = ["fspl", "length_to_delay", "path_delay", "sp_directions", "sp_rotation_matrix"]
 
 
-def length_to_delay(length, speed=c):
-    """em/_utils.py:14-44: ``length / speed`` (a division; no kernel)."""
+def _binary(name: str, a, b, *extra):
     dev = device()
-    return as_f32(length, dev) / as_f32(speed, dev)
+    a, b = as_f32(a, dev).detach(), as_f32(b, dev).detach()
+    batch = torch.broadcast_shapes(a.shape, b.shape)
+    a, b = a.expand(batch).contiguous(), b.expand(batch).contiguous()
+    out = torch.empty(batch, dtype=torch.float32, device=dev)
+    if out.numel():
+        _lib.call(name, ptr(a), ptr(b), out.numel(), *extra, ptr(out), stream())
+    return out
+
+
+def length_to_delay(length, speed=c):
+    """em/_utils.py:14-44: ``length / speed``."""
+    return _binary("drt_length_to_delay", length, speed)
 
 
 def path_length(path):
@@ -67,9 +75,5 @@ def sp_rotation_matrix(e_a_s, e_a_p, e_b_s, e_b_p):
 
 
 def fspl(d, f, *, dB: bool = False):  # noqa: N803
-    """em/_utils.py:345-367 (closed form; no kernel)."""
-    dev = device()
-    d, f = as_f32(d, dev), as_f32(f, dev)
-    if dB:
-        return 20 * torch.log10(d) + 20 * torch.log10(f) - 147.55221677811662
-    return (4 * math.pi * d * f / c) ** 2
+    """em/_utils.py:345-367."""
+    return _binary("drt_fspl", d, f, int(bool(dB)))

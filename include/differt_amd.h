@@ -398,6 +398,11 @@ typedef struct drt_em_params {
 } drt_em_params;
 
 int32_t drt_path_length(const float *paths, int64_t batch, int32_t path_length, float *out, void *stream);
+/* em/_utils.py:14-44, :345-367 (db != 0: decibels), em/_fresnel.py:10-44 (principal sqrt of complex
+ * epsilon_r * mu_r, [batch,2] -> [batch,2]) */
+int32_t drt_length_to_delay(const float *length, const float *speed, int64_t batch, float *out, void *stream);
+int32_t drt_fspl(const float *d, const float *f, int64_t batch, int32_t db, float *out, void *stream);
+int32_t drt_refractive_index(const float *epsilon_r, int64_t batch, float *out, void *stream);
 int32_t drt_sp_directions(const float *k_i, const float *k_r, const float *normals, int64_t batch,
                           float *e_i_s, float *e_i_p, float *e_r_s, float *e_r_p, void *stream);
 /* out [batch,2,2] = [[<b_s,a_s>, <b_s,a_p>], [<b_p,a_s>, <b_p,a_p>]] */
