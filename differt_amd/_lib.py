@@ -164,6 +164,8 @@ _SIGNATURES = {
     "drt_trace_paths_dense_smooth_vjp": (
         _i32, [_vp, C.POINTER(TraceParams), _f32, _i64, _vp, _i64, _vp, _i64, C.POINTER(Candidates),
                _vp, _vp, _vp, _vp, _vp, _vp]),
+    "drt_cartesian_to_spherical": (_i32, [_vp, _i64, _vp, _vp]),
+    "drt_spherical_to_cartesian": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "drt_path_length": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "drt_length_to_delay": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "drt_fspl": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),

@@ -170,11 +170,55 @@ void launch_frustum_kernel(const float *view, int64_t B, const float *tv, int64_
     hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)B), dim3(256), 0, s, view, B, tv, T, active, out);
 }
 
+// geometry/_utils.py:930-993: (r, polar, azimuth) <-> (x, y, z); r == 0 -> polar = acos(z / 1)
+__global__ __launch_bounds__(256) void cart_to_sph_kernel(const float *__restrict__ xyz, int64_t B,
+                                                          float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const V3 v = ld3(xyz + 3 * i);
+    float r = __builtin_sqrtf(dot(v, v));
+    r = (r == 0.0f) ? 1.0f : r;
+    st3(out + 3 * i, V3{r, acosf(v.z / r), atan2f(v.y, v.x)});
+}
+
+__global__ __launch_bounds__(256) void sph_to_cart_kernel(const float *__restrict__ rpa, int64_t B, int width,
+                                                          float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float *q = rpa + (int64_t)width * i;
+    const float p = q[width - 2], a = q[width - 1];
+    const float sp = sinf(p), cp = cosf(p);
+    V3 v{sp * cosf(a), sp * sinf(a), cp};
+    if (width == 3) v = v * q[0];
+    st3(out + 3 * i, v);
+}
+
 }  // namespace drt
 
 using namespace drt;
 
 extern "C" {
+
+int32_t drt_cartesian_to_spherical(const float *xyz, int64_t batch, float *rpa_out, void *stream) {
+    DRT_REQUIRE(batch >= 0, "negative size");
+    if (batch == 0) return DRT_OK;
+    DRT_REQUIRE(xyz && rpa_out, "null pointer");
+    hipLaunchKernelGGL(cart_to_sph_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, as_stream(stream),
+                       xyz, batch, rpa_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_spherical_to_cartesian(const float *rpa, int64_t batch, int32_t width, float *xyz_out, void *stream) {
+    DRT_REQUIRE(batch >= 0, "negative size");
+    DRT_REQUIRE(width == 2 || width == 3, "rpa must hold (polar, azimuth) or (r, polar, azimuth)");
+    if (batch == 0) return DRT_OK;
+    DRT_REQUIRE(rpa && xyz_out, "null pointer");
+    hipLaunchKernelGGL(sph_to_cart_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, as_stream(stream),
+                       rpa, batch, (int)width, xyz_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
 
 int32_t drt_viewing_frustum(const float *viewing_vertices, int64_t B, const float *tv, int64_t T,
                             const uint8_t *active, float *frustum_out, void *stream) {

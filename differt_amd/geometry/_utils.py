@@ -302,20 +302,24 @@ def first_triangle_hit_by_ray(
 # visibility by ray launching (reference _utils.py:369-490, 639-993, 1540-1772)
 # ------------------------------------------------------------------------------------------
 def cartesian_to_spherical(xyz):
-    """Reference ``cartesian_to_spherical`` (_utils.py:930-958): ``(r, polar, azimuth)``.
-    Generic element-wise helper (not on the hot path): torch ops."""
-    x = as_f32(xyz)
-    r = torch.sqrt((x * x).sum(-1))
-    r = torch.where(r == 0.0, torch.ones_like(r), r)
-    return torch.stack((r, torch.acos(x[..., 2] / r), torch.atan2(x[..., 1], x[..., 0])), dim=-1)
+    """Reference ``cartesian_to_spherical`` (_utils.py:930-958): ``(r, polar, azimuth)``."""
+    x = as_f32(xyz).detach().contiguous()
+    out = torch.empty_like(x)
+    B = x.numel() // 3
+    if B:
+        _lib.call("drt_cartesian_to_spherical", ptr(x), B, ptr(out), stream())
+    return out
 
 
 def spherical_to_cartesian(rpa):
     """Reference ``spherical_to_cartesian`` (_utils.py:961-993); radius 1 when missing."""
-    v = as_f32(rpa)
-    p, a = v[..., -2], v[..., -1]
-    xyz = torch.stack((torch.sin(p) * torch.cos(a), torch.sin(p) * torch.sin(a), torch.cos(p)), dim=-1)
-    return xyz * v[..., 0, None] if v.shape[-1] == 3 else xyz
+    v = as_f32(rpa).detach().contiguous()
+    w = v.shape[-1]
+    out = torch.empty((*v.shape[:-1], 3), dtype=torch.float32, device=v.device)
+    B = v.numel() // w if w else 0
+    if B:
+        _lib.call("drt_spherical_to_cartesian", ptr(v), B, w, ptr(out), stream())
+    return out
 
 
 def fibonacci_lattice(n: int, dtype=None, *, frustum=None):  # noqa: ARG001

@@ -190,6 +190,11 @@ int32_t drt_viewing_frustum(const float *viewing_vertices, int64_t num_vertices,
 int32_t drt_viewing_frustum_points(const float *viewing_vertices, int64_t num_vertices,
                                    const float *points, int64_t num_points, float *frustum_out,
                                    void *stream);
+/* geometry/_utils.py:930-993: xyz [batch,3] -> (r, polar, azimuth); rpa [batch,width] (width 2 = unit
+ * radius, 3 = with radius) -> xyz. */
+int32_t drt_cartesian_to_spherical(const float *xyz, int64_t batch, float *rpa_out, void *stream);
+int32_t drt_spherical_to_cartesian(const float *rpa, int64_t batch, int32_t width, float *xyz_out,
+                                   void *stream);
 /* n lattice directions [n,3]; frustum = device [2,3] or NULL (full sphere) */
 int32_t drt_fibonacci_lattice(int64_t n, const float *frustum, float *out, void *stream);
 /* visible_out u8 [B,T]; frustum_workspace: device float [B,6] */

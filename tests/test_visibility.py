@@ -88,6 +88,24 @@ def _np(x):
 
 
 @gpu
+def test_gpu_spherical_conversions(G):
+    """geometry/_utils.py:930-993 (round trip and the zero vector), vs the oracle."""
+    rng = np.random.default_rng(4)
+    xyz = (rng.normal(size=(5, 300, 3)) * 10).astype(np.float32)
+    xyz[0, 0] = 0
+    xyz[0, 1] = [0, 0, 2.5]
+    rpa = G.cartesian_to_spherical(xyz)
+    np.testing.assert_allclose(_np(rpa), orc.cartesian_to_spherical(xyz), rtol=1e-6, atol=1e-6)
+    assert _np(rpa)[0, 0].tolist() == [1.0, np.float32(np.pi / 2), 0.0]
+    back = G.spherical_to_cartesian(rpa)
+    np.testing.assert_allclose(_np(back)[0, 1:], xyz[0, 1:], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(_np(back), orc.spherical_to_cartesian(_np(rpa)), rtol=1e-6, atol=1e-6)
+    unit = G.spherical_to_cartesian(_np(rpa)[..., 1:])
+    assert tuple(unit.shape) == (5, 300, 3)
+    np.testing.assert_allclose(np.linalg.norm(_np(unit), axis=-1), 1.0, atol=1e-6)
+
+
+@gpu
 def test_gpu_lattice_and_frustum_vs_oracle(G, cube_tv):
     rng = np.random.default_rng(0)
     for n in (1, 7, 1000, 300_000):
