@@ -68,6 +68,10 @@ class Candidates(C.Structure):
         ("node_map", C.c_void_p),
         ("order", C.c_int32),
         ("reserved", C.c_int32),
+        ("first_map", C.c_void_p),
+        ("num_first", C.c_int64),
+        ("last_map", C.c_void_p),
+        ("num_last", C.c_int64),
     ]
 
 

@@ -25,7 +25,11 @@ struct CandSrc {
     int64_t num_nodes;
     const int32_t *node_map;
     int32_t id_scale;
-    int64_t pw[DRT_MAX_ORDER];  // pw[j] = (num_nodes-1)^(K-1-j)
+    int64_t pw[DRT_MAX_ORDER];  // pw[j] = (num_nodes-1)^(K-1-j); product mode: sizes of the positions after j
+    // product mode (visibility-pruned candidate space of the hybrid tracer): position 0 draws from
+    // first_map, position K-1 from last_map, the others from node_map / all nodes
+    int32_t product;
+    const int32_t *first_map, *last_map;
 };
 
 struct TraceArgs {
@@ -50,6 +54,26 @@ __device__ __forceinline__ void load_candidate(const CandSrc &s, int64_t row,
     if (s.table) {
 #pragma unroll
         for (int j = 0; j < K; ++j) id[j] = s.table[row * K + j];
+    } else if (s.product) {
+        // plain mixed-radix product, lexicographic; a tuple with two equal neighbours is not a path of
+        // the graph (no self loops, graph.rs): it becomes a padding row (id -1 -> invalid, never emitted)
+        uint64_t r = (uint64_t)(s.rank_lo + row);
+        int32_t prev = -1;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint64_t q = r / (uint64_t)s.pw[j];
+            r -= q * (uint64_t)s.pw[j];
+            const int32_t *map = (j == 0) ? s.first_map : ((j == K - 1) ? s.last_map : s.node_map);
+            const int32_t v = map ? map[q] : (int32_t)q;
+            bad = bad || (v == prev);
+            prev = v;
+            id[j] = v * s.id_scale;
+        }
+        if (bad) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) id[j] = -1;
+        }
     } else {
         uint64_t r = (uint64_t)(s.rank_lo + row);
         int64_t prev = -1;
@@ -187,6 +211,27 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
     s.node_map = c->node_map;
     s.id_scale = id_scale;
     for (int j = 0; j < DRT_MAX_ORDER; ++j) s.pw[j] = 1;
+    if (!c->table && (c->first_map || c->last_map || c->num_first > 0 || c->num_last > 0)) {
+        // product mode: F x N^(order-2) x L
+        DRT_REQUIRE(c->order >= 2, "the pruned product space needs order >= 2 (order 1: pass the intersection as node_map)");
+        DRT_REQUIRE(c->num_first >= 0 && c->num_last >= 0 && c->num_nodes >= 0 && c->rank_lo >= 0, "bad product space");
+        DRT_REQUIRE((c->first_map || c->num_first == 0) && (c->last_map || c->num_last == 0), "null position map");
+        s.product = 1;
+        s.first_map = c->first_map;
+        s.last_map = c->last_map;
+        unsigned __int128 pw = 1;
+        for (int j = c->order - 1; j >= 0; --j) {
+            DRT_REQUIRE(pw < ((unsigned __int128)1 << 62), "candidate space too large for 64-bit ranks");
+            s.pw[j] = (int64_t)(pw == 0 ? 1 : pw);
+            const int64_t size = (j == 0) ? c->num_first : ((j == c->order - 1) ? c->num_last : c->num_nodes);
+            pw *= (unsigned __int128)size;
+        }
+        DRT_REQUIRE((unsigned __int128)c->rank_lo + (unsigned __int128)c->num_candidates <= pw,
+                    "rank window [%lld, %lld) exceeds the product space", (long long)c->rank_lo,
+                    (long long)(c->rank_lo + c->num_candidates));
+        *out = s;
+        return DRT_OK;
+    }
     if (!c->table && c->order > 0 && c->num_candidates > 0) {
         DRT_REQUIRE(c->num_nodes >= 1 && c->rank_lo >= 0, "bad rank window");
         // total = n * (n-1)^(order-1) must fit and contain the window

@@ -176,10 +176,7 @@ class Scene:
         if compact:
             if path_candidates is not None:
                 return solver.trace_path_candidates_compact(self, path_candidates)
-            if isinstance(solver, HybridPathTracer):
-                cands, _ = solver.generate_path_candidates(self, order)
-                return solver.trace_path_candidates_compact(self, cands)
-            return solver.trace_rank_range(self, order)
+            return solver.trace_rank_range(self, order)  # hybrid: pruned product space, unranked on the GPU
 
         eff_chunk = getattr(solver, "chunk_size", None)
         if path_candidates is None and eff_chunk is not None:  # _scene.py:735-751

@@ -56,7 +56,8 @@ def _table_candidates(table: torch.Tensor) -> _lib.Candidates:
 
 
 def _rank_candidates(order: int, rank_lo: int, count: int, num_nodes: int,
-                     node_map: torch.Tensor | None) -> _lib.Candidates:
+                     node_map: torch.Tensor | None, first_map: torch.Tensor | None = None,
+                     last_map: torch.Tensor | None = None) -> _lib.Candidates:
     c = _lib.Candidates()
     c.table = None
     c.num_candidates = count
@@ -64,6 +65,10 @@ def _rank_candidates(order: int, rank_lo: int, count: int, num_nodes: int,
     c.num_nodes = num_nodes
     c.node_map = None if node_map is None else node_map.data_ptr()
     c.order = order
+    if first_map is not None:  # pruned product space F x N^(order-2) x L (hybrid tracer)
+        # an EMPTY list still selects the product mode: keep the pointers non-NULL
+        c.first_map, c.num_first = first_map.data_ptr() or 1, first_map.shape[0]
+        c.last_map, c.num_last = last_map.data_ptr() or 1, last_map.shape[0]
     return c
 
 
@@ -119,7 +124,8 @@ class _TraceCompactFn(torch.autograd.Function):
             if cand_desc["table"] is not None:
                 return _table_candidates(cand_desc["table"])
             return _rank_candidates(order, cand_desc["rank_lo"], cand_desc["count"],
-                                    cand_desc["num_nodes"], cand_desc["node_map"])
+                                    cand_desc["num_nodes"], cand_desc["node_map"],
+                                    cand_desc.get("first_map"), cand_desc.get("last_map"))
 
         while True:
             nbytes = lib.drt_trace_compact_workspace_size(max_survivors, max_paths)
@@ -441,8 +447,72 @@ class HybridPathTracer(ExhaustivePathTracer):
             graph.filter_by_mask(mask.cpu().numpy(), fast_mode=True)
         return graph, from_, to
 
-    def trace_rank_range(self, *args, **kwargs):  # noqa: ARG002
-        raise NotImplementedError("rank windows address the complete graph; the hybrid tracer prunes it")
+    def _visible_sets(self, scene):
+        """Primitive index lists (device int32, ascending): first interactions (visible from a
+        transmitter), last interactions (visible from a receiver), and the middle set (all active
+        primitives, ``None`` = every primitive) -- the node sets of the reference's pruned DiGraph
+        (_solvers.py:1013-1042)."""
+        mesh = scene.mesh
+        tx = scene.transmitters.reshape(-1, 3)
+        rx = scene.receivers.reshape(-1, 3)
+        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
+        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
+        if mesh.assume_quads:
+            vis_tx = vis_tx.reshape(-1, 2).any(dim=-1)
+            vis_rx = vis_rx.reshape(-1, 2).any(dim=-1)
+        middle = None
+        if mesh.mask is not None:
+            active = mesh.mask
+            if mesh.assume_quads:
+                active = active[0::2] & active[1::2]
+            vis_tx, vis_rx = vis_tx & active, vis_rx & active
+            middle = torch.nonzero(active).reshape(-1).to(torch.int32).contiguous()
+
+        def ids(b):
+            return torch.nonzero(b).reshape(-1).to(torch.int32).contiguous()
+
+        return ids(vis_tx), ids(vis_rx), middle, (vis_tx & vis_rx)
+
+    def num_path_candidates(self, scene, order: int) -> int:
+        """Size of the pruned rank space of :meth:`trace_rank_range` (for order >= 2 it still counts the
+        tuples with two equal neighbours, which are skipped while tracing)."""
+        first, last, middle, both = self._visible_sets(scene)
+        if order == 0:
+            return 1
+        if order == 1:
+            return int(both.sum())
+        n = scene.mesh.num_primitives if middle is None else int(middle.shape[0])
+        return int(first.shape[0]) * n ** (order - 2) * int(last.shape[0])
+
+    def trace_rank_range(self, scene, order: int, rank_lo: int = 0, rank_hi: int | None = None, *,
+                         max_survivors: int = 1 << 20, max_paths: int = 1 << 16) -> TracedPaths:
+        """GPU-resident counterpart of the pruned DiGraph enumeration (_solvers.py:996-1056): ranks
+        address ``F x N^(order-2) x L`` (first interaction visible from a transmitter, last one from a
+        receiver, inactive primitives removed) in lexicographic order -- the DFS order of the
+        reference -- and are unranked inside the trace kernels; no candidate table, no host DFS.
+        Valid paths come back in ``masked_vertices`` order, identical to tracing the host-generated
+        table (``tests/test_trace_gpu.py``)."""
+        if self.smoothing_factor is not None:
+            raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
+        first, last, middle, both = self._visible_sets(scene)
+        if order == 0:
+            return ExhaustivePathTracer.trace_rank_range(self, scene, 0, rank_lo, rank_hi,
+                                                         max_survivors=max_survivors, max_paths=max_paths)
+        if order == 1:  # the single interaction must be visible from both ends
+            node_map = torch.nonzero(both).reshape(-1).to(torch.int32).contiguous()
+            total = int(node_map.shape[0])
+            hi = total if rank_hi is None else min(int(rank_hi), total)
+            lo = min(int(rank_lo), hi)
+            desc = {"table": None, "order": 1, "rank_lo": lo, "count": hi - lo, "num_nodes": max(total, 1),
+                    "node_map": node_map}
+            return self._trace_compact(scene, desc, max_survivors, max_paths)
+        n = scene.mesh.num_primitives if middle is None else int(middle.shape[0])
+        total = int(first.shape[0]) * n ** (order - 2) * int(last.shape[0])
+        hi = total if rank_hi is None else min(int(rank_hi), total)
+        lo = min(int(rank_lo), hi)
+        desc = {"table": None, "order": order, "rank_lo": lo, "count": hi - lo, "num_nodes": n, "node_map": middle,
+                "first_map": first, "last_map": last}
+        return self._trace_compact(scene, desc, max_survivors, max_paths)
 
 
 class AbstractPathLauncher:

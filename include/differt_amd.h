@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRT_ABI_VERSION 1
+#define DRT_ABI_VERSION 2
 
 enum {
     DRT_OK = 0,
@@ -287,6 +287,17 @@ typedef struct drt_candidates {
     const int32_t *node_map;/* device [num_nodes] compact node -> primitive, or NULL */
     int32_t order;          /* interactions per path (0..DRT_MAX_ORDER) */
     int32_t reserved;
+    /* Pruned PRODUCT space (HybridPathTracer, reference _solvers.py:996-1056: first / last interaction
+     * restricted to the primitives visible from the transmitters / receivers), table == NULL and
+     * order >= 2, selected by a non-NULL first_map or last_map: position 0 draws from
+     * first_map[0..num_first), position order-1 from last_map[0..num_last), the others from
+     * node_map[0..num_nodes) (or the identity).  Ranks enumerate F x N^(order-2) x L in lexicographic
+     * order -- the DFS order of the reference's DiGraph; tuples with two equal neighbours are not
+     * paths of that graph and are skipped (they behave as padding rows). */
+    const int32_t *first_map;
+    int64_t num_first;
+    const int32_t *last_map;
+    int64_t num_last;
 } drt_candidates;
 
 /* Dense reference layout for every (tx, rx, candidate):

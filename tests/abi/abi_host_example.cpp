@@ -31,6 +31,9 @@ static T *to_device(const std::vector<T> &h) {
     return d;
 }
 
+static_assert(sizeof(drt_trace_params) == 16 && sizeof(drt_candidates) == 80 && sizeof(drt_em_params) == 40,
+              "struct layouts the ctypes binding (differt_amd/_lib.py) relies on");
+
 int main() {
     if (drt_abi_version() != DRT_ABI_VERSION) return 2;
     CHECK(drt_device_check());

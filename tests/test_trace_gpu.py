@@ -436,3 +436,59 @@ def test_normalize_and_assemble_path(G, rng):
     a, m, b = rng.normal(size=(4, 1, 3)), rng.normal(size=(1, 6, 2, 3)), rng.normal(size=(3,))
     np.testing.assert_array_equal(_np(G.assemble_path(a, m, b)), orc.assemble_path(a, m, b))
     assert tuple(G.assemble_path(a[:, 0], b).shape) == (4, 2, 3)
+
+
+# ------------------------------------------------------------------ hybrid tracer, GPU-resident ----
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+@pytest.mark.parametrize("assume_quads", [False, True])
+@pytest.mark.parametrize("mesh_mask", [False, True])
+def test_hybrid_rank_range_equals_host_enumeration(G, goldens, two_buildings, order, assume_quads, mesh_mask):
+    """The pruned product space F x N^(order-2) x L unranked on the GPU (drt_candidates.first_map /
+    last_map) yields exactly the valid paths, in the same order, as tracing the table that the host
+    DiGraph enumerates (reference _solvers.py:996-1056); rank windows concatenate to the whole."""
+    g = goldens["advanced_path_tracing_example"]
+    rng = np.random.default_rng(9)
+    mask = None
+    if mesh_mask:
+        mask = rng.random(two_buildings["triangles"].shape[0]) > 0.25
+        if assume_quads:
+            mask[1::2] = mask[0::2]
+    tx = np.asarray(g["tx"], np.float32) + np.array([[0, 0, 0], [3, -2, 1]], np.float32)
+    rx = np.asarray(g["rx"], np.float32) + np.array([[0, 0, 0], [-2, 1, 0.5], [4, 3, 1]], np.float32)
+    scene = _scene(G, two_buildings, tx, rx, assume_quads, mask)
+    solver = G.HybridPathTracer(num_rays=200_000)
+    cands, _ = solver.generate_path_candidates(scene, order)
+    ref = solver.trace_path_candidates_compact(scene, cands)
+    got = scene.trace_paths(order, solver=solver, compact=True)
+    np.testing.assert_array_equal(_np(got.objects), _np(ref.objects))
+    np.testing.assert_array_equal(_bits(_np(got.vertices)), _bits(_np(ref.vertices)))
+    total = solver.num_path_candidates(scene, order)
+    assert total >= cands.shape[0]  # the product space still counts equal-neighbour tuples
+    if order >= 2:
+        n_first, n_last = (int(x.shape[0]) for x in solver._visible_sets(scene)[:2])
+        assert 0 < n_first and 0 < n_last
+    cuts = [0, total // 3, total // 3 + 1, total]
+    parts = [solver.trace_rank_range(scene, order, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    n_valid = sum(p.objects.shape[0] for p in parts)
+    assert n_valid == ref.objects.shape[0]
+    if n_valid:
+        # the same set of paths, whatever the window cut
+        both = np.concatenate([_np(p.objects) for p in parts])
+        assert sorted(map(tuple, both.tolist())) == sorted(map(tuple, _np(ref.objects).tolist()))
+    # gradients flow through the product-space path like through any compact trace
+    txg = torch.tensor(tx, device="cuda", requires_grad=True)
+    sc = G.Scene(txg, rx, scene.mesh)
+    p = sc.trace_paths(order, solver=solver, compact=True)
+    p.vertices.square().sum().backward()
+    assert torch.isfinite(txg.grad).all()
+
+
+def test_hybrid_rank_range_empty_sets(G):
+    """No primitive visible from the receiver (it sits inside a closed box, the transmitter outside)."""
+    outer = G.Mesh.box(2.0, 2.0, 2.0, with_top=True)
+    scene = G.Scene([5.0, 0.0, 0.0], [0.0, 0.0, 0.0], outer)
+    solver = G.HybridPathTracer(num_rays=50_000)
+    for order in (1, 2, 3):
+        p = solver.trace_rank_range(scene, order)
+        ref = solver.trace_path_candidates_compact(scene, solver.generate_path_candidates(scene, order)[0])
+        assert p.objects.shape[0] == ref.objects.shape[0]
