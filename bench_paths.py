@@ -94,9 +94,42 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         "grad_tx_finite": bool(torch.isfinite(grad).all().item()),
         "grad_tx_absmax": float(grad.abs().max().item()),
     }
+    if rank == 0 and world == 1 and num_ranks is None and order == 2:
+        out["visibility_pruned"] = pruned_leg(G, mesh, tx, rx, order, nvalid)
     if cpu_sample and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_sample_rate(V, Tr, tx, rx, order, n)
     return out
+
+
+def pruned_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:
+    """Same step through HybridPathTracer.trace_rank_range: first / last interaction restricted to the
+    primitives visible from the transmitters / receivers (reference _solvers.py:996-1056), the pruned
+    product space unranked on the GPU.  Must find the same valid paths as the exhaustive step."""
+    import torch
+
+    solver = G.HybridPathTracer(num_rays=1_000_000, accel="bvh")
+
+    def step():
+        txg = torch.tensor(tx, device="cuda", requires_grad=True)
+        scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
+        paths = solver.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+        torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+        return paths.objects.shape[0], scene
+
+    try:
+        nv, scene = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nv, scene = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        first, last = (int(x.shape[0]) for x in solver._visible_sets(scene)[:2])
+        return {"s_per_step": dt, "valid_paths": int(nv), "same_valid_paths_as_exhaustive": int(nv) == int(expected_valid),
+                "visible_first": first, "visible_last": last,
+                "pruned_candidates_per_pair": solver.num_path_candidates(scene, order),
+                "note": "includes the visibility estimation (80 viewpoints x 1e6 rays on the LBVH)"}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)}
 
 
 def cpu_sample_rate(V, Tr, tx, rx, order, n, budget_s: float = 10.0) -> dict:
