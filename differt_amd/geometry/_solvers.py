@@ -473,6 +473,63 @@ class HybridPathTracer(ExhaustivePathTracer):
 
         return ids(vis_tx), ids(vis_rx), middle, (vis_tx & vis_rx)
 
+    def trace_pairs(self, scene, order: int, *, max_survivors: int = 1 << 20,
+                    max_paths: int = 1 << 14) -> TracedPaths:
+        """MI355X extension: visibility pruning PER (transmitter, receiver) pair instead of merged over
+        all of them (the reference merges, _solvers.py:969-973, which prunes little once there are many
+        end points): pair (i, j) traces ``F_i x N^(order-2) x L_j`` -- first interaction visible from
+        transmitter i, last one from receiver j -- as one GPU-unranked launch per pair.  Returns the valid
+        paths of all pairs (pair-major, lexicographic inside a pair = ``masked_vertices`` order of the
+        exhaustive tracer), differentiable like any compact trace.  Finds a subset of the exhaustive
+        tracer's valid paths that is complete up to the sampling of the visibility estimate."""
+        if order < 2:
+            return self.trace_rank_range(scene, order, max_survivors=max_survivors, max_paths=max_paths)
+        mesh = scene.mesh
+        tx = scene.transmitters.reshape(-1, 3)
+        rx = scene.receivers.reshape(-1, 3)
+        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel)
+        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel)
+        if mesh.assume_quads:
+            vis_tx = vis_tx.reshape(vis_tx.shape[0], -1, 2).any(dim=-1)
+            vis_rx = vis_rx.reshape(vis_rx.shape[0], -1, 2).any(dim=-1)
+        middle = None
+        if mesh.mask is not None:
+            active = mesh.mask
+            if mesh.assume_quads:
+                active = active[0::2] & active[1::2]
+            vis_tx, vis_rx = vis_tx & active, vis_rx & active
+            middle = torch.nonzero(active).reshape(-1).to(torch.int32).contiguous()
+        n = mesh.num_primitives if middle is None else int(middle.shape[0])
+        firsts = [torch.nonzero(v).reshape(-1).to(torch.int32).contiguous() for v in vis_tx]
+        lasts = [torch.nonzero(v).reshape(-1).to(torch.int32).contiguous() for v in vis_rx]
+        from ._scene import Scene
+
+        verts, objs, evaluated = [], [], 0
+        for i, f in enumerate(firsts):
+            for j, l in enumerate(lasts):
+                total = int(f.shape[0]) * n ** (order - 2) * int(l.shape[0])
+                evaluated += total
+                if total == 0:
+                    continue
+                sub = Scene(tx[i:i + 1], rx[j:j + 1], mesh)
+                desc = {"table": None, "order": order, "rank_lo": 0, "count": total, "num_nodes": n,
+                        "node_map": middle, "first_map": f, "last_map": l}
+                p = self._trace_compact(sub, desc, max_survivors, max_paths)
+                if p.objects.shape[0]:
+                    o = p.objects.clone()
+                    o[:, 0], o[:, -1] = i, j
+                    verts.append(p.vertices)
+                    objs.append(o)
+        self.last_num_evaluated = evaluated
+        dev = tx.device
+        if not verts:
+            return TracedPaths(torch.zeros((0, order + 2, 3), device=dev), torch.zeros((0, order + 2), dtype=torch.int32, device=dev),
+                               torch.zeros(0, dtype=torch.bool, device=dev), torch.zeros((0, order), dtype=torch.int32, device=dev),
+                               self.confidence_threshold)
+        v, o = torch.cat(verts), torch.cat(objs)
+        return TracedPaths(v, o, torch.ones(o.shape[0], dtype=torch.bool, device=dev),
+                           torch.zeros((o.shape[0], order), dtype=torch.int32, device=dev), self.confidence_threshold)
+
     def num_path_candidates(self, scene, order: int) -> int:
         """Size of the pruned rank space of :meth:`trace_rank_range` (for order >= 2 it still counts the
         tuples with two equal neighbours, which are skipped while tracing)."""

@@ -492,3 +492,28 @@ def test_hybrid_rank_range_empty_sets(G):
         p = solver.trace_rank_range(scene, order)
         ref = solver.trace_path_candidates_compact(scene, solver.generate_path_candidates(scene, order)[0])
         assert p.objects.shape[0] == ref.objects.shape[0]
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("assume_quads", [False, True])
+def test_hybrid_trace_pairs_equals_exhaustive(G, goldens, two_buildings, order, assume_quads):
+    """Per-pair visibility pruning (MI355X extension) finds the valid paths of the exhaustive tracer on
+    the two-buildings scene, in the same (pair-major, lexicographic) order, with the same vertices."""
+    g = goldens["advanced_path_tracing_example"]
+    tx = np.asarray(g["tx"], np.float32) + np.array([[0, 0, 0], [3, -2, 1]], np.float32)
+    rx = np.asarray(g["rx"], np.float32) + np.array([[0, 0, 0], [-2, 1, 0.5], [4, 3, 1]], np.float32)
+    scene = _scene(G, two_buildings, tx, rx, assume_quads)
+    solver = G.HybridPathTracer(num_rays=300_000)
+    got = solver.trace_pairs(scene, order)
+    ref = scene.trace_paths(order, compact=True)
+    np.testing.assert_array_equal(_np(got.objects), _np(ref.objects))
+    np.testing.assert_array_equal(_bits(_np(got.vertices)), _bits(_np(ref.vertices)))
+    if order >= 2:
+        assert solver.last_num_evaluated < 6 * G.ExhaustivePathTracer().num_path_candidates(scene, order)
+    txg = torch.tensor(tx, device="cuda", requires_grad=True)
+    p = G.HybridPathTracer(num_rays=300_000).trace_pairs(G.Scene(txg, rx, scene.mesh), order)
+    q = G.Scene(torch.tensor(tx, device="cuda", requires_grad=True), rx, scene.mesh)
+    e = q.trace_paths(order, compact=True)
+    p.vertices.square().sum().backward()
+    e.vertices.square().sum().backward()
+    np.testing.assert_allclose(_np(txg.grad), _np(q.transmitters.grad), rtol=1e-6, atol=1e-6)
