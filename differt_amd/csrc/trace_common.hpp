@@ -29,6 +29,7 @@ struct CandSrc {
     // product mode (visibility-pruned candidate space of the hybrid tracer): position 0 draws from
     // first_map, position K-1 from last_map, the others from node_map / all nodes
     int32_t product;
+    int32_t small;  // rank_lo + count and every pw[] fit 32 bits: unrank with 32-bit divisions
     const int32_t *first_map, *last_map;
 };
 
@@ -47,23 +48,20 @@ struct TraceArgs {
 // candidate row -> K primitive ids (table value or GPU unranking of rank_lo + row):
 // c_0 = r / (n-1)^(K-1);  d_j = (r / (n-1)^(K-1-j)) mod (n-1);  c_j = d_j + (d_j >= c_{j-1})
 // which enumerates "no two equal neighbours" tuples in lexicographic order (graph.rs:400-470).
-template <int K>
-__device__ __forceinline__ void load_candidate(const CandSrc &s, int64_t row,
-                                               int32_t (&id)[KA<K>::n]) {
-    if (K == 0) return;
-    if (s.table) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) id[j] = s.table[row * K + j];
-    } else if (s.product) {
+// UInt = uint32_t when the whole window fits 32 bits (CandSrc::small): a 64-bit division costs ~100
+// instructions on gfx950, which matters when a launch holds a single (tx, rx) pair.
+template <int K, typename UInt>
+__device__ __forceinline__ void unrank_candidate(const CandSrc &s, int64_t row, int32_t (&id)[KA<K>::n]) {
+    UInt r = (UInt)(s.rank_lo + row);
+    if (s.product) {
         // plain mixed-radix product, lexicographic; a tuple with two equal neighbours is not a path of
         // the graph (no self loops, graph.rs): it becomes a padding row (id -1 -> invalid, never emitted)
-        uint64_t r = (uint64_t)(s.rank_lo + row);
         int32_t prev = -1;
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const uint64_t q = r / (uint64_t)s.pw[j];
-            r -= q * (uint64_t)s.pw[j];
+            const UInt q = r / (UInt)s.pw[j];
+            r -= q * (UInt)s.pw[j];
             const int32_t *map = (j == 0) ? s.first_map : ((j == K - 1) ? s.last_map : s.node_map);
             const int32_t v = map ? map[q] : (int32_t)q;
             bad = bad || (v == prev);
@@ -75,12 +73,11 @@ __device__ __forceinline__ void load_candidate(const CandSrc &s, int64_t row,
             for (int j = 0; j < K; ++j) id[j] = -1;
         }
     } else {
-        uint64_t r = (uint64_t)(s.rank_lo + row);
         int64_t prev = -1;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const uint64_t q = r / (uint64_t)s.pw[j];
-            r -= q * (uint64_t)s.pw[j];
+            const UInt q = r / (UInt)s.pw[j];
+            r -= q * (UInt)s.pw[j];
             int64_t c = (int64_t)q;
             if (j > 0) c += (c >= prev) ? 1 : 0;
             prev = c;
@@ -88,6 +85,20 @@ __device__ __forceinline__ void load_candidate(const CandSrc &s, int64_t row,
             if (s.node_map) v = s.node_map[c];
             id[j] = v * s.id_scale;
         }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void load_candidate(const CandSrc &s, int64_t row,
+                                               int32_t (&id)[KA<K>::n]) {
+    if (K == 0) return;
+    if (s.table) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) id[j] = s.table[row * K + j];
+    } else if (s.small) {
+        unrank_candidate<K, uint32_t>(s, row, id);
+    } else {
+        unrank_candidate<K, uint64_t>(s, row, id);
     }
 }
 
@@ -198,6 +209,14 @@ __device__ __forceinline__ void mirror_vjp_to_mesh(const float *__restrict__ mes
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+static int32_t cand_fits_32(const CandSrc &s, int order) {
+    const uint64_t lim = 0xffffffffull;
+    if ((uint64_t)s.rank_lo + (uint64_t)s.count > lim) return 0;
+    for (int j = 0; j < order; ++j)
+        if ((uint64_t)s.pw[j] > lim) return 0;
+    return 1;
+}
+
 static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc *out) {
     DRT_REQUIRE(c, "candidates is null");
     DRT_REQUIRE(c->order >= 0 && c->order <= DRT_MAX_ORDER, "order %d out of range [0, %d]",
@@ -229,6 +248,7 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
         DRT_REQUIRE((unsigned __int128)c->rank_lo + (unsigned __int128)c->num_candidates <= pw,
                     "rank window [%lld, %lld) exceeds the product space", (long long)c->rank_lo,
                     (long long)(c->rank_lo + c->num_candidates));
+        s.small = cand_fits_32(s, c->order);
         *out = s;
         return DRT_OK;
     }
@@ -248,6 +268,7 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
                     (long long)c->rank_lo, (long long)(c->rank_lo + c->num_candidates), "available");
         for (int j = 0; j < c->order; ++j)
             if (s.pw[j] == 0) s.pw[j] = 1;  // num_nodes == 1: only order 1 has a (single) candidate
+        s.small = cand_fits_32(s, c->order);
     }
     *out = s;
     return DRT_OK;
