@@ -47,6 +47,7 @@ class TraceParams(C.Structure):
 
 
 DRT_TRACE_USE_BVH = 1
+ABI_VERSION = 2  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
 
 
 class EmParams(C.Structure):
