@@ -114,7 +114,7 @@ def test_fresnel(EM, rng):
     assert abs(complex(r_p)) < 1e-7
     np.testing.assert_allclose(float(EM.refractive_index(EM.materials["Glass"].relative_permittivity(1e9))),
                                2.503997, rtol=1e-6)
-    assert float(EM.refractive_index(EM.materials["itu_vacuum" if False else "Vacuum"].relative_permittivity(1e9))) == 1.0
+    assert float(EM.refractive_index(EM.materials["itu_vacuum"].relative_permittivity(1e9))) == 1.0
 
 
 def _box_scene(G, rng, ntx=2, nrx=3):
