@@ -134,8 +134,6 @@ def first_triangle_hit_by_ray_sharded(ray_origins, ray_directions, triangle_vert
     triangles ``[index_offset, index_offset + T_block)`` of a mesh of ``total_triangles``; all ranks
     pass the same rays.  Local packed keys -> one MIN all-reduce (8 B per ray) -> decode.  The result
     (GLOBAL indices, t) equals the single-GPU operator bit for bit, ties included."""
-    import ctypes as C  # noqa: F401
-
     from . import _lib
     from ._tensors import F32_EPS, as_f32, as_u8, device, ptr, stream
 
