@@ -124,10 +124,29 @@ def pruned_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         first, last = (int(x.shape[0]) for x in solver._visible_sets(scene)[:2])
-        return {"s_per_step": dt, "valid_paths": int(nv), "same_valid_paths_as_exhaustive": int(nv) == int(expected_valid),
-                "visible_first": first, "visible_last": last,
-                "pruned_candidates_per_pair": solver.num_path_candidates(scene, order),
-                "note": "includes the visibility estimation (80 viewpoints x 1e6 rays on the LBVH)"}
+        out = {"s_per_step": dt, "valid_paths": int(nv), "same_valid_paths_as_exhaustive": int(nv) == int(expected_valid),
+               "visible_first": first, "visible_last": last,
+               "pruned_candidates_per_pair": solver.num_path_candidates(scene, order),
+               "note": "includes the visibility estimation (80 viewpoints x 1e6 rays on the LBVH)"}
+
+        # extension: pruning per (tx, rx) pair, all pairs in one ragged launch (HybridPathTracer.trace_pairs)
+        def pstep():
+            txg = torch.tensor(tx, device="cuda", requires_grad=True)
+            scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
+            paths = solver.trace_pairs(scene, order)
+            torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+            return paths.objects.shape[0]
+
+        pstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        npp = pstep()
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0
+        out["per_pair"] = {"s_per_step": dtp, "valid_paths": int(npp), "valid_paths_per_s": npp / dtp,
+                           "same_valid_paths_as_exhaustive": int(npp) == int(expected_valid),
+                           "candidate_evals_per_step": int(solver.last_num_evaluated)}
+        return out
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}
 

@@ -47,7 +47,7 @@ class TraceParams(C.Structure):
 
 
 DRT_TRACE_USE_BVH = 1
-ABI_VERSION = 2  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
+ABI_VERSION = 3  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
 
 
 class EmParams(C.Structure):
@@ -73,6 +73,9 @@ class Candidates(C.Structure):
         ("num_first", C.c_int64),
         ("last_map", C.c_void_p),
         ("num_last", C.c_int64),
+        ("pair_offsets", C.c_void_p),
+        ("first_offsets", C.c_void_p),
+        ("last_offsets", C.c_void_p),
     ]
 
 

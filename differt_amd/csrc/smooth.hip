@@ -560,6 +560,7 @@ int32_t drt_trace_paths_dense_smooth(drt_mesh_t mesh, const drt_trace_params *pr
     CandSrc cs;
     int32_t rc = make_cand_src(cands, quads ? 2 : 1, &cs);
     if (rc != DRT_OK) return rc;
+    DRT_REQUIRE(!cs.ragged, "ragged pair spaces have no dense layout");
     const TraceArgs a = make_args(mesh, pr, tx, ntx, rx, nrx);
     const int64_t total = ntx * nrx * cs.count;
     if (total == 0) return DRT_OK;
@@ -592,6 +593,7 @@ int32_t drt_trace_paths_dense_smooth_vjp(drt_mesh_t mesh, const drt_trace_params
     CandSrc cs;
     int32_t rc = make_cand_src(cands, quads ? 2 : 1, &cs);
     if (rc != DRT_OK) return rc;
+    DRT_REQUIRE(!cs.ragged, "ragged pair spaces have no dense layout");
     const TraceArgs a = make_args(mesh, pr, tx, ntx, rx, nrx);
     const int64_t total = ntx * nrx * cs.count;
     if (total == 0 || (!vertices_cotangent && !mask_cotangent)) return DRT_OK;

@@ -160,6 +160,60 @@ __global__ __launch_bounds__(256) void trace_filter_kernel(
     }
 }
 
+// Stage A for RAGGED per-pair candidate spaces (CandSrc::ragged): one lane per (pair, candidate) row of
+// the concatenated spaces -- no (tx, rx) loops, the pair comes out of the row index.  Same checks, same
+// arithmetic (image_chain is the guarded form the fast path above is identical to).
+template <int K, bool QUADS>
+__global__ __launch_bounds__(256) void trace_filter_ragged_kernel(TraceArgs a, CandSrc cs,
+                                                                  unsigned long long *__restrict__ q_count,
+                                                                  long long *__restrict__ queue, int64_t q_cap) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t g0 = (int64_t)blockIdx.x * 256; g0 < cs.count; g0 += (int64_t)gridDim.x * 256) {
+        const int64_t g = g0 + threadIdx.x;
+        const bool in_range = g < cs.count;
+        int64_t it = 0, ir = 0;
+        int32_t id[KA<K>::n];
+        ragged_decode<K>(cs, a.nrx, in_range ? g : 0, it, ir, id);
+        Mirrors<K, QUADS> m;
+        load_mirrors<K, QUADS>(a, id, m);
+        V3 full[K + 2];
+        full[0] = ld3(a.tx + 3 * it);
+        full[K + 1] = ld3(a.rx + 3 * ir);
+        if constexpr (K > 0) {
+            V3 path[KA<K>::n];
+            image_chain<KA<K>::n>(full[0], full[K + 1], m.p, m.n, path);
+#pragma unroll
+            for (int j = 0; j < K; ++j) full[j + 1] = path[j];
+        }
+        bool alive = in_range && m.ok && m.active;
+        if (K > 0) alive = alive && inside_one<K, QUADS>(m, full, K - 1, a.eps);
+        if (__any(alive)) {
+            alive = alive && path_finite<K>(full);
+#pragma unroll
+            for (int j = K - 2; j >= 0; --j) alive = alive && inside_one<K, QUADS>(m, full, j, a.eps);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                alive = alive && same_sign(dot(full[j] - m.p[j], m.n[j]), dot(full[j + 2] - m.p[j], m.n[j]));
+#pragma unroll
+            for (int sgm = 0; sgm <= K; ++sgm) {
+                const V3 d = full[sgm + 1] - full[sgm];
+                alive = alive && !(dot(d, d) < a.min_len);
+            }
+        }
+        const unsigned long long vote = __ballot(alive);
+        if (vote) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(q_count, (unsigned long long)__popcll(vote));
+            base = __shfl(base, 0, 64);
+            if (alive) {
+                const unsigned long long below = vote & ((1ull << lane) - 1ull);
+                const unsigned long long slot = base + (unsigned long long)__popcll(below);
+                if ((int64_t)slot < q_cap) queue[slot] = g;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // path reconstruction from a flat key (stage B, emit, vjp)
 // ------------------------------------------------------------------------------------------
@@ -362,6 +416,15 @@ static void filter_grid(const Launch &L, dim3 *grid, int64_t *tx_per_block) {
 template <int K, bool QUADS, bool DENSE>
 static void launch_filter(const Launch &L, unsigned long long *qc, long long *q, int64_t qcap,
                           float *dv, int32_t *dob, uint8_t *dm) {
+    if (L.cs.ragged) {
+        if constexpr (!DENSE && K >= 2) {
+            int64_t bx = ceil_div(L.cs.count, 256);
+            if (bx > 256 * 32) bx = 256 * 32;
+            hipLaunchKernelGGL((trace_filter_ragged_kernel<K, QUADS>), dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0,
+                               L.s, L.a, L.cs, qc, q, qcap);
+        }
+        return;
+    }
     dim3 grid;
     int64_t tpb;
     filter_grid(L, &grid, &tpb);
@@ -437,6 +500,7 @@ int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *pr, const
     L.quads = mesh->assume_quads != 0;
     int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
     if (rc != DRT_OK) return rc;
+    DRT_REQUIRE(!L.cs.ragged, "ragged pair spaces have no dense layout: use drt_trace_paths_compact");
     L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
     if ((pr->flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0) {
         rc = drt_mesh_build_bvh(mesh, stream);
@@ -492,8 +556,10 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
         if (rc != DRT_OK) return rc;
         L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
     }
-    const unsigned __int128 total = (unsigned __int128)ntx * (unsigned __int128)nrx *
-                                    (unsigned __int128)L.cs.count;
+    L.cs.npairs = ntx * nrx;
+    const unsigned __int128 total = L.cs.ragged ? (unsigned __int128)L.cs.count
+                                                : (unsigned __int128)ntx * (unsigned __int128)nrx *
+                                                      (unsigned __int128)L.cs.count;
     if (total == 0) return DRT_OK;
     DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx*rx*candidates does not fit a 62-bit key");
     DRT_REQUIRE(tx && rx, "null pointer");
@@ -560,6 +626,7 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t ntx, const
     L.quads = mesh->assume_quads != 0;
     int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
     if (rc != DRT_OK) return rc;
+    L.cs.npairs = ntx * nrx;
     L.a = make_args(mesh, nullptr, tx, ntx, rx, nrx);
     const int k = cands->order;
 #define CALL(K)                                                                                  \

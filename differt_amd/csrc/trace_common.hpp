@@ -31,6 +31,10 @@ struct CandSrc {
     int32_t product;
     int32_t small;  // rank_lo + count and every pw[] fit 32 bits: unrank with 32-bit divisions
     const int32_t *first_map, *last_map;
+    // ragged mode: one row space per (tx, rx) pair, concatenated (pair_offsets = prefix sums)
+    int32_t ragged;
+    int64_t npairs, mid_pw;  // mid_pw = num_nodes^(K-2)
+    const int64_t *pair_offsets, *first_off, *last_off;
 };
 
 struct TraceArgs {
@@ -142,15 +146,67 @@ __device__ __forceinline__ bool path_finite(const V3 (&full)[K + 2]) {
     return fin;
 }
 
+// ragged mode: global row g -> (tx, rx) by binary search in the prefix sums, then the mixed-radix digits
+// of the local rank over F_tx x N^(K-2) x L_rx (last digit fastest = lexicographic order)
+template <int K, typename UInt>
+__device__ __forceinline__ void ragged_digits(const CandSrc &s, int64_t local, int64_t it, int64_t ir,
+                                              int32_t (&id)[KA<K>::n]) {
+    const int32_t *F = s.first_map + s.first_off[it];
+    const int32_t *L = s.last_map + s.last_off[ir];
+    const UInt nL = (UInt)(s.last_off[ir + 1] - s.last_off[ir]);
+    const UInt nN = (UInt)s.num_nodes;
+    UInt r = (UInt)local;
+    int32_t dig[KA<K>::n];
+    {
+        const UInt q = r / nL;
+        dig[K - 1] = L[r - q * nL];
+        r = q;
+    }
+#pragma unroll
+    for (int j = K - 2; j >= 1; --j) {
+        const UInt q = r / nN;
+        const UInt d = r - q * nN;
+        dig[j] = s.node_map ? s.node_map[d] : (int32_t)d;
+        r = q;
+    }
+    dig[0] = F[r];
+    bool bad = false;
+#pragma unroll
+    for (int j = 1; j < K; ++j) bad = bad || (dig[j] == dig[j - 1]);
+#pragma unroll
+    for (int j = 0; j < K; ++j) id[j] = bad ? -1 : dig[j] * s.id_scale;
+}
+
+template <int K>
+__device__ __forceinline__ void ragged_decode(const CandSrc &s, int64_t nrx, int64_t g, int64_t &it,
+                                              int64_t &ir, int32_t (&id)[KA<K>::n]) {
+    int64_t lo = 0, hi = s.npairs;  // largest lo with pair_offsets[lo] <= g
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (s.pair_offsets[mid] <= g) lo = mid; else hi = mid;
+    }
+    it = lo / nrx;
+    ir = lo - it * nrx;
+    const int64_t local = g - s.pair_offsets[lo];
+    if constexpr (K >= 2) {
+        if (s.small) ragged_digits<K, uint32_t>(s, local, it, ir, id);
+        else ragged_digits<K, uint64_t>(s, local, it, ir, id);
+    }
+}
+
 template <int K>
 __device__ __forceinline__ bool key_to_path(const TraceArgs &a, const CandSrc &cs, int64_t flat,
                                             int64_t &it, int64_t &ir, int32_t (&id)[KA<K>::n],
                                             V3 (&p)[KA<K>::n], V3 (&n)[KA<K>::n], V3 (&full)[K + 2]) {
-    const int64_t pair = flat / cs.count;
-    const int64_t row = flat - pair * cs.count;
-    it = pair / a.nrx;
-    ir = pair - it * a.nrx;
-    load_candidate<K>(cs, row, id);
+    if (cs.ragged) {
+        ragged_decode<K>(cs, a.nrx, flat, it, ir, id);
+    } else {
+        const int64_t pair = flat / cs.count;
+        const int64_t row = flat - pair * cs.count;
+        it = pair / a.nrx;
+        ir = pair - it * a.nrx;
+        load_candidate<K>(cs, row, id);
+    }
     bool ok = (flat >= 0) && (it < a.ntx);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -230,6 +286,24 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
     s.node_map = c->node_map;
     s.id_scale = id_scale;
     for (int j = 0; j < DRT_MAX_ORDER; ++j) s.pw[j] = 1;
+    if (!c->table && c->pair_offsets) {
+        DRT_REQUIRE(c->order >= 2, "ragged pair spaces need order >= 2");
+        DRT_REQUIRE(c->first_offsets && c->last_offsets && c->rank_lo == 0 && c->num_nodes >= 0,
+                    "bad ragged candidate space");
+        DRT_REQUIRE((c->first_map && c->last_map) || c->num_candidates == 0, "null id arrays");
+        s.ragged = 1;
+        s.product = 1;
+        s.first_map = c->first_map;
+        s.last_map = c->last_map;
+        s.pair_offsets = c->pair_offsets;
+        s.first_off = c->first_offsets;
+        s.last_off = c->last_offsets;
+        s.small = c->reserved & 1;
+        s.mid_pw = 1;
+        for (int j = 0; j < c->order - 2; ++j) s.mid_pw *= c->num_nodes;
+        *out = s;
+        return DRT_OK;
+    }
     if (!c->table && (c->first_map || c->last_map || c->num_first > 0 || c->num_last > 0)) {
         // product mode: F x N^(order-2) x L
         DRT_REQUIRE(c->order >= 2, "the pruned product space needs order >= 2 (order 1: pass the intersection as node_map)");

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRT_ABI_VERSION 2
+#define DRT_ABI_VERSION 3
 
 enum {
     DRT_OK = 0,
@@ -298,6 +298,18 @@ typedef struct drt_candidates {
     int64_t num_first;
     const int32_t *last_map;
     int64_t num_last;
+    /* RAGGED per-pair product spaces -- ONE launch for all (tx, rx) pairs, pair (i, j) having its own
+     * first / last sets (drt_trace_paths_compact / _vjp only, order >= 2), selected by pair_offsets != NULL:
+     *   first_map / last_map       CSR id arrays (device), rows delimited by
+     *   first_offsets[num_tx + 1] / last_offsets[num_rx + 1]   (device int64)
+     *   pair_offsets[num_tx * num_rx + 1]   device int64 prefix sums of the pair space sizes
+     *                                       F_i * num_nodes^(order-2) * L_j
+     *   num_candidates = pair_offsets[num_tx * num_rx] (total rows); rank_lo must be 0;
+     *   reserved bit 0 = every pair space is < 2^32 rows (32-bit unranking).
+     * Keys returned by the compact tracer are then GLOBAL ragged row indices (pair-major). */
+    const int64_t *pair_offsets;
+    const int64_t *first_offsets;
+    const int64_t *last_offsets;
 } drt_candidates;
 
 /* Dense reference layout for every (tx, rx, candidate):

@@ -31,7 +31,7 @@ static T *to_device(const std::vector<T> &h) {
     return d;
 }
 
-static_assert(sizeof(drt_trace_params) == 16 && sizeof(drt_candidates) == 80 && sizeof(drt_em_params) == 40,
+static_assert(sizeof(drt_trace_params) == 16 && sizeof(drt_candidates) == 104 && sizeof(drt_em_params) == 40,
               "struct layouts the ctypes binding (differt_amd/_lib.py) relies on");
 
 int main() {

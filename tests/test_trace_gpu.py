@@ -504,10 +504,16 @@ def test_hybrid_trace_pairs_equals_exhaustive(G, goldens, two_buildings, order, 
     rx = np.asarray(g["rx"], np.float32) + np.array([[0, 0, 0], [-2, 1, 0.5], [4, 3, 1]], np.float32)
     scene = _scene(G, two_buildings, tx, rx, assume_quads)
     solver = G.HybridPathTracer(num_rays=300_000)
-    got = solver.trace_pairs(scene, order)
+    got = solver.trace_pairs(scene, order)  # one ragged launch for all pairs
     ref = scene.trace_paths(order, compact=True)
     np.testing.assert_array_equal(_np(got.objects), _np(ref.objects))
     np.testing.assert_array_equal(_bits(_np(got.vertices)), _bits(_np(ref.vertices)))
+    loop = G.HybridPathTracer(num_rays=300_000, ragged_max_pair_size=0).trace_pairs(scene, order)  # one launch per pair
+    np.testing.assert_array_equal(_np(loop.objects), _np(ref.objects))
+    np.testing.assert_array_equal(_bits(_np(loop.vertices)), _bits(_np(ref.vertices)))
+    if order >= 2:  # keys of the ragged launch are global rows of the concatenated pair spaces, ascending
+        k = _np(got.keys)
+        assert (np.diff(k) > 0).all() and k.max() < solver.last_num_evaluated
     if order >= 2:
         assert solver.last_num_evaluated < 6 * G.ExhaustivePathTracer().num_path_candidates(scene, order)
     txg = torch.tensor(tx, device="cuda", requires_grad=True)
