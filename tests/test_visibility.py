@@ -72,6 +72,28 @@ def test_oracle_lattice_properties():
     assert len(np.unique(np.round(big[:, 2], 5))) > 5000
 
 
+def _frustum_known_answers():
+    """The four hand-made cases of differt/tests/geometry/test_utils.py:297-378:
+    (viewer, world vertices, check(a_min, a_max))."""
+    a3 = np.array([0.6, 0.7, 0.8])
+    a1, a2 = np.pi - 0.15, -np.pi + 0.15
+    a8 = np.linspace(-np.pi, np.pi, 8, endpoint=False)
+    ring = lambda a: np.stack([np.cos(a), np.sin(a), np.zeros_like(a)], axis=-1)  # noqa: E731
+    corridor = [[0, 2, 0], [10, 2, 0], [0, 2, 3], [10, 2, 3], [0, -2, 0], [10, -2, 0], [0, -2, 3], [10, -2, 3]]
+    return [
+        ([0, 0, 0], ring(a3), lambda lo, hi: hi - lo < np.pi and abs(lo - 0.6) < 0.05 and abs(hi - 0.8) < 0.05),
+        ([0, 0, 0], ring(np.array([a1, a2])), lambda lo, hi: hi - lo < np.pi),  # straddles +-pi: [0, 2 pi) domain
+        ([0, 0, 0], ring(a8), lambda lo, hi: abs(lo + np.pi) < 1e-5 and abs(hi - np.pi) < 1e-5),  # surrounded
+        ([5, 0, 1.5], np.array(corridor, float), lambda lo, hi: hi - lo >= 1.9 * np.pi),
+    ]
+
+
+def test_oracle_viewing_frustum_known_answers():
+    for viewer, verts, check in _frustum_known_answers():
+        fr = orc.viewing_frustum(np.asarray(viewer, np.float32), np.asarray(verts, np.float32))
+        assert fr.shape == (2, 3) and check(float(fr[0, 2]), float(fr[1, 2])), fr
+
+
 # ---------------------------------------------------------------------------- GPU ----
 gpu = pytest.mark.gpu
 
@@ -85,6 +107,25 @@ def G():
 
 def _np(x):
     return x.detach().cpu().numpy()
+
+
+@gpu
+def test_gpu_viewing_frustum_known_answers(G):
+    """test_utils.py:297-378 through drt_viewing_frustum_points (frustum of arbitrary world points)."""
+    import torch
+
+    from differt_amd import _lib
+    from differt_amd._tensors import ptr, stream
+
+    for viewer, verts, check in _frustum_known_answers():
+        v = torch.tensor(np.asarray(viewer, np.float32)[None], device="cuda")
+        w = torch.tensor(np.asarray(verts, np.float32), device="cuda").contiguous()
+        out = torch.empty((1, 2, 3), dtype=torch.float32, device="cuda")
+        _lib.call("drt_viewing_frustum_points", ptr(v), 1, ptr(w), w.shape[0], ptr(out), stream())
+        got = _np(out)[0]
+        assert check(float(got[0, 2]), float(got[1, 2])), got
+        np.testing.assert_allclose(got, orc.viewing_frustum(np.asarray(viewer, np.float32), np.asarray(verts, np.float32)),
+                                   atol=5e-6)
 
 
 @gpu
