@@ -129,6 +129,28 @@ def test_gpu_viewing_frustum_known_answers(G):
 
 
 @gpu
+def test_gpu_fibonacci_lattice_properties(G):
+    """differt/tests/geometry/test_utils.py:381-436: unit length, both hemispheres, frustum bounds, and no
+    azimuth "hatching" in the tail of a 1e7-point lattice (the split-modulus trick of :426-462)."""
+    for n in (1, 10, 1000):
+        pts = _np(G.fibonacci_lattice(n))
+        assert pts.shape == (n, 3)
+        np.testing.assert_allclose(np.linalg.norm(pts, axis=-1), 1.0, atol=1e-5)
+    pts = _np(G.fibonacci_lattice(1000))
+    assert (pts[:, 2] > 0).any() and (pts[:, 2] < 0).any()
+    fr = np.array([[0.0, np.pi / 4, 0.1], [1.0, np.pi / 2, 0.9]], np.float32)
+    sph = _np(G.cartesian_to_spherical(G.fibonacci_lattice(500, frustum=fr)))
+    assert sph.shape == (500, 3)
+    assert (sph[:, 1] >= np.pi / 4 - 1e-4).all() and (sph[:, 1] <= np.pi / 2 + 1e-4).all()
+    assert (sph[:, 2] >= 0.1 - 1e-4).all() and (sph[:, 2] <= 0.9 + 1e-4).all()
+    n = 10_000_000
+    i = np.arange(n - 10_000, n, dtype=np.float32)
+    assert len(np.unique((i * np.float32(0.6180339887498949)) % np.float32(1.0))) < 1000  # the naive form collapses
+    tail = np.round(_np(G.fibonacci_lattice(n)[-10_000:]), 4)
+    assert len(np.unique(tail, axis=0)) > 5000
+
+
+@gpu
 def test_gpu_spherical_conversions(G):
     """geometry/_utils.py:930-993 (round trip and the zero vector), vs the oracle."""
     rng = np.random.default_rng(4)
