@@ -146,6 +146,24 @@ def pruned_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:
         out["per_pair"] = {"s_per_step": dtp, "valid_paths": int(npp), "valid_paths_per_s": npp / dtp,
                            "same_valid_paths_as_exhaustive": int(npp) == int(expected_valid),
                            "candidate_evals_per_step": int(solver.last_num_evaluated)}
+        # the same step with the visibility estimate reused (end points that move little between steps)
+        vis = solver.estimate_visibility(G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh))
+
+        def cstep():
+            txg = torch.tensor(tx, device="cuda", requires_grad=True)
+            scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
+            paths = solver.trace_pairs(scene, order, visibility=vis)
+            torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+            return paths.objects.shape[0]
+
+        cstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ncp = cstep()
+        torch.cuda.synchronize()
+        out["per_pair"]["s_per_step_cached_visibility"] = (time.perf_counter() - t0) / 5
+        out["per_pair"]["valid_paths_cached_visibility"] = int(ncp)
         return out
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}

@@ -481,22 +481,32 @@ class HybridPathTracer(ExhaustivePathTracer):
 
         return ids(vis_tx), ids(vis_rx), middle, (vis_tx & vis_rx)
 
-    def trace_pairs(self, scene, order: int, *, max_survivors: int = 1 << 20,
-                    max_paths: int = 1 << 14) -> TracedPaths:
+    def estimate_visibility(self, scene) -> tuple[torch.Tensor, torch.Tensor]:
+        """``(bool[num_tx, T], bool[num_rx, T])``: triangles seen from every transmitter / receiver
+        (``num_rays`` lattice rays each, first hit on the LBVH).  Reusable across :meth:`trace_pairs` calls
+        while the end points move little (e.g. the steps of a gradient descent on TX positions)."""
+        mesh = scene.mesh
+        tx = scene.transmitters.reshape(-1, 3)
+        rx = scene.receivers.reshape(-1, 3)
+        return (mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel),
+                mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel))
+
+    def trace_pairs(self, scene, order: int, *, visibility: tuple[torch.Tensor, torch.Tensor] | None = None,
+                    max_survivors: int = 1 << 20, max_paths: int = 1 << 14) -> TracedPaths:
         """MI355X extension: visibility pruning PER (transmitter, receiver) pair instead of merged over
         all of them (the reference merges, _solvers.py:969-973, which prunes little once there are many
         end points): pair (i, j) traces ``F_i x N^(order-2) x L_j`` -- first interaction visible from
         transmitter i, last one from receiver j -- all pairs in ONE launch over the concatenated (ragged) spaces.  Returns the valid
         paths of all pairs (pair-major, lexicographic inside a pair = ``masked_vertices`` order of the
         exhaustive tracer), differentiable like any compact trace.  Finds a subset of the exhaustive
-        tracer's valid paths that is complete up to the sampling of the visibility estimate."""
+        tracer's valid paths that is complete up to the sampling of the visibility estimate;
+        ``visibility`` takes a cached :meth:`estimate_visibility` result."""
         if order < 2:
             return self.trace_rank_range(scene, order, max_survivors=max_survivors, max_paths=max_paths)
         mesh = scene.mesh
         tx = scene.transmitters.reshape(-1, 3)
         rx = scene.receivers.reshape(-1, 3)
-        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel)
-        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel)
+        vis_tx, vis_rx = self.estimate_visibility(scene) if visibility is None else visibility
         if mesh.assume_quads:
             vis_tx = vis_tx.reshape(vis_tx.shape[0], -1, 2).any(dim=-1)
             vis_rx = vis_rx.reshape(vis_rx.shape[0], -1, 2).any(dim=-1)

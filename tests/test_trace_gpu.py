@@ -511,6 +511,8 @@ def test_hybrid_trace_pairs_equals_exhaustive(G, goldens, two_buildings, order, 
     loop = G.HybridPathTracer(num_rays=300_000, ragged_max_pair_size=0).trace_pairs(scene, order)  # one launch per pair
     np.testing.assert_array_equal(_np(loop.objects), _np(ref.objects))
     np.testing.assert_array_equal(_bits(_np(loop.vertices)), _bits(_np(ref.vertices)))
+    cached = solver.trace_pairs(scene, order, visibility=solver.estimate_visibility(scene))
+    assert torch.equal(cached.objects, got.objects) and torch.equal(cached.vertices, got.vertices)
     if order >= 2:  # keys of the ragged launch are global rows of the concatenated pair spaces, ascending
         k = _np(got.keys)
         assert (np.diff(k) > 0).all() and k.max() < solver.last_num_evaluated
