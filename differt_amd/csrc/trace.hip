@@ -214,6 +214,110 @@ __global__ __launch_bounds__(256) void trace_filter_ragged_kernel(TraceArgs a, C
     }
 }
 
+// Stage A for ragged per-pair spaces of order >= 3 with LARGE pair spaces: lane = PREFIX (the first K-1
+// interactions of transmitter blockIdx.y: F_tx x N^(K-2) rows), inner loops over the receivers and over
+// each receiver's visible last interactions.  The unranking, the K-1 mirror gathers and the forward images
+// are paid once per prefix instead of once per candidate, the last mirror is wave-uniform (scalar loads).
+// Emits the same keys as trace_filter_ragged_kernel (global ragged rows), same arithmetic.
+template <int K, bool QUADS>
+__global__ __launch_bounds__(256) void trace_filter_prefix_kernel(TraceArgs a, CandSrc cs,
+                                                                  unsigned long long *__restrict__ q_count,
+                                                                  long long *__restrict__ queue, int64_t q_cap) {
+    static_assert(K >= 2, "prefix kernel needs at least two interactions");
+    const int lane = threadIdx.x & 63;
+    const int64_t it = blockIdx.y;
+    const int32_t *F = cs.first_map + cs.first_off[it];
+    const int64_t nF = cs.first_off[it + 1] - cs.first_off[it];
+    const int64_t nN = cs.num_nodes;
+    const int64_t prefixes = nF * cs.mid_pw;
+    const V3 tx = ld3(a.tx + 3 * it);
+    for (int64_t row0 = (int64_t)blockIdx.x * 256; row0 < prefixes; row0 += (int64_t)gridDim.x * 256) {
+        const int64_t row = row0 + threadIdx.x;
+        const bool in_range = row < prefixes;
+        // prefix digits, most significant first: f, then K-2 middle digits base N
+        int32_t id[KA<K>::n];
+        bool bad = false;
+        {
+            uint64_t r = (uint64_t)(in_range ? row : 0);
+            int32_t dig[KA<K>::n];
+#pragma unroll
+            for (int j = K - 2; j >= 1; --j) {
+                const uint64_t q = r / (uint64_t)nN;
+                const uint64_t d = r - q * (uint64_t)nN;
+                dig[j] = cs.node_map ? cs.node_map[d] : (int32_t)d;
+                r = q;
+            }
+            dig[0] = F[nF > 0 ? r : 0];
+#pragma unroll
+            for (int j = 1; j <= K - 2; ++j) bad = bad || (dig[j] == dig[j - 1]);
+#pragma unroll
+            for (int j = 0; j <= K - 2; ++j) id[j] = dig[j] * cs.id_scale;
+        }
+        Mirrors<K, QUADS> m;
+        bool prefix_ok = in_range && !bad, prefix_active = true;
+#pragma unroll
+        for (int j = 0; j <= K - 2; ++j) prefix_ok = load_one_mirror<K, QUADS>(a, id[j], j, m, prefix_active) && prefix_ok;
+        V3 img[KA<K>::n];
+        {
+            V3 prev = tx;
+#pragma unroll
+            for (int j = 0; j <= K - 2; ++j) {
+                img[j] = image_of_vertex(prev, m.p[j], m.n[j]);
+                prev = img[j];
+            }
+        }
+        for (int64_t ir = 0; ir < a.nrx; ++ir) {
+            const V3 rx = ld3(a.rx + 3 * ir);
+            const int32_t *L = cs.last_map + cs.last_off[ir];
+            const int64_t nL = cs.last_off[ir + 1] - cs.last_off[ir];
+            const int64_t key0 = cs.pair_offsets[it * a.nrx + ir] + row * nL;
+            for (int64_t l = 0; l < nL; ++l) {
+                const int32_t last = L[l];  // wave-uniform
+                id[K - 1] = last * cs.id_scale;
+                bool active = prefix_active;
+                const bool last_ok = load_one_mirror<K, QUADS>(a, id[K - 1], K - 1, m, active);
+                img[K - 1] = image_of_vertex(img[K - 2], m.p[K - 1], m.n[K - 1]);
+                V3 full[K + 2];
+                full[0] = tx;
+                full[K + 1] = rx;
+                V3 cur = rx;
+#pragma unroll
+                for (int j = K - 1; j >= 0; --j) {
+                    cur = backward_step(cur, img[j], m.p[j], m.n[j]);
+                    full[j + 1] = cur;
+                }
+                bool alive = prefix_ok && last_ok && active && (id[K - 1] != id[K - 2]);
+                alive = alive && inside_one<K, QUADS>(m, full, K - 1, a.eps);
+                if (__any(alive)) {
+                    alive = alive && path_finite<K>(full);
+#pragma unroll
+                    for (int j = K - 2; j >= 0; --j) alive = alive && inside_one<K, QUADS>(m, full, j, a.eps);
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+                        alive = alive &&
+                                same_sign(dot(full[j] - m.p[j], m.n[j]), dot(full[j + 2] - m.p[j], m.n[j]));
+#pragma unroll
+                    for (int sgm = 0; sgm <= K; ++sgm) {
+                        const V3 d = full[sgm + 1] - full[sgm];
+                        alive = alive && !(dot(d, d) < a.min_len);
+                    }
+                }
+                const unsigned long long vote = __ballot(alive);
+                if (vote) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(q_count, (unsigned long long)__popcll(vote));
+                    base = __shfl(base, 0, 64);
+                    if (alive) {
+                        const unsigned long long below = vote & ((1ull << lane) - 1ull);
+                        const unsigned long long slot = base + (unsigned long long)__popcll(below);
+                        if ((int64_t)slot < q_cap) queue[slot] = key0 + l;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // path reconstruction from a flat key (stage B, emit, vjp)
 // ------------------------------------------------------------------------------------------
@@ -417,6 +521,16 @@ template <int K, bool QUADS, bool DENSE>
 static void launch_filter(const Launch &L, unsigned long long *qc, long long *q, int64_t qcap,
                           float *dv, int32_t *dob, uint8_t *dm) {
     if (L.cs.ragged) {
+        if constexpr (!DENSE && K >= 3) {
+            if (L.cs.prefix_kernel) {
+                // rows per transmitter = F_tx * N^(K-2) <= num_first_max * mid_pw: size the grid for the largest
+                int64_t bx = ceil_div(L.cs.max_prefixes, 256);
+                if (bx > 256 * 16) bx = 256 * 16;
+                hipLaunchKernelGGL((trace_filter_prefix_kernel<K, QUADS>), dim3((unsigned)(bx < 1 ? 1 : bx), (unsigned)L.a.ntx),
+                                   dim3(256), 0, L.s, L.a, L.cs, qc, q, qcap);
+                return;
+            }
+        }
         if constexpr (!DENSE && K >= 2) {
             int64_t bx = ceil_div(L.cs.count, 256);
             if (bx > 256 * 32) bx = 256 * 32;

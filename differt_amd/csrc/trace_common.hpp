@@ -33,6 +33,8 @@ struct CandSrc {
     const int32_t *first_map, *last_map;
     // ragged mode: one row space per (tx, rx) pair, concatenated (pair_offsets = prefix sums)
     int32_t ragged;
+    int32_t prefix_kernel;   // stage A: lane = prefix (first K-1 interactions), see trace_filter_prefix_kernel
+    int64_t max_prefixes;    // max over transmitters of F_tx * num_nodes^(K-2) (grid sizing)
     int64_t npairs, mid_pw;  // mid_pw = num_nodes^(K-2)
     const int64_t *pair_offsets, *first_off, *last_off;
 };
@@ -135,6 +137,23 @@ __device__ __forceinline__ void load_mirrors(const TraceArgs &a, const int32_t (
             if (QUADS) m.active = m.active && (a.mask[s + 1] != 0);
         }
     }
+}
+
+// one mirror of a candidate (slot j); returns whether its id is in range, updates the active flag
+template <int K, bool QUADS>
+__device__ __forceinline__ bool load_one_mirror(const TraceArgs &a, int64_t i, int j, Mirrors<K, QUADS> &m,
+                                                bool &active) {
+    const bool ok = (i >= 0) && (i + (QUADS ? 1 : 0) < a.T);
+    const int64_t s = ok ? i : 0;
+    m.tri[j] = load_tri(a.tri_verts + 9 * s);
+    m.p[j] = m.tri[j].v0;
+    m.n[j] = ld3(a.normals + 3 * s);
+    if (QUADS) m.tri2[j] = load_tri(a.tri_verts + 9 * (s + 1));
+    if (a.mask) {
+        active = active && (a.mask[s] != 0);
+        if (QUADS) active = active && (a.mask[s + 1] != 0);
+    }
+    return ok;
 }
 
 template <int K>
@@ -299,8 +318,10 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
         s.first_off = c->first_offsets;
         s.last_off = c->last_offsets;
         s.small = c->reserved & 1;
+        s.prefix_kernel = (c->reserved & 2) ? 1 : 0;
         s.mid_pw = 1;
         for (int j = 0; j < c->order - 2; ++j) s.mid_pw *= c->num_nodes;
+        s.max_prefixes = c->num_first * s.mid_pw;  // ragged mode: num_first = the largest per-transmitter set
         *out = s;
         return DRT_OK;
     }

@@ -73,7 +73,8 @@ def _rank_candidates(order: int, rank_lo: int, count: int, num_nodes: int,
         c.pair_offsets = ragged["pair_offsets"].data_ptr()
         c.first_offsets = ragged["first_offsets"].data_ptr()
         c.last_offsets = ragged["last_offsets"].data_ptr()
-        c.reserved = 1 if ragged["small"] else 0
+        c.reserved = (1 if ragged["small"] else 0) | (2 if ragged.get("prefix") else 0)
+        c.num_first = ragged["max_first"]  # grid sizing of the prefix kernel
     return c
 
 
@@ -433,7 +434,12 @@ class HybridPathTracer(ExhaustivePathTracer):
 
     num_rays: int = int(1e6)
     ragged_max_pair_size: float = 2e7
-    """:meth:`trace_pairs`: mean rows per pair above which one launch per pair replaces the single ragged launch."""
+    """:meth:`trace_pairs`, ``pairs_strategy="auto"``: mean rows per pair above which (order >= 3) the prefix
+    kernel replaces the plain ragged launch."""
+    pairs_strategy: str = "auto"
+    """``"auto"``, ``"ragged"`` (one lane per (pair, candidate) row), ``"prefix"`` (order >= 3: one lane per
+    first ``order - 1`` interactions, inner loops over receivers and last interactions) or ``"loop"`` (one
+    product-space launch per pair)."""
 
     def _graph(self, scene):
         mesh = scene.mesh
@@ -533,12 +539,20 @@ class HybridPathTracer(ExhaustivePathTracer):
         pair_off[1:] = torch.cumsum(sizes, 0)
         total = int(pair_off[-1].item())
         self.last_num_evaluated = total
-        if sizes.numel() and total / sizes.numel() > self.ragged_max_pair_size:
-            # huge pair spaces: one launch per pair keeps the set sizes / end points wave-uniform (scalar
-            # loads, uniform divisors); measured on configs[3] order 3 (1e9 rows per pair): 10.6 s vs 14.2 s
+        strategy = self.pairs_strategy
+        if strategy == "auto":
+            # huge pair spaces (configs[3] order 3: 1e9 rows per pair): amortise the unranking, the mirror
+            # gathers and the forward images over the receivers and their last interactions (prefix kernel:
+            # measured 14.2 s for the plain ragged launch, 10.6 s for one launch per pair)
+            large = sizes.numel() and total / sizes.numel() > self.ragged_max_pair_size
+            strategy = "prefix" if (large and order >= 3) else "ragged"
+        if strategy == "loop":
             return self._trace_pairs_loop(scene, order, vis_tx, vis_rx, middle, n, max_survivors, max_paths)
+        if strategy not in ("ragged", "prefix"):
+            raise ValueError(f"unknown pairs_strategy {self.pairs_strategy!r}")
         ragged = {"pair_offsets": pair_off, "first_offsets": first_off, "last_offsets": last_off,
-                  "small": bool(sizes.numel() == 0 or int(sizes.max().item()) < 2**32)}
+                  "small": bool(sizes.numel() == 0 or int(sizes.max().item()) < 2**32),
+                  "prefix": strategy == "prefix" and order >= 3, "max_first": int(nf.max().item()) if nf.numel() else 0}
         desc = {"table": None, "order": order, "rank_lo": 0, "count": total, "num_nodes": n, "node_map": middle,
                 "first_map": first_ids, "last_map": last_ids, "ragged": ragged}
         p = self._trace_compact(scene, desc, max_survivors, max_paths)

@@ -305,7 +305,9 @@ typedef struct drt_candidates {
      *   pair_offsets[num_tx * num_rx + 1]   device int64 prefix sums of the pair space sizes
      *                                       F_i * num_nodes^(order-2) * L_j
      *   num_candidates = pair_offsets[num_tx * num_rx] (total rows); rank_lo must be 0;
-     *   reserved bit 0 = every pair space is < 2^32 rows (32-bit unranking).
+     *   reserved bit 0 = every pair space is < 2^32 rows (32-bit unranking); bit 1 (order >= 3) = large
+ *   pair spaces: stage A runs one lane per PREFIX (first order-1 interactions) with inner loops over
+ *   the receivers and their last interactions; num_first must then hold max_i F_i.
      * Keys returned by the compact tracer are then GLOBAL ragged row indices (pair-major). */
     const int64_t *pair_offsets;
     const int64_t *first_offsets;

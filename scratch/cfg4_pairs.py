@@ -17,11 +17,12 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 5e12
 V, Tr, centres, heights = S.manhattan(1000)
 tx, rx = S.manhattan_tx_rx(centres, heights, 16, 64)
 mesh = G.Mesh(V, Tr)
-solver = G.HybridPathTracer(num_rays=1_000_000, accel="bvh")
+STRATEGY = next((a.split("=")[1] for a in sys.argv if a.startswith("--strategy=")), "auto")
+solver = G.HybridPathTracer(num_rays=1_000_000, accel="bvh", pairs_strategy=STRATEGY)
 vt = mesh.triangles_visible_from_vertex(torch.tensor(tx, device="cuda"), num_rays=1_000_000, accel="bvh").sum(1)
 vr = mesh.triangles_visible_from_vertex(torch.tensor(rx, device="cuda"), num_rays=1_000_000, accel="bvh").sum(1)
 evals = int((vt.double().sum() * vr.double().sum()).item()) * mesh.num_primitives ** (order - 2)
-out = {"order": order, "visible_per_tx_mean": float(vt.float().mean()), "visible_per_rx_mean": float(vr.float().mean()),
+out = {"strategy": STRATEGY, "order": order, "visible_per_tx_mean": float(vt.float().mean()), "visible_per_rx_mean": float(vr.float().mean()),
        "candidate_evals_per_step": evals, "exhaustive_evals_per_step": 1024 * 10000 * 9999 ** (order - 1)}
 print(json.dumps(out), flush=True)
 if evals > budget:

@@ -56,6 +56,7 @@ while time.time() - t0 < budget:
     st["window_mismatch_cases"] += int(both != sorted(map(tuple, ro.tolist())))
     if order >= 1:
         ex = scene.trace_paths(order, compact=True)
+        solver.pairs_strategy = str(rng.choice(["ragged", "prefix", "loop", "auto"]))
         pp = solver.trace_pairs(scene, order)
         eo = {tuple(r): i for i, r in enumerate(ex.objects.cpu().numpy().tolist())}
         po = pp.objects.cpu().numpy().tolist()

@@ -508,9 +508,12 @@ def test_hybrid_trace_pairs_equals_exhaustive(G, goldens, two_buildings, order, 
     ref = scene.trace_paths(order, compact=True)
     np.testing.assert_array_equal(_np(got.objects), _np(ref.objects))
     np.testing.assert_array_equal(_bits(_np(got.vertices)), _bits(_np(ref.vertices)))
-    loop = G.HybridPathTracer(num_rays=300_000, ragged_max_pair_size=0).trace_pairs(scene, order)  # one launch per pair
-    np.testing.assert_array_equal(_np(loop.objects), _np(ref.objects))
-    np.testing.assert_array_equal(_bits(_np(loop.vertices)), _bits(_np(ref.vertices)))
+    for strategy in ("loop", "prefix", "ragged"):  # one launch per pair / lane = prefix / lane = row
+        alt = G.HybridPathTracer(num_rays=300_000, pairs_strategy=strategy).trace_pairs(scene, order)
+        np.testing.assert_array_equal(_np(alt.objects), _np(ref.objects), err_msg=strategy)
+        np.testing.assert_array_equal(_bits(_np(alt.vertices)), _bits(_np(ref.vertices)), err_msg=strategy)
+        if strategy != "loop" and order >= 2:
+            np.testing.assert_array_equal(_np(alt.keys), _np(got.keys), err_msg=strategy)
     cached = solver.trace_pairs(scene, order, visibility=solver.estimate_visibility(scene))
     assert torch.equal(cached.objects, got.objects) and torch.equal(cached.vertices, got.vertices)
     if order >= 2:  # keys of the ragged launch are global rows of the concatenated pair spaces, ascending
