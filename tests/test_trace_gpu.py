@@ -528,3 +528,39 @@ def test_hybrid_trace_pairs_equals_exhaustive(G, goldens, two_buildings, order, 
     p.vertices.square().sum().backward()
     e.vertices.square().sum().backward()
     np.testing.assert_allclose(_np(txg.grad), _np(q.transmitters.grad), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ two more reference tests ----
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("assume_quads", [False, True])
+def test_path_candidates_match_exhaustive(G, rng, order, assume_quads):
+    """differt/tests/geometry/test_scene.py:334-364 (on the canyon scene): tracing the candidates an
+    exhaustive trace returned gives the same valid paths; every valid candidate traced alone is valid."""
+    from conftest import canyon_scene
+
+    V, Tr = canyon_scene(rng)
+    scene = G.Scene([-15.0, 1.0, 8.0], [12.0, -2.0, 3.0], G.Mesh(V, Tr)).set_assume_quads(assume_quads)
+    expected = scene.trace_paths(order=order)
+    cands = expected.objects[:, 1:-1]
+    got = scene.trace_paths(path_candidates=cands)
+    assert torch.equal(got.masked_vertices, expected.masked_vertices)
+    valid = expected.masked().objects[:, 1:-1]
+    assert valid.shape[0] > 0
+    for c in valid:
+        one = scene.trace_paths(path_candidates=c[None, :])
+        assert one.mask.numel() == 1 and bool(one.mask.reshape(()))
+
+
+@pytest.mark.parametrize("shapes", [((3,), (3,), (5, 3)), ((10, 3), (10, 3), (1, 3)), ((10, 3), (1, 3), (2, 3)),
+                                    ((4, 1, 3), (1, 6, 3), (3, 3))])
+def test_image_method_returns_vertices_on_mirrors(G, rng, shapes):
+    """differt/tests/geometry/test_image_method.py:181-218: every image-method vertex lies in its mirror's
+    plane (infinite vertices excluded)."""
+    a, b = (rng.normal(size=s).astype(np.float32) for s in shapes[:2])
+    mv = rng.normal(size=shapes[2]).astype(np.float32)
+    mn = rng.normal(size=shapes[2]).astype(np.float32)
+    mn /= np.linalg.norm(mn, axis=-1, keepdims=True)
+    paths = _np(G.image_method(a, b, mv, mn))
+    d = ((paths - mv) * mn).sum(-1)
+    d = np.nan_to_num(d, posinf=0.0, neginf=0.0)
+    np.testing.assert_allclose(d, 0.0, atol=1e-4)
