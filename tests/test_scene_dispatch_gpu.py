@@ -206,3 +206,25 @@ def test_solver_interfaces(G, canyon):
     assert len(list(G.ExhaustivePathTracer().generate_path_candidates_chunks_iter(canyon, order=1, chunk_size=None))) == 1
     assert len(list(G.HybridPathTracer(chunk_size=None, num_rays=1000)
                     .generate_path_candidates_chunks_iter(canyon, order=1, chunk_size=None))) == 1
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+@pytest.mark.parametrize("method", ["exhaustive", "sbr", "hybrid"])
+def test_mesh_mask_matches_sub_mesh_without_mask(G, order, method):
+    """test_scene.py:585-647: a masked inner box neither reflects nor occludes -- the valid paths equal
+    those of the outer box alone (objects and vertices, every solver)."""
+    outer, inner = G.Mesh.box(10.0, 10.0, 10.0), G.Mesh.box(4.0, 4.0, 4.0)
+    mesh = outer + inner
+    mask = np.concatenate((np.ones(outer.num_triangles, bool), np.zeros(inner.num_triangles, bool)))
+    mesh = mesh.set_mask(torch.as_tensor(mask, device=mesh.triangles.device))
+    tx, rx = [[-5.0, 0.0, 0.0]], [[5.0, 0.0, 0.0]]
+    a, b = G.Scene(tx, rx, mesh), G.Scene(tx, rx, outer)
+    if method == "sbr":
+        got, exp = (s.launch_paths(order, solver="sbr", num_rays=200_000).masked() for s in (a, b))
+    else:
+        kw = {"num_rays": 200_000} if method == "hybrid" else {}
+        got, exp = (s.trace_paths(order, solver=method, **kw).masked() for s in (a, b))
+    assert torch.equal(got.objects, exp.objects)
+    assert torch.equal(got.vertices, exp.vertices)
+    if method != "sbr" and order <= 2:
+        assert got.objects.shape[0] > 0
