@@ -9,11 +9,13 @@ be produced directly (and in parallel) instead of stepping an odometer.
 from __future__ import annotations
 
 import ctypes as C
-import warnings
+import logging
 
 import numpy as np
 
 from .. import _lib
+
+_LOG = logging.getLogger("differt_amd.geometry.graph")
 
 __all__ = ["CompleteGraph", "DiGraph"]
 
@@ -26,6 +28,14 @@ def _count(num_nodes: int, from_: int, to: int, depth: int) -> tuple[int, bool]:
     return int(c.value), bool(o.value)
 
 
+def _no_extra_positionals(name: str, allowed: int, extra: tuple) -> None:
+    """PyO3's message for keyword-only parameters passed positionally (self is not counted)."""
+    if extra:
+        given = allowed + len(extra)
+        raise TypeError(f"{name}() takes {allowed} positional arguments but {given} "
+                        f"{'was' if given == 1 else 'were'} given")
+
+
 class _CompleteGraphPathsIter:
     """``AllPathsFromCompleteGraphIter`` (graph.rs:286-491): sized iterator over single paths."""
 
@@ -35,11 +45,9 @@ class _CompleteGraphPathsIter:
         self._args = (num_nodes, from_, to, depth, int(include_from_and_to))
         self._total, self._overflow = _count(num_nodes, from_, to, depth)
         if self._overflow:  # graph.rs:368-375
-            warnings.warn(
-                "OverflowError: overflow occurred when computing the total number of paths, "
-                f"defaulting to maximum value {_U64_MAX}.",
-                stacklevel=3,
-            )
+            # the reference logs a WARNING through pyo3-log (graph.rs:368-375), it does not raise / warn
+            _LOG.warning("OverflowError: overflow occurred when computing the total number of paths, "
+                         "defaulting to maximum value %d.", _U64_MAX)
             # the closed form overflowed; iterate up to the true count (usually astronomically large,
             # but tiny in degenerate cases such as num_nodes == 1)
             c, o = C.c_uint64(), C.c_int32()
@@ -116,9 +124,10 @@ class CompleteGraph:
             raise OverflowError("can't convert negative int to unsigned")
         self.num_nodes = int(num_nodes)
 
-    def all_paths(self, from_: int, to: int, depth: int, *, include_from_and_to: bool = True):
+    def all_paths(self, from_: int, to: int, depth: int, *args, include_from_and_to: bool = True):
         """Iterator over all paths of ``depth`` nodes from ``from_`` to ``to`` (graph.rs:193-203);
         ``from_``/``to`` may lie outside the graph (``>= num_nodes``)."""
+        _no_extra_positionals("CompleteGraph.all_paths", 3, args)
         return _CompleteGraphPathsIter(self.num_nodes, from_, to, depth, include_from_and_to)
 
     def all_paths_array(
@@ -224,9 +233,10 @@ class DiGraph:
         return int(_lib.load().drt_digraph_num_nodes(self._h))
 
     def insert_from_and_to_nodes(
-        self, *, direct_path: bool = True, from_adjacency=None, to_adjacency=None
+        self, *args, direct_path: bool = True, from_adjacency=None, to_adjacency=None
     ) -> tuple[int, int]:
-        """graph.rs:636-691."""
+        """graph.rs:636-691 (all parameters keyword-only, graph.pyi)."""
+        _no_extra_positionals("DiGraph.insert_from_and_to_nodes", 0, args)
         n = self.num_nodes
         fa = ta = None
         if from_adjacency is not None:
@@ -255,13 +265,17 @@ class DiGraph:
             raise IndexError(str(e)) from None
 
     def filter_by_mask(self, mask, fast_mode: bool = True) -> None:
-        """graph.rs:879-910."""
+        """graph.rs:879-910 (a mask shorter than the graph leaves the remaining nodes connected)."""
         m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+        if len(m) > self.num_nodes:  # graph.rs:886-893
+            raise ValueError(f"'mask' length ({len(m)}) must be smaller than or equal to the number of nodes "
+                             f"in the graph ({self.num_nodes})")
         _lib.call("drt_digraph_filter_by_mask", self._h, m.ctypes.data_as(C.c_void_p), len(m),
                   int(fast_mode))
 
-    def all_paths(self, from_: int, to: int, depth: int, *, include_from_and_to: bool = True):
+    def all_paths(self, from_: int, to: int, depth: int, *args, include_from_and_to: bool = True):
         """graph.rs:912-925 (unsized iterator)."""
+        _no_extra_positionals("DiGraph.all_paths", 3, args)
         return _DiGraphIter(self, from_, to, depth, include_from_and_to, None)
 
     def all_paths_array(self, from_: int, to: int, depth: int, *, include_from_and_to: bool = True):

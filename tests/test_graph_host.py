@@ -77,10 +77,7 @@ def test_count_formula_and_overflow():
     for n, depth in [(10, 3), (100, 5), (1000, 4), (10000, 4), (200000, 4)]:
         it = CompleteGraph(n).all_paths(n, n + 1, depth, include_from_and_to=False)
         assert len(it) == n * (n - 1) ** (depth - 3)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        it = CompleteGraph(10**6).all_paths(10**6, 10**6 + 1, 8)
-        assert any("OverflowError" in str(x.message) for x in w)
+    it = CompleteGraph(10**6).all_paths(10**6, 10**6 + 1, 8)  # logs a WARNING, see the mirrored test below
     assert it._declared == 2**64 - 1
     # a window far into a huge (non-overflowing) space is still addressable
     n = 10000
@@ -147,3 +144,109 @@ def test_mask_and_disconnect(fast_mode):
         g2.filter_by_mask(np.ones(n + 3, dtype=bool))
     with pytest.raises(IndexError):
         g2.disconnect_nodes(n + 5)
+
+
+# ------------------------------------------------------------------------------------------
+# differt-core/tests/geometry/test_graph.py mirrored one to one (host classes over the C ABI)
+# ------------------------------------------------------------------------------------------
+class TestDiGraphReference:
+    def test_insert_from_and_to_nodes(self):
+        """test_graph.py:14-31."""
+        graph = DiGraph.from_complete_graph(CompleteGraph(5))
+        assert graph.insert_from_and_to_nodes() == (5, 6)
+        assert graph.insert_from_and_to_nodes(direct_path=True) == (7, 8)
+        assert graph.insert_from_and_to_nodes(direct_path=False) == (9, 10)
+        with pytest.raises(TypeError, match="takes 0 positional arguments but 1 was given"):
+            graph.insert_from_and_to_nodes(True)
+
+    @pytest.mark.parametrize("fast_mode", [True, False])
+    def test_disconnect_nodes(self, fast_mode):
+        """test_graph.py:33-49."""
+        graph = DiGraph.from_complete_graph(CompleteGraph(6))
+        from_, to = graph.insert_from_and_to_nodes()
+        nodes = (0, 1, 2, 5)
+        graph.disconnect_nodes(*nodes, fast_mode=fast_mode)
+        for depth in range(3):
+            for path in graph.all_paths(from_, to, depth + 2, include_from_and_to=False):
+                assert not set(nodes) & set(int(x) for x in path)
+
+    @pytest.mark.parametrize("fast_mode", [True, False])
+    def test_filter_by_mask(self, fast_mode):
+        """test_graph.py:51-80."""
+        graph = DiGraph.from_complete_graph(CompleteGraph(8))
+        from_, to = graph.insert_from_and_to_nodes()
+        mask = np.array([True, False, True, False, True, False, True, False])
+        before = len(list(graph.all_paths(from_, to, 3, include_from_and_to=False)))
+        graph.filter_by_mask(mask, fast_mode=fast_mode)
+        after = list(graph.all_paths(from_, to, 3, include_from_and_to=False))
+        assert all(not {1, 3, 5, 7} & set(int(x) for x in p) for p in after)
+        assert 0 < len(after) < before
+
+    @pytest.mark.parametrize("fast_mode", [True, False])
+    def test_filter_by_mask_all_disconnected(self, fast_mode):
+        """test_graph.py:82-92."""
+        graph = DiGraph.from_complete_graph(CompleteGraph(4))
+        from_, to = graph.insert_from_and_to_nodes(direct_path=False)
+        graph.filter_by_mask(np.zeros(4, bool), fast_mode=fast_mode)
+        assert len(list(graph.all_paths(from_, to, 4, include_from_and_to=False))) == 0
+
+    def test_filter_by_mask_wrong_size(self):
+        """test_graph.py:94-118."""
+        import re
+
+        graph = DiGraph.from_complete_graph(CompleteGraph(5))
+        graph.filter_by_mask(np.array([True, False, True]), fast_mode=True)  # a smaller mask is fine
+        graph = DiGraph.from_complete_graph(CompleteGraph(5))
+        with pytest.raises(ValueError, match=re.escape(
+                "'mask' length (6) must be smaller than or equal to the number of nodes in the graph (5)")):
+            graph.filter_by_mask(np.array([True, False, True, False, False, False]), fast_mode=True)
+
+    @pytest.mark.parametrize("fast_mode", [True, False])
+    def test_disconnect_nodes_equivalence(self, fast_mode):
+        """test_graph.py:120-142."""
+        complete = CompleteGraph(3)
+        di = DiGraph.from_complete_graph(CompleteGraph(6))
+        from_, to = di.insert_from_and_to_nodes()
+        di.disconnect_nodes(3, 4, 5, fast_mode=fast_mode)
+        for depth in range(3):
+            a = complete.all_paths_array(from_, to, depth + 2, include_from_and_to=False)
+            b = di.all_paths_array(from_, to, depth + 2, include_from_and_to=False)
+            np.testing.assert_equal(np.asarray(a), np.asarray(b))
+
+    def test_from_graph_and_keyword_only(self):
+        """test_graph.py:144-158."""
+        graph = CompleteGraph(10)
+        assert isinstance(graph, CompleteGraph)
+        graph = DiGraph.from_complete_graph(graph)
+        assert isinstance(graph, DiGraph)
+        with pytest.raises(TypeError, match="takes 3 positional arguments but 4 were given"):
+            DiGraph.from_complete_graph(CompleteGraph(5)).all_paths(0, 1, 0, True)
+
+    @pytest.mark.parametrize(("num_nodes", "depth"), [(15, 2), (25, 3), (11, 4)])
+    def test_all_paths_count_from_complete_graph(self, num_nodes, depth):
+        """test_graph.py:160-178."""
+        graph = CompleteGraph(num_nodes)
+        from_, to = num_nodes, num_nodes + 1
+        n = sum(1 for _ in graph.all_paths(from_, to, depth + 2, include_from_and_to=False))
+        assert n == num_nodes * (num_nodes - 1) ** (depth - 1)
+        assert graph.all_paths_array(from_, to, depth + 2, include_from_and_to=False).shape == (n, depth)
+
+    @pytest.mark.parametrize(("num_nodes", "depth"), [(10, 1), (50, 2), (10, 3)])
+    def test_all_paths_count_from_di_graph(self, num_nodes, depth):
+        """test_graph.py:180-199."""
+        graph = DiGraph.from_complete_graph(CompleteGraph(num_nodes))
+        from_, to = graph.insert_from_and_to_nodes()
+        n = sum(1 for _ in graph.all_paths(from_, to, depth + 2, include_from_and_to=False))
+        assert n == num_nodes * (num_nodes - 1) ** (depth - 1)
+        assert graph.all_paths_array(from_, to, depth + 2, include_from_and_to=False).shape == (n, depth)
+
+    @pytest.mark.parametrize(("num_nodes", "depth"), [(10, 100), (50_000, 10)])
+    def test_all_paths_count_overflow_is_logged(self, num_nodes, depth, caplog):
+        """test_graph.py:201-226."""
+        import logging
+
+        graph = CompleteGraph(num_nodes)
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            graph.all_paths(num_nodes, num_nodes + 1, depth + 2, include_from_and_to=False)
+        assert "OverflowError: overflow occurred when computing the total number of paths" in caplog.text
