@@ -187,6 +187,8 @@ _SIGNATURES = {
                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "drt_row_cell_ids_workspace_size": (_sz, [_i64]),
     "drt_row_cell_ids": (_i32, [_vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "drt_paths_channel_vjp": (
+        _i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, C.POINTER(EmParams), _vp, _vp, _vp]),
 }
 
 # functions whose int32 result is NOT a status code

@@ -4,8 +4,9 @@ For every path of one or several :class:`TracedPaths` (all candidates, valid or 
 exported next to them, as in the reference) one HIP kernel (``drt_paths_channel``, csrc/em.hip)
 computes the complex channel coefficient and the DeepMIMO quantities: power [dBW], phase [deg],
 delay [s], angles of arrival / departure [deg].  Same assumptions as the reference: far field,
-isotropic antennas, every interaction a specular reflection.  Not differentiable here (the
-reference's is, through JAX autodiff): outputs are detached.
+isotropic antennas, every interaction a specular reflection.  Differentiable in the path vertices
+(``drt_paths_channel_vjp``: forward-mode duals per path), hence -- through the tracer's VJP -- in the
+transmitters, receivers and mesh vertices; mesh normals and material constants enter as constants.
 """
 
 from __future__ import annotations
@@ -104,10 +105,43 @@ def material_tables(material_names, radio_materials: Mapping[str, Material], fre
     return n, th
 
 
+_CHANNEL_OUTPUTS = ("a_re", "a_im", "power", "phase", "length", "delay", "aoa_az", "aoa_el", "aod_az", "aod_el")
+
+
+class _PathsChannelFn(torch.autograd.Function):
+    """``drt_paths_channel`` / ``drt_paths_channel_vjp``: the ten per-path outputs as one ``[N, 10]`` tensor,
+    differentiable in the path vertices (which carry the dependence on transmitters, receivers and mesh
+    vertices through the tracer's own VJP); normals and material constants are constants."""
+
+    @staticmethod
+    def forward(ctx, v, o, tabs, pr, order):
+        normals, fm, nc, th, T, M = tabs
+        N = v.shape[0]
+        out = torch.empty((10, N), dtype=torch.float32, device=v.device)
+        a = torch.empty((N, 2), dtype=torch.float32, device=v.device)
+        if N:
+            _lib.call("drt_paths_channel", ptr(v), ptr(o), N, order, ptr(normals), ptr(fm), T, ptr(nc), ptr(th), M,
+                      C.byref(pr), ptr(a), *(ptr(out[k]) for k in range(2, 10)), stream())
+        res = torch.cat((a, out[2:].t()), dim=1)  # [N, 10] in _CHANNEL_OUTPUTS order
+        ctx.save_for_backward(v, o)
+        ctx.cfg = (tabs, pr, order)
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        v, o = ctx.saved_tensors
+        (normals, fm, nc, th, T, M), pr, order = ctx.cfg
+        gv = torch.zeros_like(v)
+        if v.shape[0]:
+            _lib.call("drt_paths_channel_vjp", ptr(v), ptr(o), v.shape[0], order, ptr(normals), ptr(fm), T, ptr(nc),
+                      ptr(th), M, C.byref(pr), ptr(g.contiguous()), ptr(gv), stream())
+        return gv, None, None, None, None
+
+
 def paths_channel(paths: TracedPaths, mesh, n_complex, thickness, frequency: float, polarization="V") -> dict:
     """Per-path channel quantities (``drt_paths_channel``) for ONE :class:`TracedPaths` of any batch
     shape: dict of ``a`` (complex64), ``power``, ``phase``, ``length``, ``delay``, ``aoa_az``,
-    ``aoa_el``, ``aod_az``, ``aod_el``, each ``[*batch]``."""
+    ``aoa_el``, ``aod_az``, ``aod_el``, each ``[*batch]``; differentiable in ``paths.vertices``."""
     dev = device()
     tx_pol, rx_pol = polarization if isinstance(polarization, tuple) and len(polarization) == 2 else (polarization,) * 2
     pr = _lib.EmParams()
@@ -118,25 +152,20 @@ def paths_channel(paths: TracedPaths, mesh, n_complex, thickness, frequency: flo
     pr.rx_vector[:] = rxv
     batch, order = tuple(paths.objects.shape[:-1]), paths.order
     N = int(np.prod(batch, dtype=np.int64))
-    v = as_f32(paths.vertices, dev).detach().reshape(N, order + 2, 3).contiguous()
+    v = as_f32(paths.vertices, dev).reshape(N, order + 2, 3).contiguous()
     o = paths.objects.to(device=dev, dtype=torch.int32).reshape(N, order + 2).contiguous()
-    names = ("power", "phase", "length", "delay", "aoa_az", "aoa_el", "aod_az", "aod_el")
-    out = {k: torch.empty(N, dtype=torch.float32, device=dev) for k in names}
-    a = torch.empty((N, 2), dtype=torch.float32, device=dev)
-    if N:
-        normals = fm = nc = th = None
-        T = M = 0
-        if order > 0:
-            normals = mesh.normals.contiguous()
-            fm = mesh.face_materials.to(device=dev, dtype=torch.int32).contiguous()
-            nc = torch.as_tensor(np.ascontiguousarray(n_complex, dtype=np.float32), device=dev)
-            th = torch.as_tensor(np.ascontiguousarray(thickness, dtype=np.float32), device=dev)
-            T, M = mesh.num_triangles, nc.shape[0]
-        _lib.call("drt_paths_channel", ptr(v), ptr(o), N, order, ptr(normals), ptr(fm), T, ptr(nc), ptr(th), M,
-                  C.byref(pr), ptr(a), *(ptr(out[k]) for k in names), stream())
-    res = {k: t.reshape(batch) for k, t in out.items()}
-    res["a"] = torch.view_as_complex(a).reshape(batch)
-    return res
+    normals = fm = nc = th = None
+    T = M = 0
+    if order > 0:
+        normals = mesh.normals.contiguous()
+        fm = mesh.face_materials.to(device=dev, dtype=torch.int32).contiguous()
+        nc = torch.as_tensor(np.ascontiguousarray(n_complex, dtype=np.float32), device=dev)
+        th = torch.as_tensor(np.ascontiguousarray(thickness, dtype=np.float32), device=dev)
+        T, M = mesh.num_triangles, nc.shape[0]
+    res = _PathsChannelFn.apply(v, o, (normals, fm, nc, th, T, M), pr, order)
+    out = {k: res[:, i].reshape(batch) for i, k in enumerate(_CHANNEL_OUTPUTS) if i >= 2}
+    out["a"] = torch.view_as_complex(res[:, :2].contiguous()).reshape(batch)
+    return out
 
 
 def export(*, paths: TracedPaths | Iterable[TracedPaths], scene, radio_materials: Mapping[str, Material] | None = None,
@@ -172,7 +201,7 @@ def export(*, paths: TracedPaths | Iterable[TracedPaths], scene, radio_materials
             prims = _pad_cat(prims, ids, _NO_INTERACTION)  # :527-532
         types = p.interaction_types if p.interaction_types is not None else torch.zeros_like(ids)
         inter = _pad_cat(inter, types.to(torch.int32), _NO_INTERACTION)  # :534-546
-        inter_pos = _pad_cat(inter_pos, p.vertices[..., 1:-1, :].detach(), 0.0)  # :548-552
+        inter_pos = _pad_cat(inter_pos, p.vertices[..., 1:-1, :], 0.0)  # :548-552
         masks.append(p.mask)  # :679-689 (float confidences are exported as they are)
     soft = any(m.dtype != torch.bool for m in masks)
     mask = torch.cat([empty(dtype=torch.float32 if soft else torch.bool),

@@ -454,6 +454,15 @@ int32_t drt_paths_channel(const float *vertices, const int32_t *objects, int64_t
                           const drt_em_params *params, float *a, float *power, float *phase,
                           float *length, float *delay, float *aoa_az, float *aoa_el, float *aod_az,
                           float *aod_el, void *stream);
+/* VJP of drt_paths_channel with respect to the path vertices.  cotangents [N,10] in the output order
+ * (a.re, a.im, power, phase, length, delay, aoa_az, aoa_el, aod_az, aod_el); grad_vertices
+ * [N,order+2,3] is WRITTEN.  Computed by forward-mode duals inside one lane per path (3 (order+2)
+ * evaluations); the mesh normals and the material constants are constants of the differentiation. */
+int32_t drt_paths_channel_vjp(const float *vertices, const int32_t *objects, int64_t num_paths,
+                              int32_t order, const float *normals, const int32_t *face_materials,
+                              int64_t num_triangles, const float *n_complex, const float *thickness,
+                              int64_t num_materials, const drt_em_params *params,
+                              const float *cotangents, float *grad_vertices, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (a15) cell ids of equal rows -- reference: geometry/_paths.py:21-38 (`_cell_ids`), behind

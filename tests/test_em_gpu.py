@@ -242,3 +242,114 @@ def test_mesh_materials(G):
     with pytest.raises(ValueError, match="Expected either 1, 12, or 6 names"):
         mesh.set_assume_quads().set_materials("a", "b")
     assert _np(mesh.set_face_materials(3).face_materials).tolist() == [3] * 12
+
+
+# ------------------------------------------------------------------ gradients ----
+def _oracle64(fn):
+    """Evaluate oracle/em_ref.py in float64 (its casts follow the module-level F / C64)."""
+    emo.F, emo.C64 = np.float64, np.complex128
+    try:
+        with np.errstate(all="ignore"):
+            return fn()
+    finally:
+        emo.F, emo.C64 = np.float32, np.complex64
+
+
+WEIGHTS = {"a_re": 1e3, "a_im": -7e2, "power": 1e-2, "phase": 1e-3, "length": 0.3, "delay": 2e7, "aoa_az": 1e-2,
+           "aoa_el": -2e-2, "aod_az": 3e-2, "aod_el": 1e-2}
+
+
+def _loss_np(out):
+    return (WEIGHTS["a_re"] * out["a"].real + WEIGHTS["a_im"] * out["a"].imag
+            + sum(WEIGHTS[k] * out[k] for k in WEIGHTS if k not in ("a_re", "a_im")))
+
+
+def _loss_torch(out):
+    return (WEIGHTS["a_re"] * out["a"].real + WEIGHTS["a_im"] * out["a"].imag
+            + sum(WEIGHTS[k] * out[k] for k in WEIGHTS if k not in ("a_re", "a_im"))).sum()
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+@pytest.mark.parametrize("polarization", ["V", ("H", (0.3, -0.5, 0.8))])
+def test_paths_channel_vjp_vs_central_differences(G, rng, order, polarization):
+    """drt_paths_channel_vjp (forward-mode duals in the kernel) vs float64 central differences of the oracle,
+    for a weighted sum of all ten outputs, on the valid paths of a box scene with lossy slabs."""
+    from differt_amd.plugins import deepmimo
+
+    scene = _box_scene(G, rng)
+    mesh = scene.mesh.set_face_materials(np.arange(12) % 3)
+    paths = scene.trace_paths(order, compact=True)
+    if paths.objects.shape[0] > 40:
+        keep = torch.as_tensor(np.sort(rng.choice(paths.objects.shape[0], 40, replace=False)), device="cuda")
+        paths = G.TracedPaths(paths.vertices[keep], paths.objects[keep], paths.mask[keep], paths.interaction_types[keep])
+    assert paths.objects.shape[0] > 0
+    f = 1.2e9
+    n_c = emo.complex_refractive_index([5.24, 6.27, 2.0], [0.09, 0.012, 0.0], f)
+    n_tab = np.stack((n_c.real, n_c.imag), -1)
+    th = np.array([-1.0, 0.05, 0.3], np.float32)
+    v = paths.vertices.detach().clone().requires_grad_(True)
+    got = deepmimo.paths_channel(G.TracedPaths(v, paths.objects, paths.mask, paths.interaction_types), mesh, n_tab, th,
+                                 f, polarization)
+    _loss_torch(got).backward()
+    grad = _np(v.grad).astype(np.float64)
+    assert np.isfinite(grad).all() and np.abs(grad).max() > 0
+    V64, obj = _np(paths.vertices).astype(np.float64), _np(paths.objects)
+    normals = orc.mesh_normals(orc.triangle_vertices(_np(mesh.vertices), _np(mesh.triangles))).astype(np.float64)
+    n64 = _oracle64(lambda: emo.complex_refractive_index(np.array([5.24, 6.27, 2.0]), np.array([0.09, 0.012, 0.0]), f))
+
+    def loss64(Vp):
+        return _loss_np(_oracle64(lambda: emo.channel(Vp, obj, normals, np.arange(12) % 3, n64, th.astype(np.float64),
+                                                      f, polarization)))
+
+    h = 1e-6
+    fd = np.zeros_like(V64)
+    for j in range(order + 2):
+        for c in range(3):
+            up, dn = V64.copy(), V64.copy()
+            up[:, j, c] += h
+            dn[:, j, c] -= h
+            fd[:, j, c] = (loss64(up) - loss64(dn)) / (2 * h)  # paths are independent: one pair of evaluations
+    scale = np.abs(fd).max(axis=(1, 2), keepdims=True) + 1e-30
+    err = np.abs(grad - fd) / scale
+    assert err.max() < 2e-3, float(err.max())       # float32 duals vs float64 differences
+    assert np.median(err.max(axis=(1, 2))) < 2e-4
+
+
+def test_received_power_gradient_end_to_end(G, rng):
+    """d(sum of received powers in dBW)/d(tx): tracer VJP + channel VJP chained by autograd, vs float64 central
+    differences of (torch restatement of the path vertices) -> (oracle channel)."""
+    from differt_amd.plugins import deepmimo
+    from oracle import torch_ref
+
+    scene = _box_scene(G, rng, ntx=1, nrx=2)
+    mesh = scene.mesh.set_materials("itu_concrete")
+    f = 2.4e9
+    n_tab, th = deepmimo.material_tables(mesh.material_names, deepmimo.materials, f)
+    tx0 = _np(scene.transmitters).astype(np.float64)
+    txg = torch.tensor(tx0, dtype=torch.float32, device="cuda", requires_grad=True)
+    sc = G.Scene(txg, scene.receivers, mesh)
+    paths = sc.trace_paths(2, compact=True)
+    assert paths.objects.shape[0] > 3
+    out = deepmimo.paths_channel(paths, mesh, n_tab, th, f)
+    out["power"].sum().backward()
+    g = _np(txg.grad).astype(np.float64)
+    obj = _np(paths.objects)
+    Vm = torch.tensor(_np(mesh.vertices), dtype=torch.float64)
+    Trm = torch.tensor(_np(mesh.triangles), dtype=torch.long)
+    rx64 = torch.tensor(_np(scene.receivers), dtype=torch.float64)
+    normals = orc.mesh_normals(orc.triangle_vertices(_np(mesh.vertices), _np(mesh.triangles))).astype(np.float64)
+    n64 = (n_tab[:, 0] + 1j * n_tab[:, 1]).astype(np.complex128)
+
+    def total_power(txp):
+        full = torch_ref.trace_vertices(Vm, Trm, torch.tensor(txp), rx64, torch.tensor(obj[:, 1:-1].astype(np.int64)))
+        vv = full[obj[:, 0], obj[:, -1], np.arange(len(obj))].numpy()  # the traced (tx, rx, candidate) triples
+        return _oracle64(lambda: emo.channel(vv, obj, normals, np.zeros(12, int), n64, th.astype(np.float64), f))["power"].sum()
+
+    h = 1e-6
+    fd = np.zeros_like(tx0)
+    for c in range(3):
+        up, dn = tx0.copy(), tx0.copy()
+        up[0, c] += h
+        dn[0, c] -= h
+        fd[0, c] = (total_power(up) - total_power(dn)) / (2 * h)
+    np.testing.assert_allclose(g, fd, rtol=5e-3, atol=5e-3 * np.abs(fd).max())
