@@ -114,6 +114,7 @@ _SIGNATURES = {
     "drt_mesh_ray_intersect_any_triangle": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "drt_mesh_first_triangle_hit_by_ray": (_i32, [_vp, _vp, _vp, _i64, _f32, _i64, _vp, _vp, _vp]),
     "drt_mesh_triangles_visible_from_vertex": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "drt_mesh_triangles_visible_samples": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "drt_viewing_frustum": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "drt_viewing_frustum_points": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "drt_launch_paths": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _i64, _f32, _vp, _vp, _vp, _vp]),

@@ -297,6 +297,65 @@ __global__ __launch_bounds__(256) void fill_miss_kernel(int64_t R, int32_t *__re
     t[r] = kInf;
 }
 
+// Triangle-driven complement of the lattice visibility (an extension: the reference samples DIRECTIONS only,
+// so a small far-away face can fall between the rays): lane = (triangle, interior sample point); the face is
+// visible when the segment viewpoint -> sample is not blocked by any OTHER active triangle before the
+// sample (t < 1 - 1e-4).  ORs into `visible`.
+__global__ __launch_bounds__(256) void bvh_visibility_samples_kernel(
+    const BvhNode *__restrict__ nodes, int64_t T, const float *__restrict__ tv, const uint8_t *__restrict__ mask,
+    const float *__restrict__ view, float eps, uint8_t *__restrict__ visible) {
+    constexpr int kSamples = 7;
+    const int64_t b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * kSamples) return;
+    const int64_t tri = i / kSamples;
+    const int sidx = (int)(i - tri * kSamples);
+    if (mask && !mask[tri]) return;
+    if (visible[b * T + tri]) return;  // the lattice pass (or another sample) already saw it
+    // barycentric weights: centroid, three points near the vertices, three near the edge mid-points
+    const float w[kSamples][3] = {{1.f / 3, 1.f / 3, 1.f / 3}, {0.8f, 0.1f, 0.1f}, {0.1f, 0.8f, 0.1f}, {0.1f, 0.1f, 0.8f},
+                                  {0.45f, 0.45f, 0.1f}, {0.1f, 0.45f, 0.45f}, {0.45f, 0.1f, 0.45f}};
+    const float *t9 = tv + 9 * tri;
+    const V3 v0 = ld3(t9), v1 = ld3(t9 + 3), v2 = ld3(t9 + 6);
+    const V3 p = v0 * w[sidx][0] + v1 * w[sidx][1] + v2 * w[sidx][2];
+    const V3 o = ld3(view + 3 * b);
+    const RayPrep ray = prep_ray(o, p - o);
+    const float thr = 1.0f - 1e-4f;
+    bool blocked = false;
+    int32_t stack[kStack];
+    int sp = 0;
+    int32_t node = (T == 1) ? ~0 : 0;
+    for (;;) {
+        if (node < 0) {
+            const int64_t j = ~node;
+            if (j != tri && (!mask || mask[j])) {
+                float t;
+                if (moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) && t < thr) {
+                    blocked = true;
+                    break;
+                }
+            }
+        } else {
+            const BvhNode nd = nodes[node];
+            float l0, l1, r0, r1;
+            slab(ray, nd.llo, nd.lhi, l0, l1);
+            slab(ray, nd.rlo, nd.rhi, r0, r1);
+            const bool hl = (l0 <= l1) && (l1 >= 0.0f) && (l0 <= thr);
+            const bool hr = (r0 <= r1) && (r1 >= 0.0f) && (r0 <= thr);
+            if (hl && hr) {
+                if (sp < kStack) stack[sp++] = nd.right;
+                node = nd.left;
+                continue;
+            }
+            if (hl) { node = nd.left; continue; }
+            if (hr) { node = nd.right; continue; }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+    if (!blocked) visible[b * T + tri] = 1;
+}
+
 }  // namespace drt
 
 using namespace drt;
@@ -391,6 +450,23 @@ int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t m, const float *ro, const
                        reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->num_triangles, m->tri_verts,
                        m->has_mask ? m->mask : nullptr, ro, rd, R, epsilon, 1.0f - hit_tol, tt, out,
                        (int32_t *)nullptr, (float *)nullptr);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_mesh_triangles_visible_samples(drt_mesh_t m, const float *vertices, int64_t B, float epsilon,
+                                           uint8_t *visible_inout, void *stream) {
+    DRT_REQUIRE(m, "mesh is null");
+    DRT_REQUIRE(B >= 0, "negative size");
+    const int64_t T = m->num_triangles;
+    if (B == 0 || T == 0) return DRT_OK;
+    DRT_REQUIRE(vertices && visible_inout, "null pointer");
+    DRT_REQUIRE(B <= 65535, "at most 65535 viewing vertices per call");
+    int32_t rc = drt_mesh_build_bvh(m, stream);
+    if (rc != DRT_OK) return rc;
+    hipLaunchKernelGGL(bvh_visibility_samples_kernel, dim3((unsigned)ceil_div(T * 7, 256), (unsigned)B), dim3(256), 0,
+                       as_stream(stream), reinterpret_cast<const BvhNode *>(m->bvh_nodes), T, m->tri_verts,
+                       m->has_mask ? m->mask : nullptr, vertices, epsilon, visible_inout);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

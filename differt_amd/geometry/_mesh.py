@@ -261,10 +261,12 @@ class Mesh:
                 o, d, self.handle().triangle_vertices(), self.mask, hit_tol=hit_tol, epsilon=epsilon
             )
 
-    def triangles_visible_from_vertex(self, vertex, num_rays: int = int(1e6), *,
-                                      accel: str | None = None) -> torch.Tensor:
+    def triangles_visible_from_vertex(self, vertex, num_rays: int = int(1e6), *, accel: str | None = None,
+                                      sample_triangles: bool = False) -> torch.Tensor:
         """``bool[*batch, T]``: triangles visible from each vertex (_mesh.py:3164-3253); masked
-        triangles are never visible and do not occlude."""
+        triangles are never visible and do not occlude.  ``sample_triangles`` (extension, LBVH only) adds
+        the faces that have an unoccluded interior sample point: small far-away faces that fall between the
+        lattice rays."""
         v = as_f32(vertex)
         if self.is_empty:
             return torch.zeros((*v.shape[:-1], 0), dtype=torch.bool, device=v.device)
@@ -276,9 +278,14 @@ class Mesh:
             if B:
                 _lib.call("drt_mesh_triangles_visible_from_vertex", self.handle().h, ptr(vf), B, int(num_rays),
                           10.0 * F32_EPS, ptr(vis), ptr(ws), stream())
+                if sample_triangles:
+                    _lib.call("drt_mesh_triangles_visible_samples", self.handle().h, ptr(vf), B, 10.0 * F32_EPS,
+                              ptr(vis), stream())
             return vis.bool().reshape(*v.shape[:-1], T)
         if accel is not None:
             raise ValueError(f"unknown accel {accel!r}")
+        if sample_triangles:
+            raise ValueError("sample_triangles needs accel='bvh'")
         with torch.no_grad():
             return _utils.triangles_visible_from_vertex(v, self.handle().triangle_vertices(), self.mask,
                                                         num_rays=num_rays)

@@ -436,6 +436,9 @@ class HybridPathTracer(ExhaustivePathTracer):
     ragged_max_pair_size: float = 2e7
     """:meth:`trace_pairs`, ``pairs_strategy="auto"``: mean rows per pair above which (order >= 3) the prefix
     kernel replaces the plain ragged launch."""
+    sample_triangles: bool = False
+    """Extension (needs ``accel="bvh"``): complement the lattice visibility estimate with interior sample points
+    of every face (``Mesh.triangles_visible_from_vertex(sample_triangles=True)``)."""
     pairs_strategy: str = "auto"
     """``"auto"``, ``"ragged"`` (one lane per (pair, candidate) row), ``"prefix"`` (order >= 3: one lane per
     first ``order - 1`` interactions, inner loops over receivers and last interactions) or ``"loop"`` (one
@@ -445,8 +448,8 @@ class HybridPathTracer(ExhaustivePathTracer):
         mesh = scene.mesh
         tx = scene.transmitters.reshape(-1, 3)
         rx = scene.receivers.reshape(-1, 3)
-        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
-        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
+        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles).any(dim=0)
+        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles).any(dim=0)
         if mesh.assume_quads:  # _solvers.py:1024-1031
             vis_tx = vis_tx.reshape(-1, 2).any(dim=-1)
             vis_rx = vis_rx.reshape(-1, 2).any(dim=-1)
@@ -469,8 +472,8 @@ class HybridPathTracer(ExhaustivePathTracer):
         mesh = scene.mesh
         tx = scene.transmitters.reshape(-1, 3)
         rx = scene.receivers.reshape(-1, 3)
-        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
-        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel).any(dim=0)
+        vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles).any(dim=0)
+        vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles).any(dim=0)
         if mesh.assume_quads:
             vis_tx = vis_tx.reshape(-1, 2).any(dim=-1)
             vis_rx = vis_rx.reshape(-1, 2).any(dim=-1)
@@ -494,8 +497,8 @@ class HybridPathTracer(ExhaustivePathTracer):
         mesh = scene.mesh
         tx = scene.transmitters.reshape(-1, 3)
         rx = scene.receivers.reshape(-1, 3)
-        return (mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel),
-                mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel))
+        return (mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles),
+                mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles))
 
     def trace_pairs(self, scene, order: int, *, visibility: tuple[torch.Tensor, torch.Tensor] | None = None,
                     max_survivors: int = 1 << 20, max_paths: int = 1 << 14) -> TracedPaths:

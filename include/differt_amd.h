@@ -171,6 +171,12 @@ int32_t drt_mesh_triangles_visible_from_vertex(drt_mesh_t mesh, const float *ver
                                                int64_t num_vertices, int64_t num_rays, float epsilon,
                                                uint8_t *visible_out, float *frustum_workspace,
                                                void *stream);
+/* Extension: triangle-driven complement of the lattice estimate -- a face is also visible when the segment
+ * from the viewing vertex to one of 7 interior sample points of the face is not blocked by another active
+ * triangle.  ORs into visible_inout [B,T] (run it after drt_mesh_triangles_visible_from_vertex). */
+int32_t drt_mesh_triangles_visible_samples(drt_mesh_t mesh, const float *viewing_vertices,
+                                           int64_t num_vertices, float epsilon, uint8_t *visible_inout,
+                                           void *stream);
 int32_t drt_mesh_first_triangle_hit_by_ray(drt_mesh_t mesh, const float *ray_origins,
                                            const float *ray_directions, int64_t num_rays,
                                            float epsilon, int64_t batch_size, int32_t *index_out,

@@ -22,8 +22,9 @@ rx = np.stack(np.meshgrid(c0[0] + g + 20.0, c0[1] + g + 20.0, indexing="ij"), -1
 rx = np.column_stack((rx, np.full(len(rx), 1.5))).astype(np.float32)
 mesh = G.Mesh(V, Tr)
 NUM_RAYS = int(float(next((a.split("=")[1] for a in sys.argv if a.startswith("--rays=")), 1e6)))
-solver = G.HybridPathTracer(num_rays=NUM_RAYS, accel="bvh")
-out = {"num_rays": NUM_RAYS, "triangles": int(Tr.shape[0]), "num_tx": 1, "num_rx": int(rx.shape[0]),
+SAMPLES = "--samples" in sys.argv
+solver = G.HybridPathTracer(num_rays=NUM_RAYS, accel="bvh", sample_triangles=SAMPLES)
+out = {"sample_triangles": SAMPLES, "num_rays": NUM_RAYS, "triangles": int(Tr.shape[0]), "num_tx": 1, "num_rx": int(rx.shape[0]),
        "exhaustive_evals_per_step": int(rx.shape[0]) * 200000 * 199999}
 
 
@@ -44,7 +45,7 @@ out.update({"s_per_step": time.perf_counter() - t0, "valid_paths": int(paths.obj
             "candidate_evals_per_step": int(solver.last_num_evaluated), "grad_finite": bool(torch.isfinite(grad).all()),
             "grad_absmax": float(grad.abs().max())})
 print(json.dumps(out))
-if len(sys.argv) > 1 and sys.argv[1] == "--verify":
+if "--verify" in sys.argv:
     # exhaustive trace of all 4.1e13 candidates (about two minutes): the pruned search must not miss a path
     scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
     t0 = time.perf_counter()

@@ -151,6 +151,46 @@ def test_gpu_fibonacci_lattice_properties(G):
 
 
 @gpu
+def test_gpu_sample_triangles_visibility(G):
+    """Extension: interior sample points of every face complement the lattice rays.  On a small scene the
+    sample pass must equal a NumPy restatement (segment viewpoint -> sample blocked by another active
+    triangle before t = 1 - 1e-4, Moller-Trumbore of the oracle); it only ever adds faces."""
+    rng = np.random.default_rng(12)
+    outer, inner = orc.box_mesh(8.0, 6.0, 5.0, with_top=True), orc.box_mesh(2.0, 2.0, 2.0, with_top=True)
+    V = np.concatenate((outer[0], inner[0] + np.float32([1.0, 0.5, -0.3])))
+    Tr = np.concatenate((outer[1], inner[1] + 8)).astype(np.int32)
+    mask = np.ones(len(Tr), bool)
+    mask[5] = False
+    views = rng.uniform(-3.5, 3.5, (6, 3)).astype(np.float32) * np.float32([1, 0.8, 0.6])
+    tv = orc.triangle_vertices(V, Tr)
+    w = np.array([[1 / 3, 1 / 3, 1 / 3], [0.8, 0.1, 0.1], [0.1, 0.8, 0.1], [0.1, 0.1, 0.8], [0.45, 0.45, 0.1],
+                  [0.1, 0.45, 0.45], [0.45, 0.1, 0.45]], np.float32)
+    for m in (None, mask):
+        mesh = G.Mesh(V, Tr, mask=m)
+        lat = _np(mesh.triangles_visible_from_vertex(views, num_rays=1, accel="bvh"))
+        got = _np(mesh.triangles_visible_from_vertex(views, num_rays=1, accel="bvh", sample_triangles=True))
+        assert (got | lat == got).all()  # only adds
+        exp = lat.copy()
+        act = np.ones(len(Tr), bool) if m is None else m
+        for b, o in enumerate(views):
+            for j in np.flatnonzero(act):
+                pts = ((tv[j, 0][None] * w[:, :1]).astype(np.float32) + (tv[j, 1][None] * w[:, 1:2]).astype(np.float32)).astype(np.float32)
+                pts = (pts + (tv[j, 2][None] * w[:, 2:3]).astype(np.float32)).astype(np.float32)
+                others = act.copy()
+                others[j] = False
+                t, hit = orc.ray_intersect_triangle(o[None, None, :], (pts - o)[:, None, :], tv[None])
+                blocked = ((t < np.float32(1.0 - 1e-4)) & hit & others[None, :]).any(axis=1)
+                exp[b, j] |= bool((~blocked).any())
+        np.testing.assert_array_equal(got, exp)
+        assert got.sum() > lat.sum() + 10
+    dense = _np(G.Mesh(V, Tr).triangles_visible_from_vertex(views, num_rays=2_000_000, accel="bvh"))
+    both = _np(G.Mesh(V, Tr).triangles_visible_from_vertex(views, num_rays=1000, accel="bvh", sample_triangles=True))
+    assert (dense & ~both).sum() <= 2  # the sample pass recovers (nearly) everything dense lattice sampling sees
+    with pytest.raises(ValueError, match="sample_triangles needs accel"):
+        G.Mesh(V, Tr).triangles_visible_from_vertex(views, num_rays=10, sample_triangles=True)
+
+
+@gpu
 def test_gpu_spherical_conversions(G):
     """geometry/_utils.py:930-993 (round trip and the zero vector), vs the oracle."""
     rng = np.random.default_rng(4)
