@@ -129,11 +129,14 @@ def pruned_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:
                "pruned_candidates_per_pair": solver.num_path_candidates(scene, order),
                "note": "includes the visibility estimation (80 viewpoints x 1e6 rays on the LBVH)"}
 
-        # extension: pruning per (tx, rx) pair, all pairs in one ragged launch (HybridPathTracer.trace_pairs)
+        # extension: pruning per (tx, rx) pair, all pairs in one ragged launch (HybridPathTracer.trace_pairs);
+        # visibility = 1e5 lattice rays per viewpoint + 7 interior sample points per face
+        psolver = G.HybridPathTracer(num_rays=100_000, accel="bvh", sample_triangles=True)
+
         def pstep():
             txg = torch.tensor(tx, device="cuda", requires_grad=True)
             scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
-            paths = solver.trace_pairs(scene, order)
+            paths = psolver.trace_pairs(scene, order)
             torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
             return paths.objects.shape[0]
 
@@ -145,14 +148,15 @@ def pruned_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:
         dtp = time.perf_counter() - t0
         out["per_pair"] = {"s_per_step": dtp, "valid_paths": int(npp), "valid_paths_per_s": npp / dtp,
                            "same_valid_paths_as_exhaustive": int(npp) == int(expected_valid),
-                           "candidate_evals_per_step": int(solver.last_num_evaluated)}
+                           "candidate_evals_per_step": int(psolver.last_num_evaluated),
+                           "visibility": "1e5 lattice rays + 7 sample points per face, per viewpoint"}
         # the same step with the visibility estimate reused (end points that move little between steps)
-        vis = solver.estimate_visibility(G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh))
+        vis = psolver.estimate_visibility(G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh))
 
         def cstep():
             txg = torch.tensor(tx, device="cuda", requires_grad=True)
             scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
-            paths = solver.trace_pairs(scene, order, visibility=vis)
+            paths = psolver.trace_pairs(scene, order, visibility=vis)
             torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
             return paths.objects.shape[0]
 

@@ -20,11 +20,12 @@ tx, rx = S.manhattan_tx_rx(centres, heights, 16, 64)
 mesh = G.Mesh(V, Tr)
 STRATEGY = next((a.split("=")[1] for a in sys.argv if a.startswith("--strategy=")), "auto")
 SAMPLES = "--samples" in sys.argv
-solver = G.HybridPathTracer(num_rays=1_000_000, accel="bvh", pairs_strategy=STRATEGY, sample_triangles=SAMPLES)
-vt = mesh.triangles_visible_from_vertex(torch.tensor(tx, device="cuda"), num_rays=1_000_000, accel="bvh", sample_triangles=SAMPLES).sum(1)
-vr = mesh.triangles_visible_from_vertex(torch.tensor(rx, device="cuda"), num_rays=1_000_000, accel="bvh", sample_triangles=SAMPLES).sum(1)
+NUM_RAYS = int(float(next((a.split("=")[1] for a in sys.argv if a.startswith("--rays=")), 1e6)))
+solver = G.HybridPathTracer(num_rays=NUM_RAYS, accel="bvh", pairs_strategy=STRATEGY, sample_triangles=SAMPLES)
+vt = mesh.triangles_visible_from_vertex(torch.tensor(tx, device="cuda"), num_rays=NUM_RAYS, accel="bvh", sample_triangles=SAMPLES).sum(1)
+vr = mesh.triangles_visible_from_vertex(torch.tensor(rx, device="cuda"), num_rays=NUM_RAYS, accel="bvh", sample_triangles=SAMPLES).sum(1)
 evals = int((vt.double().sum() * vr.double().sum()).item()) * mesh.num_primitives ** (order - 2)
-out = {"sample_triangles": SAMPLES, "strategy": STRATEGY, "order": order, "visible_per_tx_mean": float(vt.float().mean()), "visible_per_rx_mean": float(vr.float().mean()),
+out = {"num_rays": NUM_RAYS, "sample_triangles": SAMPLES, "strategy": STRATEGY, "order": order, "visible_per_tx_mean": float(vt.float().mean()), "visible_per_rx_mean": float(vr.float().mean()),
        "candidate_evals_per_step": evals, "exhaustive_evals_per_step": 1024 * 10000 * 9999 ** (order - 1)}
 print(json.dumps(out), flush=True)
 if evals > budget:
