@@ -204,8 +204,24 @@ class Mesh:
             ma = self.mask if self.mask is not None else torch.ones(self.num_triangles, dtype=torch.bool, device=tri.device)
             mb = other.mask if other.mask is not None else torch.ones(other.num_triangles, dtype=torch.bool, device=tri.device)
             mask = torch.cat((ma, mb))
+        # materials (_mesh.py:1571-1575): names merged (unique, self first), other's indices renumbered; a
+        # mesh without materials contributes -1 when the other one has some
+        names, fm = (), None
+        if self.face_materials is not None or other.face_materials is not None:
+            table = {n: i for i, n in enumerate(dict.fromkeys((*self.material_names, *other.material_names)))}
+            names = tuple(table)
+
+            def remap(m):
+                if m.face_materials is None:
+                    return torch.full((m.num_triangles,), -1, dtype=torch.int32, device=tri.device)
+                lut = torch.as_tensor([table[n] for n in m.material_names] or [0], dtype=torch.int32, device=tri.device)
+                f = m.face_materials.to(device=tri.device, dtype=torch.int64)
+                ok = (f >= 0) & (f < len(m.material_names))
+                return torch.where(ok, lut[f.clamp(0, max(len(m.material_names) - 1, 0))], f.to(torch.int32))
+
+            fm = torch.cat((remap(self), remap(other)))
         return Mesh(torch.cat((self.vertices, other.vertices)), tri, mask,
-                    self.assume_quads and other.assume_quads)
+                    self.assume_quads and other.assume_quads, face_materials=fm, material_names=names)
 
     __add__ = append
 

@@ -242,6 +242,15 @@ def test_mesh_materials(G):
     with pytest.raises(ValueError, match="Expected either 1, 12, or 6 names"):
         mesh.set_assume_quads().set_materials("a", "b")
     assert _np(mesh.set_face_materials(3).face_materials).tolist() == [3] * 12
+    # append (_mesh.py:1571-1575): names merged, the second mesh renumbered, -1 where a mesh has no materials
+    a = G.Mesh.box().set_materials("concrete")
+    b = G.Mesh.box().set_materials(*(["glass", "concrete"] * 5))
+    c = a + b
+    assert c.material_names == ("concrete", "glass")
+    assert _np(c.face_materials).tolist() == [0] * 10 + [1, 0] * 5
+    d = G.Mesh.box() + a
+    assert _np(d.face_materials).tolist() == [-1] * 10 + [0] * 10 and d.material_names == ("concrete",)
+    assert (G.Mesh.box() + G.Mesh.box()).face_materials is None
 
 
 # ------------------------------------------------------------------ gradients ----
