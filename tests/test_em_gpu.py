@@ -362,3 +362,16 @@ def test_received_power_gradient_end_to_end(G, rng):
         dn[0, c] -= h
         fd[0, c] = (total_power(up) - total_power(dn)) / (2 * h)
     np.testing.assert_allclose(g, fd, rtol=5e-3, atol=5e-3 * np.abs(fd).max())
+
+
+def test_example_received_power_ascent():
+    """examples/received_power_gradient.py: the gradient steps do increase the received power."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location(
+        "received_power_gradient", Path(__file__).resolve().parents[1] / "examples" / "received_power_gradient.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(steps=4)
+    assert len(hist) == 4 and all(np.isfinite(hist)) and hist[-1] > hist[0]
