@@ -43,7 +43,14 @@ __device__ __forceinline__ void slab(const RayPrep &r, const float *lo, const fl
 }
 
 
+// Traversal pushes at most one node per tree level, and a Karras radix tree over DISTINCT 62-bit keys
+// (30-bit Morton code << 32 | triangle index, bvh.hip pad_and_morton_kernel) splits on a strictly
+// increasing bit position along any root-to-leaf path: depth <= 62 whatever the geometry (coincident
+// centroids only deepen the tree down the index bits).  A 64-entry stack therefore cannot overflow;
+// the `sp < kBvhStack` guards below are unreachable belt-and-braces.
+constexpr int kBvhKeyBits = 62;
 constexpr int kBvhStack = 64;
+static_assert(kBvhStack >= kBvhKeyBits, "traversal stack must cover the maximum radix-tree depth");
 
 // packed first-hit key, see ray_ops.hip: smallest t, then the LATEST batch_size-tile, then the lowest
 // index inside the tile (reference geometry/_utils.py:1865-1867, 1886)

@@ -121,12 +121,25 @@ class Mesh:
         if self.assume_quads and self.triangles.shape[0] % 2 != 0:
             raise ValueError("assume_quads requires an even number of triangles")  # _mesh.py:690-696
 
-    # ---- native handle (rebuilt when a field changes: dataclasses.replace makes a new object) ----
+    # ---- native handle: a device snapshot of (vertices, triangles, mask), keyed on the identity AND
+    # the in-place version of the tensors it was taken from, so that `optimizer.step()` on
+    # `mesh.vertices`, `mesh.vertices -= ...` or `mesh.mask = ...` can never leave the kernels (trace,
+    # normals, VJP) on stale geometry while `triangle_vertices` reads the live tensor ----
+    def _handle_key(self) -> tuple:
+        def k(t):
+            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+
+        return (k(self.vertices), k(self.triangles), k(self.mask), bool(self.assume_quads))
+
     def handle(self) -> _MeshHandle:
-        if self._handle is None:
+        key = self._handle_key()
+        if self._handle is None or getattr(self._handle, "key", None) != key:
+            if self.mask is not None and self.mask.shape[0] != self.triangles.shape[0]:
+                raise ValueError("mask must have one entry per triangle")
             self._handle = _MeshHandle(
                 self.vertices.detach().contiguous(), self.triangles, self.mask, self.assume_quads
             )
+            self._handle.key = key
         return self._handle
 
     # ---- reference properties ----
@@ -191,8 +204,13 @@ class Mesh:
         if self.mask is None:
             return self
         keep = self.mask
-        return replace(self, triangles=self.triangles[keep], mask=None, _handle=None,
-                       object_bounds=None)
+        if self.assume_quads:  # a quad survives as a whole or not at all (_mesh.py:1397-1429)
+            pairs = keep.reshape(-1, 2)
+            if bool((pairs[:, 0] != pairs[:, 1]).any()):
+                raise ValueError("assume_quads: the mask splits a quad (both triangles must share one flag)")
+        fm = None if self.face_materials is None else self.face_materials[keep].contiguous()
+        return replace(self, triangles=self.triangles[keep].contiguous(), mask=None, _handle=None,
+                       object_bounds=None, face_materials=fm)
 
     def append(self, other: "Mesh") -> "Mesh":
         """Concatenate two meshes (_mesh.py:1555-1734): indices of ``other`` are offset, masks are

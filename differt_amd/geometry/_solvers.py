@@ -537,6 +537,12 @@ class HybridPathTracer(ExhaustivePathTracer):
 
         first_ids, first_off, nf = csr(vis_tx)
         last_ids, last_off, nl = csr(vis_rx)
+        # exact total in Python integers first: the int64 tensors below would wrap silently and rows would
+        # decode to the wrong (tx, rx) pair (the C side only sees the wrapped value)
+        exact_total = int(nf.sum().item()) * n ** (order - 2) * int(nl.sum().item())
+        if exact_total >= 2**62:
+            raise OverflowError(f"per-pair candidate spaces hold {exact_total} rows in all (>= 2**62): "
+                                "trace fewer pairs per call or lower the order")
         sizes = (nf[:, None] * (n ** (order - 2)) * nl[None, :]).reshape(-1)  # pair-major, like the keys
         pair_off = torch.zeros(sizes.shape[0] + 1, dtype=torch.int64, device=sizes.device)
         pair_off[1:] = torch.cumsum(sizes, 0)

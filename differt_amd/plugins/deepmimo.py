@@ -162,6 +162,11 @@ def paths_channel(paths: TracedPaths, mesh, n_complex, thickness, frequency: flo
         nc = torch.as_tensor(np.ascontiguousarray(n_complex, dtype=np.float32), device=dev)
         th = torch.as_tensor(np.ascontiguousarray(thickness, dtype=np.float32), device=dev)
         T, M = mesh.num_triangles, nc.shape[0]
+        # Mesh.append() writes -1 for sub-meshes without materials and set_face_materials() does no bounds
+        # check: the kernel would alias such faces to material 0, so refuse them here (one reduction)
+        if fm.numel() and (fm.shape[0] != T or int(fm.min()) < 0 or int(fm.max()) >= M):
+            raise ValueError(f"face_materials must hold one index in [0, {M}) per triangle "
+                             f"(got {fm.shape[0]} entries in [{int(fm.min())}, {int(fm.max())}] for {T} triangles)")
     res = _PathsChannelFn.apply(v, o, (normals, fm, nc, th, T, M), pr, order)
     out = {k: res[:, i].reshape(batch) for i, k in enumerate(_CHANNEL_OUTPUTS) if i >= 2}
     out["a"] = torch.view_as_complex(res[:, :2].contiguous()).reshape(batch)
