@@ -204,7 +204,7 @@ def main() -> None:
                 "outputs": "t f32[R,T] + hit u8[R,T]",
             },
             "roofline": {
-                "kernel": "drt::mt_dense_kernel<4, true>",
+                "kernel": "drt::mt_dense_aligned_kernel",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

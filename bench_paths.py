@@ -38,14 +38,15 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
     total = n * (n - 1) ** (order - 1)
     count = total if num_ranks is None else min(num_ranks, total)
     tracer = G.ExhaustivePathTracer()
+    timed = G.ExhaustivePathTracer(collect_stats=True)  # one extra, untimed step for the per-kernel times
     from differt_amd.distributed import shard_interval
 
     lo, hi = shard_interval(count, world, rank)
 
-    def step():
+    def step(tr=tracer):
         txg = torch.tensor(tx, device="cuda", requires_grad=True)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
-        paths = tracer.trace_rank_range(scene, order, lo, hi, max_survivors=1 << 24, max_paths=1 << 20)
+        paths = tr.trace_rank_range(scene, order, lo, hi, max_survivors=1 << 24, max_paths=1 << 20)
         loss = torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum()
         loss.backward()
         return paths.objects.shape[0], txg.grad
@@ -53,7 +54,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
     # The timed region is collective-free (each rank works on its own block); ONE all-reduce at the
     # end combines {max time, sum of valid paths, sum of |grad|, failure flag}, and every rank reaches
     # it even if its own leg raised -- a failing rank cannot dead-lock the others.
-    nvalid, grad, dt, err = 0, None, 0.0, None
+    nvalid, grad, dt, err, stage = 0, None, 0.0, None, None
     try:
         nvalid, grad = step()  # warm-up (also sizes the queues)
         torch.cuda.synchronize()
@@ -62,6 +63,8 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
             nvalid, grad = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        step(timed)  # HIP-event stage times (drt_trace_stats) of one more, untimed step
+        stage = dict(timed.last_stats)
     except Exception as exc:  # noqa: BLE001
         err = repr(exc)
     if dist is not None and world > 1:
@@ -88,9 +91,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         "s_per_step": dt,
         "path_candidates_per_s": pairs * count / dt,
         "valid_paths_per_s": nvalid / dt,
-        # 113k + 8 FLOP per candidate before occlusion (234 at k=2, 347 at k=3), vs the
-        # 157.3 TFLOP/s FP32 vector peak (which counts an FMA as 2: one-rounding-per-op code tops at 50 %)
-        "valu_frac_of_157TF": (113 * order + 8) * pairs * count / dt / 157.3e12,
+        "roofline": paths_roofline(order, stage),
         "grad_tx_finite": bool(torch.isfinite(grad).all().item()),
         "grad_tx_absmax": float(grad.abs().max().item()),
     }
@@ -98,6 +99,54 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         out["visibility_pruned"] = pruned_leg(G, mesh, tx, rx, order, nvalid)
     if cpu_sample and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_sample_rate(V, Tr, tx, rx, order, n)
+    return out
+
+
+PEAK_VALU_ISSUE = 1024 * 32 * 2.4e9  # lane-ops/s: 1024 SIMD-32, one wave-instruction per 2 cycles, 2.4 GHz
+PEAK_FP32_FMA = 157.3e12            # MI355X_MICROARCH.md FP32 vector peak (counts an FMA as 2 flop)
+
+
+def paths_roofline(order: int, stage: dict | None) -> dict | None:
+    """Roofline of the kernel that owns the paths metric (the filter stage), from quantities that are
+    MEASURED: kernel time = HIP events around the launch (drt_trace_stats, this run); executed VALU
+    instructions per (tx, rx, candidate) = SQ_INSTS_VALU x 64 / candidates of the committed counter
+    pass (profiles/r02/pmc_trace_filter.json, `rocprofv3 --pmc SQ_INSTS_VALU ...` on this same step).
+    achieved = executed lane-operations / s; peak = the non-FMA issue ceiling (one-rounding-per-
+    operation code cannot use FMA), with the fraction of the 157.3 TFLOP/s FMA peak beside it."""
+    import json
+    from pathlib import Path
+
+    if not stage or not stage.get("filter_ms"):
+        return None
+    pmc = Path(__file__).resolve().parent / "profiles" / "r02" / "pmc_trace_filter.json"
+    per_cand = None
+    occ_per_surv_tri = None
+    if pmc.exists():
+        try:
+            rec = json.loads(pmc.read_text())
+            per_cand = rec.get("executed_valu_per_candidate", {}).get(str(order))
+            occ_per_surv_tri = rec.get("occlusion_valu_per_survivor_triangle")
+        except Exception:  # noqa: BLE001
+            per_cand = None
+    out = {
+        "kernel": f"drt::trace_filter_kernel<{order}, false, false>",
+        "bound": "valu",
+        "kernel_ms": stage["filter_ms"],
+        "candidates_per_launch": stage["candidates"],
+        "survivors": stage["survivors"],
+        "occlusion_kernel_ms": stage["occlusion_ms"],
+        "sort_emit_ms": stage["sort_emit_ms"],
+        "executed_valu_per_candidate": per_cand,
+        "executed_valu_source": "profiles/r02/pmc_trace_filter.json (SQ_INSTS_VALU pass, committed)",
+        "peak": PEAK_VALU_ISSUE,
+        "peak_fma_flops": PEAK_FP32_FMA,
+        "unit": "lane-ops/s",
+    }
+    if per_cand:
+        ach = per_cand * stage["candidates"] / (stage["filter_ms"] * 1e-3)
+        out.update({"achieved": ach, "frac": ach / PEAK_VALU_ISSUE, "frac_of_157TF": ach / PEAK_FP32_FMA})
+    if occ_per_surv_tri and stage.get("occlusion_ms"):
+        out["occlusion_valu_per_survivor_triangle"] = occ_per_surv_tri
     return out
 
 

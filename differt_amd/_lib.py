@@ -37,17 +37,33 @@ class CapacityError(DrtError):
     """A caller-provided capacity (survivor queue / output rows) was too small."""
 
 
+class TraceStats(C.Structure):
+    """``drt_trace_stats``: per-stage counters + HIP-event timers of one compact trace."""
+
+    _fields_ = [
+        ("candidates", C.c_int64),
+        ("survivors", C.c_int64),
+        ("valid", C.c_int64),
+        ("filter_ms", C.c_float),
+        ("occlusion_ms", C.c_float),
+        ("sort_emit_ms", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
 class TraceParams(C.Structure):
     _fields_ = [
         ("epsilon", C.c_float),
         ("hit_tol", C.c_float),
         ("min_len", C.c_float),
         ("flags", C.c_int32),
+        ("stats", C.POINTER(TraceStats)),
     ]
 
 
 DRT_TRACE_USE_BVH = 1
-ABI_VERSION = 3  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
+DRT_TRACE_OVERFLOW_SURVIVORS, DRT_TRACE_OVERFLOW_PATHS = 1, 2
+ABI_VERSION = 4  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
 
 
 class EmParams(C.Structure):
@@ -154,6 +170,11 @@ _SIGNATURES = {
         _i32,
         [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _i64, _i64, _vp,
          _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
+    ),
+    "drt_trace_paths_compact_async": (
+        _i32,
+        [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _i64, _i64, _vp,
+         _vp, _vp, _vp, _vp, _sz, _vp],
     ),
     "drt_trace_paths_vjp": (
         _i32,

@@ -7,8 +7,8 @@
 // Mapping choices (wave = 64 lanes, 256 CUs):
 //   dense MT   : HBM-write bound (5 B out per test).  One lane owns 4 consecutive triangles in
 //                registers and walks a chunk of rays whose origin/direction are wave-uniform
-//                (scalar loads); every lane stores 16 B of t and 4 B of hit per ray -> each wave
-//                writes full 1 KiB / 256 B segments of an output row.
+//                (scalar loads); every lane stores 16 B of t per ray (each wave writes 1 KiB of an
+//                output row); the u8 hit rows are staged in LDS and flushed as whole 128-B lines.
 //   any/first  : FP32-VALU bound.  One lane owns one ray; the block stages triangle tiles in LDS
 //                as (v0, e1, e2, active) records read back with broadcast ds_read_b128; triangle
 //                ranges are split over blockIdx.y so that small ray batches still fill the chip.
@@ -26,27 +26,60 @@ namespace drt {
 // (a1) dense
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kDenseThreads = 256;
+constexpr int kDenseCols = kDenseThreads * 4;  // triangles per block
+constexpr int kDenseGroup = 8;                 // rays whose hit bytes are staged in LDS together
 
-// TPL = triangles per lane (4 or 8).  Measured on MI355X (scratch/write_bw.hip): a CU retires one
-// wave-store in max(~50 cycles, bytes / ~10 B/clk), so the [R,T] f32 + u8 output pattern alone costs
-// 0.79 ms per 3.28 GB launch (4.2 TB/s) whatever the tile shape, and hiding it behind the ~0.7 ms of
-// VALU work needs all 8 waves/SIMD: TPL = 8 (124 VGPRs, 4 waves/SIMD, half as many `hit` stores)
-// measured 1.9 ms vs 0.97 ms for TPL = 4 (56 VGPRs), so the launcher always picks 4.
-template <int TPL, bool VEC>
-__global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
-    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
-    const float *__restrict__ tv, int64_t T, float eps, float *__restrict__ t_out,
-    uint8_t *__restrict__ hit_out, int rays_per_block) {
-    const int64_t j0 = ((int64_t)blockIdx.y * kDenseThreads + threadIdx.x) * TPL;
-    if (j0 >= T) return;
+// Stores with a wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset: the per-row address math
+// stays on the scalar unit.  Nontemporal: measured 0.83 ms vs 0.95 ms for plain stores on the bench
+// shape (profiles/r02/dense_lab.md).
+__device__ __forceinline__ void store_nt_b128(char *base, uint32_t off, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void store_nt_b128(char *base, uint32_t off, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+
+// Byte offset, inside a row segment of `hd` head bytes + `body` bytes of whole 128-B lines + a
+// tail, of the p-th stored byte when the whole lines go first, then the head, then the tail.
+__device__ __forceinline__ uint32_t line_first_offset(uint32_t p, uint32_t hd, uint32_t body) {
+    if (p < body) return hd + p;
+    const uint32_t e = p - body;
+    return (e < hd) ? e : body + e;
+}
+
+// Main dense kernel (requires T % 16 == 0, t_out / hit_out 16-B aligned).
+//   * lane = 4 consecutive triangles kept in VGPRs (v0, e1, e2); block = 1024 triangles x
+//     `rays_per_block` rays; ray origin / direction are wave-uniform scalar loads, prefetched one
+//     ray ahead; arithmetic = moller_trumbore_x4 (geom.hpp).
+//   * `t`: every lane stores 16 B per ray -> each wave writes 1 KiB of an output row.
+//   * `hit`: measured on MI355X (scratch/store_lab.hip), a store instruction that covers whole
+//     128-B lines costs 0.64x of one that straddles them, and a u8 row of T = 10 000 starts at a
+//     different 16-B phase on every ray, so a wave's 256-B segment always straddles (hit stores
+//     alone: 0.233 ms straddling vs 0.113 ms aligned per 655 MB).  The block therefore stages the
+//     packed hit dwords of kDenseGroup consecutive rays in LDS (8 x 1 KiB, double buffered, ONE
+//     barrier per group) and each wave flushes two rows with one dwordx4 store per row: the first
+//     lanes cover the whole lines of the 1-KiB row segment, the last lanes its partial head and
+//     tail.  A quarter of the hit store instructions, 7 of 9 lines written whole.
+__global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(7, 7)))
+void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
+                             const float *__restrict__ tv, int64_t T, float eps,
+                             float *__restrict__ t_out, uint8_t *__restrict__ hit_out,
+                             int rays_per_block) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_h[2][kDenseGroup][kDenseThreads];
+    const uint32_t col0 = blockIdx.y * (uint32_t)kDenseCols;
+    const uint32_t j0 = col0 + threadIdx.x * 4u;
+    const bool active = j0 < T;  // T % 4 == 0: a lane is entirely inside or outside the row
     const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
-    const int64_t r1 = (r0 + rays_per_block < R) ? r0 + rays_per_block : R;
+    const int n = (int)((r0 + rays_per_block < R) ? rays_per_block : R - r0);
+    const uint32_t W = (uint32_t)((T - col0 < kDenseCols) ? T - col0 : kDenseCols);  // hit bytes per row
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
 
-    TriE tri[TPL];
+    TriE tri[4];
 #pragma unroll
-    for (int q = 0; q < TPL; ++q) {
+    for (int q = 0; q < 4; ++q) {
         // lanes past the end re-read the last triangle; their results are never stored
         const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
         tri[q] = load_tri(tv + 9 * j);
@@ -54,38 +87,93 @@ __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
         asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z),
                           "+v"(tri[q].e2.x), "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
     }
+    uint32_t vzero, vone;
+    mt4_pin_constants(vzero, vone);
 
+    const float *po = ro + 3 * r0, *pd = rd + 3 * r0;
+    char *trow = reinterpret_cast<char *>(t_out + r0 * T);
+    const uint32_t toff = j0 * 4u;
+    V3 o = ld3(po), d = ld3(pd);
+    const int ngroups = (n + kDenseGroup - 1) / kDenseGroup;
+    for (int g = 0; g < ngroups; ++g) {
+        const int buf = g & 1;
+        const int cnt = (n - g * kDenseGroup < kDenseGroup) ? n - g * kDenseGroup : kDenseGroup;
+        for (int s = 0; s < cnt; ++s) {
+            // next ray's scalars in flight during this ray's arithmetic (the last ray is re-read)
+            const int more = (g * kDenseGroup + s + 1 < n) ? 3 : 0;
+            po += more;
+            pd += more;
+            const V3 on = ld3(po), dn = ld3(pd);
+            float t[4];
+            uint32_t hh;
+            moller_trumbore_x4(o, d, tri, eps, t, hh, vzero, vone);
+            if (active) store_nt_b128(trow, toff, f32x4{t[0], t[1], t[2], t[3]});
+            lds_h[buf][s][threadIdx.x] = hh;
+            trow += T * 4;
+            o = on;
+            d = dn;
+        }
+        // buffer `buf` is rewritten two groups later, i.e. after the NEXT barrier, which every wave
+        // reaches only after its flush below: one barrier per group is enough
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kDenseGroup / 4; ++k) {
+            const int s = wave + 4 * k;  // wave w flushes rows w and w + 4 of the group
+            if (s < cnt) {
+                const int64_t A = (r0 + (int64_t)g * kDenseGroup + s) * T + col0;  // first hit byte
+                const uint32_t head = (128u - ((uint32_t)A & 127u)) & 127u;
+                const uint32_t hd = head < W ? head : W;
+                const uint32_t body = (W - hd) & ~127u;
+                const uint32_t off = line_first_offset((uint32_t)lane * 16u, hd, body);
+                if (off < W) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(
+                        reinterpret_cast<const char *>(&lds_h[buf][s][0]) + off);
+                    store_nt_b128(reinterpret_cast<char *>(hit_out) + A, off, v);
+                }
+            }
+        }
+    }
+}
+
+// Fallback for rows that are not 16-B tileable (T % 16 != 0 or unaligned outputs): same arithmetic,
+// direct stores (VEC: T % 4 == 0 and 16-B / 4-B aligned outputs; otherwise scalar stores).
+template <bool VEC>
+__global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
+    const float *__restrict__ tv, int64_t T, float eps, float *__restrict__ t_out,
+    uint8_t *__restrict__ hit_out, int rays_per_block) {
+    const int64_t j0 = ((int64_t)blockIdx.y * kDenseThreads + threadIdx.x) * 4;
+    if (j0 >= T) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
+    const int64_t r1 = (r0 + rays_per_block < R) ? r0 + rays_per_block : R;
+
+    TriE tri[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
+        tri[q] = load_tri(tv + 9 * j);
+        asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z),
+                          "+v"(tri[q].e2.x), "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
+    }
+    uint32_t vzero, vone;
+    mt4_pin_constants(vzero, vone);
     for (int64_t r = r0; r < r1; ++r) {
         const V3 o = ld3(ro + 3 * r);  // wave-uniform -> scalar loads
         const V3 d = ld3(rd + 3 * r);
-        float t[TPL];
-        bool h[TPL];
-        moller_trumbore_n<TPL>(o, d, tri, eps, t, h);
+        float t[4];
+        uint32_t hh;
+        moller_trumbore_x4(o, d, tri, eps, t, hh, vzero, vone);
         const int64_t base = r * T + j0;
-#ifdef DRT_EXPERIMENT_NO_STORE  // roofline study only: arithmetic without stores
-        if (t[0] + t[1] + t[2] + t[3] != 12345.678f) continue;
-#endif
         if (VEC) {
-            uint32_t hh[TPL / 4];
-#pragma unroll
-            for (int g = 0; g < TPL / 4; ++g) {
-                f32x4 tt = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
-                __builtin_nontemporal_store(tt, reinterpret_cast<f32x4 *>(t_out + base + 4 * g));
-                hh[g] = (uint32_t)h[4 * g] | ((uint32_t)h[4 * g + 1] << 8) |
-                        ((uint32_t)h[4 * g + 2] << 16) | ((uint32_t)h[4 * g + 3] << 24);
-            }
-            if (TPL == 8) {
-                u32x2 h2 = {hh[0], hh[TPL / 4 - 1]};
-                __builtin_nontemporal_store(h2, reinterpret_cast<u32x2 *>(hit_out + base));
-            } else {
-                __builtin_nontemporal_store(hh[0], reinterpret_cast<uint32_t *>(hit_out + base));
-            }
+            f32x4 tt = {t[0], t[1], t[2], t[3]};
+            __builtin_nontemporal_store(tt, reinterpret_cast<f32x4 *>(t_out + base));
+            __builtin_nontemporal_store(hh, reinterpret_cast<uint32_t *>(hit_out + base));
         } else {
 #pragma unroll
-            for (int q = 0; q < TPL; ++q)
+            for (int q = 0; q < 4; ++q)
                 if (j0 + q < T) {
                     t_out[base + q] = t[q];
-                    hit_out[base + q] = (uint8_t)h[q];
+                    hit_out[base + q] = (uint8_t)((hh >> (8 * q)) & 1u);
                 }
         }
     }
@@ -344,33 +432,33 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
     if (R == 0 || T == 0) return DRT_OK;
     DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
-    // 8 triangles per lane when rows are 8-aligned and there is enough work to fill the chip
-    const bool al8 = (T % 8 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(hit_out) & 7) == 0);
+    const bool al16 = (T % 16 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(hit_out) & 15) == 0);
     const bool al4 = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(hit_out) & 3) == 0);
-    const int tpl = 4;  // see the note above mt_dense_kernel: occupancy beats fewer stores
-    (void)al8;
-    const int64_t cols = ceil_div(T, (int64_t)kDenseThreads * tpl);
+    const int64_t cols = ceil_div(T, (int64_t)kDenseCols);
     DRT_REQUIRE(cols <= 65535, "too many triangles for one launch (%lld)", (long long)T);
     // rays per block: as many as possible (amortises the 144-B/lane triangle loads) while keeping
     // >= ~640 blocks; measured on the literal configs[1] launch (256 rays): 17.2 us at 1 ray/block,
-    // 10.5 us at 4
+    // 10.5 us at 4.  Upper bound 32: 0.806 ms vs 0.83 ms at 64 on the bench shape.
     int64_t rpb = (R * cols) / 640;
     if (rpb < 1) rpb = 1;
-    if (rpb > 64) rpb = 64;
+    if (rpb > 32) rpb = 32;
+    if (al16 && rpb > kDenseGroup) rpb -= rpb % kDenseGroup;  // whole groups: no short trailing group
     const int64_t rows = ceil_div(R, rpb);
     DRT_REQUIRE(rows < (1ll << 31), "too many rays for one launch");
+    // 32-bit byte offsets inside a block's rows: rpb * T * 4 bytes must fit
+    DRT_REQUIRE(T <= (1ll << 24), "too many triangles per row for one launch (%lld)", (long long)T);
     dim3 grid((unsigned)rows, (unsigned)cols);
     hipStream_t s = as_stream(stream);
-    if (tpl == 8)
-        hipLaunchKernelGGL((mt_dense_kernel<8, true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
-                           eps, t_out, hit_out, (int)rpb);
+    if (al16)
+        hipLaunchKernelGGL(mt_dense_aligned_kernel, grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T, eps,
+                           t_out, hit_out, (int)rpb);
     else if (al4)
-        hipLaunchKernelGGL((mt_dense_kernel<4, true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
+        hipLaunchKernelGGL((mt_dense_kernel<true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
                            eps, t_out, hit_out, (int)rpb);
     else
-        hipLaunchKernelGGL((mt_dense_kernel<4, false>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
+        hipLaunchKernelGGL((mt_dense_kernel<false>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
                            eps, t_out, hit_out, (int)rpb);
     DRT_LAUNCH_CHECK();
     return DRT_OK;

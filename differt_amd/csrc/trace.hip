@@ -441,6 +441,51 @@ __global__ __launch_bounds__(256) void trace_emit_kernel(TraceArgs a, CandSrc cs
     ob[K + 1] = (int32_t)ir;
 }
 
+// Static-shape variant for the no-sync entry point: `cap` rows are always written.  Rows at or beyond
+// the device-side valid count (their sorted key is a sentinel >= 2^62) become padding: key -1,
+// vertices 0, objects -1.  Also folds the two overflow conditions into the status word.
+constexpr long long kKeySentinelMin = 1ll << 62;
+
+template <int K>
+__global__ __launch_bounds__(256) void trace_emit_padded_kernel(TraceArgs a, CandSrc cs,
+                                                                long long *__restrict__ keys, int64_t cap,
+                                                                int64_t q_cap,
+                                                                const unsigned long long *__restrict__ counters,
+                                                                long long *__restrict__ counts_out,
+                                                                float *__restrict__ vertices,
+                                                                int32_t *__restrict__ objects) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && counts_out) {
+        const long long surv = (long long)counters[0], valid = (long long)counters[1];
+        counts_out[0] = surv;
+        counts_out[1] = valid;
+        counts_out[2] = (surv > q_cap ? DRT_TRACE_OVERFLOW_SURVIVORS : 0) | (valid > cap ? DRT_TRACE_OVERFLOW_PATHS : 0);
+        counts_out[3] = 0;
+    }
+    if (i >= cap) return;
+    const long long key = keys[i];
+    float *v = vertices + i * (K + 2) * 3;
+    int32_t *ob = objects + i * (K + 2);
+    if (key >= kKeySentinelMin || key < 0) {
+        keys[i] = -1;
+#pragma unroll
+        for (int j = 0; j < (K + 2) * 3; ++j) v[j] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K + 2; ++j) ob[j] = -1;
+        return;
+    }
+    int64_t it, ir;
+    int32_t id[KA<K>::n];
+    V3 p[KA<K>::n], n[KA<K>::n], full[K + 2];
+    key_to_path<K>(a, cs, key, it, ir, id, p, n, full);
+#pragma unroll
+    for (int j = 0; j < K + 2; ++j) st3(v + j * 3, full[j]);
+    ob[0] = (int32_t)it;
+#pragma unroll
+    for (int j = 0; j < K; ++j) ob[1 + j] = id[j];
+    ob[K + 1] = (int32_t)ir;
+}
+
 // ------------------------------------------------------------------------------------------
 // VJP: cotangent of the (K+2) path vertices -> tx, rx and mesh-vertex gradients
 // ------------------------------------------------------------------------------------------
@@ -456,8 +501,11 @@ __global__ __launch_bounds__(256) void trace_vjp_kernel(
     int64_t it, ir;
     int32_t id[KA<K>::n];
     V3 p[KA<K>::n], n[KA<K>::n], full[K + 2];
-    // padding rows and non-finite paths have constant (zeroed) vertices: no gradient (SV:696-699)
-    if (!key_to_path<K>(a, cs, keys[i], it, ir, id, p, n, full) || !path_finite<K>(full)) return;
+    // padding rows and non-finite paths have constant (zeroed) vertices: no gradient (SV:696-699);
+    // key -1 = padding row of the static-shape (async) compact output
+    const long long key = keys[i];
+    if (key < 0) return;
+    if (!key_to_path<K>(a, cs, key, it, ir, id, p, n, full) || !path_finite<K>(full)) return;
     const float *g = cot + i * (K + 2) * 3;
     V3 tx_bar = ld3(g);                  // vertices[0] = tx
     V3 rx_bar = ld3(g + 3 * (K + 1));    // vertices[K+1] = rx
@@ -560,6 +608,30 @@ static void launch_occlusion(const Launch &L, const unsigned long long *qc, cons
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// HIP-event timer of the stages of one call (only when the caller asked for drt_trace_stats)
+struct StageTimer {
+    bool on;
+    hipStream_t s;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    StageTimer(bool enable, hipStream_t stream) : on(enable), s(stream) {
+        if (on)
+            for (auto &e : ev)
+                if (hipEventCreate(&e) != hipSuccess) on = false;
+    }
+    ~StageTimer() {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    void mark(int i) {
+        if (on) (void)hipEventRecord(ev[i], s);
+    }
+    float elapsed(int i, int j) {
+        float ms = 0.0f;
+        if (on && hipEventElapsedTime(&ms, ev[i], ev[j]) != hipSuccess) ms = 0.0f;
+        return ms;
+    }
+};
 
 static size_t sort_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
@@ -686,14 +758,20 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
     char *sort_tmp = reinterpret_cast<char *>(q2) + align_up((size_t)max_paths * 8, 256);
     DRT_HIP(hipMemsetAsync(counters, 0, 64, L.s));
     const int k = cands->order;
+    // optional per-stage timers (SURVEY.md section 5 "metrics"): HIP events on the caller's stream
+    drt_trace_stats *st = pr->stats;
+    StageTimer timer(st != nullptr, L.s);
+    timer.mark(0);
 #define CALL(K)                                                                                   \
     do {                                                                                          \
         if (L.quads)                                                                              \
             launch_filter<K, true, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
         else                                                                                      \
             launch_filter<K, false, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+        timer.mark(1);                                                                            \
         launch_occlusion<K, false>(L, counters, q1, max_survivors, counters + 1, q2, max_paths,  \
                                    nullptr);                                                      \
+        timer.mark(2);                                                                            \
     } while (0)
     DRT_ORDER_SWITCH(k, CALL)
 #undef CALL
@@ -701,6 +779,14 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
     unsigned long long host_counts[2] = {0, 0};
     DRT_HIP(hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, L.s));
     DRT_HIP(hipStreamSynchronize(L.s));
+    if (st) {
+        st->candidates = (int64_t)total;
+        st->survivors = (int64_t)host_counts[0];
+        st->valid = (int64_t)host_counts[1];
+        st->filter_ms = timer.elapsed(0, 1);
+        st->occlusion_ms = timer.elapsed(1, 2);
+        st->sort_emit_ms = 0.0f;
+    }
     if ((int64_t)host_counts[0] > max_survivors) {
         *num_valid_host = (int64_t)host_counts[0];
         return fail(DRT_E_CAPACITY,
@@ -721,6 +807,80 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
 #define CALL(K)                                                                                 \
     hipLaunchKernelGGL(trace_emit_kernel<K>, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, L.s, L.a, \
                        L.cs, reinterpret_cast<const long long *>(keys), nv, vertices, objects)
+    DRT_ORDER_SWITCH(k, CALL)
+#undef CALL
+    DRT_LAUNCH_CHECK();
+    if (st) {
+        timer.mark(3);
+        DRT_HIP(hipStreamSynchronize(L.s));
+        st->sort_emit_ms = timer.elapsed(2, 3);
+    }
+    return DRT_OK;
+}
+
+int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx,
+                                      int64_t ntx, const float *rx, int64_t nrx, const drt_candidates *cands,
+                                      int64_t max_survivors, int64_t max_paths, int64_t *keys,
+                                      float *vertices, int32_t *objects, int64_t *counts_dev, void *ws,
+                                      size_t ws_bytes, void *stream) {
+    DRT_REQUIRE(mesh && pr && cands, "null argument");
+    DRT_REQUIRE(ntx >= 0 && nrx >= 0 && max_survivors >= 0 && max_paths >= 0, "negative size");
+    DRT_REQUIRE(max_paths == 0 || (keys && vertices && objects), "null output");
+    Launch L;
+    L.s = as_stream(stream);
+    L.quads = mesh->assume_quads != 0;
+    int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
+    if (rc != DRT_OK) return rc;
+    L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
+    if ((pr->flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0) {
+        // building the LBVH allocates and synchronises: it must exist before a capture / async call
+        DRT_REQUIRE(mesh->bvh_nodes != nullptr,
+                    "DRT_TRACE_USE_BVH in the async entry point needs drt_mesh_build_bvh() beforehand");
+        L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
+    }
+    L.cs.npairs = ntx * nrx;
+    const unsigned __int128 total = L.cs.ragged ? (unsigned __int128)L.cs.count
+                                                : (unsigned __int128)ntx * (unsigned __int128)nrx *
+                                                      (unsigned __int128)L.cs.count;
+    DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx*rx*candidates does not fit a 62-bit key");
+    DRT_REQUIRE(total == 0 || (tx && rx), "null pointer");
+    const size_t need = drt_trace_compact_workspace_size(max_survivors, max_paths);
+    if (!ws || ws_bytes < need) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", need);
+    char *base = reinterpret_cast<char *>(ws);
+    auto *counters = reinterpret_cast<unsigned long long *>(base);  // [0] survivors, [1] valid
+    auto *q1 = reinterpret_cast<long long *>(base + 64);
+    auto *q2 = reinterpret_cast<long long *>(base + 64 + align_up((size_t)max_survivors * 8, 256));
+    char *sort_tmp = reinterpret_cast<char *>(q2) + align_up((size_t)max_paths * 8, 256);
+    DRT_HIP(hipMemsetAsync(counters, 0, 64, L.s));
+    // every slot of the valid-key queue starts as a sentinel (0x7f7f... >= 2^62 > any key): the sort
+    // then runs over the FIXED capacity and pushes the unused slots behind the valid keys
+    if (max_paths > 0) DRT_HIP(hipMemsetAsync(q2, 0x7f, (size_t)max_paths * 8, L.s));
+    const int k = cands->order;
+    if (total > 0) {
+#define CALL(K)                                                                                   \
+    do {                                                                                          \
+        if (L.quads)                                                                              \
+            launch_filter<K, true, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+        else                                                                                      \
+            launch_filter<K, false, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+        launch_occlusion<K, false>(L, counters, q1, max_survivors, counters + 1, q2, max_paths,  \
+                                   nullptr);                                                      \
+    } while (0)
+        DRT_ORDER_SWITCH(k, CALL)
+#undef CALL
+        DRT_LAUNCH_CHECK();
+    }
+    if (max_paths > 0) {
+        size_t tmp_bytes = sort_temp_bytes(max_paths);
+        DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tmp_bytes, reinterpret_cast<unsigned long long *>(q2),
+                                         reinterpret_cast<unsigned long long *>(keys), (size_t)max_paths, 0,
+                                         64, L.s));
+    }
+    const int64_t rows = max_paths > 0 ? max_paths : 1;  // one thread at least: it writes the counts
+#define CALL(K)                                                                                        \
+    hipLaunchKernelGGL(trace_emit_padded_kernel<K>, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, L.s, \
+                       L.a, L.cs, reinterpret_cast<long long *>(keys), max_paths, max_survivors, counters,   \
+                       reinterpret_cast<long long *>(counts_dev), vertices, objects)
     DRT_ORDER_SWITCH(k, CALL)
 #undef CALL
     DRT_LAUNCH_CHECK();

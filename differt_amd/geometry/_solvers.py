@@ -293,6 +293,10 @@ class ExhaustivePathTracer(AbstractPathTracer):
     accel: str | None = None
     """MI355X extension: ``"bvh"`` makes the occlusion stage walk the mesh LBVH (O(log T) per segment,
     like the reference's Warp path) instead of testing every triangle."""
+    collect_stats: bool = False
+    """Fill :attr:`last_stats` (``drt_trace_stats``: candidates / survivors / valid paths and the
+    HIP-event time of the filter, occlusion and sort+emit stages) on every compact trace; costs two
+    extra stream synchronisations per call."""
 
     # ---- candidate generation (host graph classes; lexicographic like graph.rs) ----
     def _graph(self, scene):
@@ -412,10 +416,16 @@ class ExhaustivePathTracer(AbstractPathTracer):
     def _trace_compact(self, scene, desc, max_survivors, max_paths) -> TracedPaths:
         tx = scene.transmitters.reshape(-1, 3).contiguous()
         rx = scene.receivers.reshape(-1, 3).contiguous()
+        params = _params(self.epsilon, self.hit_tol, self.min_len, self.accel)
+        st = None
+        if self.collect_stats:
+            st = _lib.TraceStats()
+            params.stats = C.pointer(st)
         verts, objs, keys = _TraceCompactFn.apply(
-            tx, rx, scene.mesh.vertices, scene.mesh, desc,
-            _params(self.epsilon, self.hit_tol, self.min_len, self.accel), max_survivors, max_paths,
+            tx, rx, scene.mesh.vertices, scene.mesh, desc, params, max_survivors, max_paths,
         )
+        if st is not None:
+            self.last_stats = {f: getattr(st, f) for f, _ in _lib.TraceStats._fields_ if f != "reserved"}
         n, order = objs.shape[0], desc["order"]
         return TracedPaths(
             verts, objs, torch.ones(n, dtype=torch.bool, device=objs.device),

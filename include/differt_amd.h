@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRT_ABI_VERSION 3
+#define DRT_ABI_VERSION 4
 
 enum {
     DRT_OK = 0,
@@ -277,13 +277,30 @@ int32_t drt_digraph_iter_next_chunk(drt_digraph_iter_t it, uint64_t max_rows, ui
  * Candidate source: either an explicit table (device int32 [C,order], negative ids = padding rows,
  * invalid) or a rank interval of the complete graph, unranked on the GPU (no table in HBM).
  * ------------------------------------------------------------------------------------------- */
+/* Per-stage counters and HIP-event timers of one drt_trace_paths_compact call (SURVEY.md section 5,
+ * "metrics" / "tracing" rows).  Filled when drt_trace_params.stats is non-NULL; costs two extra
+ * stream synchronisations, so leave it NULL on the hot path. */
+typedef struct drt_trace_stats {
+    int64_t candidates;     /* (tx, rx, candidate) rows evaluated by the filter stage */
+    int64_t survivors;      /* rows that passed the geometric checks (filter-stage output) */
+    int64_t valid;          /* rows that also passed the occlusion stage = valid paths */
+    float filter_ms;        /* filter kernel, HIP events on the call's stream */
+    float occlusion_ms;     /* occlusion kernel */
+    float sort_emit_ms;     /* radix sort of the valid keys + emit kernel */
+    int32_t reserved;
+} drt_trace_stats;
+
 typedef struct drt_trace_params {
     float epsilon;          /* MT epsilon; reference default 10*eps (_utils.py:1257-1259) */
     float hit_tol;          /* occlusion tolerance; default 100*eps (_utils.py:1418-1420) */
     float min_len;          /* squared-length threshold; default 10*eps (_solvers.py:514-516) */
     int32_t flags;          /* DRT_TRACE_* bits */
+    drt_trace_stats *stats; /* host pointer or NULL (drt_trace_paths_compact only) */
 } drt_trace_params;
 #define DRT_TRACE_USE_BVH 1 /* occlusion stage walks the mesh LBVH instead of testing every triangle */
+/* bits of counts_dev[2] written by drt_trace_paths_compact_async */
+#define DRT_TRACE_OVERFLOW_SURVIVORS 1 /* more candidates passed the geometric checks than max_survivors */
+#define DRT_TRACE_OVERFLOW_PATHS 2     /* more valid paths than max_paths */
 
 typedef struct drt_candidates {
     const int32_t *table;   /* device [num_candidates, order] or NULL */
@@ -345,10 +362,30 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *params,
                                 int32_t *objects, int64_t *num_valid_host, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
+/* The same trace with STATIC output shapes and NO host synchronisation -- the form a jax.ffi /
+ * XLA custom-call handler or a HIP graph needs (the reference's boundary is
+ * wp.jax_callable(func, output_dims=...), geometry/_mesh.py:266-276: output sizes fixed at trace
+ * time).  Capacities are fixed by the caller; all `max_paths` rows of keys / vertices / objects are
+ * written: the first counts_dev[1] rows are the valid paths in masked_vertices order, bit-identical
+ * to drt_trace_paths_compact, the others are padding (key -1, vertices 0, objects -1).
+ *   counts_dev [4] i64 (DEVICE): [0] candidates that passed the geometric checks, [1] valid paths,
+ *                                [2] status word (DRT_TRACE_OVERFLOW_* bits, 0 = complete), [3] 0.
+ * On overflow the rows written are valid paths but not all of them / not the first ones: the
+ * caller inspects counts_dev[2] whenever it reads the result back and re-runs with larger
+ * capacities.  Nothing is allocated, nothing synchronises, the launch sequence does not depend on
+ * device data: the call can be captured in a HIP graph and replayed.  With DRT_TRACE_USE_BVH the
+ * mesh LBVH must have been built before (drt_mesh_build_bvh).  Workspace as the sync variant. */
+int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
+                                      int64_t num_tx, const float *rx, int64_t num_rx,
+                                      const drt_candidates *cands, int64_t max_survivors,
+                                      int64_t max_paths, int64_t *keys, float *vertices,
+                                      int32_t *objects, int64_t *counts_dev, void *workspace,
+                                      size_t workspace_bytes, void *stream);
+
 /* VJP of the path vertices of `num_paths` traced paths w.r.t. transmitters, receivers and mesh
  * vertices (hand-derived reverse of the image method; the mask is a constant, as in the reference:
- * SURVEY.md section 3.2).  keys are those returned by drt_trace_paths_compact (or flat dense
- * indices); cotangent [num_paths,order+2,3].  Gradients are ACCUMULATED with atomic adds into
+ * SURVEY.md section 3.2).  keys are those returned by drt_trace_paths_compact[_async] (or flat dense
+ * indices; rows with key -1 are padding and contribute nothing); cotangent [num_paths,order+2,3].  Gradients are ACCUMULATED with atomic adds into
  * grad_tx [Ntx,3], grad_rx [Nrx,3], grad_vertices [Nv,3] (each may be NULL). */
 int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, const float *rx,
                             int64_t num_rx, const drt_candidates *cands, const int64_t *keys,

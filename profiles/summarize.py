@@ -31,7 +31,7 @@ def main() -> None:
     for r in csv.DictReader(trace.open()):
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         key = short(r["Kernel_Name"])
-        if "mt_dense_kernel" in key:
+        if "mt_dense" in key:
             key += f" [grid={r.get('Grid_Size_X', r.get('Grid_Size', '?'))}x{r.get('Grid_Size_Y', '')}]"
         groups[key].append(dur)
     lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
@@ -42,7 +42,7 @@ def main() -> None:
              "--no-cpu-baseline --no-paths",
              "    rocprofv3 --pmc WRITE_SIZE --output-format csv ... -- python bench.py --steps 3 --warmup 1 "
              "--no-cpu-baseline --no-paths", "",
-             "`mt_dense_kernel<4, true> [grid=262144x10]` are the timed launches of `bench.py` "
+             "`mt_dense_aligned_kernel [grid=524288x10]` are the timed launches of `bench.py` "
              "(65 536 rays x 10 000 triangles); `[grid=16384x10]` the literal 256-ray configs[1] launches.", "",
              "| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
     for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
@@ -54,7 +54,7 @@ def main() -> None:
         for f, ctr in ((fetch[0], "FETCH_SIZE"), (write[0], "WRITE_SIZE")):
             vals = defaultdict(list)
             for r in csv.DictReader(f.open()):
-                if r["Counter_Name"] == ctr and "mt_dense_kernel" in r["Kernel_Name"]:
+                if r["Counter_Name"] == ctr and "mt_dense" in r["Kernel_Name"]:
                     vals[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
             big = max(vals)  # the timed launches (largest grid)
             per[ctr] = sum(vals[big]) / len(vals[big])
@@ -68,7 +68,7 @@ def main() -> None:
             "mt_dense_kernel_bytes_per_launch": traffic,
         }
         (d.parent / "pmc_traffic.json").write_text(json.dumps(out, indent=1))
-        lines += ["", "## HBM traffic of `mt_dense_kernel<true>` (PMC, per launch of 65536 rays x 10000 triangles)",
+        lines += ["", "## HBM traffic of `mt_dense_aligned_kernel` (PMC, per launch of 65536 rays x 10000 triangles)",
                   "", f"FETCH_SIZE {per['FETCH_SIZE']:.1f} KiB, WRITE_SIZE {per['WRITE_SIZE']:.1f} KiB -> "
                   f"{traffic / 1e9:.4f} GB per launch (algorithmic 3.2787 GB)."]
     (d / "summary.md").write_text("\n".join(lines) + "\n")

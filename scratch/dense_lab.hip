@@ -134,7 +134,11 @@ __device__ __forceinline__ void mt4_fast(V3 o, V3 d, const TriE (&tr)[4], float 
         uint64_t hit[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#ifdef LAB_PROBE_NORCP
+            const float r = p[i].a0 * 0.5f;
+#else
             const float r = __builtin_amdgcn_rcpf(p[i].a0);
+#endif
             const float e = __builtin_fmaf(-p[i].a0, r, 1.0f);
             const float f = __builtin_fmaf(e, r, r);
             const float u = f * p[i].pu;
@@ -360,6 +364,186 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 }
 
 // ------------------------------------------------------------------------------------------
+// K_v4: K_v1 + line-aligned hit stores.  Measured (store_lab): a store instruction that covers whole
+// 128-B lines costs ~0.64x of one that straddles them, and with T = 10 000 every hit row starts at a
+// different 16-B phase, so each 256-B wave segment straddles.  Here the block stages the packed hit
+// bytes of GROUP = 8 consecutive rays in LDS (8 x 1 KiB, double buffered, one barrier per group) and
+// every wave then flushes two rows with ONE dwordx4 store each: lanes 0.. cover the whole 128-B lines
+// of the row segment, the last lanes the partial head and tail.  t still goes out directly.
+// PROBE: 0 = real kernel; 1 = no stores at all; 2 = rcp replaced by a move (timing probe, wrong
+// results); 3 = compares removed (timing probe)
+// ------------------------------------------------------------------------------------------
+template <bool NT, int WAVES, int PROBE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void K_v4(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R, const float *__restrict__ tv, int64_t T,
+    float eps, float *__restrict__ t_out, uint8_t *__restrict__ hit_out, int rays_per_block) {
+    constexpr int GROUP = 8;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_h[2][GROUP][256];
+    const uint32_t col0 = blockIdx.y * 1024u;
+    const uint32_t j0 = col0 + threadIdx.x * 4u;
+    const bool active = j0 < T;  // T % 4 == 0: a lane is either fully inside or fully outside
+    const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
+    const int n = (int)((r0 + rays_per_block < R) ? rays_per_block : R - r0);
+    const uint32_t W = (uint32_t)((T - col0 < 1024) ? T - col0 : 1024);  // hit bytes per row of this block
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    TriE tri[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
+        tri[q] = load_tri(tv + 9 * j);
+        asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z), "+v"(tri[q].e2.x),
+                     "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
+    }
+    uint32_t vzero, vone;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 1" : "=v"(vzero), "=v"(vone));
+    const float *po = ro + 3 * r0, *pd = rd + 3 * r0;
+    char *trow = reinterpret_cast<char *>(t_out + r0 * T);
+    const uint32_t toff = j0 * 4u;
+    float sink = 0.f;
+    V3 o = ld3(po), d = ld3(pd);
+    const int ngroups = (n + GROUP - 1) / GROUP;
+    for (int g = 0; g < ngroups; ++g) {
+        const int buf = g & 1;
+        const int cnt = (n - g * GROUP < GROUP) ? n - g * GROUP : GROUP;
+        for (int s = 0; s < cnt; ++s) {
+            // prefetch the next ray (clamped: the last ray is re-read) so that the scalar loads of ray
+            // i+1 are in flight during the arithmetic of ray i
+            const int more = (g * GROUP + s + 1 < n) ? 3 : 0;
+            po += more;
+            pd += more;
+            const V3 on = ld3(po), dn = ld3(pd);
+            float t[4];
+            uint32_t hh;
+            mt4_fast(o, d, tri, eps, t, hh, vzero, vone);
+            if (PROBE == 1) {
+                sink += t[0] + t[1] + t[2] + t[3] + (float)hh;
+            } else {
+                if (active) store_b128<NT>(trow, toff, f32x4{t[0], t[1], t[2], t[3]});
+                lds_h[buf][s][threadIdx.x] = hh;
+            }
+            trow += T * 4;
+            o = on;
+            d = dn;
+        }
+        if (PROBE == 1) continue;
+        __syncthreads();
+        // flush: wave w owns rows w and w + 4 of the group
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int s = wave + 4 * k;
+            if (s < cnt) {
+                const int64_t A = (r0 + (int64_t)g * GROUP + s) * T + col0;  // first hit byte of the row segment
+                const uint32_t phi = (uint32_t)A & 127u;
+                const uint32_t head = (128u - phi) & 127u;
+                const uint32_t hd = head < W ? head : W;
+                const uint32_t body = (W - hd) & ~127u;
+                const uint32_t p = (uint32_t)lane * 16u;
+                // lanes below body/16: whole lines; then the head pieces, then the tail pieces
+                uint32_t off;
+                if (p < body) off = hd + p;
+                else {
+                    const uint32_t e = p - body;
+                    off = (e < hd) ? e : body + e;
+                }
+                if (off < W) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(&lds_h[buf][s][0]) + off);
+                    store_b128u<NT>(reinterpret_cast<char *>(hit_out) + A, off, v);
+                }
+            }
+        }
+    }
+    if (PROBE == 1 && sink == 12345.678f) t_out[j0] = sink;
+}
+
+// ------------------------------------------------------------------------------------------
+// K_v5: both outputs staged in LDS per GROUP rays and flushed as whole 128-B lines (t rows of
+// T = 10 000 floats start at a 64-B phase on every other row).  Piece order per row segment: the
+// whole lines first, then the partial head, then the partial tail; 64 pieces of 16 B per store.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t aligned_piece(uint32_t p, uint32_t hd, uint32_t body) {
+    if (p < body) return hd + p;
+    const uint32_t e = p - body;
+    return (e < hd) ? e : body + e;
+}
+
+template <int GROUP, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void K_v5(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R, const float *__restrict__ tv, int64_t T,
+    float eps, float *__restrict__ t_out, uint8_t *__restrict__ hit_out, int rays_per_block) {
+    __shared__ __attribute__((aligned(16))) float lds_t[2][GROUP][1024];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_h[2][GROUP][256];
+    const uint32_t col0 = blockIdx.y * 1024u;
+    const uint32_t j0 = col0 + threadIdx.x * 4u;
+    const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
+    const int n = (int)((r0 + rays_per_block < R) ? rays_per_block : R - r0);
+    const uint32_t W = (uint32_t)((T - col0 < 1024) ? T - col0 : 1024);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    TriE tri[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
+        tri[q] = load_tri(tv + 9 * j);
+        asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z), "+v"(tri[q].e2.x),
+                     "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
+    }
+    uint32_t vzero, vone;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 1" : "=v"(vzero), "=v"(vone));
+    const float *po = ro + 3 * r0, *pd = rd + 3 * r0;
+    // t flush: wave w owns pieces [64 w, 64 w + 64) of every row of the group; the byte phase of a row
+    // segment is (row * 4T + 4 col0) mod 128: only two values when T % 16 == 0 -> both precomputed
+    const uint32_t W4 = W * 4u;
+    uint32_t toffs[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const uint32_t phi = (uint32_t)((((r0 + par) * T + col0) * 4) & 127);
+        const uint32_t head = (128u - phi) & 127u;
+        const uint32_t hd = head < W4 ? head : W4;
+        const uint32_t body = (W4 - hd) & ~127u;
+        toffs[par] = aligned_piece((uint32_t)(wave * 64 + lane) * 16u, hd, body);
+    }
+    V3 o = ld3(po), d = ld3(pd);
+    const int ngroups = (n + GROUP - 1) / GROUP;
+    for (int g = 0; g < ngroups; ++g) {
+        const int buf = g & 1;
+        const int cnt = (n - g * GROUP < GROUP) ? n - g * GROUP : GROUP;
+        for (int s = 0; s < cnt; ++s) {
+            const int more = (g * GROUP + s + 1 < n) ? 3 : 0;
+            po += more;
+            pd += more;
+            const V3 on = ld3(po), dn = ld3(pd);
+            float t[4];
+            uint32_t hh;
+            mt4_fast(o, d, tri, eps, t, hh, vzero, vone);
+            *reinterpret_cast<f32x4 *>(&lds_t[buf][s][threadIdx.x * 4]) = f32x4{t[0], t[1], t[2], t[3]};
+            lds_h[buf][s][threadIdx.x] = hh;
+            o = on;
+            d = dn;
+        }
+        __syncthreads();
+        const int64_t rg = r0 + (int64_t)g * GROUP;
+        for (int s = 0; s < cnt; ++s) {
+            const uint32_t off = toffs[(g * GROUP + s) & 1];
+            if (off < W4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(&lds_t[buf][s][0]) + off);
+                store_b128<true>(reinterpret_cast<char *>(t_out + (rg + s) * T + col0), off, v);
+            }
+        }
+        for (int s = wave; s < cnt; s += 4) {
+            const int64_t A = (rg + s) * T + col0;
+            const uint32_t phi = (uint32_t)A & 127u;
+            const uint32_t head = (128u - phi) & 127u;
+            const uint32_t hd = head < W ? head : W;
+            const uint32_t body = (W - hd) & ~127u;
+            const uint32_t off = aligned_piece((uint32_t)lane * 16u, hd, body);
+            if (off < W) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(&lds_h[buf][s][0]) + off);
+                store_b128u<true>(reinterpret_cast<char *>(hit_out) + A, off, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K_ws: wave specialisation.  Block = 4 compute waves + 1 store wave.  Compute waves write the
 // t / hit values of GROUP consecutive rays x 1024 triangles into an LDS buffer (double buffered);
 // the store wave drains the other buffer with 1-KiB dwordx4 stores (hit bytes as 16 B per lane:
@@ -569,29 +753,39 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 2; ++rep) {
         run("base", true, [&] { K_base<true, true><<<grid, 256>>>(ARGS); });
         run("base nostore", false, [&] { K_base<false, false><<<grid, 256>>>(ARGS); });
-        run("base t-only", false, [&] { K_base<true, false><<<grid, 256>>>(ARGS); });
-        run("base hit-only", false, [&] { K_base<false, true><<<grid, 256>>>(ARGS); });
         run("v1 nt", true, [&] { K_v1<true, true, true><<<grid, 256>>>(ARGS); });
-        run("v1 plain", true, [&] { K_v1<true, true, false><<<grid, 256>>>(ARGS); });
         run("v1 nostore", false, [&] { K_v1<false, false, true><<<grid, 256>>>(ARGS); });
-        run("v1 t-only", false, [&] { K_v1<true, false, true><<<grid, 256>>>(ARGS); });
-        run("v1 hit-only", false, [&] { K_v1<false, true, true><<<grid, 256>>>(ARGS); });
-        run("v2 quad-hit nt", true, [&] { K_v2<true><<<grid, 256>>>(ARGS); });
-        run("v2 quad-hit plain", true, [&] { K_v2<false><<<grid, 256>>>(ARGS); });
         run("v3 2rays nt", true, [&] { K_v3<true><<<grid, 256>>>(ARGS); });
-        run("v3 2rays plain", true, [&] { K_v3<false><<<grid, 256>>>(ARGS); });
-        run("ws group4 nt", true, [&] { K_ws<4, true><<<grid, 320>>>(ARGS); });
-        run("ws group4 plain", true, [&] { K_ws<4, false><<<grid, 320>>>(ARGS); });
-        run("ws group8 nt", true, [&] { K_ws<8, true><<<grid, 320>>>(ARGS); });
+        run("v4 aligned-hit nt w8", true, [&] { K_v4<true, 8, 0><<<grid, 256>>>(ARGS); });
+        run("v4 aligned-hit nt w7", true, [&] { K_v4<true, 7, 0><<<grid, 256>>>(ARGS); });
+        run("v4 aligned-hit nt w6", true, [&] { K_v4<true, 6, 0><<<grid, 256>>>(ARGS); });
+        run("v4 aligned-hit nt w5", true, [&] { K_v4<true, 5, 0><<<grid, 256>>>(ARGS); });
+        run("v5 lds t+hit g2 w8", true, [&] { K_v5<2, 8><<<grid, 256>>>(ARGS); });
+        run("v5 lds t+hit g2 w7", true, [&] { K_v5<2, 7><<<grid, 256>>>(ARGS); });
+        run("v5 lds t+hit g2 w6", true, [&] { K_v5<2, 6><<<grid, 256>>>(ARGS); });
+        run("v5 lds t+hit g4 w4", true, [&] { K_v5<4, 4><<<grid, 256>>>(ARGS); });
+        run("v5 lds t+hit g4 w6", true, [&] { K_v5<4, 6><<<grid, 256>>>(ARGS); });
+        run("v4 nostore w8", false, [&] { K_v4<true, 8, 1><<<grid, 256>>>(ARGS); });
+        run("v4 nostore w7", false, [&] { K_v4<true, 7, 1><<<grid, 256>>>(ARGS); });
+        run("v4 nostore w6", false, [&] { K_v4<true, 6, 1><<<grid, 256>>>(ARGS); });
+        run("v4 nostore w4", false, [&] { K_v4<true, 4, 1><<<grid, 256>>>(ARGS); });
     }
     // rays-per-block sweep of the best simple variant
+    for (int rp : {8, 16, 32}) {
+        char nm[64];
+        snprintf(nm, 64, "v4 nt w8 rpb=%d", rp);
+        const dim3 g4((unsigned)(R / rp), 10);
+        run(nm, true, [&] { K_v4<true, 8, 0><<<g4, 256>>>(d_o, d_d, R, d_tv, T, eps, t_new, h_new, rp); });
+        snprintf(nm, 64, "v4 nt w7 rpb=%d", rp);
+        run(nm, true, [&] { K_v4<true, 7, 0><<<g4, 256>>>(d_o, d_d, R, d_tv, T, eps, t_new, h_new, rp); });
+        snprintf(nm, 64, "v5 g2 w7 rpb=%d", rp);
+        run(nm, true, [&] { K_v5<2, 7><<<g4, 256>>>(d_o, d_d, R, d_tv, T, eps, t_new, h_new, rp); });
+    }
     for (int rp : {16, 32, 128, 256}) {
         char nm[64];
         snprintf(nm, 64, "v1 nt rpb=%d", rp);
         const dim3 g2((unsigned)(R / rp), 10);
         run(nm, true, [&] { K_v1<true, true, true><<<g2, 256>>>(d_o, d_d, R, d_tv, T, eps, t_new, h_new, rp); });
-        snprintf(nm, 64, "v2 nt rpb=%d", rp);
-        run(nm, true, [&] { K_v2<true><<<g2, 256>>>(d_o, d_d, R, d_tv, T, eps, t_new, h_new, rp); });
     }
     return 0;
 }

@@ -10,7 +10,7 @@ import csv,glob,collections
 for f in sorted(glob.glob('gpurun_out/pmc/*counter_collection.csv')):
     vals=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'mt_dense_kernel' in r['Kernel_Name'] and int(r['Grid_Size'])>10_000_000:
+        if 'mt_dense' in r['Kernel_Name'] and int(r['Grid_Size'])>10_000_000:
             vals[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in vals.items(): print(k, sum(v)/len(v), len(v))
 PY

@@ -31,7 +31,7 @@ static T *to_device(const std::vector<T> &h) {
     return d;
 }
 
-static_assert(sizeof(drt_trace_params) == 16 && sizeof(drt_candidates) == 104 && sizeof(drt_em_params) == 40,
+static_assert(sizeof(drt_trace_params) == 24 && sizeof(drt_trace_stats) == 40 && sizeof(drt_candidates) == 104 && sizeof(drt_em_params) == 40,
               "struct layouts the ctypes binding (differt_amd/_lib.py) relies on");
 
 int main() {
@@ -78,7 +78,7 @@ int main() {
     // 3. image-method trace inside the cube: order 1, every candidate rank unranked on the GPU
     std::vector<float> tx = {0.1f, -0.2f, 0.05f}, rx = {-0.3f, 0.25f, -0.1f};
     float *dtx = to_device(tx), *drx = to_device(rx);
-    drt_trace_params pr = {eps, 100.0f * 1.1920929e-7f, eps, 0};
+    drt_trace_params pr = {eps, 100.0f * 1.1920929e-7f, eps, 0, nullptr};
     drt_candidates cand = {nullptr, 12, 0, 12, nullptr, 1, 0};
     const int64_t cap = 64;
     size_t wbytes = drt_trace_compact_workspace_size(cap, cap);

@@ -23,14 +23,15 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert not unbound, f"declared in the header but no ctypes signature: {unbound}"
     stale = [s for s in _lib._SIGNATURES if s not in declared]
     assert not stale, f"ctypes signature without a declaration in the header: {stale}"
-    assert L.drt_abi_version() == _lib.ABI_VERSION == 3
+    assert L.drt_abi_version() == _lib.ABI_VERSION == 4
     assert f"#define DRT_ABI_VERSION {_lib.ABI_VERSION}" in _lib.HEADER_PATH.read_text()
 
 
 def test_struct_layouts_match_header():
-    # drt_trace_params: 3 floats + int32; drt_candidates: ptr, 3 x i64, ptr, 2 x i32, (ptr, i64) x 2, 3 x ptr;
+    # drt_trace_params: 3 floats + int32 + stats pointer; drt_trace_stats: 3 x i64, 3 x f32, i32; drt_candidates: ptr, 3 x i64, ptr, 2 x i32, (ptr, i64) x 2, 3 x ptr;
     # drt_em_params: f64, i32, 3 x f32, i32, 3 x f32
-    assert C.sizeof(_lib.TraceParams) == 16
+    assert C.sizeof(_lib.TraceParams) == 24 and _lib.TraceParams.stats.offset == 16
+    assert C.sizeof(_lib.TraceStats) == 40 and _lib.TraceStats.filter_ms.offset == 24
     assert C.sizeof(_lib.Candidates) == 104 and _lib.Candidates.pair_offsets.offset == 80
     assert _lib.Candidates.order.offset == 40 and _lib.Candidates.first_map.offset == 48
     assert _lib.Candidates.num_last.offset == 72

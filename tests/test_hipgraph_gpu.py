@@ -55,3 +55,139 @@ def test_capture_and_replay_ray_queries():
     for got, exp in zip((t, hit, blocked, idx, tmin), ref):
         assert torch.equal(got, exp)
     assert int(ref[2].sum()) > 0
+
+
+def _trace_setup(num_boxes=60, ntx=3, nrx=5, order=2):
+    import ctypes as C
+
+    import differt_amd._lib as lib
+    import differt_amd.geometry as G
+    import synthetic_scenes as S
+    from differt_amd.geometry._solvers import _params, _rank_candidates
+
+    V, Tr, centres, heights = S.manhattan(num_boxes)
+    tx, rx = S.manhattan_tx_rx(centres, heights, ntx, nrx)
+    mesh = G.Mesh(V, Tr)
+    n = mesh.num_primitives
+    count = n * (n - 1) ** (order - 1)
+    tx_d, rx_d = torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda")
+    params = _params(None, None, None)
+    cands = _rank_candidates(order, 0, count, n, None)
+    return C, lib, mesh, tx_d, rx_d, params, cands, order
+
+
+def test_trace_compact_async_matches_sync_and_flags_overflow():
+    """drt_trace_paths_compact_async (static shapes, device-side counts, no host sync) returns the
+    rows of drt_trace_paths_compact bit for bit, pads the rest, and flags both overflows."""
+    from differt_amd._tensors import ptr, stream
+
+    C, lib, mesh, tx, rx, params, cands, order = _trace_setup()
+    L = lib.load()
+    cap_s, cap_p = 1 << 16, 512
+
+    def buffers(cp):
+        return (torch.empty(cp, dtype=torch.int64, device="cuda"),
+                torch.empty((cp, order + 2, 3), dtype=torch.float32, device="cuda"),
+                torch.empty((cp, order + 2), dtype=torch.int32, device="cuda"))
+
+    nb = L.drt_trace_compact_workspace_size(cap_s, cap_p)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    k0, v0, o0 = buffers(cap_p)
+    nv = C.c_int64(0)
+    lib.call("drt_trace_paths_compact", mesh.handle().h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+             C.byref(cands), cap_s, cap_p, ptr(k0), ptr(v0), ptr(o0), C.byref(nv), ptr(ws), nb, stream())
+    n = int(nv.value)
+    assert 0 < n < cap_p
+
+    k1, v1, o1 = buffers(cap_p)
+    for x in (k1, v1, o1):
+        x.fill_(77)
+    counts = torch.full((4,), -5, dtype=torch.int64, device="cuda")
+    lib.call("drt_trace_paths_compact_async", mesh.handle().h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx),
+             rx.shape[0], C.byref(cands), cap_s, cap_p, ptr(k1), ptr(v1), ptr(o1), ptr(counts), ptr(ws), nb, stream())
+    torch.cuda.synchronize()
+    c = counts.tolist()
+    assert c[1] == n and c[2] == 0 and c[3] == 0 and c[0] >= n
+    assert torch.equal(k1[:n], k0[:n]) and torch.equal(o1[:n], o0[:n])
+    assert torch.equal(v1[:n].view(torch.int32), v0[:n].view(torch.int32))  # bit-identical vertices
+    assert bool((k1[n:] == -1).all()) and bool((o1[n:] == -1).all()) and bool((v1[n:] == 0).all())
+
+    # path-capacity overflow: status bit 2, count still exact, every written row is a valid path
+    small = max(n // 2, 1)
+    k2, v2, o2 = buffers(small)
+    lib.call("drt_trace_paths_compact_async", mesh.handle().h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx),
+             rx.shape[0], C.byref(cands), cap_s, small, ptr(k2), ptr(v2), ptr(o2), ptr(counts), ptr(ws), nb, stream())
+    torch.cuda.synchronize()
+    c = counts.tolist()
+    assert c[1] == n and c[2] == lib.DRT_TRACE_OVERFLOW_PATHS
+    assert set(k2.tolist()) <= set(k0[:n].tolist())
+    # survivor-queue overflow: status bit 1
+    lib.call("drt_trace_paths_compact_async", mesh.handle().h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx),
+             rx.shape[0], C.byref(cands), 4, cap_p, ptr(k1), ptr(v1), ptr(o1), ptr(counts), ptr(ws), nb, stream())
+    torch.cuda.synchronize()
+    c = counts.tolist()
+    assert c[0] > 4 and (c[2] & lib.DRT_TRACE_OVERFLOW_SURVIVORS)
+
+
+def test_capture_and_replay_trace_forward_and_vjp():
+    """The north-star mode under a HIP graph: async compact trace + VJP over the FIXED capacity are
+    captured once and replayed; keys / vertices / objects are bit-identical to the synchronous entry
+    point, the gradient equals the one of the synchronous pipeline."""
+    from differt_amd._tensors import ptr, stream
+
+    C, lib, mesh, tx, rx, params, cands, order = _trace_setup()
+    L = lib.load()
+    cap_s, cap_p = 1 << 16, 256
+    nb = L.drt_trace_compact_workspace_size(cap_s, cap_p)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    keys = torch.empty(cap_p, dtype=torch.int64, device="cuda")
+    verts = torch.empty((cap_p, order + 2, 3), dtype=torch.float32, device="cuda")
+    objs = torch.empty((cap_p, order + 2), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    cot = torch.randn((cap_p, order + 2, 3), device="cuda", generator=gen)
+    gtx, grx = torch.zeros_like(tx), torch.zeros_like(rx)
+    gmv = torch.zeros_like(mesh.vertices)
+    h = mesh.handle().h
+
+    def launch():
+        gtx.zero_(); grx.zero_(); gmv.zero_()
+        lib.call("drt_trace_paths_compact_async", h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+                 C.byref(cands), cap_s, cap_p, ptr(keys), ptr(verts), ptr(objs), ptr(counts), ptr(ws), nb, stream())
+        lib.call("drt_trace_paths_vjp", h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0], C.byref(cands), ptr(keys),
+                 ptr(cot), cap_p, ptr(gtx), ptr(grx), ptr(gmv), stream())
+
+    # reference: synchronous entry point + VJP over exactly the valid rows
+    k0 = torch.empty(cap_p, dtype=torch.int64, device="cuda")
+    v0 = torch.empty_like(verts)
+    o0 = torch.empty_like(objs)
+    nv = C.c_int64(0)
+    lib.call("drt_trace_paths_compact", h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+             C.byref(cands), cap_s, cap_p, ptr(k0), ptr(v0), ptr(o0), C.byref(nv), ptr(ws), nb, stream())
+    n = int(nv.value)
+    assert 0 < n < cap_p
+    rtx, rrx, rmv = torch.zeros_like(tx), torch.zeros_like(rx), torch.zeros_like(mesh.vertices)
+    lib.call("drt_trace_paths_vjp", h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0], C.byref(cands), ptr(k0),
+             ptr(cot), n, ptr(rtx), ptr(rrx), ptr(rmv), stream())
+    torch.cuda.synchronize()
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        launch()  # warm-up outside the capture (module load, rocPRIM kernels)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch()
+    for rep in range(2):
+        for x in (keys, verts, objs, counts):
+            x.fill_(13)
+        g.replay()
+        torch.cuda.synchronize()
+        assert counts.tolist()[1] == n and counts.tolist()[2] == 0
+        assert torch.equal(keys[:n], k0[:n]) and torch.equal(objs[:n], o0[:n])
+        assert torch.equal(verts[:n].view(torch.int32), v0[:n].view(torch.int32))
+        assert bool((keys[n:] == -1).all())
+        for got, exp in ((gtx, rtx), (grx, rrx), (gmv, rmv)):
+            scale = float(exp.abs().max()) + 1e-30
+            assert float((got - exp).abs().max()) <= 1e-5 * scale  # float atomics: order may differ
+    assert float(rtx.abs().max()) > 0
