@@ -94,12 +94,18 @@ def cpu_baseline(num_triangles: int, budget_s: float = 12.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 200 timed launches after 20 warm-ups: the first tens of milliseconds after an idle period run at a
+    # lower clock (a 20-step window measured 0.94 ms/step where steady state is 0.79 ms on the same box)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
     ap.add_argument("--triangles", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true")
+    ap.add_argument("--no-scaling", action="store_true", help="skip the configs[4] strong-scaling legs")
+    ap.add_argument("--cfg5-boxes", type=int, default=20000, help="boxes of the configs[4] city (10 triangles each)")
+    ap.add_argument("--cfg5-window", type=int, default=None, help="candidate ranks per pair of the strong-scaling leg")
+    ap.add_argument("--cfg5-rx-side", type=int, default=32)
     args = ap.parse_args()
 
     import torch
@@ -279,6 +285,17 @@ def main() -> None:
             paths = {"error": repr(exc)}
         if rank == 0 and paths is not None:
             result["paths"] = paths
+
+    if not args.no_scaling:  # every rank takes part: configs[4], total work fixed, split over the ranks
+        try:
+            import bench_scaling
+
+            sc = bench_scaling.run(dev, rank=rank, world=world, dist=dist, boxes=args.cfg5_boxes,
+                                   window=args.cfg5_window, rx_side=args.cfg5_rx_side)
+        except Exception as exc:  # noqa: BLE001
+            sc = {"error": repr(exc)}
+        if rank == 0:
+            result["strong_scaling"] = sc
 
     if rank == 0 and not args.no_paths:
         try:

@@ -439,7 +439,7 @@ int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t m, const float *ro, const
     DRT_REQUIRE(out, "null output");
     hipStream_t s = as_stream(stream);
     if (m->num_triangles == 0) {  // _mesh.py:3053-3057
-        DRT_HIP(hipMemsetAsync(out, 0, (size_t)R, s));
+        DRT_HIP(fill_bytes_async(out, 0, (size_t)R, s));
         return DRT_OK;
     }
     DRT_REQUIRE(ro && rd, "null pointer");

@@ -47,4 +47,7 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// memset replacement that stays correct inside a replayed HIP graph (core.hip)
+hipError_t fill_bytes_async(void *p, int byte, size_t n, hipStream_t s);
+
 }  // namespace drt

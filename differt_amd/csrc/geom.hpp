@@ -157,8 +157,8 @@ __device__ __forceinline__ void moller_trumbore_n(V3 o, V3 d, const TriE (&tr)[N
 //     `u + v <= 1`, so v_min's NaN-skipping cannot turn a miss into a hit);
 //   * otherwise the reference formula literally (a = where(a == 0, inf, a); f = 1 / a; all six
 //     comparisons) on the same phase-1 values;
-//   * the four hit flags become the four bytes of one dword with SDWA byte-select v_cndmask
-//     (lane masks stay in SGPR pairs: ballots of single compares fold into the v_cmp).
+//   * the four hit flags become the four bytes of one dword with one v_cndmask each (the mask
+//     logic stays on the scalar unit).
 // scratch/dense_lab.hip checks the formulation bit for bit against moller_trumbore_n on 6.5e8 tests
 // incl. axis-aligned / zero / 1e18 / 1e-30 / NaN / inf directions and coplanar rays.
 // ------------------------------------------------------------------------------------------
@@ -178,33 +178,9 @@ __device__ __forceinline__ MtPart mt_phase1(V3 o, V3 d, const TriE &tr) {
     return p;
 }
 
-// lane masks (one bit per lane) -> one byte per test, packed in a dword per lane.  `zero` / `one`
-// are VGPRs holding 0 / 1 (SDWA operands cannot be inline constants); see mt4_pin_constants.
-__device__ __forceinline__ uint32_t pack_hit_masks(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3,
-                                                   uint32_t zero, uint32_t one) {
-    uint32_t out;
-    asm volatile(
-        "v_cndmask_b32_e64 %0, 0, 1, %3\n\t"
-        "s_mov_b64 vcc, %4\n\t"
-        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_mov_b64 vcc, %5\n\t"
-        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_mov_b64 vcc, %6\n\t"
-        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-        : "=&v"(out)
-        : "v"(zero), "v"(one), "s"(m0), "s"(m1), "s"(m2), "s"(m3)
-        : "vcc");
-    return out;
-}
-
-__device__ __forceinline__ void mt4_pin_constants(uint32_t &zero, uint32_t &one) {
-    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 1" : "=v"(zero), "=v"(one));
-}
-
 // t_out[i] and byte i of `hits` = moller_trumbore(o, d, tr[i], eps, t_out[i])
 __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[4], float eps,
-                                                   float (&t_out)[4], uint32_t &hits, uint32_t vzero,
-                                                   uint32_t vone) {
+                                                   float (&t_out)[4], uint32_t &hits) {
     MtPart p[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i] = mt_phase1(o, d, tr[i]);
@@ -217,7 +193,7 @@ __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[
     const uint64_t okm =
         __builtin_amdgcn_ballot_w64(mn >= 0x1p-126f) & __builtin_amdgcn_ballot_w64(mx <= 0x1p+126f);
     if (__builtin_expect(okm == __builtin_amdgcn_read_exec(), 1)) {
-        uint64_t hit[4];
+        uint32_t hh = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float r = __builtin_amdgcn_rcpf(p[i].a0);
@@ -227,14 +203,16 @@ __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[
             const float v = f * p[i].pv;
             const float upv = u + v;
             const float t = f * p[i].pt;
-            const uint64_t c0 = __builtin_amdgcn_ballot_w64(__builtin_fabsf(p[i].a0) > eps);
-            const uint64_t c1 = __builtin_amdgcn_ballot_w64(__builtin_fminf(u, v) >= 0.0f);
-            const uint64_t c2 = __builtin_amdgcn_ballot_w64(upv <= 1.0f);
-            const uint64_t c3 = __builtin_amdgcn_ballot_w64(t > eps);
+            const bool c0 = __builtin_fabsf(p[i].a0) > eps;
+            const bool c1 = __builtin_fminf(u, v) >= 0.0f;
+            const bool c2 = upv <= 1.0f;
+            const bool c3 = t > eps;
             t_out[i] = t;
-            hit[i] = (c0 & c1) & (c2 & c3);
+            // one v_cndmask per test + 2 ORs per 4 tests (SDWA byte selects measured 8x the issue
+            // cost of a plain VALU instruction on gfx950: scratch/valu_mix.hip)
+            hh |= ((c0 & c1) & (c2 & c3)) ? (1u << (8 * i)) : 0u;
         }
-        hits = pack_hit_masks(hit[0], hit[1], hit[2], hit[3], vzero, vone);
+        hits = hh;
     } else {
         uint32_t hh = 0;
 #pragma unroll

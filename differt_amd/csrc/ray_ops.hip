@@ -87,8 +87,6 @@ void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restri
         asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z),
                           "+v"(tri[q].e2.x), "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
     }
-    uint32_t vzero, vone;
-    mt4_pin_constants(vzero, vone);
 
     const float *po = ro + 3 * r0, *pd = rd + 3 * r0;
     char *trow = reinterpret_cast<char *>(t_out + r0 * T);
@@ -106,7 +104,7 @@ void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restri
             const V3 on = ld3(po), dn = ld3(pd);
             float t[4];
             uint32_t hh;
-            moller_trumbore_x4(o, d, tri, eps, t, hh, vzero, vone);
+            moller_trumbore_x4(o, d, tri, eps, t, hh);
             if (active) store_nt_b128(trow, toff, f32x4{t[0], t[1], t[2], t[3]});
             lds_h[buf][s][threadIdx.x] = hh;
             trow += T * 4;
@@ -155,14 +153,12 @@ __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
         asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z),
                           "+v"(tri[q].e2.x), "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
     }
-    uint32_t vzero, vone;
-    mt4_pin_constants(vzero, vone);
     for (int64_t r = r0; r < r1; ++r) {
         const V3 o = ld3(ro + 3 * r);  // wave-uniform -> scalar loads
         const V3 d = ld3(rd + 3 * r);
         float t[4];
         uint32_t hh;
-        moller_trumbore_x4(o, d, tri, eps, t, hh, vzero, vone);
+        moller_trumbore_x4(o, d, tri, eps, t, hh);
         const int64_t base = r * T + j0;
         if (VEC) {
             f32x4 tt = {t[0], t[1], t[2], t[3]};
@@ -483,7 +479,7 @@ int32_t drt_ray_intersect_any_triangle(const float *ro, const float *rd, int64_t
     DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
     if (R == 0) return DRT_OK;
     DRT_REQUIRE(out, "null output");
-    DRT_HIP(hipMemsetAsync(out, 0, (size_t)R, as_stream(stream)));
+    DRT_HIP(fill_bytes_async(out, 0, (size_t)R, as_stream(stream)));
     if (T == 0) return DRT_OK;  // _utils.py:1441-1450
     DRT_REQUIRE(ro && rd && tv, "null pointer");
     DRT_REQUIRE(tv_ray_stride == 0 || tv_ray_stride == 9 * T, "tv_ray_stride must be 0 or 9*T");
@@ -528,7 +524,7 @@ int32_t drt_first_triangle_hit_by_ray(const float *ro, const float *rd, int64_t 
         if (ws_bytes < (size_t)R * 8 || !ws)
             return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", (size_t)R * 8);
         auto *keys = reinterpret_cast<unsigned long long *>(ws);
-        DRT_HIP(hipMemsetAsync(keys, 0xff, (size_t)R * 8, s));
+        DRT_HIP(fill_bytes_async(keys, 0xff, (size_t)R * 8, s));
         if (T > 0) {
             DRT_REQUIRE(ro && rd && tv, "null pointer");
             const int64_t ray_blocks = ceil_div(R, kQueryThreads);
@@ -561,7 +557,7 @@ int32_t drt_first_hit_keys(const float *ro, const float *rd, int64_t R, const fl
     if (R == 0) return DRT_OK;
     DRT_REQUIRE(keys, "null keys");
     hipStream_t s = as_stream(stream);
-    if (init) DRT_HIP(hipMemsetAsync(keys, 0xff, (size_t)R * 8, s));
+    if (init) DRT_HIP(fill_bytes_async(keys, 0xff, (size_t)R * 8, s));
     if (T_block == 0) return DRT_OK;
     DRT_REQUIRE(ro && rd && tv_block, "null pointer");
     const TileTie tt = make_tie(total_triangles, batch_size);

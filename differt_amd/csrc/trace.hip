@@ -851,10 +851,10 @@ int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *p
     auto *q1 = reinterpret_cast<long long *>(base + 64);
     auto *q2 = reinterpret_cast<long long *>(base + 64 + align_up((size_t)max_survivors * 8, 256));
     char *sort_tmp = reinterpret_cast<char *>(q2) + align_up((size_t)max_paths * 8, 256);
-    DRT_HIP(hipMemsetAsync(counters, 0, 64, L.s));
+    DRT_HIP(fill_bytes_async(counters, 0, 64, L.s));
     // every slot of the valid-key queue starts as a sentinel (0x7f7f... >= 2^62 > any key): the sort
     // then runs over the FIXED capacity and pushes the unused slots behind the valid keys
-    if (max_paths > 0) DRT_HIP(hipMemsetAsync(q2, 0x7f, (size_t)max_paths * 8, L.s));
+    if (max_paths > 0) DRT_HIP(fill_bytes_async(q2, 0x7f, (size_t)max_paths * 8, L.s));
     const int k = cands->order;
     if (total > 0) {
 #define CALL(K)                                                                                   \

@@ -82,98 +82,11 @@ __global__ __launch_bounds__(256) void K_base(const float *__restrict__ ro, cons
 //   * anything else: the generic phased routine (identical results by construction).
 // hit bytes are packed with SDWA byte-select v_cndmask (4 instead of 6 instructions).
 // ------------------------------------------------------------------------------------------
-// lane masks (one bit per lane, SGPR pairs) -> one byte per test, packed in a dword per lane
-__device__ __forceinline__ uint32_t pack_hits(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, uint32_t zero,
-                                              uint32_t one) {
-    uint32_t out;
-    asm volatile(
-        "v_cndmask_b32_e64 %0, 0, 1, %3\n\t"
-        "s_mov_b64 vcc, %4\n\t"
-        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_mov_b64 vcc, %5\n\t"
-        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_mov_b64 vcc, %6\n\t"
-        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-        : "=&v"(out)
-        : "v"(zero), "v"(one), "s"(m0), "s"(m1), "s"(m2), "s"(m3)
-        : "vcc");
-    return out;
-}
-
-// Phase 1: everything that does not depend on the reciprocal (41 of the 45 arithmetic operations);
-// only (a, <s,h>, <q,d>, <q,e2>) stay live, so four tests fit in 16 VGPRs next to the triangles.
-struct MtPart {
-    float a0, pu, pv, pt;
-};
-__device__ __forceinline__ MtPart mt_phase1(V3 o, V3 d, const TriE &tr) {
-    const V3 h = cross(d, tr.e2);
-    MtPart p;
-    p.a0 = dot(h, tr.e1);
-    const V3 s = o - tr.v0;
-    p.pu = dot(s, h);
-    const V3 q = cross(s, tr.e1);
-    p.pv = dot(q, d);
-    p.pt = dot(q, tr.e2);
-    return p;
-}
-
+// the production formulation (geom.hpp); vzero / vone are leftovers of the SDWA packing experiment
+// (v_cndmask_b32_sdwa measured 8x the issue cost of a plain VALU instruction, scratch/valu_mix.hip)
 __device__ __forceinline__ void mt4_fast(V3 o, V3 d, const TriE (&tr)[4], float eps, float (&t_out)[4],
-                                         uint32_t &hits, uint32_t vzero, uint32_t vone) {
-    MtPart p[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = mt_phase1(o, d, tr[i]);
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p[0].a0), __builtin_fabsf(p[1].a0)),
-                                     __builtin_fmaxf(__builtin_fabsf(p[2].a0), __builtin_fabsf(p[3].a0)));
-    const float mn = __builtin_fminf(__builtin_fminf(__builtin_fabsf(p[0].a0), __builtin_fabsf(p[1].a0)),
-                                     __builtin_fminf(__builtin_fabsf(p[2].a0), __builtin_fabsf(p[3].a0)));
-    // fmax/fmin skip a NaN operand: a NaN determinant next to in-range ones stays on the fast path,
-    // where rcp / fma propagate it exactly like the division does (t = NaN, hit = false)
-    // ballots of single compares fold into the v_cmp itself; the ANDs are SALU work
-    const uint64_t okm = __builtin_amdgcn_ballot_w64(mn >= 0x1p-126f) & __builtin_amdgcn_ballot_w64(mx <= 0x1p+126f);
-    if (__builtin_expect(okm == __builtin_amdgcn_read_exec(), 1)) {
-        uint64_t hit[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#ifdef LAB_PROBE_NORCP
-            const float r = p[i].a0 * 0.5f;
-#else
-            const float r = __builtin_amdgcn_rcpf(p[i].a0);
-#endif
-            const float e = __builtin_fmaf(-p[i].a0, r, 1.0f);
-            const float f = __builtin_fmaf(e, r, r);
-            const float u = f * p[i].pu;
-            const float v = f * p[i].pv;
-            const float upv = u + v;
-            const float t = f * p[i].pt;
-            const uint64_t c0 = __builtin_amdgcn_ballot_w64(__builtin_fabsf(p[i].a0) > eps);
-            const uint64_t c1 = __builtin_amdgcn_ballot_w64(__builtin_fminf(u, v) >= 0.0f);
-            const uint64_t c2 = __builtin_amdgcn_ballot_w64(upv <= 1.0f);
-            const uint64_t c3 = __builtin_amdgcn_ballot_w64(t > eps);
-            t_out[i] = t;
-            hit[i] = (c0 & c1) & (c2 & c3);
-        }
-        hits = pack_hits(hit[0], hit[1], hit[2], hit[3], vzero, vone);
-    } else {
-        // some lane of the wave has a == 0, a denormal / huge / non-finite determinant: the reference
-        // formula literally (a = where(a == 0, inf, a); f = 1 / a; all six comparisons)
-        uint32_t hh = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool zero = (p[i].a0 == 0.0f);
-            const float f = 1.0f / (zero ? kInf : p[i].a0);
-            bool hit = (zero ? kInf : __builtin_fabsf(p[i].a0)) > eps;
-            const float u = f * p[i].pu;
-            hit = hit & (u >= 0.0f) & (u <= 1.0f);
-            const float v = f * p[i].pv;
-            const float upv = u + v;
-            hit = hit & (v >= 0.0f) & (upv <= 1.0f);
-            const float t = f * p[i].pt;
-            hit = hit & (t > eps);
-            t_out[i] = t;
-            hh |= (uint32_t)hit << (8 * i);
-        }
-        hits = hh;
-    }
+                                         uint32_t &hits, uint32_t, uint32_t) {
+    moller_trumbore_x4(o, d, tr, eps, t_out, hits);
 }
 
 // stores with a wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset: no per-row VALU address math

@@ -60,3 +60,16 @@ def manhattan_tx_rx(centres, heights, num_tx: int, num_rx: int, pitch: float = 4
     rx = np.column_stack((lo[0] + (gx + 0.5) * pitch + jitter[:, 0], lo[1] + (gy + 0.5) * pitch + jitter[:, 1],
                           np.full(num_rx, 1.5))).astype(np.float32)
     return tx, rx
+
+
+def cfg5_scene(num_boxes: int = 20000, rx_side: int = 32, pitch: float = 40.0):
+    """BASELINE configs[4]: one transmitter on a mast above the middle of a `num_boxes`-box Manhattan
+    city (20 000 boxes = 200 000 triangles), receivers on a `rx_side` x `rx_side` street-level grid
+    (32 x 32 = 1024).  Returns (vertices, triangles, tx[1,3], rx[rx_side^2,3])."""
+    V, Tr, centres, heights = manhattan(num_boxes, pitch)
+    c0 = centres.mean(axis=0)
+    tx = np.array([[c0[0], c0[1], heights.max() + 10.0]], dtype=np.float32)
+    g = (np.arange(rx_side) - (rx_side - 1) / 2) * pitch
+    rx = np.stack(np.meshgrid(c0[0] + g + pitch / 2, c0[1] + g + pitch / 2, indexing="ij"), -1).reshape(-1, 2)
+    rx = np.column_stack((rx, np.full(len(rx), 1.5))).astype(np.float32)
+    return V, Tr, tx, rx

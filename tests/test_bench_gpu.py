@@ -17,7 +17,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = Path(__file__).resolve().parents[1]
-COMMON = ["--steps", "2", "--warmup", "1", "--rays", "2048", "--no-cpu-baseline", "--no-paths"]
+COMMON = ["--steps", "2", "--warmup", "1", "--rays", "2048", "--no-cpu-baseline", "--no-paths",
+          # configs[4] strong-scaling legs on a small city (400 boxes = 4000 triangles, 4 x 4 receivers, whole space)
+          "--cfg5-boxes", "400", "--cfg5-rx-side", "4"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline"}
 
@@ -37,6 +39,18 @@ def test_single_gpu_line():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] == "hbm"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    _check_strong(d["strong_scaling"], 1)
+    Path(os.environ.get("DRT_BENCH_N1_JSON", "/tmp/drt_bench_n1.json")).write_text(json.dumps(d["strong_scaling"]))
+
+
+def _check_strong(sc: dict, world: int):
+    assert sc["scaling"] == "strong" and sc["n_gpus"] == world, sc
+    cs, tb = sc["candidate_sharded"], sc["triangle_block"]
+    assert "error" not in cs and "error" not in tb, sc
+    assert cs["path_candidates_per_s"] > 0 and cs["valid_paths"] > 0 and cs["keys_sorted"] and cs["grad_tx_finite"]
+    assert tb["rays_per_s"] > 0 and 0 < tb["hit_fraction"] <= 1
+    if world > 1:
+        assert sc["ranks_seen_by_backend"] == world
 
 
 def test_two_ranks_share_gpu():
@@ -48,3 +62,13 @@ def test_two_ranks_share_gpu():
     d = _last_json(r.stdout)  # rank 0 only
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "TEST HOOK" in d["data"]
     assert d["value"] > 0 and d["config"]["rays_per_gpu"] == 2048
+    _check_strong(d["strong_scaling"], 2)
+    ref = Path(os.environ.get("DRT_BENCH_N1_JSON", "/tmp/drt_bench_n1.json"))
+    if ref.exists():  # same fixed work as the single-rank run: same valid paths, same first hits, same gradient
+        one = json.loads(ref.read_text())
+        two = d["strong_scaling"]
+        assert two["candidate_sharded"]["valid_paths"] == one["candidate_sharded"]["valid_paths"]
+        assert two["candidate_sharded"]["path_candidates_per_step"] == one["candidate_sharded"]["path_candidates_per_step"]
+        assert two["triangle_block"]["checksum_idx"] == one["triangle_block"]["checksum_idx"]
+        g1, g2 = one["candidate_sharded"]["grad_tx_absmax"], two["candidate_sharded"]["grad_tx_absmax"]
+        assert abs(g1 - g2) <= 1e-5 * max(abs(g1), 1e-30)

@@ -48,12 +48,13 @@ def test_capture_and_replay_ray_queries():
         x.zero_()
     with torch.cuda.graph(g):
         launch()
-    for x in (t, hit, blocked, idx, tmin):
-        x.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    for got, exp in zip((t, hit, blocked, idx, tmin), ref):
-        assert torch.equal(got, exp)
+    for rep in range(3):  # several replays: a graph must not depend on what the previous one left behind
+        for x in (t, hit, blocked, idx, tmin):
+            x.fill_(3)
+        g.replay()
+        torch.cuda.synchronize()
+        for got, exp in zip((t, hit, blocked, idx, tmin), ref):
+            assert torch.equal(got, exp), rep
     assert int(ref[2].sum()) > 0
 
 
@@ -178,7 +179,7 @@ def test_capture_and_replay_trace_forward_and_vjp():
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         launch()
-    for rep in range(2):
+    for rep in range(3):
         for x in (keys, verts, objs, counts):
             x.fill_(13)
         g.replay()
