@@ -49,8 +49,13 @@ __device__ __forceinline__ bool inside_one(const Mirrors<K, QUADS> &m, const V3 
 // ------------------------------------------------------------------------------------------
 // stage A
 // ------------------------------------------------------------------------------------------
+#ifndef DRT_FILTER_WAVES  // occupancy experiment hook (profiles/r02): waves per SIMD the register allocator targets
+#define DRT_FILTER_ATTR
+#else
+#define DRT_FILTER_ATTR __attribute__((amdgpu_waves_per_eu(DRT_FILTER_WAVES, DRT_FILTER_WAVES)))
+#endif
 template <int K, bool QUADS, bool DENSE>
-__global__ __launch_bounds__(256) void trace_filter_kernel(
+__global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
     TraceArgs a, const float *__restrict__ txp, const float *__restrict__ rxp, CandSrc cs,
     unsigned long long *__restrict__ q_count,
     long long *__restrict__ queue, int64_t q_cap, int64_t tx_per_block,

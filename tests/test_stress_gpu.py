@@ -1,0 +1,94 @@
+"""Bounded slices of the randomized GPU-vs-oracle stress drivers (scratch/*_stress.py) inside the
+`-m gpu` suite, plus run-to-run determinism of the cfg3 trace (hard part 6).
+
+Each driver draws random scenes for a fixed wall-clock budget and counts mismatches; the bar is the
+same as everywhere else: hit flags / indices / masks / objects bit-exact, `t` and path vertices bit
+patterns identical (the full-length runs are recorded under profiles/)."""
+
+from __future__ import annotations
+
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+BUDGET_S = 12  # per driver; the whole module stays under ~90 s
+
+
+def _run(script: str) -> dict:
+    r = subprocess.run([sys.executable, f"scratch/{script}", str(BUDGET_S)], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_dense_moller_trumbore_vs_oracle_stress():
+    st = _run("oracle_stress.py")
+    assert st["cases"] > 0 and st["tests"] > 1e6 and st["hits"] > 0
+    assert st["hit_mismatch"] == 0 and st["t_mismatch"] == 0, st
+
+
+def test_any_hit_first_hit_vs_oracle_stress():
+    st = _run("query_oracle_stress.py")
+    assert st["cases"] > 0 and st["tests"] > 1e6 and st["hits"] > 0
+    assert st["any_mismatch"] == 0 and st["idx_mismatch"] == 0 and st["t_mismatch"] == 0, st
+
+
+def test_fused_tracer_vs_oracle_stress():
+    st = _run("trace_oracle_stress.py")
+    assert st["cases"] > 5 and st["candidate_evals"] > 1e4
+    assert st["mask_mismatch"] == 0 and st["vertex_mismatch"] == 0 and st["object_mismatch"] == 0, st
+    assert st["compact_mismatch"] == 0, st
+
+
+def test_hybrid_candidate_space_stress():
+    st = _run("hybrid_stress.py")
+    assert st["cases"] > 5
+    assert st["object_mismatch_cases"] == 0 and st["vertex_mismatch_cases"] == 0 and st["pairs_not_subset"] == 0, st
+
+
+def test_bvh_vs_brute_force_stress():
+    r = subprocess.run([sys.executable, "scratch/bvh_stress.py", "20"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    st = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    bad = {k: v for k, v in st.items() if "mismatch" in k and v}
+    assert not bad, st
+
+
+def test_cfg3_window_is_deterministic_run_to_run():
+    """Two runs of the cfg3 step (16 TX x 64 RX, 10k-triangle city, order 2, fwd + grad) over a 5e6-rank
+    window: keys, objects and vertex BITS identical (the radix sort removes the atomic append order);
+    the gradients come from float atomics, so only their difference is bounded and reported."""
+    import differt_amd.geometry as G
+    import synthetic_scenes as S
+
+    V, Tr, centres, heights = S.manhattan(1000)
+    tx, rx = S.manhattan_tx_rx(centres, heights, 16, 64)
+    mesh = G.Mesh(V, Tr)
+
+    def step():
+        txg = torch.tensor(tx, device="cuda", requires_grad=True)
+        mv = mesh.with_vertices(mesh.vertices.detach().clone().requires_grad_(True))
+        scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mv)
+        p = G.ExhaustivePathTracer().trace_rank_range(scene, 2, 0, 5_000_000)
+        torch.sqrt((torch.diff(p.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+        return p, txg.grad.clone(), mv.vertices.grad.clone()
+
+    a, ga, gva = step()
+    b, gb, gvb = step()
+    assert a.objects.shape[0] > 0
+    assert torch.equal(a.keys, b.keys) and torch.equal(a.objects, b.objects)
+    assert torch.equal(a.vertices.detach().view(torch.int32), b.vertices.detach().view(torch.int32))
+    for x, y in ((ga, gb), (gva, gvb)):
+        scale = float(x.abs().max()) + 1e-30
+        diff = float((x - y).abs().max())
+        assert diff <= 1e-5 * scale, (diff, scale)  # atomics may re-associate the few per-vertex sums
