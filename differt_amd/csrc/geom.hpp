@@ -234,6 +234,40 @@ __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[
     }
 }
 
+// Reverse mode of t = f * <q, e2> (hard-mode Moller-Trumbore, _utils.py:1263-1316; the reference gets
+// it from jax autodiff, `hit` carries no gradient): cotangents of (o, d, v0, v1, v2) for t_bar.
+// a = where(a == 0, inf, a) is a constant branch: f = 0 and no gradient flows through a.
+struct MtHardBar {
+    V3 o, d, v0, v1, v2;
+};
+__device__ __forceinline__ MtHardBar mt_t_vjp(V3 o, V3 d, V3 v0, V3 v1, V3 v2, float tbar) {
+    const V3 e1 = v1 - v0, e2 = v2 - v0;
+    const V3 h = cross(d, e2);
+    float a = dot(h, e1);
+    const bool degenerate = (a == 0.0f);
+    a = degenerate ? kInf : a;
+    const float f = 1.0f / a;
+    const V3 s = o - v0;
+    const V3 q = cross(s, e1);
+    const float w = dot(q, e2);
+    const float fbar = tbar * w, wbar = tbar * f;  // t = f * w
+    const V3 qbar = e2 * wbar;
+    V3 e2bar = q * wbar;
+    const V3 sbar = cross(e1, qbar);  // q = s x e1
+    V3 e1bar = cross(qbar, s);
+    const float abar = degenerate ? 0.0f : -(fbar * f) * f;  // f = 1 / a
+    const V3 hbar = e1 * abar;                               // a = <h, e1>
+    e1bar = e1bar + h * abar;
+    MtHardBar r;
+    r.d = cross(e2, hbar);  // h = d x e2
+    e2bar = e2bar + cross(hbar, d);
+    r.o = sbar;  // s = o - v0
+    r.v0 = V3{0, 0, 0} - sbar - e1bar - e2bar;
+    r.v1 = e1bar;
+    r.v2 = e2bar;
+    return r;
+}
+
 // _solver_image_method.py:73-79: x - (2 * <x - p, n>) * n
 __device__ __forceinline__ V3 image_of_vertex(V3 x, V3 p, V3 n) {
     float c = 2.0f * dot(x - p, n);

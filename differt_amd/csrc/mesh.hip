@@ -41,7 +41,62 @@ __global__ __launch_bounds__(256) void mesh_prepare_kernel(const float *__restri
 
 using namespace drt;
 
+// Ray preparation of the reference's Warp-backed mesh queries (opt-in `semantics="warp"`):
+//   mode 0, any-hit  (_mesh.py:3065-3070): direction normalised (len = |d|, zero vector kept: UT:29-72),
+//           origin moved by hit_tol * len along it, segment shortened to len * (1 - 2 hit_tol);
+//           written back as a SEGMENT (o', d' = dir * max_t) so that the any-hit operator with
+//           hit_tol = 0 evaluates `0 < t <= max_t` on it;
+//   mode 1, first-hit (_mesh.py:195-199): origin nudged by 1e-5 * d, direction unchanged.
+__global__ __launch_bounds__(256) void warp_ray_prep_kernel(const float *__restrict__ ro,
+                                                            const float *__restrict__ rd, int64_t n, int mode,
+                                                            float param, float *__restrict__ o_out,
+                                                            float *__restrict__ d_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = ld3(ro + 3 * i), d = ld3(rd + 3 * i);
+    if (mode == 0) {
+        const float len = sqrtf(dot(d, d));
+        const float den = (len == 0.0f) ? 1.0f : len;
+        const V3 dir = V3{d.x / den, d.y / den, d.z / den};
+        const float off = param * len;
+        const float max_t = len * (1.0f - 2.0f * param);
+        st3(o_out + 3 * i, V3{o.x + dir.x * off, o.y + dir.y * off, o.z + dir.z * off});
+        st3(d_out + 3 * i, dir * max_t);
+    } else {
+        st3(o_out + 3 * i, V3{o.x + d.x * param, o.y + d.y * param, o.z + d.z * param});
+        st3(d_out + 3 * i, d);
+    }
+}
+
+// t += nudge on hits (res.t + epsilon, _mesh.py:199); misses keep (-1, inf)
+__global__ __launch_bounds__(256) void warp_first_hit_finish_kernel(const int32_t *__restrict__ idx,
+                                                                    float *__restrict__ t, int64_t n, float nudge) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && idx[i] >= 0) t[i] = t[i] + nudge;
+}
+
 extern "C" {
+
+int32_t drt_warp_ray_prep(const float *ro, const float *rd, int64_t n, int32_t mode, float param, float *o_out,
+                          float *d_out, void *stream) {
+    DRT_REQUIRE(n >= 0 && (mode == 0 || mode == 1), "bad argument");
+    if (n == 0) return DRT_OK;
+    DRT_REQUIRE(ro && rd && o_out && d_out, "null pointer");
+    hipLaunchKernelGGL(warp_ray_prep_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), ro, rd,
+                       n, (int)mode, param, o_out, d_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_warp_first_hit_finish(const int32_t *idx, float *t, int64_t n, float nudge, void *stream) {
+    DRT_REQUIRE(n >= 0, "negative size");
+    if (n == 0) return DRT_OK;
+    DRT_REQUIRE(idx && t, "null pointer");
+    hipLaunchKernelGGL(warp_first_hit_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       as_stream(stream), idx, t, n, nudge);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
 
 int32_t drt_mesh_destroy(drt_mesh_t m) {
     if (!m) return DRT_OK;

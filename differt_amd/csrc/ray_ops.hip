@@ -28,6 +28,12 @@ namespace drt {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kDenseThreads = 256;
+
+__device__ __forceinline__ void atomic_add3f(float *p, V3 v) {
+    atomicAdd(p + 0, v.x);
+    atomicAdd(p + 1, v.y);
+    atomicAdd(p + 2, v.z);
+}
 constexpr int kDenseCols = kDenseThreads * 4;  // triangles per block
 constexpr int kDenseGroup = 8;                 // rays whose hit bytes are staged in LDS together
 
@@ -354,30 +360,12 @@ __global__ __launch_bounds__(256) void first_hit_vjp_kernel(
         const V3 v0 = ld3(vertices + 3 * (int64_t)i0), v1 = ld3(vertices + 3 * (int64_t)i1),
                  v2 = ld3(vertices + 3 * (int64_t)i2);
         const V3 o = ld3(ro + 3 * r), d = ld3(rd + 3 * r);
-        const float tbar = tbar_in[r];
-        const V3 e1 = v1 - v0, e2 = v2 - v0;
-        const V3 h = cross(d, e2);
-        float a = dot(h, e1);
-        const bool degenerate = (a == 0.0f);
-        a = degenerate ? kInf : a;
-        const float f = 1.0f / a;
-        const V3 s = o - v0;
-        const V3 q = cross(s, e1);
-        const float w = dot(q, e2);
-        // t = f * w
-        const float fbar = tbar * w, wbar = tbar * f;
-        const V3 qbar = e2 * wbar;
-        V3 e2bar = q * wbar;
-        const V3 sbar = cross(e1, qbar);  // q = s x e1
-        V3 e1bar = cross(qbar, s);
-        const float abar = degenerate ? 0.0f : -(fbar * f) * f;  // f = 1/a
-        const V3 hbar = e1 * abar;                               // a = <h, e1>
-        e1bar = e1bar + h * abar;
-        dbar = cross(e2, hbar);                                  // h = d x e2
-        e2bar = e2bar + cross(hbar, d);
-        obar = sbar;                                             // s = o - v0
+        const MtHardBar g = mt_t_vjp(o, d, v0, v1, v2, tbar_in[r]);
+        obar = g.o;
+        dbar = g.d;
+        const V3 e1bar = g.v1, e2bar = g.v2;
         if (gv) {
-            const V3 v0bar = V3{0, 0, 0} - sbar - e1bar - e2bar;
+            const V3 v0bar = g.v0;
             atomicAdd(gv + 3 * (int64_t)i0 + 0, v0bar.x);
             atomicAdd(gv + 3 * (int64_t)i0 + 1, v0bar.y);
             atomicAdd(gv + 3 * (int64_t)i0 + 2, v0bar.z);
@@ -391,6 +379,72 @@ __global__ __launch_bounds__(256) void first_hit_vjp_kernel(
     }
     if (go) st3(go + 3 * r, obar);
     if (gd) st3(gd + 3 * r, dbar);
+}
+
+// ------------------------------------------------------------------------------------------
+// (a1) reverse mode of the hard-mode `t` of ray_intersect_triangle (_utils.py:1316; also the free
+// first_triangle_hit_by_ray, whose t is the paired operator on the hit triangle)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// dense: lane = triangle (its 9 cotangents accumulate in registers over the block's rays, one set
+// of atomics at the end), rays wave-uniform (their 6 cotangents: wave reduction, one atomic per wave)
+__global__ __launch_bounds__(256) void mt_dense_vjp_kernel(
+    const float *__restrict__ ro, const float *__restrict__ rd, int64_t R, const float *__restrict__ tv,
+    int64_t T, const float *__restrict__ tbar, float *__restrict__ go, float *__restrict__ gd,
+    float *__restrict__ gtv, int rays_per_block) {
+    const int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    const bool in = j < T;
+    const int64_t jj = in ? j : T - 1;
+    const V3 v0 = ld3(tv + 9 * jj), v1 = ld3(tv + 9 * jj + 3), v2 = ld3(tv + 9 * jj + 6);
+    const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
+    const int64_t r1 = (r0 + rays_per_block < R) ? r0 + rays_per_block : R;
+    V3 a0{0, 0, 0}, a1{0, 0, 0}, a2{0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = r0; r < r1; ++r) {
+        const V3 o = ld3(ro + 3 * r), d = ld3(rd + 3 * r);
+        const float tb = in ? tbar[r * T + j] : 0.0f;
+        MtHardBar g = mt_t_vjp(o, d, v0, v1, v2, tb);
+        if (!in || tb == 0.0f) g = MtHardBar{};  // a zero cotangent contributes nothing (also kills 0 * inf)
+        a0 = a0 + g.v0;
+        a1 = a1 + g.v1;
+        a2 = a2 + g.v2;
+        if (go) {
+            const float x = wave_sum(g.o.x), y = wave_sum(g.o.y), z = wave_sum(g.o.z);
+            if (lane == 0) atomic_add3f(go + 3 * r, V3{x, y, z});
+        }
+        if (gd) {
+            const float x = wave_sum(g.d.x), y = wave_sum(g.d.y), z = wave_sum(g.d.z);
+            if (lane == 0) atomic_add3f(gd + 3 * r, V3{x, y, z});
+        }
+    }
+    if (gtv && in) {
+        atomic_add3f(gtv + 9 * j, a0);
+        atomic_add3f(gtv + 9 * j + 3, a1);
+        atomic_add3f(gtv + 9 * j + 6, a2);
+    }
+}
+
+// paired: lane = element, every gradient has its own slot (plain stores)
+__global__ __launch_bounds__(256) void mt_paired_vjp_kernel(
+    const float *__restrict__ ro, const float *__restrict__ rd, const float *__restrict__ tv, int64_t n,
+    const float *__restrict__ tbar, float *__restrict__ go, float *__restrict__ gd, float *__restrict__ gtv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float tb = tbar[i];
+    MtHardBar g = mt_t_vjp(ld3(ro + 3 * i), ld3(rd + 3 * i), ld3(tv + 9 * i), ld3(tv + 9 * i + 3), ld3(tv + 9 * i + 6), tb);
+    if (tb == 0.0f) g = MtHardBar{};
+    if (go) st3(go + 3 * i, g.o);
+    if (gd) st3(gd + 3 * i, g.d);
+    if (gtv) {
+        st3(gtv + 9 * i, g.v0);
+        st3(gtv + 9 * i + 3, g.v1);
+        st3(gtv + 9 * i + 6, g.v2);
+    }
 }
 
 static TileTie make_tie(int64_t T, int64_t batch_size) {
@@ -468,6 +522,30 @@ int32_t drt_ray_intersect_triangle_paired(const float *ro, const float *rd, cons
     DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
     hipLaunchKernelGGL(mt_paired_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
                        as_stream(stream), ro, rd, tv, n, eps, t_out, hit_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_ray_intersect_triangle_vjp(const float *ro, const float *rd, int64_t R, const float *tv,
+                                       int64_t T, int32_t dense, const float *t_cot, float *go,
+                                       float *gd, float *gtv, void *stream) {
+    DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
+    DRT_REQUIRE(dense || R == T, "paired layout needs one triangle per ray");
+    if (R == 0 || T == 0) return DRT_OK;
+    DRT_REQUIRE(ro && rd && tv && t_cot, "null pointer");
+    hipStream_t s = as_stream(stream);
+    if (dense) {
+        const int64_t cols = ceil_div(T, 256);
+        DRT_REQUIRE(cols <= 65535, "too many triangles for one launch (%lld)", (long long)T);
+        int64_t rpb = (R * cols) / 2048;
+        if (rpb < 1) rpb = 1;
+        if (rpb > 64) rpb = 64;
+        hipLaunchKernelGGL(mt_dense_vjp_kernel, dim3((unsigned)ceil_div(R, rpb), (unsigned)cols), dim3(256), 0, s,
+                           ro, rd, R, tv, T, t_cot, go, gd, gtv, (int)rpb);
+    } else {
+        hipLaunchKernelGGL(mt_paired_vjp_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s, ro, rd, tv, R,
+                           t_cot, go, gd, gtv);
+    }
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

@@ -59,22 +59,31 @@ class _FirstHitFn(torch.autograd.Function):
     hit face only; indices carry no gradient."""
 
     @staticmethod
-    def forward(ctx, vertices, origins, directions, triangles, mask, epsilon, batch_size, bvh_handle=None):
+    def forward(ctx, vertices, origins, directions, triangles, mask, epsilon, batch_size, bvh_handle=None,
+                nudge=0.0):
         R = origins.shape[0]
         idx = torch.full((R,), -1, dtype=torch.int32, device=origins.device)
         t = torch.full((R,), float("inf"), dtype=torch.float32, device=origins.device)
+        qo, qd = origins, directions
+        if R and nudge:  # Warp semantics (_mesh.py:195-199): query from origin + 1e-5 * direction
+            qo, qd = torch.empty_like(origins), torch.empty_like(directions)
+            _lib.call("drt_warp_ray_prep", ptr(origins), ptr(directions), R, 1, float(nudge), ptr(qo), ptr(qd), stream())
         if R and bvh_handle is not None:
-            _lib.call("drt_mesh_first_triangle_hit_by_ray", bvh_handle.h, ptr(origins), ptr(directions), R,
+            _lib.call("drt_mesh_first_triangle_hit_by_ray", bvh_handle.h, ptr(qo), ptr(qd), R,
                       epsilon, batch_size, ptr(idx), ptr(t), stream())
         elif R:
             tv = vertices[triangles.long()].contiguous()
             ws = torch.empty(R, dtype=torch.int64, device=origins.device)
             m = None if mask is None else mask.to(torch.uint8).contiguous()
             _lib.call(
-                "drt_first_triangle_hit_by_ray", ptr(origins), ptr(directions), R, ptr(tv),
+                "drt_first_triangle_hit_by_ray", ptr(qo), ptr(qd), R, ptr(tv),
                 tv.shape[0], 0, ptr(m), 0, epsilon, batch_size, ptr(idx), ptr(t), ptr(ws), R * 8,
                 stream(),
             )
+        if R and nudge:
+            _lib.call("drt_warp_first_hit_finish", ptr(idx), ptr(t), R, float(nudge), stream())
+        # the backward pass differentiates the UN-nudged distance on the hit face, like the reference's
+        # custom VJP (_mesh.py:327-338)
         ctx.save_for_backward(vertices, origins, directions, triangles, idx)
         ctx.mark_non_differentiable(idx)
         return idx, t
@@ -90,7 +99,7 @@ class _FirstHitFn(torch.autograd.Function):
                 "drt_first_hit_vjp", ptr(vertices), ptr(triangles), ptr(origins), ptr(directions),
                 ptr(idx), ptr(gt.contiguous()), R, ptr(gv), ptr(go), ptr(gd), stream(),
             )
-        return gv, go, gd, None, None, None, None, None
+        return gv, go, gd, None, None, None, None, None, None
 
 
 @dataclass
@@ -272,14 +281,30 @@ class Mesh:
 
     # ---- mesh-bound ray queries ----
     def ray_intersect_any_triangle(self, ray_origins, ray_directions, *, hit_tol: float | None = None,
-                                   epsilon: float | None = None, accel: str | None = None) -> torch.Tensor:
+                                   epsilon: float | None = None, accel: str | None = None,
+                                   semantics: str = "jax") -> torch.Tensor:
         """Whether each ray is blocked by an active triangle (_mesh.py:3018-3094; non-differentiable
         like the reference, :3087-3094).  The predicate is the pure-JAX operator's
-        (_utils.py:1469); the reference dispatches to a Warp BVH query here, see DESIGN.md."""
+        (_utils.py:1469); the reference dispatches to a Warp BVH query here, see DESIGN.md.
+
+        ``semantics="warp"`` (opt-in) prepares the rays like the reference's Warp path (:3065-3070):
+        unit direction, origin moved ``hit_tol * |d|`` along it, segment shortened to
+        ``|d| * (1 - 2 hit_tol)``; the triangle test itself stays this library's Moller-Trumbore (Warp's
+        own routine is third-party: parity beyond the reference's equality test is unpinned)."""
         o, d = as_f32(ray_origins), as_f32(ray_directions)
         batch = torch.broadcast_shapes(o.shape[:-1], d.shape[:-1])
         if self.is_empty:  # _mesh.py:3053-3057
             return torch.zeros(batch, dtype=torch.bool, device=o.device)
+        if semantics not in ("jax", "warp"):
+            raise ValueError(f"unknown semantics {semantics!r}")
+        if semantics == "warp":
+            tol = 100.0 * F32_EPS if hit_tol is None else float(hit_tol)
+            of = o.detach().expand(*batch, 3).contiguous().reshape(-1, 3)
+            df = d.detach().expand(*batch, 3).contiguous().reshape(-1, 3)
+            o2, d2 = torch.empty_like(of), torch.empty_like(df)
+            _lib.call("drt_warp_ray_prep", ptr(of), ptr(df), of.shape[0], 0, tol, ptr(o2), ptr(d2), stream())
+            return self.ray_intersect_any_triangle(o2.reshape(*batch, 3), d2.reshape(*batch, 3), hit_tol=0.0,
+                                                   epsilon=epsilon, accel=accel)
         if accel == "bvh":  # own LBVH, the counterpart of the reference's Warp BVH (csrc/bvh.hip)
             of = o.detach().expand(*batch, 3).contiguous().reshape(-1, 3)
             df = d.detach().expand(*batch, 3).contiguous().reshape(-1, 3)
@@ -325,9 +350,13 @@ class Mesh:
                                                         num_rays=num_rays)
 
     def first_triangle_hit_by_ray(self, ray_origins, ray_directions, *, epsilon: float | None = None,
-                                  batch_size: int | None = 512, accel: str | None = None):
+                                  batch_size: int | None = 512, accel: str | None = None,
+                                  semantics: str = "jax"):
         """Closest hit ``(index, t)``; ``t`` is differentiable w.r.t. origins, directions and mesh
-        vertices (_mesh.py:3096-3162, custom VJP :258-344).  Miss = ``(-1, inf)``."""
+        vertices (_mesh.py:3096-3162, custom VJP :258-344).  Miss = ``(-1, inf)``.
+
+        ``semantics="warp"`` (opt-in): query from ``origin + 1e-5 * direction`` and add ``1e-5`` back to
+        ``t`` like the reference's Warp kernel (_mesh.py:195-199); gradients unchanged (:327-338)."""
         o, d = as_f32(ray_origins), as_f32(ray_directions)
         batch = torch.broadcast_shapes(o.shape[:-1], d.shape[:-1])
         if self.is_empty:  # _mesh.py:3129-3136
@@ -338,7 +367,10 @@ class Mesh:
         eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
         if accel not in (None, "bvh"):
             raise ValueError(f"unknown accel {accel!r}")
+        if semantics not in ("jax", "warp"):
+            raise ValueError(f"unknown semantics {semantics!r}")
         idx, t = _FirstHitFn.apply(self.vertices.contiguous(), of, df, self.triangles, self.mask, eps,
                                    0 if batch_size is None else int(batch_size),
-                                   self.handle() if accel == "bvh" else None)
+                                   self.handle() if accel == "bvh" else None,
+                                   1e-5 if semantics == "warp" else 0.0)
         return idx.reshape(batch), t.reshape(batch)

@@ -72,6 +72,42 @@ class _MtSmoothFn(torch.autograd.Function):
         return go, gd, gtv, None, None, None
 
 
+class _MtHardFn(torch.autograd.Function):
+    """Hard-mode Moller-Trumbore on flat buffers with the reference's differentiable ``t``
+    (_utils.py:1316: plain JAX arithmetic, so ``jax.grad`` flows through ``t``; ``hit`` is a bool).
+    ``dense``: rays ``[R,3]`` x triangles ``[T,3,3]`` -> ``[R,T]``; else paired ``[R]``."""
+
+    @staticmethod
+    def forward(ctx, o, d, tv, eps, dense):
+        R, T = o.shape[0], tv.shape[0]
+        shape = (R, T) if dense else (R,)
+        t = torch.empty(shape, dtype=torch.float32, device=o.device)
+        hit = torch.empty(shape, dtype=torch.uint8, device=o.device)
+        if t.numel():
+            if dense:
+                _lib.call("drt_ray_intersect_triangle_dense", ptr(o), ptr(d), R, ptr(tv), T, eps, ptr(t), ptr(hit),
+                          stream())
+            else:
+                _lib.call("drt_ray_intersect_triangle_paired", ptr(o), ptr(d), ptr(tv), R, eps, ptr(t), ptr(hit),
+                          stream())
+        ctx.save_for_backward(o, d, tv)
+        ctx.dense = dense
+        ctx.mark_non_differentiable(hit)
+        return t, hit
+
+    @staticmethod
+    def backward(ctx, gt, _gh):
+        o, d, tv = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        go = torch.zeros_like(o) if need[0] else None
+        gd = torch.zeros_like(d) if need[1] else None
+        gtv = torch.zeros_like(tv) if need[2] else None
+        if o.numel() and tv.numel() and gt is not None:
+            _lib.call("drt_ray_intersect_triangle_vjp", ptr(o), ptr(d), o.shape[0], ptr(tv), tv.shape[0],
+                      int(ctx.dense), ptr(gt.contiguous()), ptr(go), ptr(gd), ptr(gtv), stream())
+        return go, gd, gtv, None, None
+
+
 class _AnySmoothFn(torch.autograd.Function):
     """Smoothed any-triangle confidence (_utils.py:1436-1537) on the flat layout of
     :func:`_flatten_query`; differentiable in the rays and the triangle vertices."""
@@ -178,6 +214,21 @@ def ray_intersect_triangle(
             tvf = tv.expand(*batch, 3, 3).contiguous().reshape(n, 3, 3)
             t, hit = _MtSmoothFn.apply(of, df, tvf, eps, sf, False)
         return t.reshape(batch), hit.reshape(batch)
+    if torch.is_grad_enabled() and (o.requires_grad or d.requires_grad or tv.requires_grad):
+        # differentiable `t` like the reference (the flat views below are autograd-tracked, so the
+        # broadcasting is undone by torch: expanded inputs receive summed gradients)
+        if dense:
+            T, rb = batch[-1], batch[:-1]
+            of = o.reshape(ob[:-1] + (3,)).expand(*rb, 3).contiguous().reshape(-1, 3)
+            df = d.reshape(db[:-1] + (3,)).expand(*rb, 3).contiguous().reshape(-1, 3)
+            t, hit = _MtHardFn.apply(of, df, tv.reshape(T, 3, 3).contiguous(), eps, True)
+        else:
+            n = int(np.prod(batch, dtype=np.int64))
+            of = o.expand(*batch, 3).contiguous().reshape(n, 3)
+            df = d.expand(*batch, 3).contiguous().reshape(n, 3)
+            tvf = tv.expand(*batch, 3, 3).contiguous().reshape(n, 3, 3)
+            t, hit = _MtHardFn.apply(of, df, tvf, eps, False)
+        return t.reshape(batch), hit.reshape(batch).bool()
     t = torch.empty(batch, dtype=torch.float32, device=dev)
     hit = torch.empty(batch, dtype=torch.uint8, device=dev)
     if t.numel() == 0:
@@ -295,6 +346,16 @@ def first_triangle_hit_by_ray(
             ptr(o), ptr(d), R, ptr(tv), T, tvs, ptr(act), acts, eps,
             0 if batch_size is None else int(batch_size), ptr(idx), ptr(t), ptr(ws), R * 8, stream(),
         )
+    if R and torch.is_grad_enabled() and (o.requires_grad or d.requires_grad or tv.requires_grad):
+        # the reference's t is differentiable (argmin picks one triangle, t = min over the hits,
+        # _utils.py:1886-1960): re-evaluate the paired operator on the hit triangle -- the same
+        # arithmetic, hence the same bits -- with its VJP attached; misses keep the constant inf
+        hitm = idx >= 0
+        sel = idx.clamp(min=0).long()
+        rows = torch.arange(R, device=dev)
+        tv_hit = tv[sel] if tvs == 0 else tv[rows, sel]
+        t_hit, _ = _MtHardFn.apply(o, d, tv_hit.contiguous(), eps, False)
+        t = torch.where(hitm, t_hit, t)
     return idx.reshape(batch), t.reshape(batch)
 
 

@@ -102,6 +102,19 @@ int32_t drt_first_hit_keys(const float *ray_origins, const float *ray_directions
 int32_t drt_first_hit_finalize(const uint64_t *keys, int64_t num_rays, int64_t total_triangles,
                                int64_t batch_size, int32_t *index_out, float *t_out, void *stream);
 
+/* Reverse mode of the hard-mode `t` of ray_intersect_triangle (reference: t = f * <q, e2> is plain
+ * JAX code, geometry/_utils.py:1263-1316, differentiated by jax; `hit` carries no gradient).
+ *   dense != 0: rays [R,3] x triangles [T,3,3], t_cotangent [R,T]; grad_origins / grad_directions
+ *               [R,3] and grad_triangle_vertices [T,3,3] are ACCUMULATED with atomic adds
+ *               (zero-initialise them);
+ *   dense == 0: paired, R == T elements, t_cotangent [R]; every gradient is WRITTEN.
+ * Each gradient pointer may be NULL.  A zero cotangent contributes exactly zero (no 0 * inf NaN). */
+int32_t drt_ray_intersect_triangle_vjp(const float *ray_origins, const float *ray_directions,
+                                       int64_t num_rays, const float *triangle_vertices,
+                                       int64_t num_triangles, int32_t dense, const float *t_cotangent,
+                                       float *grad_origins, float *grad_directions,
+                                       float *grad_triangle_vertices, void *stream);
+
 /* (a5) backward of the first-hit distance -- reference: geometry/_mesh.py:226-344: the cotangent of
  * t flows through Moller-Trumbore on the hit face only.  Gradients are ACCUMULATED (atomic adds)
  * into grad_vertices [Nv,3] (may be NULL); grad_origins / grad_directions [R,3] are written. */
@@ -181,6 +194,20 @@ int32_t drt_mesh_first_triangle_hit_by_ray(drt_mesh_t mesh, const float *ray_ori
                                            const float *ray_directions, int64_t num_rays,
                                            float epsilon, int64_t batch_size, int32_t *index_out,
                                            float *t_out, void *stream);
+
+/* Opt-in Warp query semantics of the reference's mesh-bound operators (third-party warp-lang BVH
+ * queries behind geometry/_mesh.py:142-223; the normative predicate of this library stays the
+ * pure-JAX operator, which the reference asserts equal: tests/geometry/test_mesh.py:1984-2002).
+ *   mode 0 (any-hit, _mesh.py:3065-3070): normalise the direction, move the origin hit_tol * |d| along
+ *     it, shorten the segment to |d| * (1 - 2 hit_tol); param = hit_tol.  Outputs a segment
+ *     (origin', direction' = unit direction * max_t): query it with hit_tol = 0.
+ *   mode 1 (first-hit, _mesh.py:195-199): origin' = origin + param * direction (param = 1e-5).
+ * drt_warp_first_hit_finish adds the nudge back to t on hits (res.t + epsilon). */
+int32_t drt_warp_ray_prep(const float *ray_origins, const float *ray_directions, int64_t num_rays,
+                          int32_t mode, float param, float *origins_out, float *directions_out,
+                          void *stream);
+int32_t drt_warp_first_hit_finish(const int32_t *hit_index, float *t_inout, int64_t num_rays, float nudge,
+                                  void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (f2, "next" row) visibility by ray launching -- reference: geometry/_utils.py:369-490

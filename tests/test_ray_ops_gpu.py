@@ -168,3 +168,96 @@ def test_empty(G):
     assert (_np(i) == -1).all() and np.isinf(_np(t)).all()
     t, h = G.ray_intersect_triangle(np.zeros((0, 1, 3), np.float32), np.zeros((0, 1, 3), np.float32), np.zeros((5, 3, 3), np.float32))
     assert t.shape == (0, 5)
+
+
+# ------------------------------------------------------------------ hard-mode t is differentiable ----
+def _f64_grads(fn, *xs):
+    ys = [torch.tensor(np.asarray(x, np.float64), requires_grad=True) for x in xs]
+    fn(*ys).backward()
+    return [y.grad.numpy() for y in ys]
+
+
+def _close(got, exp, rtol=1e-5):
+    scale = float(np.abs(exp).max()) + 1e-30
+    assert float(np.abs(got - exp).max()) <= rtol * scale, (float(np.abs(got - exp).max()), scale)
+
+
+@pytest.mark.parametrize("shape", ["dense", "paired", "broadcast"])
+def test_ray_intersect_triangle_t_gradients(shape):
+    """Reference: t of ray_intersect_triangle is plain JAX arithmetic (_utils.py:1316), so jax.grad
+    flows through it; here drt_ray_intersect_triangle_vjp, checked against float64 autograd of the
+    torch restatement (<= 1e-5 rel of the largest entry).  Forward values stay bit-identical."""
+    import differt_amd.geometry as G
+    from oracle import torch_ref
+
+    rng = np.random.default_rng(17)
+    R, T = 37, 53
+    eps = 10 * 1.1920929e-7
+    tvn = (rng.uniform(-5, 5, (T, 1, 3)) + rng.normal(size=(T, 3, 3))).astype(np.float32)
+    on = rng.uniform(-8, 8, (R, 3)).astype(np.float32)
+    dn = (tvn.mean(axis=1)[rng.integers(0, T, R)] - on + rng.normal(size=(R, 3)) * 0.3).astype(np.float32)
+    if shape == "dense":
+        args = (on[:, None, :], dn[:, None, :], tvn)
+    elif shape == "paired":
+        args = (on, dn, tvn[rng.integers(0, T, R)])
+    else:  # one origin broadcast against [R] directions and [R] triangles
+        args = (on[:1], dn, tvn[rng.integers(0, T, R)])
+    w = rng.normal(size=np.broadcast_shapes(args[0].shape[:-1], args[1].shape[:-1], args[2].shape[:-2])).astype(np.float32)
+
+    o, d, tv = (torch.tensor(a, device="cuda", requires_grad=True) for a in args)
+    t, hit = G.ray_intersect_triangle(o, d, tv)
+    t0, hit0 = G.ray_intersect_triangle(o.detach(), d.detach(), tv.detach())
+    assert torch.equal(t.detach().view(torch.int32), t0.view(torch.int32)) and torch.equal(hit, hit0)
+    assert hit.dtype == torch.bool and not hit.requires_grad
+    (t * torch.tensor(w, device="cuda")).sum().backward()
+
+    def ref(o64, d64, tv64):
+        tt, _ = torch_ref.ray_intersect_triangle(o64, d64, tv64, epsilon=eps)
+        return (tt * torch.tensor(w, dtype=torch.float64)).sum()
+
+    for got, exp in zip((o.grad, d.grad, tv.grad), _f64_grads(ref, *args)):
+        _close(got.cpu().numpy(), exp)
+
+
+def test_ray_intersect_triangle_t_gradient_degenerate_and_zero_cotangent():
+    """a == 0 (ray parallel to the plane): the reference turns a into a constant inf, f = 0 -> zero
+    gradient, no NaN; a zero cotangent never produces 0 * inf."""
+    import differt_amd.geometry as G
+
+    tv = torch.tensor([[[0.0, 0, 0], [1, 0, 0], [0, 1, 0]]], device="cuda", requires_grad=True)
+    o = torch.tensor([[0.2, 0.2, 1.0], [0.2, 0.2, 1.0]], device="cuda", requires_grad=True)
+    d = torch.tensor([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0]], device="cuda", requires_grad=True)  # first one is parallel
+    t, hit = G.ray_intersect_triangle(o, d, tv.expand(2, 3, 3))
+    assert hit.tolist() == [False, True]
+    (t * torch.tensor([1.0, 0.0], device="cuda")).sum().backward()
+    for g in (o.grad, d.grad, tv.grad):
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) == 0.0
+
+
+def test_first_triangle_hit_by_ray_free_function_t_gradient():
+    """_utils.py:1775-1960: the free operator's t is differentiable too (min over the hit distances)."""
+    import differt_amd.geometry as G
+    from oracle import torch_ref
+
+    rng = np.random.default_rng(23)
+    R, T = 64, 200
+    eps = 10 * 1.1920929e-7
+    tvn = (rng.uniform(-20, 20, (T, 1, 3)) + rng.normal(size=(T, 3, 3)) * 3).astype(np.float32)
+    on = rng.uniform(-25, 25, (R, 3)).astype(np.float32)
+    dn = (tvn.mean(axis=1)[rng.integers(0, T, R)] - on).astype(np.float32)
+    o, d, tv = (torch.tensor(a, device="cuda", requires_grad=True) for a in (on, dn, tvn))
+    idx, t = G.first_triangle_hit_by_ray(o, d, tv)
+    idx0, t0 = G.first_triangle_hit_by_ray(o.detach(), d.detach(), tv.detach())
+    assert torch.equal(idx, idx0) and torch.equal(t.detach().view(torch.int32), t0.view(torch.int32))
+    hitm = (idx >= 0).cpu().numpy()
+    assert hitm.sum() > R // 2
+    w = rng.normal(size=R).astype(np.float32)
+    torch.where(idx >= 0, t * torch.tensor(w, device="cuda"), torch.zeros_like(t)).sum().backward()
+    sel = idx.clamp(min=0).long().cpu().numpy()
+
+    def ref(o64, d64, tv64):
+        tt, _ = torch_ref.ray_intersect_triangle(o64, d64, tv64[torch.as_tensor(sel)], epsilon=eps)
+        return (tt * torch.tensor(w * hitm, dtype=torch.float64)).sum()
+
+    for got, exp in zip((o.grad, d.grad, tv.grad), _f64_grads(ref, on, dn, tvn)):
+        _close(got.cpu().numpy(), exp)

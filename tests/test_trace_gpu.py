@@ -564,3 +564,54 @@ def test_image_method_returns_vertices_on_mirrors(G, rng, shapes):
     d = ((paths - mv) * mn).sum(-1)
     d = np.nan_to_num(d, posinf=0.0, neginf=0.0)
     np.testing.assert_allclose(d, 0.0, atol=1e-4)
+
+
+# ------------------------------------------------------------------ Warp-semantics opt-in ----
+def test_mesh_queries_warp_semantics_match_the_jax_operators(G):
+    """Mirror of differt/tests/geometry/test_mesh.py:1984-2028: on Mesh.box(2, 2, 2) with 10 random
+    rays the reference asserts its Warp-backed mesh queries EQUAL to the pure-JAX operators (any-hit
+    exactly, first-hit indices exactly and t at rtol = atol = 1e-5).  Same assertion for the opt-in
+    `semantics="warp"` ray preparation (origin offset hit_tol*|d| / max_t = |d|(1-2 hit_tol),
+    _mesh.py:3065-3070; origin nudge 1e-5, _mesh.py:195-199) -- over many seeds instead of one."""
+    mesh = G.Mesh.box(2.0, 2.0, 2.0)
+    tv = mesh.triangle_vertices
+    blocked_any = 0
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        o = rng.uniform(-5, 5, (10, 3)).astype(np.float32)
+        d = rng.uniform(-1, 1, (10, 3)).astype(np.float32)
+        expected = G.ray_intersect_any_triangle(o, d, tv)
+        got = mesh.ray_intersect_any_triangle(o, d, semantics="warp")
+        assert torch.equal(got, expected), seed
+        blocked_any += int(expected.sum())
+        ei, et = G.first_triangle_hit_by_ray(o, d, tv)
+        gi, gt = mesh.first_triangle_hit_by_ray(o, d, semantics="warp")
+        assert torch.equal(gi, ei), seed
+        np.testing.assert_allclose(_np(gt), _np(et), rtol=1e-5, atol=1e-5)
+        bi, bt = mesh.first_triangle_hit_by_ray(o, d, semantics="warp", accel="bvh")
+        assert torch.equal(bi, ei) and torch.equal(bt.view(torch.int32), gt.view(torch.int32))
+    assert blocked_any > 0
+    # segment-style rays that START on a face (the case the offset exists for): leaving the face is not a hit
+    o = torch.tensor([[1.0, 0.2, 0.1]], device="cuda")  # on the x = +1 face
+    assert not bool(mesh.ray_intersect_any_triangle(o, torch.tensor([[2.0, 0.0, 0.0]], device="cuda"), semantics="warp"))
+    assert bool(mesh.ray_intersect_any_triangle(o, torch.tensor([[-4.0, 0.0, 0.0]], device="cuda"), semantics="warp"))
+    with pytest.raises(ValueError):
+        mesh.ray_intersect_any_triangle(o, o, semantics="optix")
+
+
+def test_mesh_first_hit_warp_semantics_jacobians(G):
+    """test_mesh.py:2028-2072 for the opt-in mode: the nudge does not enter the gradient."""
+    mesh = G.Mesh.box(2.0, 2.0, 2.0)
+    o0 = torch.tensor([[0.0, 0.0, 3.0], [0.0, 3.0, 0.0], [3.0, 0.0, 0.0]], device="cuda")
+    d0 = torch.tensor([[0.0, 0.0, -1.0], [0.0, -1.0, 0.0], [-1.0, 0.0, 0.0]], device="cuda")
+    outs = []
+    for sem in ("jax", "warp"):
+        o, d = o0.clone().requires_grad_(True), d0.clone().requires_grad_(True)
+        m = mesh.with_vertices(mesh.vertices.detach().clone().requires_grad_(True))
+        idx, t = m.first_triangle_hit_by_ray(o, d, semantics=sem)
+        assert (idx >= 0).all()
+        t.sum().backward()
+        outs.append((t.detach(), o.grad, d.grad, m.vertices.grad))
+    np.testing.assert_allclose(_np(outs[1][0]), _np(outs[0][0]), rtol=1e-5, atol=1e-5)
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        np.testing.assert_allclose(_np(b), _np(a), rtol=1e-5, atol=1e-5)
