@@ -655,6 +655,40 @@ class HybridPathTracer(ExhaustivePathTracer):
         return self._trace_compact(scene, desc, max_survivors, max_paths)
 
 
+class _LaunchPathsFn(torch.autograd.Function):
+    """Bounce points of the fused SBR kernel, differentiable in (ray origins, ray directions, mesh
+    vertices) through ``drt_launch_paths_vjp`` (reference: launch_paths is plain differentiable JAX
+    around ``Mesh.first_triangle_hit_by_ray``, _solvers.py:385-444)."""
+
+    @staticmethod
+    def forward(ctx, ro, rd, mesh_vertices, mesh, rx, order, eps, max_dist):
+        ntx, R = ro.shape[0], ro.shape[1]
+        nrx, dev = rx.shape[0], ro.device
+        tris = torch.empty((ntx, R, order), dtype=torch.int32, device=dev)
+        verts = torch.empty((ntx, R, order, 3), dtype=torch.float32, device=dev)
+        masks = torch.zeros((ntx, nrx, R, order + 1), dtype=torch.uint8, device=dev)
+        _lib.call("drt_launch_paths", mesh.handle().h, ptr(ro), ptr(rd), ntx, R, ptr(rx), nrx,
+                  order, eps, 512, max_dist, ptr(tris), ptr(verts), ptr(masks), stream())
+        ctx.mesh, ctx.cfg = mesh, (order, eps)
+        ctx.save_for_backward(ro, rd, tris)
+        ctx.mark_non_differentiable(tris, masks)
+        return verts, tris, masks
+
+    @staticmethod
+    def backward(ctx, gv, _gt, _gm):
+        ro, rd, tris = ctx.saved_tensors
+        order, eps = ctx.cfg
+        mesh = ctx.mesh
+        need = ctx.needs_input_grad
+        go = torch.zeros_like(ro) if need[0] else None
+        gd = torch.zeros_like(rd) if need[1] else None
+        gmv = torch.zeros_like(mesh.vertices) if need[2] else None
+        if ro.numel():
+            _lib.call("drt_launch_paths_vjp", mesh.handle().h, ptr(ro), ptr(rd), ro.shape[0], ro.shape[1], order,
+                      eps, ptr(tris), ptr(gv.contiguous()), ptr(go), ptr(gd), ptr(gmv), stream())
+        return go, gd, gmv, None, None, None, None, None
+
+
 class AbstractPathLauncher:
     """Ray-launching solver interface of the reference (_solvers.py:250-491): subclasses provide
     ``launch_rays``; ``launch_paths`` runs first-hit / ``filter_rays`` / ``bounce_rays`` for
@@ -673,12 +707,9 @@ class AbstractPathLauncher:
         ro, rd = ro.contiguous(), rd.contiguous()
         ntx, nrx, R = tx.shape[0], rx.shape[0], ro.shape[1]
         dev = tx.device
-        tris = torch.empty((ntx, R, order), dtype=torch.int32, device=dev)
-        verts = torch.empty((ntx, R, order, 3), dtype=torch.float32, device=dev)
-        masks = torch.zeros((ntx, nrx, R, order + 1), dtype=torch.uint8, device=dev)
         eps = 10.0 * F32_EPS if self.epsilon is None else float(self.epsilon)
-        _lib.call("drt_launch_paths", scene.mesh.handle().h, ptr(ro), ptr(rd), ntx, R, ptr(rx), nrx,
-                  order, eps, 512, float(self.max_dist), ptr(tris), ptr(verts), ptr(masks), stream())
+        verts, tris, masks = _LaunchPathsFn.apply(ro, rd, scene.mesh.vertices, scene.mesh, rx.detach(), order, eps,
+                                                  float(self.max_dist))
         # reference layout [num_tx, num_rx, num_rays, ...] (_solvers.py:446-490): broadcast views
         inner = verts[:, None].expand(ntx, nrx, R, order, 3)
         vertices = torch.cat((tx[:, None, None, None, :].expand(ntx, nrx, R, 1, 3), inner,

@@ -249,6 +249,18 @@ int32_t drt_launch_paths(drt_mesh_t mesh, const float *ray_origins, const float 
                          int32_t order, float epsilon, int64_t batch_size, float max_dist,
                          int32_t *triangles_out, float *vertices_out, uint8_t *masks_out, void *stream);
 
+/* Reverse mode of the bounce points of drt_launch_paths w.r.t. ray origins, ray directions and mesh
+ * vertices (the reference's launch_paths is differentiable: geometry/_solvers.py:385-444 around the
+ * custom VJP of Mesh.first_triangle_hit_by_ray, _mesh.py:258-344).  triangles_in = triangles_out of
+ * the forward call; vertices_cotangent [Ntx, num_rays, order, 3].  grad_origins / grad_directions
+ * [Ntx, num_rays, 3] are WRITTEN, grad_vertices [Nv,3] is ACCUMULATED (atomic adds); each may be NULL.
+ * The receiver masks are booleans and carry no gradient. */
+int32_t drt_launch_paths_vjp(drt_mesh_t mesh, const float *ray_origins, const float *ray_directions,
+                             int64_t num_tx, int64_t num_rays, int32_t order, float epsilon,
+                             const int32_t *triangles_in, const float *vertices_cotangent,
+                             float *grad_origins, float *grad_directions, float *grad_vertices,
+                             void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (a12-a14) path-candidate enumeration -- reference: differt-core/src/geometry/graph.rs
  * (CompleteGraph :127-277, iterator :286-491, count :314-377) and geometry/_utils.py:1047-1132.

@@ -104,3 +104,75 @@ def test_gpu_sbr_two_buildings_goldens(goldens, two_buildings, order):
     ero, erd = orc.sbr_launch_rays(two_buildings["vertices"], two_buildings["triangles"], g["tx"], g["rx"], 5000)
     np.testing.assert_allclose(_np(rd), erd, atol=2e-5)
     np.testing.assert_array_equal(_np(ro), ero)
+
+
+@gpu
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_gpu_launch_paths_vjp_vs_float64_autograd(order):
+    """launch_paths is differentiable in the reference (_solvers.py:385-444: a lax.scan of plain JAX
+    code around Mesh.first_triangle_hit_by_ray with its custom VJP, _mesh.py:258-344).  Here
+    drt_launch_paths_vjp: gradients of a random linear functional of the bounce points w.r.t. the
+    transmitter positions (ray origins), the ray directions and the mesh vertices, against float64
+    autograd of the torch restatement of the same chain on the same hit triangles (<= 1e-5 rel)."""
+    import torch
+
+    import differt_amd.geometry as G
+    from conftest import canyon_scene
+    from oracle import torch_ref
+
+    rng = np.random.default_rng(100 + order)
+    V, Tr = canyon_scene(rng, nextra=4)
+    ntx, R = 2, 600
+    tx = np.stack([rng.uniform(-15, 15, ntx), rng.uniform(-2, 2, ntx), rng.uniform(5, 12, ntx)], -1).astype(np.float32)
+    rx = np.zeros((1, 3), np.float32)
+    rdn = rng.normal(size=(ntx, R, 3)).astype(np.float32)
+    rdn /= np.linalg.norm(rdn, axis=-1, keepdims=True)
+    W = rng.normal(size=(ntx, R, order, 3)).astype(np.float32)
+
+    txg = torch.tensor(tx, device="cuda", requires_grad=True)
+    rdg = torch.tensor(rdn, device="cuda", requires_grad=True)
+    mesh = G.Mesh(V, Tr)
+    mesh = mesh.with_vertices(mesh.vertices.detach().clone().requires_grad_(True))
+
+    class Fixed(G.AbstractPathLauncher):
+        max_dist = 1.0
+
+        def launch_rays(self, scene):
+            return txg[:, None, :].expand(ntx, R, 3).contiguous(), rdg
+
+    got = G.Scene(txg, rx, mesh).launch_paths(order, solver=Fixed())
+    inner = got.vertices[:, 0, :, 1:-1]  # [ntx, R, order, 3]
+    tris = _np(got.objects)[:, 0, :, 1:-1].astype(np.int64)
+    # rays that leave the scene keep their last point: weight only complete chains so that the functional
+    # is smooth (a miss has t = 0 and contributes through the reflection only, which the test also covers
+    # through the first bounces of incomplete chains being excluded symmetrically on both sides)
+    full = (tris >= 0).all(axis=-1)
+    assert full.mean() > 0.3
+    Wm = W * full[..., None, None]
+    (inner * torch.tensor(Wm, device="cuda")).sum().backward()
+
+    # float64 restatement on the same hit triangles
+    V64 = torch.tensor(V.astype(np.float64), requires_grad=True)
+    tx64 = torch.tensor(tx.astype(np.float64), requires_grad=True)
+    rd64 = torch.tensor(rdn.astype(np.float64), requires_grad=True)
+    T64 = torch.tensor(Tr.astype(np.int64))
+    o = tx64[:, None, :].expand(ntx, R, 3).reshape(-1, 3)
+    d = rd64.reshape(-1, 3)
+    nrm = torch_ref.normals(V64, T64)
+    pts = []
+    for b in range(order):
+        face = torch.tensor(tris[..., b].reshape(-1))
+        t = torch_ref.differentiable_distance(V64, T64, o, d, face)
+        inside = torch.isfinite(t)
+        t = torch.where(inside, t, torch.zeros_like(t))
+        o = o + t[:, None] * d
+        n = nrm[torch.where(face >= 0, face, torch.full_like(face, Tr.shape[0] - 1))]
+        d = d - 2.0 * (d * n).sum(-1, keepdim=True) * n
+        pts.append(o)
+    ref = torch.stack(pts, dim=1).reshape(ntx, R, order, 3)
+    np.testing.assert_allclose(_np(inner)[full], ref.detach().numpy()[full], rtol=2e-4, atol=2e-4)
+    (ref * torch.tensor(Wm.astype(np.float64))).sum().backward()
+    for got_g, exp_g in ((txg.grad, tx64.grad), (rdg.grad, rd64.grad), (mesh.vertices.grad, V64.grad)):
+        e = exp_g.numpy()
+        scale = float(np.abs(e).max()) + 1e-30
+        assert float(np.abs(_np(got_g) - e).max()) <= 2e-5 * scale, (float(np.abs(_np(got_g) - e).max()), scale)
