@@ -1,0 +1,388 @@
+// beam.hip -- conservative ("beam") pruning of the exhaustive candidate space, GPU resident.
+//
+// Reference context: the exhaustive tracer enumerates n (n-1)^(k-1) candidates per (tx, rx) pair
+// (geometry/_solvers.py:803-848) and the hybrid tracer prunes them with SAMPLED visibility
+// (_solvers.py:1013-1056), which is lossy.  This file prunes with a geometric argument instead.
+//
+// A specular path tx -> P_1 in m_1 -> ... -> P_k in m_k -> rx unfolds into straight lines through
+// the images I_j of the transmitter (I_0 = tx, I_j = mirror image of I_{j-1} in the plane of m_j):
+// P_{j+1} lies on the ray from I_j through P_j, i.e. inside the pyramid with apex I_j spanned by the
+// primitive m_j, and rx lies inside the pyramid (I_k, m_k).  Moreover the reference's same-side
+// check (_solver_image_method.py:443-454) needs P_{j-1} and P_{j+1} on one side of the plane of m_j.
+// Both are NECESSARY conditions of a valid path, so a prefix (m_1..m_j) can be discarded together
+// with all of its n^(k-j) extensions when
+//   (S) the previous point set (tx or the primitive m_{j-1}) lies strictly on one side of the plane of
+//       m_j and the next primitive strictly on the other, or
+//   (B) every vertex of the next primitive lies strictly outside one face plane of the pyramid
+//       (I_j, m_j) (for quads: of both triangles' pyramids),
+// "strictly" meaning by more than a margin derived from E, a bound on the position error of the
+// reference's own float32 reflection points (DESIGN.md section 9 derives E from the scene magnitude,
+// the order and the smallest incidence cosine covered by the guarantee): plane-side tests use 4 E
+// (two points, each within E of its primitive, plus the rounding of the dot products); pyramid faces
+// use E (1 + |x - I_j| / h_j) with h_j the distance of the apex from the mirror plane -- an error E at
+// the mirror opens the pyramid by the angle E / h_j, and an apex (nearly) in the mirror plane
+// switches the test off by itself.  The tests only ever REMOVE candidates
+// that the reference arithmetic rejects; what survives is evaluated by the ordinary trace kernels
+// with the reference arithmetic, so results are those of the exhaustive tracer.
+//
+// Pipeline (device lists, wave-ballot compaction, no host enumeration):
+//   beam_seed    level-1 prefixes (tx, m_1) for all active primitives
+//   beam_expand  level-j -> level-(j+1) prefixes, tests (S) and (B) against every primitive
+//   beam_emit    level-k prefixes x receivers -> packed rows  ((tx nrx + rx) n^k + sum_j m_j n^(k-j))
+#include "common.hpp"
+#include "geom.hpp"
+#include "mesh.hpp"
+
+#pragma clang fp contract(off)
+
+namespace drt {
+
+struct BeamEntry {  // == drt_beam_entry (32 bytes)
+    int32_t tx;
+    int32_t id[3];
+    float apex[3];
+    int32_t side_prev;  // side of the previous point set w.r.t. the plane of the last mirror: +1 / -1 / 0 (near, straddling)
+};
+static_assert(sizeof(BeamEntry) == 32, "BeamEntry layout");
+
+struct BeamMesh {
+    const float *tv;       // [T,3,3]
+    const float *normals;  // [T,3]
+    const uint8_t *mask;   // [T] or null
+    int64_t nprim;
+    int32_t scale;  // triangles per primitive (2 with assume_quads)
+};
+
+__device__ __forceinline__ bool prim_active(const BeamMesh &M, int64_t p) {
+    if (!M.mask) return true;
+    const int64_t f = p * M.scale;
+    return M.mask[f] != 0 && (M.scale == 1 || M.mask[f + 1] != 0);
+}
+
+// mirror plane of a primitive: first vertex and normal of its first triangle (_solvers.py:552-562)
+__device__ __forceinline__ void prim_plane(const BeamMesh &M, int64_t p, V3 &pt, V3 &n) {
+    const int64_t f = p * M.scale;
+    pt = ld3(M.tv + 9 * f);
+    n = ld3(M.normals + 3 * f);
+}
+
+__device__ __forceinline__ int side_of_range(float dmin, float dmax, float E) {
+    return (dmin > E) ? 1 : ((dmax < -E) ? -1 : 0);
+}
+
+// side of all vertices of primitive p w.r.t. plane (pt, n)
+__device__ __forceinline__ int side_of_prim(const BeamMesh &M, int64_t p, V3 pt, V3 n, float E) {
+    float dmin = kInf, dmax = -kInf;
+    const float *v = M.tv + 9 * p * M.scale;
+    for (int i = 0; i < 3 * M.scale; ++i) {
+        const float d = dot(ld3(v + 3 * i) - pt, n);
+        dmin = fminf(dmin, d);
+        dmax = fmaxf(dmax, d);
+    }
+    if (!(dmin == dmin) || !(dmax == dmax)) return 0;  // NaN geometry: never prune
+    return side_of_range(dmin, dmax, E);
+}
+
+// inward unit normals of the three face planes of the pyramid (apex I, triangle u v w); a degenerate
+// face (apex on the edge line, or apex in the triangle's plane) gets a zero normal: it never separates
+struct Pyramid {
+    V3 n[3];
+};
+__device__ __forceinline__ V3 face_normal(V3 I, V3 a, V3 b, V3 third) {
+    const V3 N = cross(a - I, b - I);
+    const float len = __builtin_sqrtf(dot(N, N));
+    const float s = dot(third - I, N);
+    if (!(len > 0.0f) || !(s == s) || s == 0.0f || !is_finite(len)) return V3{0, 0, 0};
+    const float inv = ((s > 0.0f) ? 1.0f : -1.0f) / len;
+    return N * inv;
+}
+__device__ __forceinline__ Pyramid make_pyramid(V3 I, const float *tri9) {
+    const V3 u = ld3(tri9), v = ld3(tri9 + 3), w = ld3(tri9 + 6);
+    Pyramid P;
+    P.n[0] = face_normal(I, u, v, w);
+    P.n[1] = face_normal(I, v, w, u);
+    P.n[2] = face_normal(I, w, u, v);
+    return P;
+}
+
+constexpr int kBeamTile = 128;  // primitives per LDS tile (x up to 6 vertices x 12 B = 9 KiB)
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float *__restrict__ tx, int64_t ntx,
+                                                        float E, BeamEntry *__restrict__ out, int64_t cap,
+                                                        unsigned long long *__restrict__ count) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in = g < ntx * M.nprim;
+    const int64_t it = in ? g / M.nprim : 0, a = in ? g - it * M.nprim : 0;
+    const bool keep = in && prim_active(M, a);
+    BeamEntry e{};
+    if (keep) {
+        V3 pt, n;
+        prim_plane(M, a, pt, n);
+        const V3 t = ld3(tx + 3 * it);
+        const V3 I = image_of_vertex(t, pt, n);
+        const float d = dot(t - pt, n);
+        e.tx = (int32_t)it;
+        e.id[0] = (int32_t)a;
+        e.id[1] = e.id[2] = -1;
+        e.apex[0] = I.x;
+        e.apex[1] = I.y;
+        e.apex[2] = I.z;
+        e.side_prev = (d == d) ? side_of_range(d, d, 4.0f * E) : 0;
+    }
+    const unsigned long long vote = __ballot(keep);
+    if (vote) {
+        unsigned long long base = 0;
+        if (lane == __builtin_ctzll(vote)) base = atomicAdd(count, (unsigned long long)__popcll(vote));
+        base = __shfl(base, __builtin_ctzll(vote), 64);
+        if (keep) {
+            const unsigned long long slot = base + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
+            if ((int64_t)slot < cap) out[slot] = e;
+        }
+    }
+}
+
+// lane = prefix; the block walks all primitives through LDS tiles
+template <int SCALE>
+__global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
+                                                          int level, float E, BeamEntry *__restrict__ out,
+                                                          int64_t cap, unsigned long long *__restrict__ count) {
+    __shared__ float lds_v[kBeamTile][3 * SCALE][3];
+    __shared__ uint8_t lds_act[kBeamTile];
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = g < n_in;
+    BeamEntry e{};
+    if (have) e = in[g];
+    const int32_t m = have ? e.id[level - 1] : 0;
+    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    V3 pm{0, 0, 0}, nm{0, 0, 1};
+    Pyramid pyr[SCALE];
+    float inv_h = kInf;  // 1 / distance of the apex from the plane of m (inf: the pyramid test never prunes)
+    if (have) {
+        prim_plane(M, m, pm, nm);
+        const float h = __builtin_fabsf(dot(I - pm, nm));
+        inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) pyr[t] = make_pyramid(I, M.tv + 9 * ((int64_t)m * SCALE + t));
+    } else {
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) pyr[t] = Pyramid{};
+    }
+    for (int64_t base = 0; base < M.nprim; base += kBeamTile) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kBeamTile * 3 * SCALE; i += 256) {
+            const int64_t p = base + i / (3 * SCALE);
+            const int vtx = i % (3 * SCALE);
+            V3 v{0, 0, 0};
+            if (p < M.nprim) v = ld3(M.tv + 9 * p * SCALE + 3 * vtx);
+            lds_v[i / (3 * SCALE)][vtx][0] = v.x;
+            lds_v[i / (3 * SCALE)][vtx][1] = v.y;
+            lds_v[i / (3 * SCALE)][vtx][2] = v.z;
+        }
+        if (threadIdx.x < kBeamTile) {
+            const int64_t p = base + threadIdx.x;
+            lds_act[threadIdx.x] = (uint8_t)(p < M.nprim && prim_active(M, p));
+        }
+        __syncthreads();
+        const int nt = (int)((M.nprim - base < kBeamTile) ? M.nprim - base : kBeamTile);
+        for (int j = 0; j < nt; ++j) {
+            if (!lds_act[j]) continue;  // wave-uniform
+            const int32_t c = (int32_t)(base + j);
+            // (S) sides of c w.r.t. the plane of m, (B) all vertices outside one face of every pyramid of m
+            float dmin = kInf, dmax = -kInf;
+            bool out_face[SCALE][3];
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) out_face[t][f] = true;
+            bool nan = false;
+#pragma unroll
+            for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
+                const V3 x = V3{lds_v[j][vtx][0], lds_v[j][vtx][1], lds_v[j][vtx][2]};
+                const float d = dot(x - pm, nm);
+                nan = nan || !(d == d);
+                dmin = fminf(dmin, d);
+                dmax = fmaxf(dmax, d);
+                const V3 w = x - I;
+                const float thr = -(E + E * (__builtin_sqrtf(dot(w, w)) * inv_h));  // -inf / NaN: never separates
+#pragma unroll
+                for (int t = 0; t < SCALE; ++t)
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        const float s = dot(w, pyr[t].n[f]);
+                        out_face[t][f] = out_face[t][f] && (s < thr);  // NaN compares false
+                    }
+            }
+            bool separated = true;
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
+            const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
+            const bool keep = have && (c != m) && !separated && !(e.side_prev * side_c == -1);
+            const unsigned long long vote = __ballot(keep);
+            if (vote) {
+                unsigned long long b0 = 0;
+                const int leader = __builtin_ctzll(vote);
+                if (lane == leader) b0 = atomicAdd(count, (unsigned long long)__popcll(vote));
+                b0 = __shfl(b0, leader, 64);
+                if (keep) {
+                    const unsigned long long slot = b0 + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
+                    if ((int64_t)slot < cap) {
+                        V3 pc, nc;
+                        prim_plane(M, c, pc, nc);
+                        const V3 I2 = image_of_vertex(I, pc, nc);
+                        BeamEntry o = e;
+                        o.id[level] = c;
+                        o.apex[0] = I2.x;
+                        o.apex[1] = I2.y;
+                        o.apex[2] = I2.z;
+                        o.side_prev = side_of_prim(M, m, pc, nc, 4.0f * E);
+                        out[slot] = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// lane = level-k prefix, loop over the receivers
+template <int SCALE>
+__global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
+                                                        int order, const float *__restrict__ rx, int64_t nrx, float E,
+                                                        long long *__restrict__ rows, int64_t cap,
+                                                        unsigned long long *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = g < n_in;
+    BeamEntry e{};
+    if (have) e = in[g];
+    const int32_t c = have ? e.id[order - 1] : 0;
+    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    V3 pc{0, 0, 0}, nc{0, 0, 1};
+    Pyramid pyr[SCALE];
+    long long tail = 0;  // sum_j id_j n^(k-1-j)
+    float inv_h = kInf;
+    if (have) {
+        prim_plane(M, c, pc, nc);
+        const float h = __builtin_fabsf(dot(I - pc, nc));
+        inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) pyr[t] = make_pyramid(I, M.tv + 9 * ((int64_t)c * SCALE + t));
+        for (int j = 0; j < order; ++j) tail = tail * (long long)M.nprim + (long long)e.id[j];
+    } else {
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) pyr[t] = Pyramid{};
+    }
+    long long npow = 1;
+    for (int j = 0; j < order; ++j) npow *= (long long)M.nprim;
+    for (int64_t ir = 0; ir < nrx; ++ir) {
+        const V3 r = ld3(rx + 3 * ir);  // wave-uniform
+        const float d = dot(r - pc, nc);
+        const int side_r = (d == d) ? side_of_range(d, d, 4.0f * E) : 0;
+        const V3 w = r - I;
+        const float thr = -(E + E * (__builtin_sqrtf(dot(w, w)) * inv_h));
+        bool inside_any = false;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            bool inside = true;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) inside = inside && !(dot(w, pyr[t].n[f]) < thr);
+            inside_any = inside_any || inside;
+        }
+        const bool keep = have && inside_any && !(e.side_prev * side_r == -1);
+        const unsigned long long vote = __ballot(keep);
+        if (vote) {
+            unsigned long long b0 = 0;
+            const int leader = __builtin_ctzll(vote);
+            if (lane == leader) b0 = atomicAdd(count, (unsigned long long)__popcll(vote));
+            b0 = __shfl(b0, leader, 64);
+            if (keep) {
+                const unsigned long long slot = b0 + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
+                if ((int64_t)slot < cap) rows[slot] = ((long long)e.tx * (long long)nrx + (long long)ir) * npow + tail;
+            }
+        }
+    }
+}
+
+static BeamMesh beam_mesh(drt_mesh_t m) {
+    BeamMesh M;
+    M.tv = m->tri_verts;
+    M.normals = m->normals;
+    M.mask = m->has_mask ? m->mask : nullptr;
+    M.scale = m->assume_quads ? 2 : 1;
+    M.nprim = m->num_triangles / M.scale;
+    return M;
+}
+
+}  // namespace drt
+
+using namespace drt;
+
+extern "C" {
+
+int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t ntx, float margin, drt_beam_entry *out,
+                      int64_t capacity, int64_t *count_dev, void *stream) {
+    DRT_REQUIRE(mesh && count_dev, "null argument");
+    DRT_REQUIRE(ntx >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
+    const BeamMesh M = beam_mesh(mesh);
+    const int64_t n = ntx * M.nprim;
+    if (n == 0) return DRT_OK;
+    DRT_REQUIRE(tx && (out || capacity == 0), "null pointer");
+    hipLaunchKernelGGL(beam_seed_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), M, tx, ntx,
+                       margin, reinterpret_cast<BeamEntry *>(out), capacity,
+                       reinterpret_cast<unsigned long long *>(count_dev));
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t level, float margin,
+                        drt_beam_entry *out, int64_t capacity, int64_t *count_dev, void *stream) {
+    DRT_REQUIRE(mesh && count_dev, "null argument");
+    DRT_REQUIRE(n_in >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
+    DRT_REQUIRE(level >= 1 && level <= 2, "expansion goes from level 1 or 2 (orders up to 3)");
+    const BeamMesh M = beam_mesh(mesh);
+    if (n_in == 0 || M.nprim == 0) return DRT_OK;
+    DRT_REQUIRE(in && (out || capacity == 0), "null pointer");
+    const dim3 grid((unsigned)ceil_div(n_in, 256));
+    if (M.scale == 2)
+        hipLaunchKernelGGL(beam_expand_kernel<2>, grid, dim3(256), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                           reinterpret_cast<BeamEntry *>(out), capacity, reinterpret_cast<unsigned long long *>(count_dev));
+    else
+        hipLaunchKernelGGL(beam_expand_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                           reinterpret_cast<BeamEntry *>(out), capacity, reinterpret_cast<unsigned long long *>(count_dev));
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t order, const float *rx,
+                      int64_t nrx, int64_t ntx, float margin, int64_t *rows_out, int64_t capacity, int64_t *count_dev,
+                      void *stream) {
+    DRT_REQUIRE(mesh && count_dev, "null argument");
+    DRT_REQUIRE(n_in >= 0 && nrx >= 0 && ntx >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
+    DRT_REQUIRE(order >= 1 && order <= 3, "beam pruning covers orders 1..3");
+    const BeamMesh M = beam_mesh(mesh);
+    // packed rows must fit 62 bits: (ntx nrx) n^order
+    unsigned __int128 total = (unsigned __int128)(ntx > 0 ? ntx : 1) * (unsigned __int128)(nrx > 0 ? nrx : 1);
+    for (int j = 0; j < order; ++j) total *= (unsigned __int128)(M.nprim > 0 ? M.nprim : 1);
+    DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx * rx * primitives^order does not fit a 62-bit row key");
+    if (n_in == 0 || nrx == 0) return DRT_OK;
+    DRT_REQUIRE(in && rx && (rows_out || capacity == 0), "null pointer");
+    const dim3 grid((unsigned)ceil_div(n_in, 256));
+    if (M.scale == 2)
+        hipLaunchKernelGGL(beam_emit_kernel<2>, grid, dim3(256), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)order, rx, nrx, margin,
+                           reinterpret_cast<long long *>(rows_out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev));
+    else
+        hipLaunchKernelGGL(beam_emit_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)order, rx, nrx, margin,
+                           reinterpret_cast<long long *>(rows_out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev));
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+}  // extern "C"

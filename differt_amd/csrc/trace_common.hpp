@@ -207,6 +207,13 @@ __device__ __forceinline__ void ragged_decode(const CandSrc &s, int64_t nrx, int
     it = lo / nrx;
     ir = lo - it * nrx;
     const int64_t local = g - s.pair_offsets[lo];
+    if (s.table) {  // per-pair table (beam-pruned rows): ids are stored, nothing to unrank
+        if constexpr (K >= 1) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) id[j] = s.table[g * K + j];
+        }
+        return;
+    }
     if constexpr (K >= 2) {
         if (s.small) ragged_digits<K, uint32_t>(s, local, it, ir, id);
         else ragged_digits<K, uint64_t>(s, local, it, ir, id);
@@ -305,6 +312,14 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
     s.node_map = c->node_map;
     s.id_scale = id_scale;
     for (int j = 0; j < DRT_MAX_ORDER; ++j) s.pw[j] = 1;
+    if (c->table && c->pair_offsets) {  // per-pair table: rows grouped by pair, CSR offsets
+        DRT_REQUIRE(c->order >= 1, "a per-pair table needs order >= 1");
+        s.ragged = 1;
+        s.pair_offsets = c->pair_offsets;
+        s.small = 1;
+        *out = s;
+        return DRT_OK;
+    }
     if (!c->table && c->pair_offsets) {
         DRT_REQUIRE(c->order >= 2, "ragged pair spaces need order >= 2");
         DRT_REQUIRE(c->first_offsets && c->last_offsets && c->rank_lo == 0 && c->num_nodes >= 0,

@@ -128,7 +128,10 @@ class _TraceCompactFn(torch.autograd.Function):
 
         def make_cands():
             if cand_desc["table"] is not None:
-                return _table_candidates(cand_desc["table"])
+                c = _table_candidates(cand_desc["table"])
+                if cand_desc.get("pair_offsets") is not None:  # per-pair table (beam-pruned rows)
+                    c.pair_offsets = cand_desc["pair_offsets"].data_ptr()
+                return c
             return _rank_candidates(order, cand_desc["rank_lo"], cand_desc["count"],
                                     cand_desc["num_nodes"], cand_desc["node_map"],
                                     cand_desc.get("first_map"), cand_desc.get("last_map"),
@@ -412,6 +415,143 @@ class ExhaustivePathTracer(AbstractPathTracer):
         table = as_i32(path_candidates).contiguous()
         desc = {"table": table, "order": table.shape[1]}
         return self._trace_compact(scene, desc, max_survivors, max_paths)
+
+    # ---- conservative ("beam") pruning: the lossless counterpart of the hybrid tracer's sampling ----
+    def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.125, kappa: float = 16.0,
+                          chunk_entries: int = 1 << 21, max_entries: int = 1 << 26, max_rows: int = 1 << 27,
+                          max_survivors: int = 1 << 22, max_paths: int = 1 << 16) -> TracedPaths:
+        """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
+        enumeration _solvers.py:803-848 and the SAMPLED pruning of the hybrid tracer :1013-1056).
+
+        A prefix of mirrors is dropped only when a necessary condition of a valid specular path --
+        next primitive inside the pyramid spanned by the image of the transmitter and the current
+        mirror; previous and next point on one side of the mirror plane (the reference's same-side
+        check) -- fails by more than a margin built from ``E = kappa * ulp(M) / cos_min**order``
+        (``M`` = largest coordinate magnitude of the scene), a bound on the error of the reference's own
+        float32 reflection points for paths whose incidence angles all satisfy ``cos >= cos_min``
+        (DESIGN.md section 9).  Survivors are traced by the ordinary kernels, so valid paths, their order
+        (``masked_vertices`` order of the exhaustive tracer) and vertex bits are those of
+        :meth:`trace_rank_range` over the full space; ``keys`` are ``(tx*num_rx + rx) * n**order +
+        sum_j m_j * n**(order-1-j)`` (``n`` primitives, ``m_j`` primitive ids).  Orders 1..3."""
+        if self.smoothing_factor is not None:
+            raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
+        if order == 0:
+            return self.trace_rank_range(scene, 0, max_survivors=max_survivors, max_paths=max_paths)
+        if not 1 <= order <= 3:
+            raise ValueError("beam pruning covers orders 1..3")
+        mesh = scene.mesh
+        if mesh.mask is not None and not self.disconnect_inactive_triangles:
+            pass  # inactive primitives are never mirrors in either case (the trace marks them invalid)
+        tx = scene.transmitters.reshape(-1, 3).contiguous()
+        rx = scene.receivers.reshape(-1, 3).contiguous()
+        ntx, nrx, dev = tx.shape[0], rx.shape[0], tx.device
+        n = mesh.num_primitives
+        scale = 2 if mesh.assume_quads else 1
+        empty = TracedPaths(torch.zeros((0, order + 2, 3), device=dev), torch.zeros((0, order + 2), dtype=torch.int32, device=dev),
+                            torch.zeros(0, dtype=torch.bool, device=dev), torch.zeros((0, order), dtype=torch.int32, device=dev),
+                            self.confidence_threshold, torch.zeros(0, dtype=torch.int64, device=dev))
+        if n == 0 or ntx == 0 or nrx == 0:
+            return empty
+        if ntx * nrx * n ** order >= 2 ** 62:
+            raise OverflowError("tx * rx * primitives**order does not fit a 62-bit row key")
+        mag = max(float(mesh.vertices.detach().abs().max()), float(tx.detach().abs().max()), float(rx.detach().abs().max()), 1e-30)
+        ulp = 2.0 ** (int(np.floor(np.log2(mag))) - 23)
+        margin = float(kappa) * ulp / float(cos_min) ** order
+        h = mesh.handle().h
+        txd, rxd = tx.detach(), rx.detach()
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        stats = {"margin_m": margin, "levels": [], "rows": 0, "chunks": 0}
+
+        def entries(cap):
+            return torch.empty((max(cap, 1), 8), dtype=torch.int32, device=dev)  # 32-byte records
+
+        lvl = entries(ntx * n)
+        _lib.call("drt_beam_seed", h, ptr(txd), ntx, margin, ptr(lvl), ntx * n, ptr(count), stream())
+        cur, ncur = lvl, int(count.item())
+        stats["levels"].append(ncur)
+
+        def expand(src, nsrc, level, cap):
+            """level -> level + 1; returns (buffer, count) or None when `cap` was too small."""
+            out = entries(cap)
+            count.zero_()
+            _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, ptr(out), cap, ptr(count), stream())
+            c = int(count.item())
+            return (out, c) if c <= cap else None
+
+        # all but the last expansion are done in one piece (they are small: |L1| = ntx * n)
+        for level in range(1, order - 1):
+            cap = min(max_entries, max(ncur * 64, 1 << 16))
+            res = expand(cur, ncur, level, cap)
+            while res is None:
+                cap *= 4
+                if cap > 16 * max_entries:
+                    raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam prefix list does not fit: raise max_entries")
+                res = expand(cur, ncur, level, cap)
+            cur, ncur = res
+            stats["levels"].append(ncur)
+
+        npow = n ** order
+        parts = []
+        rows_buf = torch.empty(max_rows, dtype=torch.int64, device=dev)
+
+        def process(src, nsrc):
+            """level-`order` prefixes -> rows -> trace; returns False when `max_rows` was too small."""
+            count.zero_()
+            _lib.call("drt_beam_emit", h, ptr(src), nsrc, order, ptr(rxd), nrx, ntx, margin, ptr(rows_buf), max_rows,
+                      ptr(count), stream())
+            r = int(count.item())
+            if r > max_rows:
+                return False
+            stats["rows"] += r
+            if r == 0:
+                return True
+            rows = torch.sort(rows_buf[:r]).values
+            pair = torch.div(rows, npow, rounding_mode="floor")
+            rest = rows - pair * npow
+            cols = []
+            for j in range(order):
+                pw = n ** (order - 1 - j)
+                dgt = torch.div(rest, pw, rounding_mode="floor")
+                rest = rest - dgt * pw
+                cols.append((dgt * scale).to(torch.int32))
+            table = torch.stack(cols, dim=1).contiguous()
+            offs = torch.searchsorted(pair, torch.arange(ntx * nrx + 1, dtype=torch.int64, device=dev)).contiguous()
+            desc = {"table": table, "order": order, "pair_offsets": offs}
+            p = self._trace_compact(scene, desc, max_survivors, max_paths)
+            if p.objects.shape[0]:
+                parts.append((rows[p.keys], p.vertices, p.objects))
+            return True
+
+        if order == 1:
+            if not process(cur, ncur):
+                raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam rows do not fit: raise max_rows")
+        else:
+            i0, step = 0, max(int(chunk_entries), 1)
+            while i0 < ncur:
+                i1 = min(i0 + step, ncur)
+                src = cur[i0:i1]
+                res = expand(src, i1 - i0, order - 1, max_entries)
+                ok = res is not None and process(res[0], res[1])
+                if not ok:
+                    if step == 1:
+                        raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "one prefix overflows max_entries / max_rows")
+                    step = max(step // 4, 1)
+                    continue
+                if len(stats["levels"]) < order:
+                    stats["levels"].append(0)
+                stats["levels"][-1] += res[1]
+                stats["chunks"] += 1
+                i0 = i1
+        self.last_beam_stats = stats
+        if not parts:
+            return empty
+        keys = torch.cat([p[0] for p in parts])
+        perm = torch.argsort(keys, stable=True)
+        verts = torch.cat([p[1] for p in parts])[perm]
+        objs = torch.cat([p[2] for p in parts])[perm]
+        nv = objs.shape[0]
+        return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=dev),
+                           torch.zeros((nv, order), dtype=torch.int32, device=dev), self.confidence_threshold, keys[perm])
 
     def _trace_compact(self, scene, desc, max_survivors, max_paths) -> TracedPaths:
         tx = scene.transmitters.reshape(-1, 3).contiguous()

@@ -374,6 +374,10 @@ typedef struct drt_candidates {
     const int64_t *pair_offsets;
     const int64_t *first_offsets;
     const int64_t *last_offsets;
+    /* PER-PAIR TABLE (drt_trace_paths_compact / _async / _vjp): table != NULL together with pair_offsets
+     * != NULL -- rows [pair_offsets[p], pair_offsets[p+1]) of `table` are the candidates of pair
+     * p = tx * num_rx + rx (triangle ids, already even for quads); first / last maps unused.  Keys are
+     * global table rows.  This is how the rows of drt_beam_emit are traced. */
 } drt_candidates;
 
 /* Dense reference layout for every (tx, rx, candidate):
@@ -430,6 +434,35 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
                             int64_t num_rx, const drt_candidates *cands, const int64_t *keys,
                             const float *vertices_cotangent, int64_t num_paths, float *grad_tx,
                             float *grad_rx, float *grad_vertices, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conservative ("beam") pruning of the exhaustive candidate space -- the lossless counterpart of the
+ * reference's sampled visibility pruning (geometry/_solvers.py:1013-1056).  A prefix of mirrors is
+ * dropped only when a NECESSARY condition of a valid specular path fails by more than `margin`
+ * (next primitive outside the pyramid spanned by the image of the transmitter and the current
+ * mirror, or on the wrong side of the mirror plane for the reference's same-side check,
+ * _solver_image_method.py:443-454); see csrc/beam.hip and DESIGN.md section 9.  Orders 1..3.
+ *   drt_beam_seed    level-1 prefixes (tx, m1) of all active primitives        -> out[0 .. *count)
+ *   drt_beam_expand  level -> level + 1 prefixes (level = ids already present)  -> out[0 .. *count)
+ *   drt_beam_emit    level-`order` prefixes x receivers -> packed candidate rows
+ *                    ((tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j)), n = primitives
+ * count_dev (device int64, zeroed by the caller) receives the number of records produced; records
+ * beyond `capacity` are dropped, so count > capacity means "re-run with more room".  Rows, once
+ * sorted, feed drt_trace_paths_compact as a per-pair table (drt_candidates.table + pair_offsets).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct drt_beam_entry {
+    int32_t tx;
+    int32_t id[3];      /* primitive ids of the prefix, unused slots -1 */
+    float apex[3];      /* image of the transmitter through the prefix's mirrors */
+    int32_t side_prev;  /* +1 / -1 / 0: side of the previous point set w.r.t. the last mirror plane */
+} drt_beam_entry;
+int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t num_tx, float margin, drt_beam_entry *out,
+                      int64_t capacity, int64_t *count_dev, void *stream);
+int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t level, float margin,
+                        drt_beam_entry *out, int64_t capacity, int64_t *count_dev, void *stream);
+int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t order, const float *rx,
+                      int64_t num_rx, int64_t num_tx, float margin, int64_t *rows_out, int64_t capacity,
+                      int64_t *count_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (f4) smoothed ("soft mask") mode -- reference: differt/src/differt/utils.py:70-89
