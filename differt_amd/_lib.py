@@ -133,6 +133,7 @@ _SIGNATURES = {
     "drt_mesh_triangles_visible_samples": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "drt_viewing_frustum": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "drt_viewing_frustum_points": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "drt_viewing_frustum_general": (_i32, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "drt_launch_paths": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _i64, _f32, _vp, _vp, _vp, _vp]),
     "drt_fibonacci_lattice": (_i32, [_i64, _vp, _vp, _vp]),
     "drt_triangles_visible_from_vertex": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp]),

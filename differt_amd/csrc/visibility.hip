@@ -164,6 +164,94 @@ __global__ __launch_bounds__(256) void frustum_points_kernel(const float *__rest
         o[0] = r_min; o[1] = p_min; o[2] = a_min; o[3] = r_max; o[4] = p_max; o[5] = a_max;
     }
 }
+// General form of viewing_frustum (_utils.py:639-927): per-viewer point sets (stride 3 N or 0 = shared),
+// per-point mask (stride N or 0), and `reduce` (one frustum over every batch entry: the min / max run over
+// viewers AND points before the azimuth / polar selection logic, :838-846 with axis = None).
+__device__ __forceinline__ void frustum_finish(const float (&m)[8], float *o) {
+    float r_min = m[0], r_max = -m[1], p_min = m[2], p_max = -m[3];
+    float a_min = m[4], a_max = -m[5], a0_min = m[6], a0_max = -m[7];
+    const float a_width = a_max - a_min, a0_width = a0_max - a0_min;
+    if (a_width > a0_width) { a_min = a0_min; a_max = a0_max; }
+    if (fminf(a_width, a0_width) > 1.5f * kPi) { a_min = -kPi; a_max = kPi; }
+    float p0_min = p_min, p0_max = p_max;
+    if (p_min == p_max) { p_min = 0.0f; p0_max = kPi; }
+    if ((p_max - p_min) > (p0_max - p0_min)) { p_min = p0_min; p_max = p0_max; }
+    o[0] = r_min; o[1] = p_min; o[2] = a_min; o[3] = r_max; o[4] = p_max; o[5] = a_max;
+}
+
+__global__ __launch_bounds__(256) void frustum_general_kernel(const float *__restrict__ view,
+                                                              const float *__restrict__ pts, int64_t N,
+                                                              int64_t pts_stride, const uint8_t *__restrict__ act,
+                                                              int64_t act_stride, float *__restrict__ raw,
+                                                              float *__restrict__ out) {
+    const int64_t b = blockIdx.x;
+    const V3 vv = ld3(view + 3 * b);
+    const float *P = pts + b * pts_stride;
+    const uint8_t *A = act ? act + b * act_stride : nullptr;
+    float r_min = kInf, r_max = 0.0f, p_min = kPi, p_max = 0.0f;
+    float a_min = kPi, a_max = -kPi, a0_min = kTwoPi, a0_max = 0.0f;
+    for (int64_t k = threadIdx.x; k < N; k += 256) {
+        if (A && !A[k]) continue;
+        const V3 x = ld3(P + 3 * k) - vv;
+        float r = __builtin_sqrtf(dot(x, x));
+        r = (r == 0.0f) ? 1.0f : r;
+        const float p = acosf(x.z / r);
+        const float a = atan2f(x.y, x.x);
+        const float a0 = fmodf(a + kTwoPi, kTwoPi);
+        r_min = fminf(r_min, r); r_max = fmaxf(r_max, r);
+        p_min = fminf(p_min, p); p_max = fmaxf(p_max, p);
+        a_min = fminf(a_min, a); a_max = fmaxf(a_max, a);
+        a0_min = fminf(a0_min, a0); a0_max = fmaxf(a0_max, a0);
+    }
+    __shared__ float red[8][256];
+    float vals[8] = {r_min, -r_max, p_min, -p_max, a_min, -a_max, a0_min, -a0_max};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = vals[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = red[k][0];
+        if (raw) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) raw[8 * b + k] = m[k];
+        } else {
+            frustum_finish(m, out + 6 * b);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void frustum_reduce_kernel(const float *__restrict__ raw, int64_t B,
+                                                             float *__restrict__ out) {
+    __shared__ float red[8][256];
+    float m[8] = {kInf, 0.0f, kPi, 0.0f, kPi, kPi, kTwoPi, 0.0f};  // minima of (x, -x_max): identities
+    for (int64_t b = threadIdx.x; b < B; b += 256)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fminf(m[k], raw[8 * b + k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = m[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = red[k][0];
+        frustum_finish(m, out);
+    }
+}
+
 
 void launch_frustum_kernel(const float *view, int64_t B, const float *tv, int64_t T,
                            const uint8_t *active, float *out, hipStream_t s) {
@@ -238,6 +326,26 @@ int32_t drt_viewing_frustum_points(const float *viewing_vertices, int64_t B, con
     DRT_REQUIRE(viewing_vertices && frustum_out && (N == 0 || points), "null pointer");
     hipLaunchKernelGGL(frustum_points_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream),
                        viewing_vertices, points, N, frustum_out);
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_viewing_frustum_general(const float *viewing_vertices, int64_t B, const float *points, int64_t N,
+                                    int64_t points_viewer_stride, const uint8_t *active,
+                                    int64_t active_viewer_stride, int32_t reduce, float *workspace,
+                                    float *frustum_out, void *stream) {
+    DRT_REQUIRE(B >= 0 && N >= 0, "negative size");
+    if (B == 0) return DRT_OK;
+    DRT_REQUIRE(viewing_vertices && frustum_out && (N == 0 || points), "null pointer");
+    DRT_REQUIRE(points_viewer_stride == 0 || points_viewer_stride == 3 * N, "points_viewer_stride must be 0 or 3*N");
+    DRT_REQUIRE(active_viewer_stride == 0 || active_viewer_stride == N, "active_viewer_stride must be 0 or N");
+    DRT_REQUIRE(!reduce || workspace, "reduce needs a workspace of 8*B floats");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(frustum_general_kernel, dim3((unsigned)B), dim3(256), 0, s, viewing_vertices, points, N,
+                       points_viewer_stride, active, active_viewer_stride, reduce ? workspace : (float *)nullptr,
+                       frustum_out);
+    if (reduce)
+        hipLaunchKernelGGL(frustum_reduce_kernel, dim3(1), dim3(256), 0, s, workspace, B, frustum_out);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

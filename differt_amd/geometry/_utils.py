@@ -399,30 +399,35 @@ def fibonacci_lattice(n: int, dtype=None, *, frustum=None):  # noqa: ARG001
     return out
 
 
-def _triangle_world(triangle_vertices, active_triangles):
-    dev = device()
-    tv = as_f32(triangle_vertices, dev)
-    if tv.dim() != 3:
-        raise NotImplementedError("batched triangle sets are not supported by the visibility kernels")
-    act = None if active_triangles is None else as_u8(active_triangles, dev).reshape(-1).contiguous()
-    return dev, tv.contiguous(), act
-
-
 def viewing_frustum(viewing_vertex, world_vertices, *, active_vertices=None, reduce: bool = False):
-    """Spherical bounding region ``[*batch, 2, 3]`` of the world seen from a vertex
-    (_utils.py:639-927).  The kernel consumes triangles (vertices + centres are derived inside, as
-    ``triangles_visible_from_vertex`` does, :1669-1673): ``world_vertices`` must be ``[T, 3, 3]``
-    triangle vertices and ``active_vertices`` a per-triangle mask."""
-    if reduce:
-        raise NotImplementedError("reduce=True is not needed on the hot path")
-    dev, tv, act = _triangle_world(world_vertices, active_vertices)
+    """Spherical bounding region of the world seen from a vertex, reference signature and semantics
+    (_utils.py:639-927): ``viewing_vertex [*#batch, 3]``, ``world_vertices [*#batch, N, 3]`` POINTS,
+    ``active_vertices [*#batch, N]``; returns ``[*batch, 2, 3]`` (r, polar, azimuth extents), or one
+    ``[2, 3]`` frustum over every batch entry with ``reduce=True``."""
+    dev = device()
     v = as_f32(viewing_vertex, dev)
-    batch = v.shape[:-1]
-    vf = v.reshape(-1, 3).contiguous()
-    out = torch.empty((vf.shape[0], 2, 3), dtype=torch.float32, device=dev)
-    _lib.call("drt_viewing_frustum", ptr(vf), vf.shape[0], ptr(tv), tv.shape[0], ptr(act), ptr(out),
-              stream())
-    return out.reshape(*batch, 2, 3)
+    w = as_f32(world_vertices, dev)
+    act = None if active_vertices is None else as_u8(active_vertices, dev)
+    N = w.shape[-2]
+    batch = torch.broadcast_shapes(v.shape[:-1], w.shape[:-2], act.shape[:-1] if act is not None else ())
+    B = int(np.prod(batch, dtype=np.int64))
+    vf = v.expand(*batch, 3).contiguous().reshape(B, 3)
+    if all(s_ == 1 for s_ in w.shape[:-2]):
+        wf, wstride = w.reshape(N, 3).contiguous(), 0
+    else:
+        wf, wstride = w.expand(*batch, N, 3).contiguous().reshape(B, N, 3), 3 * N
+    if act is None:
+        af, astride = None, 0
+    elif all(s_ == 1 for s_ in act.shape[:-1]):
+        af, astride = act.reshape(N).contiguous(), 0
+    else:
+        af, astride = act.expand(*batch, N).contiguous().reshape(B, N), N
+    out = torch.empty((1 if reduce else max(B, 1), 2, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty((max(B, 1), 8), dtype=torch.float32, device=dev) if reduce else None
+    if B:
+        _lib.call("drt_viewing_frustum_general", ptr(vf), B, ptr(wf), N, wstride, ptr(af), astride, int(reduce),
+                  ptr(ws), ptr(out), stream())
+    return out.reshape(2, 3) if reduce else out[:B].reshape(*batch, 2, 3)
 
 
 def triangles_visible_from_vertex(
@@ -434,22 +439,43 @@ def triangles_visible_from_vertex(
     **kwargs: Any,
 ):
     """Which triangles receive the first hit of at least one of ``num_rays`` lattice rays launched
-    inside the viewing frustum (_utils.py:1540-1772).  ``bool[*batch, T]``."""
+    inside the viewing frustum (_utils.py:1540-1772).  ``bool[*batch, T]``; ``triangle_vertices`` /
+    ``active_triangles`` may carry their own broadcastable batch (``*#batch``) like in the reference:
+    every distinct triangle set gets its own launch."""
     epsilon = kwargs.pop("epsilon", None)
     if kwargs:
         raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
-    dev, tv, act = _triangle_world(triangle_vertices, active_triangles)
+    dev = device()
+    tv = as_f32(triangle_vertices, dev)
+    act = None if active_triangles is None else as_u8(active_triangles, dev)
     v = as_f32(vertex, dev)
-    batch = v.shape[:-1]
-    vf = v.reshape(-1, 3).contiguous()
-    B, T = vf.shape[0], tv.shape[0]
-    vis = torch.zeros((B, T), dtype=torch.uint8, device=dev)
-    if B and T:
-        eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
-        ws = torch.empty((B, 6), dtype=torch.float32, device=dev)
-        _lib.call("drt_triangles_visible_from_vertex", ptr(vf), B, ptr(tv), T, ptr(act), int(num_rays),
-                  eps, ptr(vis), ptr(ws), stream())
-    return vis.bool().reshape(*batch, T)
+    T = tv.shape[-3]
+    eps = 10.0 * F32_EPS if epsilon is None else float(epsilon)
+
+    def launch(vf, tvf, actf):
+        B = vf.shape[0]
+        vis = torch.zeros((B, T), dtype=torch.uint8, device=dev)
+        if B and T:
+            ws = torch.empty((B, 6), dtype=torch.float32, device=dev)
+            _lib.call("drt_triangles_visible_from_vertex", ptr(vf), B, ptr(tvf), T, ptr(actf), int(num_rays),
+                      eps, ptr(vis), ptr(ws), stream())
+        return vis
+
+    shared_tv = all(s_ == 1 for s_ in tv.shape[:-3])
+    shared_act = act is None or all(s_ == 1 for s_ in act.shape[:-1])
+    if shared_tv and shared_act:
+        batch = v.shape[:-1]
+        vis = launch(v.reshape(-1, 3).contiguous(), tv.reshape(T, 3, 3).contiguous(),
+                     None if act is None else act.reshape(T).contiguous())
+        return vis.bool().reshape(*batch, T)
+    batch = torch.broadcast_shapes(v.shape[:-1], tv.shape[:-3], act.shape[:-1] if act is not None else ())
+    B = int(np.prod(batch, dtype=np.int64))
+    vf = v.expand(*batch, 3).reshape(B, 3)
+    tvb = tv.expand(*batch, T, 3, 3).reshape(B, T, 3, 3)
+    actb = None if act is None else act.expand(*batch, T).reshape(B, T)
+    rows = [launch(vf[b:b + 1].contiguous(), tvb[b].contiguous(), None if actb is None else actb[b].contiguous())
+            for b in range(B)]
+    return (torch.cat(rows) if rows else torch.zeros((0, T), dtype=torch.uint8, device=dev)).bool().reshape(*batch, T)
 
 
 # ------------------------------------------------------------------------------------------

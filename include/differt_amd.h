@@ -223,6 +223,14 @@ int32_t drt_viewing_frustum(const float *viewing_vertices, int64_t num_vertices,
 int32_t drt_viewing_frustum_points(const float *viewing_vertices, int64_t num_vertices,
                                    const float *points, int64_t num_points, float *frustum_out,
                                    void *stream);
+/* General form (geometry/_utils.py:639-927): per-viewer point sets (points_viewer_stride = 3*N) or one
+ * shared set (0); optional per-point mask with its own stride (N or 0); reduce != 0 -> ONE frustum
+ * [2,3] over all viewers and points (min / max taken before the azimuth / polar selection, axis=None
+ * in the reference), workspace = 8*B floats; else frustum_out [B,2,3]. */
+int32_t drt_viewing_frustum_general(const float *viewing_vertices, int64_t num_viewers, const float *points,
+                                    int64_t num_points, int64_t points_viewer_stride, const uint8_t *active,
+                                    int64_t active_viewer_stride, int32_t reduce, float *workspace,
+                                    float *frustum_out, void *stream);
 /* geometry/_utils.py:930-993: xyz [batch,3] -> (r, polar, azimuth); rpa [batch,width] (width 2 = unit
  * radius, 3 = with radius) -> xyz. */
 int32_t drt_cartesian_to_spherical(const float *xyz, int64_t batch, float *rpa_out, void *stream);

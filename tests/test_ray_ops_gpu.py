@@ -196,8 +196,14 @@ def test_ray_intersect_triangle_t_gradients(shape):
     eps = 10 * 1.1920929e-7
     # well-conditioned pairs (roughly horizontal triangles, rays pointing down within ~35 degrees): with
     # near-parallel ray / triangle pairs 1/a is huge and float32 itself is 1e-4 off the float64 truth
-    edges = rng.normal(size=(T, 3, 3)) * np.array([1.5, 1.5, 0.25])
-    tvn = (rng.uniform(-5, 5, (T, 1, 3)) * np.array([1.0, 1.0, 0.3]) + edges).astype(np.float32)
+    def flat_triangles(num, size, span):
+        # no slivers: e1 ~ (+x), e2 ~ (+y), small tilt -> |a| = |d . (e1 x e2)| stays O(|d| size^2)
+        v0 = rng.uniform(-span, span, (num, 3)) * np.array([1.0, 1.0, 0.3])
+        e1 = np.column_stack((rng.uniform(1, 2, num), rng.uniform(-0.3, 0.3, num), rng.uniform(-0.25, 0.25, num))) * size
+        e2 = np.column_stack((rng.uniform(-0.3, 0.3, num), rng.uniform(1, 2, num), rng.uniform(-0.25, 0.25, num))) * size
+        return np.stack((v0, v0 + e1, v0 + e2), axis=1).astype(np.float32)
+
+    tvn = flat_triangles(T, 1.0, 5.0)
     on = np.column_stack((rng.uniform(-4, 4, R), rng.uniform(-4, 4, R), rng.uniform(8, 12, R))).astype(np.float32)
     dn = np.column_stack((rng.uniform(-4, 4, (R, 2)), -rng.uniform(8, 12, R))).astype(np.float32)
     if shape == "dense":
@@ -246,8 +252,10 @@ def test_first_triangle_hit_by_ray_free_function_t_gradient():
     rng = np.random.default_rng(23)
     R, T = 64, 200
     eps = 10 * 1.1920929e-7
-    edges = rng.normal(size=(T, 3, 3)) * np.array([3.0, 3.0, 0.4])
-    tvn = (rng.uniform(-20, 20, (T, 1, 3)) * np.array([1.0, 1.0, 0.2]) + edges).astype(np.float32)
+    v0 = rng.uniform(-20, 20, (T, 3)) * np.array([1.0, 1.0, 0.2])
+    e1 = np.column_stack((rng.uniform(3, 6, T), rng.uniform(-1, 1, T), rng.uniform(-0.5, 0.5, T)))
+    e2 = np.column_stack((rng.uniform(-1, 1, T), rng.uniform(3, 6, T), rng.uniform(-0.5, 0.5, T)))
+    tvn = np.stack((v0, v0 + e1, v0 + e2), axis=1).astype(np.float32)
     on = np.column_stack((rng.uniform(-15, 15, R), rng.uniform(-15, 15, R), rng.uniform(20, 30, R))).astype(np.float32)
     tgt = tvn.mean(axis=1)[rng.integers(0, T, R)]
     dn = (tgt - on).astype(np.float32)

@@ -219,8 +219,19 @@ def test_gpu_lattice_and_frustum_vs_oracle(G, cube_tv):
     world = np.concatenate((tv, tv.mean(axis=-2, keepdims=True, dtype=np.float32)), axis=-2).reshape(-1, 3)
     for a in (None, act):
         exp = orc.viewing_frustum(views, world, active_vertices=None if a is None else np.repeat(a, 4))
-        got = _np(G.viewing_frustum(views, tv, active_vertices=a))
+        got = _np(G.viewing_frustum(views, world, active_vertices=None if a is None else np.repeat(a, 4)))
         np.testing.assert_allclose(got, exp, atol=5e-6)
+        # reduce=True (_utils.py:838-846 with axis=None): one frustum over every viewer; per-viewer point
+        # sets and masks broadcast like in the reference
+        per_view = np.stack([world + 0.01 * i for i in range(len(views))]).astype(np.float32)
+        r1 = _np(G.viewing_frustum(views, per_view, reduce=True))
+        assert r1.shape == (2, 3)
+        each = _np(G.viewing_frustum(views, per_view))
+        assert each.shape == (len(views), 2, 3)
+        np.testing.assert_allclose(r1[0, 0], each[:, 0, 0].min(), rtol=1e-6)
+        np.testing.assert_allclose(r1[1, 0], each[:, 1, 0].max(), rtol=1e-6)
+        np.testing.assert_allclose(r1[0, 1], each[:, 0, 1].min(), rtol=1e-6)
+        np.testing.assert_allclose(r1[1, 1], each[:, 1, 1].max(), rtol=1e-6)
         for b in range(2):
             e = orc.fibonacci_lattice(5000, frustum=exp[b])
             g = _np(G.fibonacci_lattice(5000, frustum=got[b]))
@@ -302,3 +313,21 @@ def test_gpu_hybrid_equals_exhaustive_on_goldens(G, goldens, two_buildings, orde
         assert hyb.mask.shape[-1] < exh.mask.shape[-1]  # the candidate set really is pruned
     cp = scene.trace_paths(order, solver="hybrid", num_rays=200_000, compact=True)
     np.testing.assert_array_equal(_np(cp.objects), eo)
+
+
+@gpu
+def test_gpu_visibility_batched_triangle_sets(G, cube_tv):
+    """_utils.py:1540-1772 accepts `*#batch` on the triangle set and the mask too: each batch entry sees
+    its own triangles (here: the cube and a shifted copy; second entry with two faces masked)."""
+    import torch
+
+    tv = np.stack((cube_tv, cube_tv + np.float32(0.25)))  # [2, 12, 3, 3]
+    act = np.ones((2, 12), bool)
+    act[1, :4] = False
+    vertex = np.array([[2.0, 2.0, 2.0], [2.0, 2.0, 2.0]], np.float32)
+    got = G.triangles_visible_from_vertex(vertex, tv, act, num_rays=100_000)
+    assert tuple(got.shape) == (2, 12)
+    for b in range(2):
+        one = G.triangles_visible_from_vertex(vertex[b], tv[b], act[b], num_rays=100_000)
+        assert torch.equal(got[b], one)
+    assert int(got[0].sum()) == 6 and not bool(got[1, :4].any())
