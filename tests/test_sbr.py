@@ -132,7 +132,8 @@ def test_gpu_launch_paths_vjp_vs_float64_autograd(order):
     txg = torch.tensor(tx, device="cuda", requires_grad=True)
     rdg = torch.tensor(rdn, device="cuda", requires_grad=True)
     mesh = G.Mesh(V, Tr)
-    mesh = mesh.with_vertices(mesh.vertices.detach().clone().requires_grad_(True))
+    vleaf = mesh.vertices.detach().clone().requires_grad_(True)  # the leaf (Mesh keeps a reshaped view)
+    mesh = mesh.with_vertices(vleaf)
 
     class Fixed(G.AbstractPathLauncher):
         max_dist = 1.0
@@ -172,7 +173,7 @@ def test_gpu_launch_paths_vjp_vs_float64_autograd(order):
     ref = torch.stack(pts, dim=1).reshape(ntx, R, order, 3)
     np.testing.assert_allclose(_np(inner)[full], ref.detach().numpy()[full], rtol=2e-4, atol=2e-4)
     (ref * torch.tensor(Wm.astype(np.float64))).sum().backward()
-    for got_g, exp_g in ((txg.grad, tx64.grad), (rdg.grad, rd64.grad), (mesh.vertices.grad, V64.grad)):
+    for got_g, exp_g in ((txg.grad, tx64.grad), (rdg.grad, rd64.grad), (vleaf.grad, V64.grad)):
         e = exp_g.numpy()
         scale = float(np.abs(e).max()) + 1e-30
         assert float(np.abs(_np(got_g) - e).max()) <= 2e-5 * scale, (float(np.abs(_np(got_g) - e).max()), scale)

@@ -77,11 +77,12 @@ def test_cfg3_window_is_deterministic_run_to_run():
 
     def step():
         txg = torch.tensor(tx, device="cuda", requires_grad=True)
-        mv = mesh.with_vertices(mesh.vertices.detach().clone().requires_grad_(True))
+        vl = mesh.vertices.detach().clone().requires_grad_(True)  # the leaf (Mesh keeps a reshaped view)
+        mv = mesh.with_vertices(vl)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mv)
         p = G.ExhaustivePathTracer().trace_rank_range(scene, 2, 0, 5_000_000)
         torch.sqrt((torch.diff(p.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
-        return p, txg.grad.clone(), mv.vertices.grad.clone()
+        return p, txg.grad.clone(), vl.grad.clone()
 
     a, ga, gva = step()
     b, gb, gvb = step()

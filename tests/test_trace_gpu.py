@@ -607,11 +607,12 @@ def test_mesh_first_hit_warp_semantics_jacobians(G):
     outs = []
     for sem in ("jax", "warp"):
         o, d = o0.clone().requires_grad_(True), d0.clone().requires_grad_(True)
-        m = mesh.with_vertices(mesh.vertices.detach().clone().requires_grad_(True))
+        vl = mesh.vertices.detach().clone().requires_grad_(True)  # the leaf (Mesh keeps a reshaped view)
+        m = mesh.with_vertices(vl)
         idx, t = m.first_triangle_hit_by_ray(o, d, semantics=sem)
         assert (idx >= 0).all()
         t.sum().backward()
-        outs.append((t.detach(), o.grad, d.grad, m.vertices.grad))
+        outs.append((t.detach(), o.grad, d.grad, vl.grad))
     np.testing.assert_allclose(_np(outs[1][0]), _np(outs[0][0]), rtol=1e-5, atol=1e-5)
     for a, b in zip(outs[0][1:], outs[1][1:]):
         np.testing.assert_allclose(_np(b), _np(a), rtol=1e-5, atol=1e-5)
