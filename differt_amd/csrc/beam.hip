@@ -105,6 +105,31 @@ __device__ __forceinline__ Pyramid make_pyramid(V3 I, const float *tri9) {
     return P;
 }
 
+// Pyramid (apex I) over the triangle `t` of primitive `p` after reflecting it in the planes of the
+// primitives refl[0..nrefl) in turn ("unfolding"): a specular path is a straight line from the last
+// image of the transmitter that crosses the unfolded images of ALL earlier mirrors, not only the last
+// one.  Also returns 1 / distance of the apex from the unfolded triangle's plane (for the margin).
+__device__ __forceinline__ Pyramid unfolded_pyramid(const BeamMesh &M, V3 I, int64_t p, int t, const int32_t *refl,
+                                                    int nrefl, float &inv_h) {
+    const float *tri = M.tv + 9 * (p * M.scale + t);
+    V3 v[3] = {ld3(tri), ld3(tri + 3), ld3(tri + 6)};
+    for (int r = 0; r < nrefl; ++r) {
+        V3 pt, n;
+        prim_plane(M, refl[r], pt, n);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
+    }
+    Pyramid P;
+    P.n[0] = face_normal(I, v[0], v[1], v[2]);
+    P.n[1] = face_normal(I, v[1], v[2], v[0]);
+    P.n[2] = face_normal(I, v[2], v[0], v[1]);
+    const V3 c = cross(v[1] - v[0], v[2] - v[0]);
+    const float len = __builtin_sqrtf(dot(c, c));
+    const float h = (len > 0.0f) ? __builtin_fabsf(dot(I - v[0], c)) / len : 0.0f;
+    inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+    return P;
+}
+
 constexpr int kBeamTile = 128;  // primitives per LDS tile (x up to 6 vertices x 12 B = 9 KiB)
 
 // ---------------------------------------------------------------------------------------------
@@ -159,16 +184,25 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
     const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
     V3 pm{0, 0, 0}, nm{0, 0, 1};
     Pyramid pyr[SCALE];
-    float inv_h = kInf;  // 1 / distance of the apex from the plane of m (inf: the pyramid test never prunes)
+    Pyramid pyr0[SCALE];  // level 2: the first mirror id[0] unfolded in the plane of m (zero normals otherwise)
+    float inv_h = kInf;   // 1 / distance of the apex from the plane of m (inf: the pyramid test never prunes)
+    float inv_h0[SCALE];
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        pyr[t] = Pyramid{};
+        pyr0[t] = Pyramid{};
+        inv_h0[t] = kInf;
+    }
     if (have) {
         prim_plane(M, m, pm, nm);
         const float h = __builtin_fabsf(dot(I - pm, nm));
         inv_h = (h > 0.0f) ? 1.0f / h : kInf;
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) pyr[t] = make_pyramid(I, M.tv + 9 * ((int64_t)m * SCALE + t));
-    } else {
+        if (level == 2) {
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) pyr[t] = Pyramid{};
+            for (int t = 0; t < SCALE; ++t) pyr0[t] = unfolded_pyramid(M, I, e.id[0], t, &e.id[1], 1, inv_h0[t]);
+        }
     }
     for (int64_t base = 0; base < M.nprim; base += kBeamTile) {
         __syncthreads();
@@ -192,11 +226,11 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             const int32_t c = (int32_t)(base + j);
             // (S) sides of c w.r.t. the plane of m, (B) all vertices outside one face of every pyramid of m
             float dmin = kInf, dmax = -kInf;
-            bool out_face[SCALE][3];
+            bool out_face[SCALE][3], out_face0[SCALE][3];
 #pragma unroll
             for (int t = 0; t < SCALE; ++t)
 #pragma unroll
-                for (int f = 0; f < 3; ++f) out_face[t][f] = true;
+                for (int f = 0; f < 3; ++f) out_face[t][f] = out_face0[t][f] = true;
             bool nan = false;
 #pragma unroll
             for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
@@ -206,18 +240,27 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
                 dmin = fminf(dmin, d);
                 dmax = fmaxf(dmax, d);
                 const V3 w = x - I;
-                const float thr = -(E + E * (__builtin_sqrtf(dot(w, w)) * inv_h));  // -inf / NaN: never separates
+                const float wl = __builtin_sqrtf(dot(w, w));
+                const float thr = -(E + E * (wl * inv_h));  // -inf / NaN: never separates
 #pragma unroll
-                for (int t = 0; t < SCALE; ++t)
+                for (int t = 0; t < SCALE; ++t) {
+                    const float thr0 = -(E + E * (wl * inv_h0[t]));
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
                         const float s = dot(w, pyr[t].n[f]);
                         out_face[t][f] = out_face[t][f] && (s < thr);  // NaN compares false
+                        const float s0 = dot(w, pyr0[t].n[f]);
+                        out_face0[t][f] = out_face0[t][f] && (s0 < thr0);
                     }
+                }
             }
-            bool separated = true;
+            bool separated = true, separated0 = true;
 #pragma unroll
-            for (int t = 0; t < SCALE; ++t) separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
+            for (int t = 0; t < SCALE; ++t) {
+                separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
+                separated0 = separated0 && (out_face0[t][0] || out_face0[t][1] || out_face0[t][2]);
+            }
+            separated = separated || separated0;  // outside the cone of the last mirror OR of the unfolded first one
             const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
             const bool keep = have && (c != m) && !separated && !(e.side_prev * side_c == -1);
             const unsigned long long vote = __ballot(keep);
@@ -260,19 +303,27 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     const int32_t c = have ? e.id[order - 1] : 0;
     const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
     V3 pc{0, 0, 0}, nc{0, 0, 1};
-    Pyramid pyr[SCALE];
+    // pyramids (apex = last image) over the last mirror and over every earlier mirror unfolded through the
+    // later ones: the receiver must see ALL of them in line -- the exact-geometry form of "every reflection
+    // point lies inside its primitive"
+    Pyramid pyr[3][SCALE];
+    float inv_h[3][SCALE];
     long long tail = 0;  // sum_j id_j n^(k-1-j)
-    float inv_h = kInf;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            pyr[j][t] = Pyramid{};
+            inv_h[j][t] = kInf;
+        }
     if (have) {
         prim_plane(M, c, pc, nc);
-        const float h = __builtin_fabsf(dot(I - pc, nc));
-        inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+        for (int j = 0; j < order; ++j) {
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) pyr[t] = make_pyramid(I, M.tv + 9 * ((int64_t)c * SCALE + t));
-        for (int j = 0; j < order; ++j) tail = tail * (long long)M.nprim + (long long)e.id[j];
-    } else {
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) pyr[t] = Pyramid{};
+            for (int t = 0; t < SCALE; ++t)
+                pyr[j][t] = unfolded_pyramid(M, I, e.id[j], t, &e.id[j + 1], order - 1 - j, inv_h[j][t]);
+            tail = tail * (long long)M.nprim + (long long)e.id[j];
+        }
     }
     long long npow = 1;
     for (int j = 0; j < order; ++j) npow *= (long long)M.nprim;
@@ -281,16 +332,24 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
         const float d = dot(r - pc, nc);
         const int side_r = (d == d) ? side_of_range(d, d, 4.0f * E) : 0;
         const V3 w = r - I;
-        const float thr = -(E + E * (__builtin_sqrtf(dot(w, w)) * inv_h));
-        bool inside_any = false;
+        const float wl = __builtin_sqrtf(dot(w, w));
+        bool inside_all = true;
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            bool inside = true;
+        for (int j = 0; j < 3; ++j) {
+            if (j < order) {
+                bool inside_any = false;
 #pragma unroll
-            for (int f = 0; f < 3; ++f) inside = inside && !(dot(w, pyr[t].n[f]) < thr);
-            inside_any = inside_any || inside;
+                for (int t = 0; t < SCALE; ++t) {
+                    const float thr = -(E + E * (wl * inv_h[j][t]));
+                    bool inside = true;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) inside = inside && !(dot(w, pyr[j][t].n[f]) < thr);
+                    inside_any = inside_any || inside;
+                }
+                inside_all = inside_all && inside_any;
+            }
         }
-        const bool keep = have && inside_any && !(e.side_prev * side_r == -1);
+        const bool keep = have && inside_all && !(e.side_prev * side_r == -1);
         const unsigned long long vote = __ballot(keep);
         if (vote) {
             unsigned long long b0 = 0;

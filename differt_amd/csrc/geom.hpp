@@ -80,20 +80,40 @@ __device__ __forceinline__ TriE load_tri(const float *tv) {
 }
 
 // _utils.py:1273-1322, hard mode.  Returns hit; t always written (also for misses).
+// Fast path when every determinant of the WAVE lies in [2^-126, 2^126] (no zero / denormal / huge /
+// non-finite value): reciprocal = v_rcp + one Newton step (exhaustively verified), no `a == 0`
+// handling, `u <= 1` dropped (implied by v >= 0 && u + v <= 1: rounding is monotone), `u >= 0 && v >= 0`
+// as min(u, v) >= 0 (a NaN in u or v makes u + v NaN, which fails u + v <= 1).  Otherwise the
+// reference formula literally.  Same arithmetic, same bits either way (see moller_trumbore_x4).
 __device__ __forceinline__ bool moller_trumbore(V3 o, V3 d, const TriE &tr, float eps, float &t_out) {
-    V3 h = cross(d, tr.e2);
+    const V3 h = cross(d, tr.e2);
     const float a0 = dot(h, tr.e1);
-    const bool zero = (a0 == 0.0f);                       // a = where(a == 0, inf, a)
-    bool hit = (zero ? kInf : __builtin_fabsf(a0)) > eps;  // |a| > eps
-    const float f = mt_reciprocal(a0, zero);               // f = 1 / a
-    V3 s = o - tr.v0;
-    float u = f * dot(s, h);
+    const V3 s = o - tr.v0;
+    const float pu = dot(s, h);
+    const V3 q = cross(s, tr.e1);
+    const float pv = dot(q, d);
+    const float pt = dot(q, tr.e2);
+    const float aa = __builtin_fabsf(a0);
+    if (__builtin_expect(__all((aa >= 0x1p-126f) & (aa <= 0x1p+126f)), 1)) {
+        const float r = __builtin_amdgcn_rcpf(a0);
+        const float e = __builtin_fmaf(-a0, r, 1.0f);
+        const float f = __builtin_fmaf(e, r, r);
+        const float u = f * pu;
+        const float v = f * pv;
+        const float upv = u + v;
+        const float t = f * pt;
+        t_out = t;
+        return (aa > eps) & (__builtin_fminf(u, v) >= 0.0f) & (upv <= 1.0f) & (t > eps);
+    }
+    const bool zero = (a0 == 0.0f);                        // a = where(a == 0, inf, a)
+    bool hit = (zero ? kInf : aa) > eps;                   // |a| > eps
+    const float f = 1.0f / (zero ? kInf : a0);             // f = 1 / a
+    const float u = f * pu;
     hit = hit && (u >= 0.0f) && (u <= 1.0f);
-    V3 q = cross(s, tr.e1);
-    float v = f * dot(q, d);
-    float upv = u + v;
+    const float v = f * pv;
+    const float upv = u + v;
     hit = hit && (v >= 0.0f) && (upv <= 1.0f);
-    float t = f * dot(q, tr.e2);
+    const float t = f * pt;
     hit = hit && (t > eps);
     t_out = t;
     return hit;

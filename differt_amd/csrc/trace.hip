@@ -104,8 +104,11 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                         const V3 v = m.p[j] - cur;
                         const float un = dot(dir, m.n[j]);
                         const float vn = dot(v, m.n[j]);
-                        const bool trouble = (un == 0.0f) || !(is_finite(cur.x) && is_finite(cur.y) &&
-                                                               is_finite(cur.z));
+                        // |x| + |y| + |z| < inf: one compare instead of three; an overflowing sum of
+                        // finite components only sends the wave to the guarded form (same bits)
+                        const bool trouble = (un == 0.0f) ||
+                                             !(((__builtin_fabsf(cur.x) + __builtin_fabsf(cur.y)) +
+                                                __builtin_fabsf(cur.z)) < kInf);
                         if (__builtin_expect(__any(trouble), 0)) {
                             cur = backward_step(cur, img[j], m.p[j], m.n[j]);
                         } else {

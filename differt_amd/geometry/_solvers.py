@@ -417,8 +417,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
         return self._trace_compact(scene, desc, max_survivors, max_paths)
 
     # ---- conservative ("beam") pruning: the lossless counterpart of the hybrid tracer's sampling ----
-    def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.125, kappa: float = 16.0,
-                          chunk_entries: int = 1 << 21, max_entries: int = 1 << 26, max_rows: int = 1 << 27,
+    def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.25, kappa: float = 8.0,
+                          chunk_entries: int = 1 << 12, max_entries: int = 1 << 26, max_rows: int = 1 << 27,
                           max_survivors: int = 1 << 22, max_paths: int = 1 << 16) -> TracedPaths:
         """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
         enumeration _solvers.py:803-848 and the SAMPLED pruning of the hybrid tracer :1013-1056).
@@ -470,24 +470,25 @@ class ExhaustivePathTracer(AbstractPathTracer):
         cur, ncur = lvl, int(count.item())
         stats["levels"].append(ncur)
 
-        def expand(src, nsrc, level, cap):
-            """level -> level + 1; returns (buffer, count) or None when `cap` was too small."""
-            out = entries(cap)
+        def expand(src, nsrc, level, out, cap):
+            """level -> level + 1 into `out`; returns the count, or None when `cap` was too small."""
             count.zero_()
             _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, ptr(out), cap, ptr(count), stream())
             c = int(count.item())
-            return (out, c) if c <= cap else None
+            return c if c <= cap else None
 
         # all but the last expansion are done in one piece (they are small: |L1| = ntx * n)
         for level in range(1, order - 1):
             cap = min(max_entries, max(ncur * 64, 1 << 16))
-            res = expand(cur, ncur, level, cap)
-            while res is None:
+            while True:
+                out = entries(cap)
+                c = expand(cur, ncur, level, out, cap)
+                if c is not None:
+                    break
                 cap *= 4
                 if cap > 16 * max_entries:
                     raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam prefix list does not fit: raise max_entries")
-                res = expand(cur, ncur, level, cap)
-            cur, ncur = res
+            cur, ncur = out, c
             stats["levels"].append(ncur)
 
         npow = n ** order
@@ -526,21 +527,25 @@ class ExhaustivePathTracer(AbstractPathTracer):
             if not process(cur, ncur):
                 raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam rows do not fit: raise max_rows")
         else:
-            i0, step = 0, max(int(chunk_entries), 1)
+            # last expansion in slices sized from the measured fan-out (a small probe slice first), so that the
+            # level-`order` list of a slice and its rows fit their buffers; a slice that overflows is split
+            out = entries(max_entries)
+            i0, step = 0, max(min(int(chunk_entries), ncur), 1)
+            stats["levels"].append(0)
             while i0 < ncur:
                 i1 = min(i0 + step, ncur)
-                src = cur[i0:i1]
-                res = expand(src, i1 - i0, order - 1, max_entries)
-                ok = res is not None and process(res[0], res[1])
+                c = expand(cur[i0:i1], i1 - i0, order - 1, out, max_entries)
+                rows_before = stats["rows"]
+                ok = c is not None and process(out, c)
                 if not ok:
                     if step == 1:
                         raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "one prefix overflows max_entries / max_rows")
                     step = max(step // 4, 1)
                     continue
-                if len(stats["levels"]) < order:
-                    stats["levels"].append(0)
-                stats["levels"][-1] += res[1]
+                stats["levels"][-1] += c
                 stats["chunks"] += 1
+                fan = max(c / (i1 - i0), (stats["rows"] - rows_before) / (i1 - i0) * (max_entries / max_rows), 1e-9)
+                step = int(min(max(0.5 * max_entries / fan, 1), 4 * step if stats["chunks"] > 1 else 1 << 40, ncur))
                 i0 = i1
         self.last_beam_stats = stats
         if not parts:
