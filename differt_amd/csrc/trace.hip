@@ -587,7 +587,7 @@ static void launch_filter(const Launch &L, unsigned long long *qc, long long *q,
                 return;
             }
         }
-        if constexpr (!DENSE && K >= 2) {
+        if constexpr (!DENSE && K >= 1) {  // K == 1 only occurs with a per-pair TABLE (beam-pruned rows)
             int64_t bx = ceil_div(L.cs.count, 256);
             if (bx > 256 * 32) bx = 256 * 32;
             hipLaunchKernelGGL((trace_filter_ragged_kernel<K, QUADS>), dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0,
