@@ -27,8 +27,10 @@
 //
 // Pipeline (device lists, wave-ballot compaction, no host enumeration):
 //   beam_seed    level-1 prefixes (tx, m_1) for all active primitives
-//   beam_expand  level-j -> level-(j+1) prefixes, tests (S) and (B) against every primitive
-//   beam_emit    level-k prefixes x receivers -> packed rows  ((tx nrx + rx) n^k + sum_j m_j n^(k-j))
+//   beam_expand  level-j prefixes x primitives, tests (S) and (B) -> 8-byte (prefix, primitive) records
+//   beam_finish  records -> level-(j+1) prefixes (intermediate levels only)
+//   beam_emit    level-k prefixes (or level-(k-1) prefixes + records) x receivers -> packed rows
+//                ((tx nrx + rx) n^k + sum_j m_j n^(k-1-j))
 #include "common.hpp"
 #include "geom.hpp"
 #include "mesh.hpp"
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
 // lane = prefix; the block walks all primitives through LDS tiles
 template <int SCALE>
 __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
-                                                          int level, float E, BeamEntry *__restrict__ out,
+                                                          int level, float E, unsigned long long *__restrict__ out,
                                                           int64_t cap, unsigned long long *__restrict__ count) {
     __shared__ float lds_v[kBeamTile][3 * SCALE][3];
     __shared__ uint8_t lds_act[kBeamTile];
@@ -240,7 +242,8 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
                 dmin = fminf(dmin, d);
                 dmax = fmaxf(dmax, d);
                 const V3 w = x - I;
-                const float wl = __builtin_sqrtf(dot(w, w));
+                // |w|_1 >= |w|_2: a slightly larger margin (conservative), no square root in the loop
+                const float wl = (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z);
                 const float thr = -(E + E * (wl * inv_h));  // -inf / NaN: never separates
 #pragma unroll
                 for (int t = 0; t < SCALE; ++t) {
@@ -263,6 +266,9 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             separated = separated || separated0;  // outside the cone of the last mirror OR of the unfolded first one
             const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
             const bool keep = have && (c != m) && !separated && !(e.side_prev * side_c == -1);
+            // survivors leave as 8-byte (source prefix, primitive) records: ONE ballot + ONE atomic per
+            // wave and a plain store -- building the child prefix here (plane gather, image, side of the
+            // parent mirror: dependent global loads under divergence) measured 10x the whole test loop
             const unsigned long long vote = __ballot(keep);
             if (vote) {
                 unsigned long long b0 = 0;
@@ -271,27 +277,41 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
                 b0 = __shfl(b0, leader, 64);
                 if (keep) {
                     const unsigned long long slot = b0 + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
-                    if ((int64_t)slot < cap) {
-                        V3 pc, nc;
-                        prim_plane(M, c, pc, nc);
-                        const V3 I2 = image_of_vertex(I, pc, nc);
-                        BeamEntry o = e;
-                        o.id[level] = c;
-                        o.apex[0] = I2.x;
-                        o.apex[1] = I2.y;
-                        o.apex[2] = I2.z;
-                        o.side_prev = side_of_prim(M, m, pc, nc, 4.0f * E);
-                        out[slot] = o;
-                    }
+                    if ((int64_t)slot < cap) out[slot] = ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c;
                 }
             }
         }
     }
 }
 
+// (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the
+// parent mirror w.r.t. the new mirror's plane
+__device__ __forceinline__ BeamEntry beam_child(const BeamMesh &M, const BeamEntry &e, int level, int32_t c, float E) {
+    V3 pc, nc;
+    prim_plane(M, c, pc, nc);
+    const V3 I2 = image_of_vertex(V3{e.apex[0], e.apex[1], e.apex[2]}, pc, nc);
+    BeamEntry o = e;
+    o.id[level] = c;
+    o.apex[0] = I2.x;
+    o.apex[1] = I2.y;
+    o.apex[2] = I2.z;
+    o.side_prev = side_of_prim(M, e.id[level - 1], pc, nc, 4.0f * E);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void beam_finish_kernel(BeamMesh M, const BeamEntry *__restrict__ src,
+                                                          const unsigned long long *__restrict__ rec, int64_t n,
+                                                          int level, float E, BeamEntry *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long r = rec[i];
+    out[i] = beam_child(M, src[r >> 32], level, (int32_t)(uint32_t)r, E);
+}
+
 // lane = level-k prefix, loop over the receivers
 template <int SCALE>
-__global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
+__global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in,
+                                                        const unsigned long long *__restrict__ rec, int64_t n_in,
                                                         int order, const float *__restrict__ rx, int64_t nrx, float E,
                                                         long long *__restrict__ rows, int64_t cap,
                                                         unsigned long long *__restrict__ count) {
@@ -299,7 +319,14 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
-    if (have) e = in[g];
+    if (have) {
+        if (rec) {  // (level order-1 prefix, last primitive) record: build the level-`order` prefix here
+            const unsigned long long r = rec[g];
+            e = beam_child(M, in[r >> 32], order - 1, (int32_t)(uint32_t)r, E);
+        } else {
+            e = in[g];
+        }
+    }
     const int32_t c = have ? e.id[order - 1] : 0;
     const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
     V3 pc{0, 0, 0}, nc{0, 0, 1};
@@ -396,7 +423,7 @@ int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t ntx, float margi
 }
 
 int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t level, float margin,
-                        drt_beam_entry *out, int64_t capacity, int64_t *count_dev, void *stream) {
+                        uint64_t *out, int64_t capacity, int64_t *count_dev, void *stream) {
     DRT_REQUIRE(mesh && count_dev, "null argument");
     DRT_REQUIRE(n_in >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
     DRT_REQUIRE(level >= 1 && level <= 2, "expansion goes from level 1 or 2 (orders up to 3)");
@@ -407,18 +434,34 @@ int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in,
     if (M.scale == 2)
         hipLaunchKernelGGL(beam_expand_kernel<2>, grid, dim3(256), 0, as_stream(stream), M,
                            reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                           reinterpret_cast<BeamEntry *>(out), capacity, reinterpret_cast<unsigned long long *>(count_dev));
+                           reinterpret_cast<unsigned long long *>(out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev));
     else
         hipLaunchKernelGGL(beam_expand_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
                            reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                           reinterpret_cast<BeamEntry *>(out), capacity, reinterpret_cast<unsigned long long *>(count_dev));
+                           reinterpret_cast<unsigned long long *>(out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev));
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }
 
-int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t order, const float *rx,
-                      int64_t nrx, int64_t ntx, float margin, int64_t *rows_out, int64_t capacity, int64_t *count_dev,
-                      void *stream) {
+int32_t drt_beam_finish(drt_mesh_t mesh, const drt_beam_entry *src, const uint64_t *records, int64_t n,
+                        int32_t level, float margin, drt_beam_entry *out, void *stream) {
+    DRT_REQUIRE(mesh, "null argument");
+    DRT_REQUIRE(n >= 0 && level >= 1 && level <= 2 && margin >= 0.0f, "bad argument");
+    if (n == 0) return DRT_OK;
+    DRT_REQUIRE(src && records && out, "null pointer");
+    hipLaunchKernelGGL(beam_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream),
+                       beam_mesh(mesh), reinterpret_cast<const BeamEntry *>(src),
+                       reinterpret_cast<const unsigned long long *>(records), n, (int)level, margin,
+                       reinterpret_cast<BeamEntry *>(out));
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t n_in,
+                      int32_t order, const float *rx, int64_t nrx, int64_t ntx, float margin, int64_t *rows_out,
+                      int64_t capacity, int64_t *count_dev, void *stream) {
     DRT_REQUIRE(mesh && count_dev, "null argument");
     DRT_REQUIRE(n_in >= 0 && nrx >= 0 && ntx >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
     DRT_REQUIRE(order >= 1 && order <= 3, "beam pruning covers orders 1..3");
@@ -429,15 +472,17 @@ int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, i
     DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx * rx * primitives^order does not fit a 62-bit row key");
     if (n_in == 0 || nrx == 0) return DRT_OK;
     DRT_REQUIRE(in && rx && (rows_out || capacity == 0), "null pointer");
+    DRT_REQUIRE(!records || order >= 2, "records address level order-1 prefixes: order >= 2");
     const dim3 grid((unsigned)ceil_div(n_in, 256));
+    const auto *rec = reinterpret_cast<const unsigned long long *>(records);
     if (M.scale == 2)
         hipLaunchKernelGGL(beam_emit_kernel<2>, grid, dim3(256), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)order, rx, nrx, margin,
+                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx, nrx, margin,
                            reinterpret_cast<long long *>(rows_out), capacity,
                            reinterpret_cast<unsigned long long *>(count_dev));
     else
         hipLaunchKernelGGL(beam_emit_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)order, rx, nrx, margin,
+                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx, nrx, margin,
                            reinterpret_cast<long long *>(rows_out), capacity,
                            reinterpret_cast<unsigned long long *>(count_dev));
     DRT_LAUNCH_CHECK();

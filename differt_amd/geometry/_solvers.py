@@ -418,7 +418,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
 
     # ---- conservative ("beam") pruning: the lossless counterpart of the hybrid tracer's sampling ----
     def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.25, kappa: float = 8.0,
-                          chunk_entries: int = 1 << 12, max_entries: int = 1 << 26, max_rows: int = 1 << 27,
+                          chunk_entries: int = 1 << 12, max_entries: int = 1 << 28, max_rows: int = 1 << 27,
                           max_survivors: int = 1 << 22, max_paths: int = 1 << 16) -> TracedPaths:
         """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
         enumeration _solvers.py:803-848 and the SAMPLED pruning of the hybrid tracer :1013-1056).
@@ -471,35 +471,41 @@ class ExhaustivePathTracer(AbstractPathTracer):
         stats["levels"].append(ncur)
 
         def expand(src, nsrc, level, out, cap):
-            """level -> level + 1 into `out`; returns the count, or None when `cap` was too small."""
+            """level-`level` prefixes x primitives -> 8-byte (prefix, primitive) records in `out`; returns the
+            count, or None when `cap` was too small."""
             count.zero_()
             _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, ptr(out), cap, ptr(count), stream())
             c = int(count.item())
             return c if c <= cap else None
 
+        def records(cap):
+            return torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+
         # all but the last expansion are done in one piece (they are small: |L1| = ntx * n)
         for level in range(1, order - 1):
             cap = min(max_entries, max(ncur * 64, 1 << 16))
             while True:
-                out = entries(cap)
-                c = expand(cur, ncur, level, out, cap)
+                rec = records(cap)
+                c = expand(cur, ncur, level, rec, cap)
                 if c is not None:
                     break
                 cap *= 4
                 if cap > 16 * max_entries:
                     raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam prefix list does not fit: raise max_entries")
-            cur, ncur = out, c
+            nxt = entries(c)
+            _lib.call("drt_beam_finish", h, ptr(cur), ptr(rec), c, level, margin, ptr(nxt), stream())
+            cur, ncur = nxt, c
             stats["levels"].append(ncur)
 
         npow = n ** order
         parts = []
         rows_buf = torch.empty(max_rows, dtype=torch.int64, device=dev)
 
-        def process(src, nsrc):
-            """level-`order` prefixes -> rows -> trace; returns False when `max_rows` was too small."""
+        def process(src, rec, nsrc):
+            """prefixes (+ records of the last expansion) -> rows -> trace; False when `max_rows` was too small."""
             count.zero_()
-            _lib.call("drt_beam_emit", h, ptr(src), nsrc, order, ptr(rxd), nrx, ntx, margin, ptr(rows_buf), max_rows,
-                      ptr(count), stream())
+            _lib.call("drt_beam_emit", h, ptr(src), ptr(rec), nsrc, order, ptr(rxd), nrx, ntx, margin, ptr(rows_buf),
+                      max_rows, ptr(count), stream())
             r = int(count.item())
             if r > max_rows:
                 return False
@@ -524,19 +530,19 @@ class ExhaustivePathTracer(AbstractPathTracer):
             return True
 
         if order == 1:
-            if not process(cur, ncur):
+            if not process(cur, None, ncur):
                 raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam rows do not fit: raise max_rows")
         else:
             # last expansion in slices sized from the measured fan-out (a small probe slice first), so that the
             # level-`order` list of a slice and its rows fit their buffers; a slice that overflows is split
-            out = entries(max_entries)
+            out = records(max_entries)
             i0, step = 0, max(min(int(chunk_entries), ncur), 1)
             stats["levels"].append(0)
             while i0 < ncur:
                 i1 = min(i0 + step, ncur)
                 c = expand(cur[i0:i1], i1 - i0, order - 1, out, max_entries)
                 rows_before = stats["rows"]
-                ok = c is not None and process(out, c)
+                ok = c is not None and process(cur[i0:i1], out, c)
                 if not ok:
                     if step == 1:
                         raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "one prefix overflows max_entries / max_rows")

@@ -451,9 +451,13 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
  * mirror, or on the wrong side of the mirror plane for the reference's same-side check,
  * _solver_image_method.py:443-454); see csrc/beam.hip and DESIGN.md section 9.  Orders 1..3.
  *   drt_beam_seed    level-1 prefixes (tx, m1) of all active primitives        -> out[0 .. *count)
- *   drt_beam_expand  level -> level + 1 prefixes (level = ids already present)  -> out[0 .. *count)
- *   drt_beam_emit    level-`order` prefixes x receivers -> packed candidate rows
- *                    ((tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j)), n = primitives
+ *   drt_beam_expand  level-`level` prefixes x primitives -> surviving (prefix index << 32 | primitive)
+ *                    records, 8 bytes each                                      -> out[0 .. *count)
+ *   drt_beam_finish  records -> level + 1 prefixes (needed between two expansions)
+ *   drt_beam_emit    prefixes x receivers -> packed candidate rows
+ *                    ((tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j)), n = primitives;
+ *                    records == NULL: `in` holds level-`order` prefixes (order 1: straight from the
+ *                    seed); else `in` holds level-(order-1) prefixes and `records` the last expansion
  * count_dev (device int64, zeroed by the caller) receives the number of records produced; records
  * beyond `capacity` are dropped, so count > capacity means "re-run with more room".  Rows, once
  * sorted, feed drt_trace_paths_compact as a per-pair table (drt_candidates.table + pair_offsets).
@@ -467,10 +471,12 @@ typedef struct drt_beam_entry {
 int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t num_tx, float margin, drt_beam_entry *out,
                       int64_t capacity, int64_t *count_dev, void *stream);
 int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t level, float margin,
-                        drt_beam_entry *out, int64_t capacity, int64_t *count_dev, void *stream);
-int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t order, const float *rx,
-                      int64_t num_rx, int64_t num_tx, float margin, int64_t *rows_out, int64_t capacity,
-                      int64_t *count_dev, void *stream);
+                        uint64_t *records_out, int64_t capacity, int64_t *count_dev, void *stream);
+int32_t drt_beam_finish(drt_mesh_t mesh, const drt_beam_entry *src, const uint64_t *records, int64_t num_records,
+                        int32_t level, float margin, drt_beam_entry *out, void *stream);
+int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t num_in,
+                      int32_t order, const float *rx, int64_t num_rx, int64_t num_tx, float margin,
+                      int64_t *rows_out, int64_t capacity, int64_t *count_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (f4) smoothed ("soft mask") mode -- reference: differt/src/differt/utils.py:70-89
