@@ -170,6 +170,21 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
     }
 }
 
+constexpr int kBeamWaveBuf = 192;  // records staged per wave before one flush (>= 128: a flush moves 64+)
+
+// wave-private LDS staging buffer -> output list: ONE global atomic for `n` records
+__device__ __forceinline__ void beam_flush(const unsigned long long *buf, int n, int lane,
+                                           unsigned long long *__restrict__ out, int64_t cap,
+                                           unsigned long long *__restrict__ count) {
+    unsigned long long b0 = 0;
+    if (lane == 0) b0 = atomicAdd(count, (unsigned long long)n);
+    b0 = __shfl(b0, 0, 64);
+    for (int i = lane; i < n; i += 64) {
+        const unsigned long long slot = b0 + (unsigned long long)i;
+        if ((int64_t)slot < cap) out[slot] = buf[i];
+    }
+}
+
 // lane = prefix; the block walks all primitives through LDS tiles
 template <int SCALE>
 __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
@@ -206,6 +221,9 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             for (int t = 0; t < SCALE; ++t) pyr0[t] = unfolded_pyramid(M, I, e.id[0], t, &e.id[1], 1, inv_h0[t]);
         }
     }
+    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int wcount = 0;  // wave-uniform: records waiting in wbuf[wave]
     for (int64_t base = 0; base < M.nprim; base += kBeamTile) {
         __syncthreads();
         for (int i = threadIdx.x; i < kBeamTile * 3 * SCALE; i += 256) {
@@ -266,22 +284,26 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             separated = separated || separated0;  // outside the cone of the last mirror OR of the unfolded first one
             const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
             const bool keep = have && (c != m) && !separated && !(e.side_prev * side_c == -1);
-            // survivors leave as 8-byte (source prefix, primitive) records: ONE ballot + ONE atomic per
-            // wave and a plain store -- building the child prefix here (plane gather, image, side of the
-            // parent mirror: dependent global loads under divergence) measured 10x the whole test loop
+            // survivors leave as 8-byte (source prefix, primitive) records, staged per wave in LDS and
+            // flushed 64+ at a time: one global atomic per FLUSH.  One atomic per iteration meant 7e9
+            // atomics on ONE address for configs[3] (40 s: the L2 atomic unit, not the arithmetic, set
+            // the pace); building the child prefix here (dependent global loads under divergence) was
+            // worse still.
             const unsigned long long vote = __ballot(keep);
             if (vote) {
-                unsigned long long b0 = 0;
-                const int leader = __builtin_ctzll(vote);
-                if (lane == leader) b0 = atomicAdd(count, (unsigned long long)__popcll(vote));
-                b0 = __shfl(b0, leader, 64);
                 if (keep) {
-                    const unsigned long long slot = b0 + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
-                    if ((int64_t)slot < cap) out[slot] = ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c;
+                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
+                    wbuf[wave][slot] = ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c;
+                }
+                wcount += __popcll(vote);
+                if (wcount > kBeamWaveBuf - 64) {  // room for one more full ballot is gone: flush
+                    beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+                    wcount = 0;
                 }
             }
         }
     }
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
 }
 
 // (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the
