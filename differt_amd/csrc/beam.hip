@@ -31,6 +31,7 @@
 //   beam_finish  records -> level-(j+1) prefixes (intermediate levels only)
 //   beam_emit    level-k prefixes (or level-(k-1) prefixes + records) x receivers -> packed rows
 //                ((tx nrx + rx) n^k + sum_j m_j n^(k-1-j))
+#include "bvh.hpp"
 #include "common.hpp"
 #include "geom.hpp"
 #include "mesh.hpp"
@@ -189,7 +190,8 @@ __device__ __forceinline__ void beam_flush(const unsigned long long *buf, int n,
 template <int SCALE>
 __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
                                                           int level, float E, unsigned long long *__restrict__ out,
-                                                          int64_t cap, unsigned long long *__restrict__ count) {
+                                                          int64_t cap, unsigned long long *__restrict__ count,
+                                                          int64_t prims_per_split) {
     __shared__ float lds_v[kBeamTile][3 * SCALE][3];
     __shared__ uint8_t lds_act[kBeamTile];
     const int lane = threadIdx.x & 63;
@@ -224,23 +226,27 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
     __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int wcount = 0;  // wave-uniform: records waiting in wbuf[wave]
-    for (int64_t base = 0; base < M.nprim; base += kBeamTile) {
+    // few prefixes x many primitives (configs[4]: 2e5 x 2e5) would leave most CUs idle with one block per
+    // 256 prefixes: blockIdx.y splits the primitive range so that the launch holds >= ~2048 blocks
+    const int64_t prim_begin = (int64_t)blockIdx.y * prims_per_split;
+    const int64_t prim_end = (prim_begin + prims_per_split < M.nprim) ? prim_begin + prims_per_split : M.nprim;
+    for (int64_t base = prim_begin; base < prim_end; base += kBeamTile) {
         __syncthreads();
         for (int i = threadIdx.x; i < kBeamTile * 3 * SCALE; i += 256) {
             const int64_t p = base + i / (3 * SCALE);
             const int vtx = i % (3 * SCALE);
             V3 v{0, 0, 0};
-            if (p < M.nprim) v = ld3(M.tv + 9 * p * SCALE + 3 * vtx);
+            if (p < prim_end) v = ld3(M.tv + 9 * p * SCALE + 3 * vtx);
             lds_v[i / (3 * SCALE)][vtx][0] = v.x;
             lds_v[i / (3 * SCALE)][vtx][1] = v.y;
             lds_v[i / (3 * SCALE)][vtx][2] = v.z;
         }
         if (threadIdx.x < kBeamTile) {
             const int64_t p = base + threadIdx.x;
-            lds_act[threadIdx.x] = (uint8_t)(p < M.nprim && prim_active(M, p));
+            lds_act[threadIdx.x] = (uint8_t)(p < prim_end && prim_active(M, p));
         }
         __syncthreads();
-        const int nt = (int)((M.nprim - base < kBeamTile) ? M.nprim - base : kBeamTile);
+        const int nt = (int)((prim_end - base < kBeamTile) ? prim_end - base : kBeamTile);
         for (int j = 0; j < nt; ++j) {
             if (!lds_act[j]) continue;  // wave-uniform
             const int32_t c = (int32_t)(base + j);
@@ -300,6 +306,206 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
                     beam_flush(wbuf[wave], wcount, lane, out, cap, count);
                     wcount = 0;
                 }
+            }
+        }
+    }
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same expansion as a walk over the mesh LBVH (csrc/bvh.hip): lane = prefix, a subtree is skipped
+// when its (padded) box fails the SAME tests as a primitive would -- every point of the box outside one
+// face plane of every pyramid of a cone, or the box strictly on the wrong side of the mirror plane.
+// The box versions use the box's support along the plane normal and the largest margin inside the box,
+// so "box pruned" implies "every primitive inside pruned": the survivors are exactly those of the
+// brute-force kernel, found in O(survivors x depth) instead of O(primitives) per prefix.
+// With quads a primitive can be reached through either of its triangles: the second triangle emits only
+// if the first one's own box is pruned (duplicates left by the padding of stored boxes are removed when
+// the rows are sorted).
+// ---------------------------------------------------------------------------------------------
+template <int SCALE>
+struct BeamCtx {
+    V3 I, pm, nm;
+    float inv_h, inv_h0[SCALE], E;
+    Pyramid pyr[SCALE], pyr0[SCALE];
+    int side_prev;
+
+    __device__ __forceinline__ bool cone_outside_box(const Pyramid (&P)[SCALE], const float (&ih)[SCALE], V3 w, V3 e,
+                                                     float wl) const {
+        bool sep = true;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            const float thr = -(E + E * (wl * ih[t]));
+            bool st = false;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const V3 n = P[t].n[f];
+                const float smax = dot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
+                                                __builtin_fabsf(n.z) * e.z);
+                st = st || (smax < thr);
+            }
+            sep = sep && st;
+        }
+        return sep;
+    }
+
+    // true: no primitive inside [lo, hi] can survive
+    __device__ __forceinline__ bool box_pruned(const float *lo, const float *hi) const {
+        const V3 c = V3{0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+        const V3 e = V3{0.5f * (hi[0] - lo[0]), 0.5f * (hi[1] - lo[1]), 0.5f * (hi[2] - lo[2])};
+        if (!(e.x >= 0.0f) || !(e.y >= 0.0f) || !(e.z >= 0.0f)) return false;  // NaN / empty box: keep
+        if (side_prev != 0) {
+            const float dc = dot(c - pm, nm);
+            const float r = (__builtin_fabsf(nm.x) * e.x + __builtin_fabsf(nm.y) * e.y) + __builtin_fabsf(nm.z) * e.z;
+            const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, 4.0f * E) : 0;
+            if (side_prev * sb == -1) return true;
+        }
+        const V3 w = c - I;
+        // largest |x - I|_1 inside the box -> the largest (most demanding) margin
+        const float wl = ((__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z)) + ((e.x + e.y) + e.z);
+        float ih[SCALE];
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) ih[t] = inv_h;
+        return cone_outside_box(pyr, ih, w, e, wl) || cone_outside_box(pyr0, inv_h0, w, e, wl);
+    }
+
+    // the per-vertex test of the brute-force kernel for primitive c
+    __device__ __forceinline__ bool prim_survives(const BeamMesh &M, int64_t c) const {
+        const float *v = M.tv + 9 * c * SCALE;
+        float dmin = kInf, dmax = -kInf;
+        bool out_face[SCALE][3], out_face0[SCALE][3];
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) out_face[t][f] = out_face0[t][f] = true;
+        bool nan = false;
+#pragma unroll
+        for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
+            const V3 x = ld3(v + 3 * vtx);
+            const float d = dot(x - pm, nm);
+            nan = nan || !(d == d);
+            dmin = fminf(dmin, d);
+            dmax = fmaxf(dmax, d);
+            const V3 w = x - I;
+            const float wl = (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z);
+            const float thr = -(E + E * (wl * inv_h));
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) {
+                const float thr0 = -(E + E * (wl * inv_h0[t]));
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    out_face[t][f] = out_face[t][f] && (dot(w, pyr[t].n[f]) < thr);
+                    out_face0[t][f] = out_face0[t][f] && (dot(w, pyr0[t].n[f]) < thr0);
+                }
+            }
+        }
+        bool separated = true, separated0 = true;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
+            separated0 = separated0 && (out_face0[t][0] || out_face0[t][1] || out_face0[t][2]);
+        }
+        const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
+        return !(separated || separated0) && !(side_prev * side_c == -1);
+    }
+};
+
+template <int SCALE>
+__global__ __launch_bounds__(256) void beam_expand_bvh_kernel(BeamMesh M, const BvhNode *__restrict__ nodes, int64_t T,
+                                                              const BeamEntry *__restrict__ in, int64_t n_in, int level,
+                                                              float E, unsigned long long *__restrict__ out,
+                                                              int64_t cap, unsigned long long *__restrict__ count) {
+    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = g < n_in;
+    BeamEntry e{};
+    if (have) e = in[g];
+    const int32_t m = have ? e.id[level - 1] : 0;
+    BeamCtx<SCALE> ctx;
+    ctx.E = E;
+    ctx.I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    ctx.pm = V3{0, 0, 0};
+    ctx.nm = V3{0, 0, 1};
+    ctx.inv_h = kInf;
+    ctx.side_prev = e.side_prev;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        ctx.pyr[t] = Pyramid{};
+        ctx.pyr0[t] = Pyramid{};
+        ctx.inv_h0[t] = kInf;
+    }
+    if (have) {
+        prim_plane(M, m, ctx.pm, ctx.nm);
+        const float h = __builtin_fabsf(dot(ctx.I - ctx.pm, ctx.nm));
+        ctx.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) ctx.pyr[t] = make_pyramid(ctx.I, M.tv + 9 * ((int64_t)m * SCALE + t));
+        if (level == 2) {
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) ctx.pyr0[t] = unfolded_pyramid(M, ctx.I, e.id[0], t, &e.id[1], 1, ctx.inv_h0[t]);
+        }
+    }
+    int32_t stack[kBvhStack];
+    int sp = 0;
+    int32_t node = (T == 1) ? ~0 : 0;
+    bool active = have;
+    int wcount = 0;
+    // wave-synchronous walk: every active lane handles ONE node per trip, survivors of the trip are
+    // appended with one ballot
+    while (__any(active)) {
+        bool keep = false;
+        int32_t kc = 0;
+        if (active) {
+            if (node < 0) {  // leaf = triangle ~node of primitive c
+                const int32_t tri = ~node;
+                const int32_t c = tri / SCALE;
+                bool first = true;
+                if (SCALE == 2 && (tri & 1)) {
+                    // the quad's first triangle gets there too unless its own box is pruned
+                    const float *v = M.tv + 9 * (int64_t)(tri - 1);
+                    float lo[3], hi[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
+                        hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+                    }
+                    first = ctx.box_pruned(lo, hi);
+                }
+                if (first && c != m && prim_active(M, c) && ctx.prim_survives(M, c)) {
+                    keep = true;
+                    kc = c;
+                }
+                if (sp == 0) active = false; else node = stack[--sp];
+            } else {
+                const BvhNode nd = nodes[node];
+                const bool gl = !ctx.box_pruned(nd.llo, nd.lhi);
+                const bool gr = !ctx.box_pruned(nd.rlo, nd.rhi);
+                if (gl && gr) {
+                    if (sp < kBvhStack) stack[sp++] = nd.right;
+                    node = nd.left;
+                } else if (gl) {
+                    node = nd.left;
+                } else if (gr) {
+                    node = nd.right;
+                } else if (sp == 0) {
+                    active = false;
+                } else {
+                    node = stack[--sp];
+                }
+            }
+        }
+        const unsigned long long vote = __ballot(keep);
+        if (vote) {
+            if (keep) {
+                const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
+                wbuf[wave][slot] = ((unsigned long long)(uint32_t)g << 32) | (uint32_t)kc;
+            }
+            wcount += __popcll(vote);
+            if (wcount > kBeamWaveBuf - 64) {
+                beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+                wcount = 0;
             }
         }
     }
@@ -445,24 +651,49 @@ int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t ntx, float margi
 }
 
 int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t level, float margin,
-                        uint64_t *out, int64_t capacity, int64_t *count_dev, void *stream) {
+                        int32_t use_bvh, uint64_t *out, int64_t capacity, int64_t *count_dev, void *stream) {
     DRT_REQUIRE(mesh && count_dev, "null argument");
     DRT_REQUIRE(n_in >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
     DRT_REQUIRE(level >= 1 && level <= 2, "expansion goes from level 1 or 2 (orders up to 3)");
     const BeamMesh M = beam_mesh(mesh);
     if (n_in == 0 || M.nprim == 0) return DRT_OK;
     DRT_REQUIRE(in && (out || capacity == 0), "null pointer");
-    const dim3 grid((unsigned)ceil_div(n_in, 256));
+    if (use_bvh) {
+        int32_t rc = drt_mesh_build_bvh(mesh, stream);
+        if (rc != DRT_OK) return rc;
+        const auto *nodes = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
+        const dim3 g1((unsigned)ceil_div(n_in, 256));
+        if (M.scale == 2)
+            hipLaunchKernelGGL(beam_expand_bvh_kernel<2>, g1, dim3(256), 0, as_stream(stream), M, nodes,
+                               mesh->num_triangles, reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                               reinterpret_cast<unsigned long long *>(out), capacity,
+                               reinterpret_cast<unsigned long long *>(count_dev));
+        else
+            hipLaunchKernelGGL(beam_expand_bvh_kernel<1>, g1, dim3(256), 0, as_stream(stream), M, nodes,
+                               mesh->num_triangles, reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                               reinterpret_cast<unsigned long long *>(out), capacity,
+                               reinterpret_cast<unsigned long long *>(count_dev));
+        DRT_LAUNCH_CHECK();
+        return DRT_OK;
+    }
+    const int64_t bx = ceil_div(n_in, 256), tiles = ceil_div(M.nprim, kBeamTile);
+    int64_t by = ceil_div(2048, bx);
+    if (by > tiles) by = tiles;
+    if (by > 65535) by = 65535;
+    if (by < 1) by = 1;
+    const int64_t pps = ceil_div(tiles, by) * kBeamTile;  // whole tiles per split
+    by = ceil_div(M.nprim, pps);
+    const dim3 grid((unsigned)bx, (unsigned)by);
     if (M.scale == 2)
         hipLaunchKernelGGL(beam_expand_kernel<2>, grid, dim3(256), 0, as_stream(stream), M,
                            reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
                            reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev));
+                           reinterpret_cast<unsigned long long *>(count_dev), pps);
     else
         hipLaunchKernelGGL(beam_expand_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
                            reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
                            reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev));
+                           reinterpret_cast<unsigned long long *>(count_dev), pps);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

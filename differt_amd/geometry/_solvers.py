@@ -418,7 +418,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
 
     # ---- conservative ("beam") pruning: the lossless counterpart of the hybrid tracer's sampling ----
     def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.25, kappa: float = 8.0,
-                          chunk_entries: int = 1 << 12, max_entries: int = 1 << 28, max_rows: int = 1 << 27,
+                          use_bvh: bool = True, chunk_entries: int = 1 << 12, max_entries: int = 1 << 28,
+                          max_rows: int = 1 << 27,
                           max_survivors: int = 1 << 22, max_paths: int = 1 << 16) -> TracedPaths:
         """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
         enumeration _solvers.py:803-848 and the SAMPLED pruning of the hybrid tracer :1013-1056).
@@ -474,7 +475,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
             """level-`level` prefixes x primitives -> 8-byte (prefix, primitive) records in `out`; returns the
             count, or None when `cap` was too small."""
             count.zero_()
-            _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, ptr(out), cap, ptr(count), stream())
+            _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, int(use_bvh), ptr(out), cap, ptr(count),
+                      stream())
             c = int(count.item())
             return c if c <= cap else None
 
@@ -512,7 +514,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
             stats["rows"] += r
             if r == 0:
                 return True
-            rows = torch.sort(rows_buf[:r]).values
+            # (with quads the LBVH walk may reach a primitive through both of its triangles: unique)
+            rows = torch.unique_consecutive(torch.sort(rows_buf[:r]).values)
             pair = torch.div(rows, npow, rounding_mode="floor")
             rest = rows - pair * npow
             cols = []

@@ -452,7 +452,9 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
  * _solver_image_method.py:443-454); see csrc/beam.hip and DESIGN.md section 9.  Orders 1..3.
  *   drt_beam_seed    level-1 prefixes (tx, m1) of all active primitives        -> out[0 .. *count)
  *   drt_beam_expand  level-`level` prefixes x primitives -> surviving (prefix index << 32 | primitive)
- *                    records, 8 bytes each                                      -> out[0 .. *count)
+ *                    records, 8 bytes each                                      -> out[0 .. *count);
+ *                    use_bvh != 0 walks the mesh LBVH with the box form of the same tests (same
+ *                    survivors; with assume_quads a record may repeat -- de-duplicate the sorted rows)
  *   drt_beam_finish  records -> level + 1 prefixes (needed between two expansions)
  *   drt_beam_emit    prefixes x receivers -> packed candidate rows
  *                    ((tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j)), n = primitives;
@@ -471,7 +473,8 @@ typedef struct drt_beam_entry {
 int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t num_tx, float margin, drt_beam_entry *out,
                       int64_t capacity, int64_t *count_dev, void *stream);
 int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t level, float margin,
-                        uint64_t *records_out, int64_t capacity, int64_t *count_dev, void *stream);
+                        int32_t use_bvh, uint64_t *records_out, int64_t capacity, int64_t *count_dev,
+                        void *stream);
 int32_t drt_beam_finish(drt_mesh_t mesh, const drt_beam_entry *src, const uint64_t *records, int64_t num_records,
                         int32_t level, float margin, drt_beam_entry *out, void *stream);
 int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t num_in,
