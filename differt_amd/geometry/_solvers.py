@@ -511,11 +511,11 @@ class ExhaustivePathTracer(AbstractPathTracer):
             r = int(count.item())
             if r > max_rows:
                 return False
-            stats["rows"] += r
             if r == 0:
                 return True
             # (with quads the LBVH walk may reach a primitive through both of its triangles: unique)
             rows = torch.unique_consecutive(torch.sort(rows_buf[:r]).values)
+            stats["rows"] += int(rows.shape[0])
             pair = torch.div(rows, npow, rounding_mode="floor")
             rest = rows - pair * npow
             cols = []
