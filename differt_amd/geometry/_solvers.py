@@ -418,7 +418,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
 
     # ---- conservative ("beam") pruning: the lossless counterpart of the hybrid tracer's sampling ----
     def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.25, kappa: float = 8.0,
-                          use_bvh: bool = True, chunk_entries: int = 1 << 12, max_entries: int = 1 << 28,
+                          use_bvh: bool = False, chunk_entries: int = 1 << 12, max_entries: int = 1 << 28,
                           max_rows: int = 1 << 27,
                           max_survivors: int = 1 << 22, max_paths: int = 1 << 16) -> TracedPaths:
         """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
