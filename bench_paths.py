@@ -157,7 +157,7 @@ def beam_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:
     order, same vertex bits as the exhaustive step."""
     import torch
 
-    tracer = G.ExhaustivePathTracer()
+    tracer = G.ExhaustivePathTracer(accel="bvh")  # occlusion of the few surviving rows on the LBVH
 
     def step():
         txg = torch.tensor(tx, device="cuda", requires_grad=True)

@@ -512,6 +512,202 @@ __global__ __launch_bounds__(256) void beam_expand_bvh_kernel(BeamMesh M, const 
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Transposed expansion: lane = PRIMITIVE (64 consecutive primitives per wave are spatially coherent in any
+// sensible mesh), prefixes are wave-uniform: a block stages the derived data of 256 prefixes in LDS (apex,
+// mirror plane, pyramids), every wave then walks them and first tests the bounding SPHERE of its 64
+// primitives against the prefix's cones and mirror plane -- one uniform decision that skips the 64
+// per-primitive tests for most (prefix, wave) pairs.  With lanes = prefixes (beam_expand_kernel) such a
+// pre-test cannot pay: 64 unrelated cones almost never agree.  Same survivors, by construction: the sphere
+// test is the box test of the LBVH variant with a ball instead of a box.
+// ---------------------------------------------------------------------------------------------
+template <int SCALE>
+struct alignas(16) BeamPrefD {  // derived data of one prefix, as staged in LDS
+    float I[3], pm[3], nm[3];
+    float inv_h;
+    int32_t side_prev, m;
+    float pyr[SCALE][9], pyr0[SCALE][9];
+    float inv_h0[SCALE];
+    float pad[(4 - ((12 + 19 * SCALE) & 3)) & 3];
+};
+
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+
+template <int SCALE>
+__global__ __launch_bounds__(256) void beam_expand_t_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
+                                                            int level, float E, unsigned long long *__restrict__ out,
+                                                            int64_t cap, unsigned long long *__restrict__ count,
+                                                            int64_t prefixes_per_split) {
+    __shared__ BeamPrefD<SCALE> pd[256];
+    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool lane_ok = c < M.nprim && prim_active(M, c);
+    V3 vx[3 * SCALE];
+#pragma unroll
+    for (int k = 0; k < 3 * SCALE; ++k) vx[k] = lane_ok ? ld3(M.tv + 9 * c * SCALE + 3 * k) : V3{0, 0, 0};
+    // bounding sphere of the wave's primitives (centre = mean vertex of the active lanes)
+    float cnt = lane_ok ? (float)(3 * SCALE) : 0.0f;
+    V3 sum{0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3 * SCALE; ++k) sum = sum + vx[k];
+    cnt = wave_sum_f(cnt);
+    const float inv_cnt = (cnt > 0.0f) ? 1.0f / cnt : 0.0f;
+    const V3 sc = V3{wave_sum_f(lane_ok ? sum.x : 0.0f) * inv_cnt, wave_sum_f(lane_ok ? sum.y : 0.0f) * inv_cnt,
+                     wave_sum_f(lane_ok ? sum.z : 0.0f) * inv_cnt};
+    float r2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3 * SCALE; ++k) {
+        const V3 dv = vx[k] - sc;
+        r2 = fmaxf(r2, lane_ok ? dot(dv, dv) : 0.0f);
+    }
+    // radius rounded up generously (sqrt + a relative pad); NaN geometry -> NaN radius -> never culls
+    const float sr = __builtin_sqrtf(wave_max_f(r2)) * 1.0001f + 1e-30f;
+    const bool wave_any = cnt > 0.0f;
+
+    const int64_t p_begin = (int64_t)blockIdx.y * prefixes_per_split;
+    const int64_t p_end = (p_begin + prefixes_per_split < n_in) ? p_begin + prefixes_per_split : n_in;
+    int wcount = 0;
+    for (int64_t base = p_begin; base < p_end; base += 256) {
+        __syncthreads();
+        {  // stage the derived data of prefix base + threadIdx.x
+            const int64_t g = base + threadIdx.x;
+            BeamPrefD<SCALE> d{};
+            d.m = -1;
+            d.inv_h = kInf;
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) d.inv_h0[t] = kInf;
+            if (g < p_end) {
+                const BeamEntry e = in[g];
+                const int32_t m = (level == 1) ? e.id[0] : e.id[1];
+                const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
+                V3 pm, nm;
+                prim_plane(M, m, pm, nm);
+                const float h = __builtin_fabsf(dot(I - pm, nm));
+                d.I[0] = I.x; d.I[1] = I.y; d.I[2] = I.z;
+                d.pm[0] = pm.x; d.pm[1] = pm.y; d.pm[2] = pm.z;
+                d.nm[0] = nm.x; d.nm[1] = nm.y; d.nm[2] = nm.z;
+                d.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+                d.side_prev = e.side_prev;
+                d.m = m;
+#pragma unroll
+                for (int t = 0; t < SCALE; ++t) {
+                    const Pyramid P = make_pyramid(I, M.tv + 9 * ((int64_t)m * SCALE + t));
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        d.pyr[t][3 * f] = P.n[f].x; d.pyr[t][3 * f + 1] = P.n[f].y; d.pyr[t][3 * f + 2] = P.n[f].z;
+                    }
+                    if (level == 2) {
+                        const int32_t refl = e.id[1];
+                        const Pyramid Q = unfolded_pyramid(M, I, e.id[0], t, &refl, 1, d.inv_h0[t]);
+#pragma unroll
+                        for (int f = 0; f < 3; ++f) {
+                            d.pyr0[t][3 * f] = Q.n[f].x; d.pyr0[t][3 * f + 1] = Q.n[f].y; d.pyr0[t][3 * f + 2] = Q.n[f].z;
+                        }
+                    }
+                }
+            }
+            pd[threadIdx.x] = d;
+        }
+        __syncthreads();
+        const int nt = (int)((p_end - base < 256) ? p_end - base : 256);
+        if (!wave_any) continue;  // wave-uniform; the barriers above are outside this branch
+        for (int j = 0; j < nt; ++j) {
+            const BeamPrefD<SCALE> &d = pd[j];  // broadcast reads
+            const V3 I = V3{d.I[0], d.I[1], d.I[2]}, pm = V3{d.pm[0], d.pm[1], d.pm[2]}, nm = V3{d.nm[0], d.nm[1], d.nm[2]};
+            const float inv_h = d.inv_h;
+            const int side_prev = d.side_prev;
+            // ---- uniform: bounding sphere of the wave's primitives vs this prefix ----
+            {
+                const V3 w = sc - I;
+                const float wl = ((__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z)) + 1.7320509f * sr;
+                bool sep = true, sep0 = true;
+#pragma unroll
+                for (int t = 0; t < SCALE; ++t) {
+                    const float thr = -(E + E * (wl * inv_h)), thr0 = -(E + E * (wl * d.inv_h0[t]));
+                    bool st = false, st0 = false;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        st = st || (dot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) + sr < thr);
+                        st0 = st0 || (dot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) + sr < thr0);
+                    }
+                    sep = sep && st;
+                    sep0 = sep0 && st0;
+                }
+                bool cull = sep || sep0;
+                if (side_prev != 0) {
+                    const float dc = dot(sc - pm, nm);
+                    const int sb = (dc == dc) ? side_of_range(dc - sr, dc + sr, 4.0f * E) : 0;
+                    cull = cull || (side_prev * sb == -1);
+                }
+                // identical on every lane; make it a scalar branch for the compiler
+                if (__builtin_amdgcn_readfirstlane((int)cull)) continue;
+            }
+            // ---- per lane: the primitive test ----
+            float dmin = kInf, dmax = -kInf;
+            bool out_face[SCALE][3], out_face0[SCALE][3];
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) out_face[t][f] = out_face0[t][f] = true;
+            bool nan = false;
+#pragma unroll
+            for (int k = 0; k < 3 * SCALE; ++k) {
+                const V3 x = vx[k];
+                const float dd = dot(x - pm, nm);
+                nan = nan || !(dd == dd);
+                dmin = fminf(dmin, dd);
+                dmax = fmaxf(dmax, dd);
+                const V3 w = x - I;
+                const float wl = (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z);
+                const float thr = -(E + E * (wl * inv_h));
+#pragma unroll
+                for (int t = 0; t < SCALE; ++t) {
+                    const float thr0 = -(E + E * (wl * d.inv_h0[t]));
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        out_face[t][f] = out_face[t][f] &&
+                                         (dot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) < thr);
+                        out_face0[t][f] = out_face0[t][f] &&
+                                          (dot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) < thr0);
+                    }
+                }
+            }
+            bool separated = true, separated0 = true;
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) {
+                separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
+                separated0 = separated0 && (out_face0[t][0] || out_face0[t][1] || out_face0[t][2]);
+            }
+            const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
+            const bool keep = lane_ok && ((int32_t)c != d.m) && !(separated || separated0) && !(side_prev * side_c == -1);
+            const unsigned long long vote = __ballot(keep);
+            if (vote) {
+                if (keep) {
+                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
+                    wbuf[wave][slot] = ((unsigned long long)(uint32_t)(base + j) << 32) | (uint32_t)c;
+                }
+                wcount += __popcll(vote);
+                if (wcount > kBeamWaveBuf - 64) {
+                    beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+                    wcount = 0;
+                }
+            }
+        }
+    }
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+}
+
 // (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the
 // parent mirror w.r.t. the new mirror's plane
 __device__ __forceinline__ BeamEntry beam_child(const BeamMesh &M, const BeamEntry &e, int level, int32_t c, float E) {
@@ -658,7 +854,30 @@ int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in,
     const BeamMesh M = beam_mesh(mesh);
     if (n_in == 0 || M.nprim == 0) return DRT_OK;
     DRT_REQUIRE(in && (out || capacity == 0), "null pointer");
-    if (use_bvh) {
+    if (use_bvh == 0) {  // default: lane = primitive, prefixes staged in LDS, wave-level sphere culling
+        const int64_t bx = ceil_div(M.nprim, 256);
+        int64_t by = ceil_div(4096, bx);
+        const int64_t ptiles = ceil_div(n_in, 256);
+        if (by > ptiles) by = ptiles;
+        if (by > 65535) by = 65535;
+        if (by < 1) by = 1;
+        const int64_t pps = ceil_div(ptiles, by) * 256;
+        by = ceil_div(n_in, pps);
+        const dim3 gt((unsigned)bx, (unsigned)by);
+        if (M.scale == 2)
+            hipLaunchKernelGGL(beam_expand_t_kernel<2>, gt, dim3(256), 0, as_stream(stream), M,
+                               reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                               reinterpret_cast<unsigned long long *>(out), capacity,
+                               reinterpret_cast<unsigned long long *>(count_dev), pps);
+        else
+            hipLaunchKernelGGL(beam_expand_t_kernel<1>, gt, dim3(256), 0, as_stream(stream), M,
+                               reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                               reinterpret_cast<unsigned long long *>(out), capacity,
+                               reinterpret_cast<unsigned long long *>(count_dev), pps);
+        DRT_LAUNCH_CHECK();
+        return DRT_OK;
+    }
+    if (use_bvh == 1) {
         int32_t rc = drt_mesh_build_bvh(mesh, stream);
         if (rc != DRT_OK) return rc;
         const auto *nodes = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);

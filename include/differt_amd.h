@@ -453,8 +453,10 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
  *   drt_beam_seed    level-1 prefixes (tx, m1) of all active primitives        -> out[0 .. *count)
  *   drt_beam_expand  level-`level` prefixes x primitives -> surviving (prefix index << 32 | primitive)
  *                    records, 8 bytes each                                      -> out[0 .. *count);
- *                    use_bvh != 0 walks the mesh LBVH with the box form of the same tests (same
- *                    survivors; with assume_quads a record may repeat -- de-duplicate the sorted rows)
+ *                    use_bvh selects the mapping (same survivors): 0 = lane per primitive, prefixes
+ *                    staged in LDS, wave-level bounding-sphere culling (default, fastest measured);
+ *                    1 = walk of the mesh LBVH with the box form of the tests (with assume_quads a
+ *                    record may repeat -- de-duplicate the sorted rows); 2 = lane per prefix, brute force
  *   drt_beam_finish  records -> level + 1 prefixes (needed between two expansions)
  *   drt_beam_emit    prefixes x receivers -> packed candidate rows
  *                    ((tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j)), n = primitives;

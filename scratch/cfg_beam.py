@@ -16,7 +16,7 @@ which = [a for a in sys.argv[1:] if a.startswith("cfg")] or ["cfg3", "cfg4"]
 
 def run(name, V, Tr, tx, rx, order, verify=None):
     mesh = G.Mesh(V, Tr)
-    tracer = G.ExhaustivePathTracer()
+    tracer = G.ExhaustivePathTracer(accel="bvh")  # occlusion stage on the LBVH (bit-identical, O(log T))
 
     def step():
         txg = torch.tensor(tx, device="cuda", requires_grad=True)

@@ -642,10 +642,11 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
     bp = tracer.trace_beam_pruned(scene, 3)
     _assert_same_paths(ex, bp)
     st_bvh = dict(tracer.last_beam_stats)
-    brute = tracer.trace_beam_pruned(scene, 3, use_bvh=False)  # every (prefix, primitive) pair tested
-    _assert_same_paths(ex, brute)
-    # the LBVH walk prunes subtrees with the box form of the same tests: identical survivors at every level
-    assert st_bvh["levels"] == tracer.last_beam_stats["levels"] and st_bvh["rows"] == tracer.last_beam_stats["rows"]
+    for mapping in ("prefix", "bvh"):  # lane per prefix (every pair tested) / walk of the mesh LBVH
+        other = tracer.trace_beam_pruned(scene, 3, expansion=mapping)
+        _assert_same_paths(ex, other)
+        # sphere / box culling are the same tests on a ball / box: identical survivors at every level
+        assert st_bvh["levels"] == tracer.last_beam_stats["levels"] and st_bvh["rows"] == tracer.last_beam_stats["rows"]
     n = Tr.shape[0]
     evaluated, total = tracer.last_beam_stats["rows"], 64 * n * (n - 1) ** 2
     assert ex.objects.shape[0] > 0 and evaluated < total / 20, (evaluated, total)
@@ -685,8 +686,9 @@ def test_beam_pruned_equals_exhaustive_quads_masks_orders(G, rng, order, assume_
         bp = tracer.trace_beam_pruned(scene, order)
         _assert_same_paths(ex, bp)
         rows_bvh = tracer.last_beam_stats["rows"]
-        _assert_same_paths(ex, tracer.trace_beam_pruned(scene, order, use_bvh=False))
-        assert tracer.last_beam_stats["rows"] == rows_bvh  # same candidate rows after de-duplication
+        for mapping in ("prefix", "bvh"):
+            _assert_same_paths(ex, tracer.trace_beam_pruned(scene, order, expansion=mapping))
+            assert tracer.last_beam_stats["rows"] == rows_bvh  # same candidate rows after de-duplication
         if bp.objects.shape[0]:
             gref, = torch.autograd.grad(torch.sqrt((torch.diff(ex.vertices, dim=-2) ** 2).sum(-1)).sum(), txg)
             ggot, = torch.autograd.grad(torch.sqrt((torch.diff(bp.vertices, dim=-2) ** 2).sum(-1)).sum(), txg)
