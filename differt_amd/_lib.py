@@ -62,6 +62,7 @@ class TraceParams(C.Structure):
 
 
 DRT_TRACE_USE_BVH = 1
+DRT_TRACE_SKIP_OCCLUSION = 2
 DRT_TRACE_OVERFLOW_SURVIVORS, DRT_TRACE_OVERFLOW_PATHS = 1, 2
 ABI_VERSION = 4  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
 

@@ -14,6 +14,8 @@
 //                ranges are split over blockIdx.y so that small ray batches still fill the chip.
 //   per-ray triangle sets: one wavefront per ray, lanes stride over the ray's triangles,
 //                ballot / shuffle reduction.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "geom.hpp"
 #include "tri_tile.hpp"
@@ -491,7 +493,12 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     // rays per block: as many as possible (amortises the 144-B/lane triangle loads) while keeping
     // >= ~640 blocks; measured on the literal configs[1] launch (256 rays): 17.2 us at 1 ray/block,
     // 10.5 us at 4.  Upper bound 32: 0.806 ms vs 0.83 ms at 64 on the bench shape.
-    int64_t rpb = (R * cols) / 640;
+    static const int64_t target_blocks = [] {  // experiment hook: DRT_DENSE_BLOCKS=<n> (default 640)
+        const char *e = getenv("DRT_DENSE_BLOCKS");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v > 0 ? v : 640);
+    }();
+    int64_t rpb = (R * cols) / target_blocks;
     if (rpb < 1) rpb = 1;
     if (rpb > 32) rpb = 32;
     if (al16 && rpb > kDenseGroup) rpb -= rpb % kDenseGroup;  // whole groups: no short trailing group

@@ -362,13 +362,13 @@ __global__ __launch_bounds__(256) void trace_occlusion_kernel(
 #pragma unroll
         for (int s = 0; s <= K; ++s) dir[s] = full[s + 1] - full[s];
         bool blocked = !have;  // idle waves count as done
-        for (int64_t base = 0; base < a.T; base += kTile) {
+        for (int64_t base = 0; base < a.T_occ; base += kTile) {
             // block-wide early exit (also the barrier that protects the previous tile's readers)
             if (__syncthreads_and(blocked ? 1 : 0)) break;
-            stage_tile(lds, a.tri_verts, a.mask, base, a.T);
+            stage_tile(lds, a.tri_verts, a.mask, base, a.T_occ);
             __syncthreads();
             if (!blocked) {
-                const int n = (int)((a.T - base < kTile) ? a.T - base : kTile);
+                const int n = (int)((a.T_occ - base < kTile) ? a.T_occ - base : kTile);
                 bool hit = false;
                 for (int j = lane; j < n; j += 64) {
                     const TriRec rec = lds[j];
@@ -607,7 +607,7 @@ static void launch_occlusion(const Launch &L, const unsigned long long *qc, cons
                              int64_t qcap, unsigned long long *vc, long long *v, int64_t vcap,
                              uint8_t *dm) {
     // persistent-style grid: the survivor count lives on the device
-    if (L.bvh && L.a.T > 0)
+    if (L.bvh && L.a.T_occ > 0)
         hipLaunchKernelGGL((trace_occlusion_bvh_kernel<K, DENSE>), dim3(256 * 8), dim3(256), 0, L.s, L.a,
                            L.cs, L.bvh, qc, q, qcap, vc, v, vcap, dm);
     else

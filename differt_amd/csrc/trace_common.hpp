@@ -44,6 +44,7 @@ struct TraceArgs {
     const float *normals;    // [T,3]
     const uint8_t *mask;     // [T] or null
     int64_t T;
+    int64_t T_occ;  // triangles the occlusion stage tests: T, or 0 with DRT_TRACE_SKIP_OCCLUSION
     const float *tx;
     int64_t ntx;
     const float *rx;
@@ -391,6 +392,7 @@ static TraceArgs make_args(drt_mesh_t mesh, const drt_trace_params *pr, const fl
     a.normals = mesh->normals;
     a.mask = mesh->has_mask ? mesh->mask : nullptr;
     a.T = mesh->num_triangles;
+    a.T_occ = (pr && (pr->flags & DRT_TRACE_SKIP_OCCLUSION)) ? 0 : a.T;
     a.tx = tx;
     a.ntx = ntx;
     a.rx = rx;

@@ -22,6 +22,8 @@ import torch.distributed as dist
 
 __all__ = [
     "allreduce_grads",
+    "reduce_any_hit",
+    "trace_rank_range_triangle_sharded",
     "first_triangle_hit_by_ray_sharded",
     "gather_paths",
     "globalize_keys",
@@ -103,6 +105,56 @@ def reduce_first_hit(packed_keys: torch.Tensor, group=None) -> torch.Tensor:
     if world > 1:
         dist.all_reduce(packed_keys, op=dist.ReduceOp.MIN, group=group)
     return packed_keys
+
+
+def reduce_any_hit(blocked: torch.Tensor, group=None) -> torch.Tensor:
+    """MAX all-reduce of per-path ``blocked`` flags (uint8): a path is occluded if ANY rank's triangle block
+    occludes one of its segments."""
+    world, _ = _world(group)
+    if world > 1:
+        dist.all_reduce(blocked, op=dist.ReduceOp.MAX, group=group)
+    return blocked
+
+
+def trace_rank_range_triangle_sharded(tracer, scene, order: int, rank_lo: int = 0, rank_hi: int | None = None, *,
+                                      tri_lo: int | None = None, tri_hi: int | None = None, group=None, **kwargs):
+    """Triangle-block sharding of the tracer's OCCLUSION stage (BASELINE configs[4], scenes whose triangle data
+    should not be tested whole on one GPU): every rank runs the geometric stage on the same candidates (the
+    mirror planes of a candidate can be any triangle, so vertices / normals stay replicated -- 48 B per
+    triangle), tests the k+1 segments of each survivor against ITS block ``[tri_lo, tri_hi)`` only
+    (default: ``shard_interval(T, world, rank)``) and ONE MAX all-reduce of a byte per survivor decides.
+    Returns the valid paths as a ``TracedPaths`` identical to the unsharded ``trace_rank_range`` (the
+    occlusion predicate is an OR over triangles, so any partition gives the same mask)."""
+    from .geometry._paths import TracedPaths
+    from .geometry._utils import ray_intersect_any_triangle
+
+    world, rank = _world(group)
+    mesh = scene.mesh
+    T = mesh.num_triangles
+    if tri_lo is None or tri_hi is None:
+        tri_lo, tri_hi = shard_interval(T, world, rank)
+    tracer._skip_occlusion = True  # geometric survivors only (DRT_TRACE_SKIP_OCCLUSION)
+    try:
+        p = tracer.trace_rank_range(scene, order, rank_lo, rank_hi, **kwargs)
+    finally:
+        tracer._skip_occlusion = False
+    S = p.objects.shape[0]
+    blocked = torch.zeros(S, dtype=torch.uint8, device=p.objects.device)
+    if S and tri_hi > tri_lo:
+        v = p.vertices.detach()
+        o = v[:, :-1, :].reshape(-1, 3)
+        d = (v[:, 1:, :] - v[:, :-1, :]).reshape(-1, 3)
+        tvb = mesh.triangle_vertices.detach()[tri_lo:tri_hi].contiguous()
+        act = None if mesh.mask is None else mesh.mask[tri_lo:tri_hi].contiguous()
+        hit = ray_intersect_any_triangle(o, d, tvb, act, hit_tol=tracer.hit_tol, epsilon=tracer.epsilon)
+        blocked = hit.reshape(S, order + 1).any(dim=1).to(torch.uint8)
+    reduce_any_hit(blocked, group=group)
+    keep = blocked == 0
+    n = int(keep.sum().item())
+    dev = p.objects.device
+    return TracedPaths(p.vertices[keep], p.objects[keep], torch.ones(n, dtype=torch.bool, device=dev),
+                       torch.zeros((n, order), dtype=torch.int32, device=dev), tracer.confidence_threshold,
+                       p.keys[keep])
 
 
 def trace_rank_range_sharded(tracer, scene, order: int, rank_lo: int = 0, rank_hi: int | None = None,

@@ -35,14 +35,14 @@ __all__ = [
 ]
 
 
-def _params(epsilon, hit_tol, min_len, accel=None) -> _lib.TraceParams:
+def _params(epsilon, hit_tol, min_len, accel=None, skip_occlusion: bool = False) -> _lib.TraceParams:
     if accel not in (None, "bvh"):
         raise ValueError(f"unknown accel {accel!r}")
     return _lib.TraceParams(
         10.0 * F32_EPS if epsilon is None else float(epsilon),   # _utils.py:1257-1259
         100.0 * F32_EPS if hit_tol is None else float(hit_tol),  # _utils.py:1418-1420
         10.0 * F32_EPS if min_len is None else float(min_len),   # _solvers.py:514-516
-        _lib.DRT_TRACE_USE_BVH if accel == "bvh" else 0,
+        (_lib.DRT_TRACE_USE_BVH if accel == "bvh" else 0) | (_lib.DRT_TRACE_SKIP_OCCLUSION if skip_occlusion else 0),
     )
 
 
@@ -576,7 +576,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
     def _trace_compact(self, scene, desc, max_survivors, max_paths) -> TracedPaths:
         tx = scene.transmitters.reshape(-1, 3).contiguous()
         rx = scene.receivers.reshape(-1, 3).contiguous()
-        params = _params(self.epsilon, self.hit_tol, self.min_len, self.accel)
+        params = _params(self.epsilon, self.hit_tol, self.min_len, self.accel,
+                         skip_occlusion=bool(getattr(self, "_skip_occlusion", False)))
         st = None
         if self.collect_stats:
             st = _lib.TraceStats()

@@ -345,6 +345,10 @@ typedef struct drt_trace_params {
     drt_trace_stats *stats; /* host pointer or NULL (drt_trace_paths_compact only) */
 } drt_trace_params;
 #define DRT_TRACE_USE_BVH 1 /* occlusion stage walks the mesh LBVH instead of testing every triangle */
+#define DRT_TRACE_SKIP_OCCLUSION 2 /* return the candidates that pass the GEOMETRIC checks; the caller tests
+                                      occlusion itself (triangle-block sharding: every rank tests the segments
+                                      against its block with drt_ray_intersect_any_triangle, then one MAX
+                                      all-reduce of u8 per path) */
 /* bits of counts_dev[2] written by drt_trace_paths_compact_async */
 #define DRT_TRACE_OVERFLOW_SURVIVORS 1 /* more candidates passed the geometric checks than max_survivors */
 #define DRT_TRACE_OVERFLOW_PATHS 2     /* more valid paths than max_paths */

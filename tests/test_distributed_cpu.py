@@ -18,6 +18,7 @@ from differt_amd.distributed import (
     allreduce_grads,
     gather_paths,
     globalize_keys,
+    reduce_any_hit,
     reduce_first_hit,
     shard_interval,
 )
@@ -111,6 +112,15 @@ def _worker(rank: int, world: int, port: int, tmp: str):
         gt = np.where(miss, np.inf, (glob >> np.uint64(32)).astype(np.uint32).view(np.float32))
         assert np.array_equal(gidx, ei) and np.array_equal(gt.astype(np.float32), et)
         assert (ei >= 0).sum() > 10
+
+        # triangle-block sharding of the tracer's occlusion stage: a segment is blocked if ANY rank's block
+        # blocks it -> MAX all-reduce of one byte per path == the unsharded any-hit
+        tol = 100 * np.finfo(np.float32).eps
+        blocked_local = orc.ray_intersect_any_triangle(ro, rd, tvs[tlo:thi], hit_tol=tol)
+        flags = torch.tensor(blocked_local.astype(np.uint8))
+        reduce_any_hit(flags)
+        assert np.array_equal(flags.numpy().astype(bool), orc.ray_intersect_any_triangle(ro, rd, tvs, hit_tol=tol))
+        assert 0 < int(flags.sum()) < R
         Path(tmp, f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()

@@ -152,6 +152,28 @@ def test_cfg3_full_size(G, manhattan):
         cand = np.asarray([[ci, dj + (dj >= ci)]], np.int32)
         o = orc.trace_path_candidates(V, Tr, tx[it: it + 1], rx[ir: ir + 1], cand)
         assert bool(o["mask"].reshape(-1)[0]) == (k in valid), (k, cand)
+    # completeness at FULL size, by an independent route: the geometric (beam) pruning reaches the valid paths
+    # through necessary conditions on pyramids / mirror sides instead of evaluating the 1.02e11 candidates; a
+    # path that the filter kernel wrongly dropped at full scale would show up here (and vice versa)
+    bp = tracer.trace_beam_pruned(scene, order)
+    assert torch.equal(bp.objects, paths.objects)
+    assert torch.equal(bp.vertices.detach().view(torch.int32), paths.vertices.detach().view(torch.int32))
+    assert tracer.last_beam_stats["rows"] < 1e-4 * 1024 * total
+    # triangle-block sharding of the occlusion stage, 8 blocks emulated on one GPU: a path is valid iff no block
+    # occludes it -> the intersection of the per-block results is the unsharded result
+    from differt_amd.distributed import trace_rank_range_triangle_sharded
+
+    lo, hi = shard_interval(total, 7, 3)  # one rank window is enough (the geometric stage is the same code)
+    ref_keys = set(_np(tracer.trace_rank_range(scene, order, lo, hi, max_survivors=1 << 22).keys).tolist())
+    common = None
+    for b in range(8):
+        t0, t1 = shard_interval(n, 8, b)
+        part = trace_rank_range_triangle_sharded(tracer, scene, order, lo, hi, tri_lo=t0, tri_hi=t1,
+                                                 max_survivors=1 << 22)
+        ks = set(_np(part.keys).tolist())
+        common = ks if common is None else (common & ks)
+        assert ref_keys <= ks  # a block can only occlude less than the whole mesh
+    assert common == ref_keys and len(ref_keys) > 0
     # gradient of the total valid path length w.r.t. TX: finite, and equal to float64 autograd
     from oracle import torch_ref
 
