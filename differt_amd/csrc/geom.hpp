@@ -199,6 +199,8 @@ __device__ __forceinline__ MtPart mt_phase1(V3 o, V3 d, const TriE &tr) {
 }
 
 // t_out[i] and byte i of `hits` = moller_trumbore(o, d, tr[i], eps, t_out[i])
+// EPS_COVERS: the caller guarantees eps >= 2^-126 (launcher-side dispatch, see ray_ops.hip)
+template <bool EPS_COVERS>
 __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[4], float eps,
                                                    float (&t_out)[4], uint32_t &hits) {
     MtPart p[4];
@@ -210,8 +212,11 @@ __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[
                                      __builtin_fminf(__builtin_fabsf(p[2].a0), __builtin_fabsf(p[3].a0)));
     // fmax / fmin skip a NaN operand: a NaN determinant next to in-range ones stays on the fast
     // path, where rcp / fma propagate it exactly like the division does (t = NaN, hit = false)
-    const uint64_t okm =
-        __builtin_amdgcn_ballot_w64(mn >= 0x1p-126f) & __builtin_amdgcn_ballot_w64(mx <= 0x1p+126f);
+    // eps >= 2^-126 (any sensible epsilon): demanding min|a| > eps covers the lower range bound AND makes
+    // the `|a| > eps` compare of every test redundant on the fast path (a determinant at or below eps sends
+    // the wave to the literal formula instead)
+    const uint64_t okm = (EPS_COVERS ? __builtin_amdgcn_ballot_w64(mn > eps) : __builtin_amdgcn_ballot_w64(mn >= 0x1p-126f)) &
+                         __builtin_amdgcn_ballot_w64(mx <= 0x1p+126f);
     if (__builtin_expect(okm == __builtin_amdgcn_read_exec(), 1)) {
         uint32_t hh = 0;
 #pragma unroll
@@ -223,7 +228,7 @@ __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[
             const float v = f * p[i].pv;
             const float upv = u + v;
             const float t = f * p[i].pt;
-            const bool c0 = __builtin_fabsf(p[i].a0) > eps;
+            const bool c0 = EPS_COVERS || (__builtin_fabsf(p[i].a0) > eps);
             const bool c1 = __builtin_fminf(u, v) >= 0.0f;
             const bool c2 = upv <= 1.0f;
             const bool c3 = t > eps;

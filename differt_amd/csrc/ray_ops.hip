@@ -38,6 +38,7 @@ __device__ __forceinline__ void atomic_add3f(float *p, V3 v) {
 }
 constexpr int kDenseCols = kDenseThreads * 4;  // triangles per block
 constexpr int kDenseGroup = 8;                 // rays whose hit bytes are staged in LDS together
+constexpr int kDenseStageDwords = 5 * 64 * 4;  // LDS triangle staging per wave: 5 x b128 per lane (32 lanes x 4 triangles x 9 floats = 1152 dwords used)
 
 // Stores with a wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset: the per-row address math
 // stays on the scalar unit.  Nontemporal: measured 0.83 ms vs 0.95 ms for plain stores on the bench
@@ -70,12 +71,19 @@ __device__ __forceinline__ uint32_t line_first_offset(uint32_t p, uint32_t hd, u
 //     barrier per group) and each wave flushes two rows with one dwordx4 store per row: the first
 //     lanes cover the whole lines of the 1-KiB row segment, the last lanes its partial head and
 //     tail.  A quarter of the hit store instructions, 7 of 9 lines written whole.
+//   * EPS_COVERS (eps >= 2^-126, launcher-side): one compare per test less on the fast path (geom.hpp).
+template <bool EPS_COVERS>
 __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(7, 7)))
 void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
                              const float *__restrict__ tv, int64_t T, float eps,
                              float *__restrict__ t_out, uint8_t *__restrict__ hit_out,
-                             int rays_per_block) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_h[2][kDenseGroup][kDenseThreads];
+                             int rays_per_block, int stage_tris) {
+    // one LDS allocation, two uses: triangle staging (20 KiB, start of the block) and then the hit rows
+    // of kDenseGroup rays x 2 buffers (16 KiB)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4 * kDenseStageDwords];
+    static_assert(sizeof(lds_raw) >= 2 * kDenseGroup * kDenseThreads * sizeof(uint32_t), "hit rows fit");
+    uint32_t (*lds_h)[kDenseGroup][kDenseThreads] =
+        reinterpret_cast<uint32_t (*)[kDenseGroup][kDenseThreads]>(lds_raw);
     const uint32_t col0 = blockIdx.y * (uint32_t)kDenseCols;
     const uint32_t j0 = col0 + threadIdx.x * 4u;
     const bool active = j0 < T;  // T % 4 == 0: a lane is entirely inside or outside the row
@@ -85,12 +93,62 @@ void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restri
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
 
+    // Triangles.  A lane's 4 triangles are 144 contiguous bytes, so a direct per-lane load touches 64
+    // different 128-B lines per instruction (9 x 64 tag look-ups per wave: measured 10 us of the 14.8-us
+    // launch at 1 ray per block, scratch/literal_lab.hip).  Instead the wave reads its 9216-B segment
+    // coalesced (16 B per lane, 8 lines per instruction) into LDS, half a wave's worth at a time, and every
+    // lane picks its 36 dwords back with 9 conflict-free ds_read_b128 (stride 36 dwords).
     TriE tri[4];
+    if (stage_tris) {
+        uint32_t *stg = lds_raw + wave * kDenseStageDwords;
+        const int64_t jw = (int64_t)col0 + wave * 256;                  // first triangle of the wave
+        const int64_t nv = (T - jw < 256) ? ((T - jw > 0) ? T - jw : 0) : 256;  // valid triangles of the wave
+        const char *src = reinterpret_cast<const char *>(tv + 9 * jw);
+        f32x4 raw[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) raw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nv > 0) {  // wave-uniform
+            const uint32_t last16 = (uint32_t)nv * 36u - 16u;  // chunks past the row's end re-read its last 16 B
+            f32x4 ld[2][5];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {  // all ten loads in flight before the first LDS write
+                    const uint32_t off = (uint32_t)h * (32u * 144u) + (uint32_t)(k * 64 + lane) * 16u;
+                    ld[h][k] = *reinterpret_cast<const f32x4 *>(src + (off < last16 ? off : last16));  // re-read by every row block: cached
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) *reinterpret_cast<f32x4 *>(stg + 4 * (k * 64 + lane)) = ld[h][k];
+                if ((lane >> 5) == h) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q)
+                        raw[q] = *reinterpret_cast<const f32x4 *>(stg + 36 * (lane & 31) + 4 * q);
+                }
+            }
+        }
+        if (!active) {  // lanes past the end of the row: any finite triangle (results never stored)
+            const f32x4 *last = reinterpret_cast<const f32x4 *>(tv + 9 * (T - 4));
+#pragma unroll
+            for (int q = 0; q < 9; ++q) raw[q] = last[q];
+        }
+        const float *rf = reinterpret_cast<const float *>(raw);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            tri[q] = make_tri(V3{rf[9 * q], rf[9 * q + 1], rf[9 * q + 2]}, V3{rf[9 * q + 3], rf[9 * q + 4], rf[9 * q + 5]},
+                              V3{rf[9 * q + 6], rf[9 * q + 7], rf[9 * q + 8]});
+        __syncthreads();  // the staging area becomes the hit rows
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // lanes past the end re-read the last triangle; their results are never stored
+            const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
+            tri[q] = load_tri(tv + 9 * j);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        // lanes past the end re-read the last triangle; their results are never stored
-        const int64_t j = (j0 + q < T) ? j0 + q : T - 1;
-        tri[q] = load_tri(tv + 9 * j);
         // keep the edges live in VGPRs (otherwise they may be re-derived from the vertices per ray)
         asm volatile("" : "+v"(tri[q].e1.x), "+v"(tri[q].e1.y), "+v"(tri[q].e1.z),
                           "+v"(tri[q].e2.x), "+v"(tri[q].e2.y), "+v"(tri[q].e2.z));
@@ -112,7 +170,7 @@ void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restri
             const V3 on = ld3(po), dn = ld3(pd);
             float t[4];
             uint32_t hh;
-            moller_trumbore_x4(o, d, tri, eps, t, hh);
+            moller_trumbore_x4<EPS_COVERS>(o, d, tri, eps, t, hh);
             if (active) store_nt_b128(trow, toff, f32x4{t[0], t[1], t[2], t[3]});
             lds_h[buf][s][threadIdx.x] = hh;
             trow += T * 4;
@@ -166,7 +224,7 @@ __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
         const V3 d = ld3(rd + 3 * r);
         float t[4];
         uint32_t hh;
-        moller_trumbore_x4(o, d, tri, eps, t, hh);
+        moller_trumbore_x4<false>(o, d, tri, eps, t, hh);
         const int64_t base = r * T + j0;
         if (VEC) {
             f32x4 tt = {t[0], t[1], t[2], t[3]};
@@ -490,13 +548,14 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
                      ((reinterpret_cast<uintptr_t>(hit_out) & 3) == 0);
     const int64_t cols = ceil_div(T, (int64_t)kDenseCols);
     DRT_REQUIRE(cols <= 65535, "too many triangles for one launch (%lld)", (long long)T);
-    // rays per block: as many as possible (amortises the 144-B/lane triangle loads) while keeping
-    // >= ~640 blocks; measured on the literal configs[1] launch (256 rays): 17.2 us at 1 ray/block,
-    // 10.5 us at 4.  Upper bound 32: 0.806 ms vs 0.83 ms at 64 on the bench shape.
-    static const int64_t target_blocks = [] {  // experiment hook: DRT_DENSE_BLOCKS=<n> (default 640)
+    // rays per block: as many as possible (amortises the triangle loads) while keeping >= ~1280 blocks.
+    // Measured on the literal configs[1] launch (256 rays, inside a HIP graph, with the LDS-staged triangle
+    // loads): 7.5 / 7.4 / 9.2 us at 640 / 1280 / 2560 blocks; 1024 rays: 20.1 / 17.9 / 18.5 us
+    // (profiles/r02/literal_lab.txt).  Upper bound 32: 0.806 ms vs 0.83 ms at 64 on the bench shape.
+    static const int64_t target_blocks = [] {  // experiment hook: DRT_DENSE_BLOCKS=<n> (default 1280)
         const char *e = getenv("DRT_DENSE_BLOCKS");
         const long v = e ? atol(e) : 0;
-        return (int64_t)(v > 0 ? v : 640);
+        return (int64_t)(v > 0 ? v : 1280);
     }();
     int64_t rpb = (R * cols) / target_blocks;
     if (rpb < 1) rpb = 1;
@@ -508,9 +567,21 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     DRT_REQUIRE(T <= (1ll << 24), "too many triangles per row for one launch (%lld)", (long long)T);
     dim3 grid((unsigned)rows, (unsigned)cols);
     hipStream_t s = as_stream(stream);
-    if (al16)
-        hipLaunchKernelGGL(mt_dense_aligned_kernel, grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T, eps,
-                           t_out, hit_out, (int)rpb);
+    // coalesced LDS staging of the triangles needs 16-B aligned rows of 4 triangles (experiment hook:
+    // DRT_DENSE_STAGE=0 keeps the direct per-lane loads)
+    static const bool stage_ok = [] {
+        const char *e = getenv("DRT_DENSE_STAGE");
+        return !(e && e[0] == '0');
+    }();
+    // worth it only when a block walks few rays (configs[1]: 8.0 -> 7.4 us; at 32 rays per block the direct
+    // loads hide behind the other blocks' arithmetic and staging costs 1 %: profiles/r02/literal_lab.txt)
+    const int stage = (stage_ok && rpb <= kDenseGroup && (reinterpret_cast<uintptr_t>(tv) & 15) == 0) ? 1 : 0;
+    if (al16 && eps >= 0x1p-126f)
+        hipLaunchKernelGGL((mt_dense_aligned_kernel<true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
+                           eps, t_out, hit_out, (int)rpb, stage);
+    else if (al16)
+        hipLaunchKernelGGL((mt_dense_aligned_kernel<false>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
+                           eps, t_out, hit_out, (int)rpb, stage);
     else if (al4)
         hipLaunchKernelGGL((mt_dense_kernel<true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
                            eps, t_out, hit_out, (int)rpb);

@@ -52,7 +52,8 @@ while time.time() - t0 < budget:
         tv = (rng.normal(size=(T, 3, 3)) * 10.0 ** ex).astype(np.float32)
         o = (rng.normal(size=(R, 3)) * 10.0 ** rng.uniform(-20, 18, (R, 1))).astype(np.float32)
         d = (rng.normal(size=(R, 3)) * 10.0 ** rng.uniform(-20, 18, (R, 1))).astype(np.float32)
-    eps = None if rng.random() < 0.7 else float(10.0 ** rng.uniform(-8, -1))
+    u = rng.random()
+    eps = None if u < 0.65 else (float(10.0 ** rng.uniform(-8, -1)) if u < 0.93 else float(rng.choice([0.0, 1e-42, 1e-38])))
     with np.errstate(all="ignore"):
         et, eh = orc.ray_intersect_triangle_dense(o, d, tv, epsilon=eps)
     t, hit = G.ray_intersect_triangle(torch.as_tensor(o, device="cuda")[:, None, :], torch.as_tensor(d, device="cuda")[:, None, :],

@@ -58,6 +58,24 @@ def test_dense_bit_exact(G, rng, R, T):
     np.testing.assert_array_equal(_np(t).view(np.uint32), et.view(np.uint32))
 
 
+@pytest.mark.parametrize("epsilon", [0.0, 1e-40, 1.1754944e-38, 1e-3, 0.5])
+def test_dense_epsilon_range(G, rng, epsilon):
+    """The aligned kernel has an `eps >= 2^-126` instantiation whose fast path drops the per-test
+    `|a| > eps` compare (min|a| > eps is demanded of the whole wave instead) and a general one:
+    both sides of the 2^-126 threshold, and epsilons large enough that waves mix determinants
+    above and below them, stay bit-exact."""
+    R, T = 48, 2048
+    tv = rng.normal(size=(T, 3, 3)).astype(np.float32) * 3
+    cen = tv.mean(axis=1)
+    o = (cen[:R] + rng.normal(size=(R, 3)) * 5).astype(np.float32)
+    d = ((cen[:R] - o) * 2).astype(np.float32)
+    et, eh = orc.ray_intersect_triangle_dense(o, d, tv, epsilon=epsilon)
+    t, hit = G.ray_intersect_triangle(o[:, None, :], d[:, None, :], tv, epsilon=epsilon)
+    assert eh.sum() > 0 and not eh.all()
+    np.testing.assert_array_equal(_np(hit), eh)
+    np.testing.assert_array_equal(_np(t).view(np.uint32), et.view(np.uint32))
+
+
 def test_dense_hits_present(G, rng):
     """Make sure the parity above is not vacuous: rays aimed at triangle centroids do hit."""
     T = 2048
