@@ -43,7 +43,7 @@ def main() -> None:
              "    rocprofv3 --pmc WRITE_SIZE --output-format csv ... -- python bench.py --steps 3 --warmup 1 "
              "--no-cpu-baseline --no-paths", "",
              "`mt_dense_aligned_kernel [grid=524288x10]` are the timed launches of `bench.py` "
-             "(65 536 rays x 10 000 triangles); `[grid=16384x10]` the literal 256-ray configs[1] launches.", "",
+             "(65 536 rays x 10 000 triangles); `[grid=32768x10]` the literal 256-ray configs[1] launches.", "",
              "| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
     for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"| `{k}` | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | "

@@ -44,7 +44,8 @@ def test_known_answers(G, goldens):
         assert bool(_np((t < 1.0) & hit)[0]) == case["expected"]
 
 
-@pytest.mark.parametrize("R,T", [(1, 1), (7, 5), (256, 10000), (33, 1023), (64, 4099), (300, 1028)])
+@pytest.mark.parametrize("R,T", [(1, 1), (7, 5), (256, 10000), (33, 1023), (64, 4099), (300, 1028), (3, 16), (5, 1040),
+                                 (40, 2064), (2000, 1024)])
 def test_dense_bit_exact(G, rng, R, T):
     """cfg2 shape (256 x 10000) and ragged sizes (T % 4 != 0 -> scalar-store path)."""
     o = (rng.uniform(-1, 1, (R, 3)) * 50).astype(np.float32)
@@ -54,6 +55,22 @@ def test_dense_bit_exact(G, rng, R, T):
     et, eh = orc.ray_intersect_triangle_dense(o, d, tv)
     t, hit = G.ray_intersect_triangle(o[:, None, :], d[:, None, :], tv)
     assert t.shape == (R, T)
+    np.testing.assert_array_equal(_np(hit), eh)
+    np.testing.assert_array_equal(_np(t).view(np.uint32), et.view(np.uint32))
+
+
+def test_dense_unaligned_triangle_pointer(G, rng):
+    """A triangle array that starts 4 bytes off a 16-B boundary takes the direct-load path of the aligned
+    kernel (no LDS staging of the triangles): same bits."""
+    R, T = 16, 2048
+    flat = torch.as_tensor(rng.normal(size=9 * T + 1).astype(np.float32) * 3, device="cuda")
+    tv = flat[1:].view(T, 3, 3)
+    assert tv.data_ptr() % 16 == 4 and tv.is_contiguous()
+    o = rng.normal(size=(R, 3)).astype(np.float32) * 5
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    et, eh = orc.ray_intersect_triangle_dense(o, d, _np(tv))
+    t, hit = G.ray_intersect_triangle(torch.as_tensor(o, device="cuda")[:, None, :],
+                                      torch.as_tensor(d, device="cuda")[:, None, :], tv)
     np.testing.assert_array_equal(_np(hit), eh)
     np.testing.assert_array_equal(_np(t).view(np.uint32), et.view(np.uint32))
 
