@@ -79,6 +79,14 @@ __device__ __forceinline__ TriE load_tri(const float *tv) {
     return make_tri(ld3(tv), ld3(tv + 3), ld3(tv + 6));
 }
 
+// Lower bound of the fast path's determinant range, folded with the reference's `|a| > eps` test:
+// every |a| of the wave must EXCEED max(eps, largest denormal).  Either way |a| >= 2^-126 and |a| > eps
+// follow, so the fast path needs no per-test `|a| > eps` compare; a determinant at or below eps sends
+// the wave to the literal formula instead (same bits).  A NaN eps gives a NaN threshold: never fast.
+__device__ __forceinline__ float mt_fast_threshold(float eps) {
+    return (eps < 0x1p-126f) ? 0x1.fffffcp-127f : eps;
+}
+
 // _utils.py:1273-1322, hard mode.  Returns hit; t always written (also for misses).
 // Fast path when every determinant of the WAVE lies in [2^-126, 2^126] (no zero / denormal / huge /
 // non-finite value): reciprocal = v_rcp + one Newton step (exhaustively verified), no `a == 0`
@@ -94,7 +102,11 @@ __device__ __forceinline__ bool moller_trumbore(V3 o, V3 d, const TriE &tr, floa
     const float pv = dot(q, d);
     const float pt = dot(q, tr.e2);
     const float aa = __builtin_fabsf(a0);
-    if (__builtin_expect(__all((aa >= 0x1p-126f) & (aa <= 0x1p+126f)), 1)) {
+    // two ballots of plain compares: the masks meet on the scalar unit (a ballot of `c1 & c2` costs a
+    // v_cndmask + v_cmp to rebuild the lane mask)
+    const uint64_t okm = __builtin_amdgcn_ballot_w64(aa > mt_fast_threshold(eps)) &
+                         __builtin_amdgcn_ballot_w64(aa <= 0x1p+126f);
+    if (__builtin_expect(okm == __builtin_amdgcn_read_exec(), 1)) {
         const float r = __builtin_amdgcn_rcpf(a0);
         const float e = __builtin_fmaf(-a0, r, 1.0f);
         const float f = __builtin_fmaf(e, r, r);
@@ -103,7 +115,7 @@ __device__ __forceinline__ bool moller_trumbore(V3 o, V3 d, const TriE &tr, floa
         const float upv = u + v;
         const float t = f * pt;
         t_out = t;
-        return (aa > eps) & (__builtin_fminf(u, v) >= 0.0f) & (upv <= 1.0f) & (t > eps);
+        return (__builtin_fminf(u, v) >= 0.0f) & (upv <= 1.0f) & (t > eps);
     }
     const bool zero = (a0 == 0.0f);                        // a = where(a == 0, inf, a)
     bool hit = (zero ? kInf : aa) > eps;                   // |a| > eps
@@ -117,6 +129,47 @@ __device__ __forceinline__ bool moller_trumbore(V3 o, V3 d, const TriE &tr, floa
     hit = hit && (t > eps);
     t_out = t;
     return hit;
+}
+
+// Wave-mask form for the tracer's filter stage: bit l of the result = lane l is in `want` and
+// moller_trumbore(o, d, tr, eps) hits.  Same arithmetic; the masks of the single compares meet on the
+// scalar unit, and <q, e2> / the `t > eps` test are evaluated only when some wanted lane passes the
+// barycentric tests (wave-uniform branch; a rejected candidate's t is never used).
+__device__ __forceinline__ uint64_t moller_trumbore_wave(V3 o, V3 d, const TriE &tr, float eps, uint64_t want) {
+    const V3 h = cross(d, tr.e2);
+    const float a0 = dot(h, tr.e1);
+    const V3 s = o - tr.v0;
+    const float pu = dot(s, h);
+    const V3 q = cross(s, tr.e1);
+    const float pv = dot(q, d);
+    const float aa = __builtin_fabsf(a0);
+    const uint64_t okm = __builtin_amdgcn_ballot_w64(aa > mt_fast_threshold(eps)) &
+                         __builtin_amdgcn_ballot_w64(aa <= 0x1p+126f);
+    if (__builtin_expect(okm == __builtin_amdgcn_read_exec(), 1)) {
+        const float r = __builtin_amdgcn_rcpf(a0);
+        const float e = __builtin_fmaf(-a0, r, 1.0f);
+        const float f = __builtin_fmaf(e, r, r);
+        const float u = f * pu;
+        const float v = f * pv;
+        const float upv = u + v;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(__builtin_fminf(u, v) >= 0.0f) &
+                           __builtin_amdgcn_ballot_w64(upv <= 1.0f) & want;
+        if (__builtin_expect(m == 0, 1)) return 0;
+        const float t = f * dot(q, tr.e2);
+        return m & __builtin_amdgcn_ballot_w64(t > eps);
+    }
+    const float pt = dot(q, tr.e2);
+    const bool zero = (a0 == 0.0f);
+    bool hit = (zero ? kInf : aa) > eps;
+    const float f = 1.0f / (zero ? kInf : a0);
+    const float u = f * pu;
+    hit = hit && (u >= 0.0f) && (u <= 1.0f);
+    const float v = f * pv;
+    const float upv = u + v;
+    hit = hit && (v >= 0.0f) && (upv <= 1.0f);
+    const float t = f * pt;
+    hit = hit && (t > eps);
+    return __builtin_amdgcn_ballot_w64(hit) & want;
 }
 
 // N independent tests of one ray against N triangles, arithmetic identical to moller_trumbore but
@@ -199,8 +252,6 @@ __device__ __forceinline__ MtPart mt_phase1(V3 o, V3 d, const TriE &tr) {
 }
 
 // t_out[i] and byte i of `hits` = moller_trumbore(o, d, tr[i], eps, t_out[i])
-// EPS_COVERS: the caller guarantees eps >= 2^-126 (launcher-side dispatch, see ray_ops.hip)
-template <bool EPS_COVERS>
 __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[4], float eps,
                                                    float (&t_out)[4], uint32_t &hits) {
     MtPart p[4];
@@ -212,10 +263,7 @@ __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[
                                      __builtin_fminf(__builtin_fabsf(p[2].a0), __builtin_fabsf(p[3].a0)));
     // fmax / fmin skip a NaN operand: a NaN determinant next to in-range ones stays on the fast
     // path, where rcp / fma propagate it exactly like the division does (t = NaN, hit = false)
-    // eps >= 2^-126 (any sensible epsilon): demanding min|a| > eps covers the lower range bound AND makes
-    // the `|a| > eps` compare of every test redundant on the fast path (a determinant at or below eps sends
-    // the wave to the literal formula instead)
-    const uint64_t okm = (EPS_COVERS ? __builtin_amdgcn_ballot_w64(mn > eps) : __builtin_amdgcn_ballot_w64(mn >= 0x1p-126f)) &
+    const uint64_t okm = __builtin_amdgcn_ballot_w64(mn > mt_fast_threshold(eps)) &
                          __builtin_amdgcn_ballot_w64(mx <= 0x1p+126f);
     if (__builtin_expect(okm == __builtin_amdgcn_read_exec(), 1)) {
         uint32_t hh = 0;
@@ -228,14 +276,13 @@ __device__ __forceinline__ void moller_trumbore_x4(V3 o, V3 d, const TriE (&tr)[
             const float v = f * p[i].pv;
             const float upv = u + v;
             const float t = f * p[i].pt;
-            const bool c0 = EPS_COVERS || (__builtin_fabsf(p[i].a0) > eps);
             const bool c1 = __builtin_fminf(u, v) >= 0.0f;
             const bool c2 = upv <= 1.0f;
             const bool c3 = t > eps;
             t_out[i] = t;
             // one v_cndmask per test + 2 ORs per 4 tests (SDWA byte selects measured 8x the issue
             // cost of a plain VALU instruction on gfx950: scratch/valu_mix.hip)
-            hh |= ((c0 & c1) & (c2 & c3)) ? (1u << (8 * i)) : 0u;
+            hh |= (c1 & (c2 & c3)) ? (1u << (8 * i)) : 0u;
         }
         hits = hh;
     } else {

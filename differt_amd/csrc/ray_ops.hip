@@ -71,8 +71,6 @@ __device__ __forceinline__ uint32_t line_first_offset(uint32_t p, uint32_t hd, u
 //     barrier per group) and each wave flushes two rows with one dwordx4 store per row: the first
 //     lanes cover the whole lines of the 1-KiB row segment, the last lanes its partial head and
 //     tail.  A quarter of the hit store instructions, 7 of 9 lines written whole.
-//   * EPS_COVERS (eps >= 2^-126, launcher-side): one compare per test less on the fast path (geom.hpp).
-template <bool EPS_COVERS>
 __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(7, 7)))
 void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
                              const float *__restrict__ tv, int64_t T, float eps,
@@ -170,7 +168,7 @@ void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restri
             const V3 on = ld3(po), dn = ld3(pd);
             float t[4];
             uint32_t hh;
-            moller_trumbore_x4<EPS_COVERS>(o, d, tri, eps, t, hh);
+            moller_trumbore_x4(o, d, tri, eps, t, hh);
             if (active) store_nt_b128(trow, toff, f32x4{t[0], t[1], t[2], t[3]});
             lds_h[buf][s][threadIdx.x] = hh;
             trow += T * 4;
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
         const V3 d = ld3(rd + 3 * r);
         float t[4];
         uint32_t hh;
-        moller_trumbore_x4<false>(o, d, tri, eps, t, hh);
+        moller_trumbore_x4(o, d, tri, eps, t, hh);
         const int64_t base = r * T + j0;
         if (VEC) {
             f32x4 tt = {t[0], t[1], t[2], t[3]};
@@ -576,12 +574,9 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     // worth it only when a block walks few rays (configs[1]: 8.0 -> 7.4 us; at 32 rays per block the direct
     // loads hide behind the other blocks' arithmetic and staging costs 1 %: profiles/r02/literal_lab.txt)
     const int stage = (stage_ok && rpb <= kDenseGroup && (reinterpret_cast<uintptr_t>(tv) & 15) == 0) ? 1 : 0;
-    if (al16 && eps >= 0x1p-126f)
-        hipLaunchKernelGGL((mt_dense_aligned_kernel<true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
-                           eps, t_out, hit_out, (int)rpb, stage);
-    else if (al16)
-        hipLaunchKernelGGL((mt_dense_aligned_kernel<false>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
-                           eps, t_out, hit_out, (int)rpb, stage);
+    if (al16)
+        hipLaunchKernelGGL(mt_dense_aligned_kernel, grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T, eps,
+                           t_out, hit_out, (int)rpb, stage);
     else if (al4)
         hipLaunchKernelGGL((mt_dense_kernel<true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
                            eps, t_out, hit_out, (int)rpb);

@@ -46,6 +46,17 @@ __device__ __forceinline__ bool inside_one(const Mirrors<K, QUADS> &m, const V3 
     return h;
 }
 
+// wave-mask form (bit l = lane l of `want` passes), see moller_trumbore_wave
+template <int K, bool QUADS>
+__device__ __forceinline__ uint64_t inside_one_wave(const Mirrors<K, QUADS> &m, const V3 (&full)[K + 2], int j,
+                                                    float eps, uint64_t want) {
+    const V3 o = full[j];
+    const V3 d = full[j + 1] - full[j];
+    uint64_t h = moller_trumbore_wave(o, d, m.tri[j], eps, want);
+    if (QUADS) h |= moller_trumbore_wave(o, d, m.tri2[j], eps, want & ~h);  // SV:615-627 any over the pair
+    return h;
+}
+
 // ------------------------------------------------------------------------------------------
 // stage A
 // ------------------------------------------------------------------------------------------
@@ -71,6 +82,8 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
         load_candidate<K>(cs, in_range ? row : 0, id);
         load_mirrors<K, QUADS>(a, id, m);
         const bool cand_ok = in_range && m.ok;
+        // lanes that can survive at all, as a wave mask: the per-receiver tests below stay on the scalar unit
+        const uint64_t live_mask = __builtin_amdgcn_ballot_w64(cand_ok && m.active);
 
         for (int64_t it = it0; it < it1; ++it) {
             // txp / rxp are separate `const __restrict__` kernel arguments so that these wave-uniform
@@ -86,8 +99,15 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                     prev = img[j];
                 }
             }
-            for (int64_t ir = 0; ir < a.nrx; ++ir) {
-                const V3 rx = ld3(rxp + 3 * ir);
+            const float *prx = rxp;
+            V3 rx_next = ld3(prx);
+            const int nrx = (int)a.nrx;  // < 2^31 (checked by the launcher); 32-bit scalar loop control
+            for (int ir = 0; ir < nrx; ++ir) {
+                // the next receiver's scalar loads are in flight during this one's arithmetic (the last
+                // one is re-read)
+                const V3 rx = rx_next;
+                prx += (ir + 1 < nrx) ? 3 : 0;
+                rx_next = ld3(prx);
                 V3 full[K + 2];
                 full[0] = tx;
                 full[K + 1] = rx;
@@ -104,25 +124,30 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                         const V3 v = m.p[j] - cur;
                         const float un = dot(dir, m.n[j]);
                         const float vn = dot(v, m.n[j]);
-                        // |x| + |y| + |z| < inf: one compare instead of three; an overflowing sum of
-                        // finite components only sends the wave to the guarded form (same bits)
-                        const bool trouble = (un == 0.0f) ||
-                                             !(((__builtin_fabsf(cur.x) + __builtin_fabsf(cur.y)) +
-                                                __builtin_fabsf(cur.z)) < kInf);
-                        if (__builtin_expect(__any(trouble), 0)) {
+                        // Both guard cases leave a non-finite quotient: un == 0 gives +-inf or NaN; a
+                        // non-finite previous point makes BOTH differences to it, hence un and vn,
+                        // non-finite (a term +-inf * n_i is +-inf or NaN and nothing finite cancels it), and
+                        // inf / inf = NaN.  One compare of the speculative quotient covers them; a finite
+                        // overflow only sends the wave to the guarded form (same bits).
+                        const float t = vn / un;
+                        // (llvm.amdgcn.fcmp, predicate 4 = ordered less-than: a plain v_cmp whose lane mask
+                        // stays on the scalar unit; `fabs(t) < inf` as an expression becomes a class test
+                        // plus a v_cndmask / v_cmp pair to rebuild the mask)
+                        if (__builtin_expect(__builtin_amdgcn_fcmpf(__builtin_fabsf(t), kInf, 4) !=
+                                                 __builtin_amdgcn_read_exec(), 0)) {
                             cur = backward_step(cur, img[j], m.p[j], m.n[j]);
                         } else {
-                            const float t = vn / un;
                             cur = V3{cur.x + dir.x * t, cur.y + dir.y * t, cur.z + dir.z * t};
                         }
                         full[j + 1] = cur;
                     }
                 }
-                bool alive = cand_ok && m.active;
                 // most selective test first: the last reflection point lies in its triangle
-                if (K > 0) alive = alive && inside_one<K, QUADS>(m, full, K - 1, a.eps);
-                bool fin = true;
-                if (DENSE || __any(alive)) {
+                uint64_t alive_mask = live_mask;
+                if (K > 0) alive_mask = inside_one_wave<K, QUADS>(m, full, K - 1, a.eps, live_mask);
+                bool alive = false, fin = true;
+                if (DENSE || alive_mask != 0) {
+                    alive = (alive_mask >> lane) & 1ull;
                     fin = path_finite<K>(full);
                     alive = alive && fin;
 #pragma unroll
@@ -138,7 +163,7 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                         alive = alive && !(dot(d, d) < a.min_len);
                     }
                 }
-                const int64_t flat = (it * a.nrx + ir) * cs.count + row;
+                const int64_t flat = (it * a.nrx + (int64_t)ir) * cs.count + row;
                 if (DENSE && in_range) {
                     float *v = d_vertices + flat * 3 * (K + 2);
 #pragma unroll
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                     d_mask[flat] = (uint8_t)alive;  // stage B clears it when the path is blocked
                 }
                 // wave-level compaction of the survivors: one ballot + one atomic per wave
-                const unsigned long long vote = __ballot(alive);
+                const unsigned long long vote = (DENSE || alive_mask != 0) ? __ballot(alive) : 0ull;
                 if (vote) {
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(q_count, (unsigned long long)__popcll(vote));
@@ -689,6 +714,7 @@ int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *pr, const
                               size_t ws_bytes, void *stream) {
     DRT_REQUIRE(mesh && pr && cands, "null argument");
     DRT_REQUIRE(ntx >= 0 && nrx >= 0, "negative size");
+    DRT_REQUIRE(nrx < (1ll << 31), "too many receivers for one launch");
     Launch L;
     L.s = as_stream(stream);
     L.quads = mesh->assume_quads != 0;
@@ -738,6 +764,7 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
                                 size_t ws_bytes, void *stream) {
     DRT_REQUIRE(mesh && pr && cands && num_valid_host, "null argument");
     DRT_REQUIRE(ntx >= 0 && nrx >= 0 && max_survivors >= 0 && max_paths >= 0, "negative size");
+    DRT_REQUIRE(nrx < (1ll << 31), "too many receivers for one launch");
     *num_valid_host = 0;
     Launch L;
     L.s = as_stream(stream);
@@ -833,6 +860,7 @@ int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *p
                                       size_t ws_bytes, void *stream) {
     DRT_REQUIRE(mesh && pr && cands, "null argument");
     DRT_REQUIRE(ntx >= 0 && nrx >= 0 && max_survivors >= 0 && max_paths >= 0, "negative size");
+    DRT_REQUIRE(nrx < (1ll << 31), "too many receivers for one launch");
     DRT_REQUIRE(max_paths == 0 || (keys && vertices && objects), "null output");
     Launch L;
     L.s = as_stream(stream);

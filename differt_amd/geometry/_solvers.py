@@ -643,6 +643,21 @@ class HybridPathTracer(ExhaustivePathTracer):
         mesh = scene.mesh
         tx = scene.transmitters.reshape(-1, 3)
         rx = scene.receivers.reshape(-1, 3)
+        # num_path_candidates() followed by trace_rank_range() (e.g. trace_rank_range_sharded) would otherwise
+        # launch the visibility rays twice: memoise the last result on everything it depends on
+        # (end points by VALUE: a fresh tensor of an optimisation step may reuse the previous one's memory)
+        def key():
+            return (mesh._handle_key(), self.num_rays, self.accel, self.sample_triangles,
+                    tx.detach().cpu().numpy().tobytes(), rx.detach().cpu().numpy().tobytes())
+
+        cached = getattr(self, "_vis_cache", None)
+        if cached is not None and cached[0] == key():
+            return cached[1]
+        out = self._visible_sets_uncached(mesh, tx, rx)
+        self._vis_cache = (key(), out)  # after the call: the first query may move the mesh to the device
+        return out
+
+    def _visible_sets_uncached(self, mesh, tx, rx):
         vis_tx = mesh.triangles_visible_from_vertex(tx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles).any(dim=0)
         vis_rx = mesh.triangles_visible_from_vertex(rx, num_rays=self.num_rays, accel=self.accel, sample_triangles=self.sample_triangles).any(dim=0)
         if mesh.assume_quads:

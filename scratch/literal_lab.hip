@@ -63,7 +63,7 @@ void lab_kernel(const float *__restrict__ ro, const float *__restrict__ rd, int6
                 for (int q = 0; q < 4; ++q) t[q] = tri[q].v0.x + o.x + d.y + tri[q].e1.y + tri[q].e2.z;
                 hh = __float_as_uint(t[0]) & 0x01010101u;
             } else {
-                moller_trumbore_x4<true>(o, d, tri, eps, t, hh);
+                moller_trumbore_x4(o, d, tri, eps, t, hh);
             }
             if (!(MODE & 2)) {
                 if (active) store_nt_b128(trow, toff, f32x4{t[0], t[1], t[2], t[3]});

@@ -494,6 +494,22 @@ def test_hybrid_rank_range_empty_sets(G):
         assert p.objects.shape[0] == ref.objects.shape[0]
 
 
+def test_hybrid_visible_sets_memo_follows_the_end_points(G):
+    """num_path_candidates() + trace_rank_range() share one visibility estimate, keyed on the end
+    points BY VALUE: moving the transmitter in place must not return the stale sets."""
+    box = G.Mesh.box(2.0, 2.0, 2.0, with_top=True)
+    tx = torch.tensor([[5.0, 0.3, 0.1]], device="cuda")
+    rx = torch.tensor([[-5.0, 0.2, 0.3]], device="cuda")
+    solver = G.HybridPathTracer(num_rays=50_000)
+    scene = G.Scene(tx, rx, box)
+    a = solver._visible_sets(scene)
+    assert solver._visible_sets(scene) is a  # memo hit
+    first_a = a[0].cpu().tolist()
+    tx.copy_(torch.tensor([[0.3, 5.0, 0.1]], device="cuda"))  # same storage, new position
+    b = solver._visible_sets(scene)
+    assert b is not a and b[0].cpu().tolist() != first_a
+
+
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("assume_quads", [False, True])
 def test_hybrid_trace_pairs_equals_exhaustive(G, goldens, two_buildings, order, assume_quads):
