@@ -135,7 +135,10 @@ __device__ __forceinline__ bool moller_trumbore(V3 o, V3 d, const TriE &tr, floa
 // moller_trumbore(o, d, tr, eps) hits.  Same arithmetic; the masks of the single compares meet on the
 // scalar unit, and <q, e2> / the `t > eps` test are evaluated only when some wanted lane passes the
 // barycentric tests (wave-uniform branch; a rejected candidate's t is never used).
-__device__ __forceinline__ uint64_t moller_trumbore_wave(V3 o, V3 d, const TriE &tr, float eps, uint64_t want) {
+// WANT_T: also return t in `t_out`, meaningful for the lanes of a NON-ZERO result only.
+template <bool WANT_T = false>
+__device__ __forceinline__ uint64_t moller_trumbore_wave(V3 o, V3 d, const TriE &tr, float eps, uint64_t want,
+                                                         float *t_out = nullptr) {
     const V3 h = cross(d, tr.e2);
     const float a0 = dot(h, tr.e1);
     const V3 s = o - tr.v0;
@@ -156,6 +159,7 @@ __device__ __forceinline__ uint64_t moller_trumbore_wave(V3 o, V3 d, const TriE 
                            __builtin_amdgcn_ballot_w64(upv <= 1.0f) & want;
         if (__builtin_expect(m == 0, 1)) return 0;
         const float t = f * dot(q, tr.e2);
+        if (WANT_T) *t_out = t;
         return m & __builtin_amdgcn_ballot_w64(t > eps);
     }
     const float pt = dot(q, tr.e2);
@@ -169,6 +173,7 @@ __device__ __forceinline__ uint64_t moller_trumbore_wave(V3 o, V3 d, const TriE 
     hit = hit && (v >= 0.0f) && (upv <= 1.0f);
     const float t = f * pt;
     hit = hit && (t > eps);
+    if (WANT_T) *t_out = t;
     return __builtin_amdgcn_ballot_w64(hit) & want;
 }
 

@@ -265,22 +265,31 @@ __global__ __launch_bounds__(kQueryThreads) void any_hit_shared_kernel(
     __shared__ TriRec lds[kTile];
     const int64_t r = (int64_t)blockIdx.x * kQueryThreads + threadIdx.x;
     const bool valid = r < R;
-    const V3 o = valid ? ld3(ro + 3 * r) : V3{0, 0, 0};
-    const V3 d = valid ? ld3(rd + 3 * r) : V3{0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    // idle lanes of the last wave repeat the last ray (a zero ray would push the whole wave off
+    // Moller-Trumbore's fast path); they are never in `want`
+    const int64_t rr = valid ? r : R - 1;
+    const V3 o = ld3(ro + 3 * rr);
+    const V3 d = ld3(rd + 3 * rr);
     const int64_t begin = (int64_t)blockIdx.y * tri_per_split;
     const int64_t end = (begin + tri_per_split < T) ? begin + tri_per_split : T;
-    bool any = !valid;  // idle lanes count as "done" for the wave-level early exit
+    bool any = false;
+    uint64_t want = __builtin_amdgcn_ballot_w64(valid);  // rays of this wave still unblocked
     for (int64_t base = begin; base < end; base += kTile) {
         __syncthreads();
         stage_tile(lds, tv, active, base, end);
         __syncthreads();
-        if (__all(any)) continue;  // wave-uniform: every ray of this wave is already blocked
+        if (want == 0) continue;  // wave-uniform: every ray of this wave is already blocked
         const int n = (int)((end - base < kTile) ? end - base : kTile);
         for (int j = 0; j < n; ++j) {
             const TriRec rec = lds[j];  // broadcast read
             float t;
-            bool h = moller_trumbore(o, d, rec_tri(rec), eps, t);
-            any = any || (h && (t < thr) && rec.active);
+            const uint64_t m = moller_trumbore_wave<true>(o, d, rec_tri(rec), eps, want, &t);
+            if (m != 0) {  // rare, wave-uniform: the distance / activity tests and the update of `want`
+                asm volatile("" ::: "memory");  // keep this a scalar branch (not folded into a lane mask)
+                any = any || (((m >> lane) & 1ull) && (t < thr) && rec.active);
+                want &= ~__builtin_amdgcn_ballot_w64(any);
+            }
         }
     }
     if (valid && any) out[r] = 1;
@@ -305,10 +314,13 @@ __global__ __launch_bounds__(kQueryThreads) void first_hit_shared_kernel(
     __shared__ TriRec lds[kTile];
     const int64_t r = (int64_t)blockIdx.x * kQueryThreads + threadIdx.x;
     const bool valid = r < R;
-    const V3 o = valid ? ld3(ro + 3 * r) : V3{0, 0, 0};
-    const V3 d = valid ? ld3(rd + 3 * r) : V3{0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    const int64_t rr = valid ? r : R - 1;  // idle lanes repeat the last ray (see any_hit_shared_kernel)
+    const V3 o = ld3(ro + 3 * rr);
+    const V3 d = ld3(rd + 3 * rr);
     const int64_t begin = (int64_t)blockIdx.y * tri_per_split;
     const int64_t end = (begin + tri_per_split < T) ? begin + tri_per_split : T;
+    const uint64_t want = __builtin_amdgcn_ballot_w64(valid);
     uint64_t best = ~0ull;
     for (int64_t base = begin; base < end; base += kTile) {
         __syncthreads();
@@ -318,11 +330,15 @@ __global__ __launch_bounds__(kQueryThreads) void first_hit_shared_kernel(
         for (int j = 0; j < n; ++j) {
             const TriRec rec = lds[j];
             float t;
-            bool h = moller_trumbore(o, d, rec_tri(rec), eps, t);
-            // a hit with t == +inf is treated as a miss by the reference (isinf/isfinite fix-ups)
-            if (h && rec.active && is_finite(t)) {
-                uint64_t k = first_hit_key(t, index_offset + base + j, tt);
-                best = (k < best) ? k : best;
+            const uint64_t m = moller_trumbore_wave<true>(o, d, rec_tri(rec), eps, want, &t);
+            // rare, wave-uniform: key construction only when some ray of the wave hits this triangle.
+            // A hit with t == +inf is treated as a miss by the reference (isinf/isfinite fix-ups)
+            if (m != 0) {
+                asm volatile("" ::: "memory");  // keep this a scalar branch (not folded into a lane mask)
+                if (((m >> lane) & 1ull) && rec.active && is_finite(t)) {
+                    uint64_t k = first_hit_key(t, index_offset + base + j, tt);
+                    best = (k < best) ? k : best;
+                }
             }
         }
     }
