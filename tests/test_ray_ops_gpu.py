@@ -77,10 +77,9 @@ def test_dense_unaligned_triangle_pointer(G, rng):
 
 @pytest.mark.parametrize("epsilon", [0.0, 1e-40, 1.1754944e-38, 1e-3, 0.5])
 def test_dense_epsilon_range(G, rng, epsilon):
-    """The aligned kernel has an `eps >= 2^-126` instantiation whose fast path drops the per-test
-    `|a| > eps` compare (min|a| > eps is demanded of the whole wave instead) and a general one:
-    both sides of the 2^-126 threshold, and epsilons large enough that waves mix determinants
-    above and below them, stay bit-exact."""
+    """The fast path folds the reference's `|a| > eps` into its range check (every |a| of the wave must
+    exceed max(eps, largest denormal), geom.hpp `mt_fast_threshold`): both sides of the 2^-126 threshold, and
+    epsilons large enough that waves mix determinants above and below them, stay bit-exact."""
     R, T = 48, 2048
     tv = rng.normal(size=(T, 3, 3)).astype(np.float32) * 3
     cen = tv.mean(axis=1)
