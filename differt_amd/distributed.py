@@ -9,6 +9,8 @@ the mesh (a few MB) is replicated, and NO collective runs during compute.  The e
                            sort of the (few) valid paths by their global flat key: the result is the
                            single-GPU order of ``TracedPaths.masked_vertices`` on every rank;
 * ``allreduce_grads``   -- one SUM all-reduce of the [N_tx,3] (+[N_rx,3], +[N_v,3]) gradients;
+* ``trace_beam_pruned_sharded`` -- the conservatively pruned full-coverage search, split by
+                           (transmitter, first mirror) prefix; same epilogue;
 * ``reduce_first_hit``  -- triangle-block sharding (BASELINE configs[4]): every rank holds a block
                            of triangles and produces packed ``(t, tie)`` 64-bit keys for the same
                            rays; a MIN all-reduce picks the global first hit with the reference's
@@ -30,6 +32,7 @@ __all__ = [
     "reduce_first_hit",
     "shard_interval",
     "trace_rank_range_sharded",
+    "trace_beam_pruned_sharded",
 ]
 
 
@@ -176,6 +179,21 @@ def trace_rank_range_sharded(tracer, scene, order: int, rank_lo: int = 0, rank_h
     if not gather or world == 1:
         return keys, local.vertices, local.objects
     return gather_paths(keys, local.vertices.detach(), local.objects, group=group)
+
+
+def trace_beam_pruned_sharded(tracer, scene, order: int, group=None, gather: bool = True, **kwargs):
+    """Prefix sharding of ``ExhaustivePathTracer.trace_beam_pruned`` (full coverage of the candidate space
+    with the guarantee of DESIGN.md section 9): rank r expands every world-th (transmitter, first mirror)
+    prefix starting at r against its replica of the mesh -- no collective during compute; the epilogue is the
+    one of the exhaustive sharding (``gather_paths``: keys are already global).  Returns ``(keys, vertices,
+    objects)``: gathered and sorted (= the single-GPU result, bit for bit) on every rank when ``gather``,
+    else this rank's part with ``vertices`` attached to autograd (call ``allreduce_grads`` after
+    ``backward``)."""
+    world, rank = _world(group)
+    local = tracer.trace_beam_pruned(scene, order, prefix_shard=(rank, world) if world > 1 else None, **kwargs)
+    if not gather or world == 1:
+        return local.keys, local.vertices, local.objects
+    return gather_paths(local.keys, local.vertices.detach(), local.objects, group=group)
 
 
 def first_triangle_hit_by_ray_sharded(ray_origins, ray_directions, triangle_vertices_block,

@@ -420,7 +420,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
     def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.25, kappa: float = 8.0,
                           expansion: str = "auto", chunk_entries: int = 1 << 12, max_entries: int = 1 << 28,
                           max_rows: int = 1 << 27,
-                          max_survivors: int = 1 << 22, max_paths: int = 1 << 16) -> TracedPaths:
+                          max_survivors: int = 1 << 22, max_paths: int = 1 << 16,
+                          prefix_shard: tuple[int, int] | None = None) -> TracedPaths:
         """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
         enumeration _solvers.py:803-848 and the SAMPLED pruning of the hybrid tracer :1013-1056).
 
@@ -433,7 +434,13 @@ class ExhaustivePathTracer(AbstractPathTracer):
         (DESIGN.md section 9).  Survivors are traced by the ordinary kernels, so valid paths, their order
         (``masked_vertices`` order of the exhaustive tracer) and vertex bits are those of
         :meth:`trace_rank_range` over the full space; ``keys`` are ``(tx*num_rx + rx) * n**order +
-        sum_j m_j * n**(order-1-j)`` (``n`` primitives, ``m_j`` primitive ids).  Orders 1..3."""
+        sum_j m_j * n**(order-1-j)`` (``n`` primitives, ``m_j`` primitive ids).  Orders 1..3.
+
+        ``prefix_shard=(rank, world)`` keeps every ``world``-th level-1 prefix (transmitter, first mirror)
+        starting at ``rank``: the multi-GPU split of ``differt_amd.distributed.trace_beam_pruned_sharded``
+        -- every valid path has exactly one level-1 prefix, so the shards' results partition the full
+        result (strided rather than blocked: consecutive primitives are spatial neighbours with similar
+        fan-out)."""
         if self.smoothing_factor is not None:
             raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
         if order == 0:
@@ -475,6 +482,14 @@ class ExhaustivePathTracer(AbstractPathTracer):
         lvl = entries(ntx * n)
         _lib.call("drt_beam_seed", h, ptr(txd), ntx, margin, ptr(lvl), ntx * n, ptr(count), stream())
         cur, ncur = lvl, int(count.item())
+        if prefix_shard is not None:
+            srank, sworld = int(prefix_shard[0]), int(prefix_shard[1])
+            if sworld <= 0 or not 0 <= srank < sworld:
+                raise ValueError("prefix_shard = (rank, world) with 0 <= rank < world")
+            cur = cur[:ncur][srank::sworld].contiguous()
+            ncur = int(cur.shape[0])
+            if ncur == 0:
+                cur = entries(1)
         stats["levels"].append(ncur)
 
         def expand(src, nsrc, level, out, cap):

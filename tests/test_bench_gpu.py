@@ -49,6 +49,10 @@ def _check_strong(sc: dict, world: int):
     assert "error" not in cs and "error" not in tb, sc
     assert cs["path_candidates_per_s"] > 0 and cs["valid_paths"] > 0 and cs["keys_sorted"] and cs["grad_tx_finite"]
     assert tb["rays_per_s"] > 0 and 0 < tb["hit_fraction"] <= 1
+    bs = sc["beam_sharded"]
+    assert "error" not in bs, sc
+    # the window of the candidate-sharded leg is the WHOLE space on this small city: same valid paths
+    assert bs["valid_paths"] == cs["valid_paths"] and bs["grad_tx_finite"] and bs["s_per_step"] > 0
     if world > 1:
         assert sc["ranks_seen_by_backend"] == world
 
@@ -71,4 +75,8 @@ def test_two_ranks_share_gpu():
         assert two["candidate_sharded"]["path_candidates_per_step"] == one["candidate_sharded"]["path_candidates_per_step"]
         assert two["triangle_block"]["checksum_idx"] == one["triangle_block"]["checksum_idx"]
         g1, g2 = one["candidate_sharded"]["grad_tx_absmax"], two["candidate_sharded"]["grad_tx_absmax"]
+        assert abs(g1 - g2) <= 1e-5 * max(abs(g1), 1e-30)
+        assert two["beam_sharded"]["valid_paths"] == one["beam_sharded"]["valid_paths"]
+        assert two["beam_sharded"]["checksum_keys"] == one["beam_sharded"]["checksum_keys"]
+        g1, g2 = one["beam_sharded"]["grad_tx_absmax"], two["beam_sharded"]["grad_tx_absmax"]
         assert abs(g1 - g2) <= 1e-5 * max(abs(g1), 1e-30)

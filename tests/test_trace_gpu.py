@@ -494,6 +494,32 @@ def test_hybrid_rank_range_empty_sets(G):
         assert p.objects.shape[0] == ref.objects.shape[0]
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("world", [2, 5])
+def test_beam_pruned_prefix_shards_partition_the_result(G, order, world):
+    """Multi-GPU split of the beam-pruned tracer (distributed.trace_beam_pruned_sharded), emulated on one GPU:
+    the shards' valid paths are disjoint and their key-sorted union is the unsharded result bit for bit."""
+    import synthetic_scenes as S
+
+    V, Tr, c, h = S.manhattan(24, pitch=30.0, seed=5)
+    tx, rx = S.manhattan_tx_rx(c, h, 3, 6, seed=6, pitch=30.0)
+    mesh = G.Mesh(V, Tr)
+    scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(rx, device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    full = tracer.trace_beam_pruned(scene, order)
+    parts = [tracer.trace_beam_pruned(scene, order, prefix_shard=(r, world)) for r in range(world)]
+    keys = torch.cat([p.keys for p in parts])
+    assert keys.shape[0] == full.keys.shape[0] and torch.unique(keys).shape[0] == keys.shape[0]
+    perm = torch.argsort(keys)
+    assert torch.equal(keys[perm], full.keys)
+    assert torch.equal(torch.cat([p.objects for p in parts])[perm], full.objects)
+    assert torch.equal(torch.cat([p.vertices for p in parts])[perm].view(torch.int32), full.vertices.view(torch.int32))
+    if order == 2:
+        assert full.keys.shape[0] > 0
+    with pytest.raises(ValueError):
+        tracer.trace_beam_pruned(scene, order, prefix_shard=(world, world))
+
+
 def test_hybrid_visible_sets_memo_follows_the_end_points(G):
     """num_path_candidates() + trace_rank_range() share one visibility estimate, keyed on the end
     points BY VALUE: moving the transmitter in place must not return the stale sets."""
