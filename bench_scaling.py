@@ -199,7 +199,7 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
         st = getattr(btracer, "last_beam_stats", {})
         out["beam_sharded"] = {
             "coverage": f"all {total} candidates of each of the {rx.shape[0]} pairs ({int(rx.shape[0]) * total:.3e} "
-                        f"path candidates), level-1 prefixes dealt round-robin to the ranks",
+                        f"path candidates), level-1 prefix (t, m) on rank (t n + m) mod N",
             "s_per_step": dt,
             "valid_paths": int(gk.shape[0]),
             "valid_paths_per_s": int(gk.shape[0]) / dt,

@@ -183,8 +183,8 @@ def trace_rank_range_sharded(tracer, scene, order: int, rank_lo: int = 0, rank_h
 
 def trace_beam_pruned_sharded(tracer, scene, order: int, group=None, gather: bool = True, **kwargs):
     """Prefix sharding of ``ExhaustivePathTracer.trace_beam_pruned`` (full coverage of the candidate space
-    with the guarantee of DESIGN.md section 9): rank r expands every world-th (transmitter, first mirror)
-    prefix starting at r against its replica of the mesh -- no collective during compute; the epilogue is the
+    with the guarantee of DESIGN.md section 9): rank r expands the (transmitter t, first mirror m) prefixes
+    with (t * n + m) % world == r against its replica of the mesh -- no collective during compute; the epilogue is the
     one of the exhaustive sharding (``gather_paths``: keys are already global).  Returns ``(keys, vertices,
     objects)``: gathered and sorted (= the single-GPU result, bit for bit) on every rank when ``gather``,
     else this rank's part with ``vertices`` attached to autograd (call ``allreduce_grads`` after

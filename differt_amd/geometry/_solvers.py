@@ -436,8 +436,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
         :meth:`trace_rank_range` over the full space; ``keys`` are ``(tx*num_rx + rx) * n**order +
         sum_j m_j * n**(order-1-j)`` (``n`` primitives, ``m_j`` primitive ids).  Orders 1..3.
 
-        ``prefix_shard=(rank, world)`` keeps every ``world``-th level-1 prefix (transmitter, first mirror)
-        starting at ``rank``: the multi-GPU split of ``differt_amd.distributed.trace_beam_pruned_sharded``
+        ``prefix_shard=(rank, world)`` keeps the level-1 prefixes (transmitter ``t``, first mirror ``m``) with
+        ``(t * n + m) % world == rank``: the multi-GPU split of ``differt_amd.distributed.trace_beam_pruned_sharded``
         -- every valid path has exactly one level-1 prefix, so the shards' results partition the full
         result (strided rather than blocked: consecutive primitives are spatial neighbours with similar
         fan-out)."""
@@ -486,7 +486,11 @@ class ExhaustivePathTracer(AbstractPathTracer):
             srank, sworld = int(prefix_shard[0]), int(prefix_shard[1])
             if sworld <= 0 or not 0 <= srank < sworld:
                 raise ValueError("prefix_shard = (rank, world) with 0 <= rank < world")
-            cur = cur[:ncur][srank::sworld].contiguous()
+            # by CONTENT (transmitter * n + first primitive), not by position: the seed kernel compacts with
+            # atomics, so the order of the list differs from call to call and from rank to rank
+            lvl1 = cur[:ncur]
+            owner = (lvl1[:, 0].to(torch.int64) * n + lvl1[:, 1].to(torch.int64)) % sworld
+            cur = lvl1[owner == srank].contiguous()
             ncur = int(cur.shape[0])
             if ncur == 0:
                 cur = entries(1)
