@@ -815,6 +815,178 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     }
 }
 
+// beam_emit for MANY receivers (configs[4]: 1024): the receivers arrive sorted along a Morton curve in
+// clusters of 64 with an axis-aligned bounding box each (a receiver grid is flat: a ball would be a poor
+// bound).  lane = prefix as above, but a lane first tests each cluster's box against its pyramids / mirror
+// plane (the same inequalities with the box's extent along the face normal added, so a
+// culled cluster holds no receiver the per-receiver test would keep), and only the (prefix, cluster) pairs
+// that survive are tested per receiver -- TRANSPOSED: the prefix's data is broadcast from LDS and lane =
+// receiver of the cluster, so those tests run with full lanes instead of once per wave-any.  Same per-receiver
+// arithmetic as beam_emit_kernel -> the same set of rows (measured on configs[4]: emit 551 -> see
+// profiles/r02/beam.md).
+template <int SCALE>
+struct alignas(16) BeamEmitD {
+    float I[3];
+    int32_t side_prev;
+    float pc[3];
+    int32_t tx;
+    float nc[3];
+    int32_t pad;
+    long long tail;
+    float inv_h[3][SCALE];
+    float pyr[3][SCALE][9];
+};
+
+template <int SCALE>
+__global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
+    BeamMesh M, const BeamEntry *__restrict__ in, const unsigned long long *__restrict__ rec, int64_t n_in, int order,
+    const float *__restrict__ rx_sorted, const int32_t *__restrict__ rx_index, const float *__restrict__ boxes,
+    int64_t nrx, float E, long long *__restrict__ rows, int64_t cap, unsigned long long *__restrict__ count) {
+    __shared__ BeamEmitD<SCALE> lds[128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    const bool have = g < n_in;
+    BeamEntry e{};
+    if (have) {
+        if (rec) {
+            const unsigned long long r = rec[g];
+            e = beam_child(M, in[r >> 32], order - 1, (int32_t)(uint32_t)r, E);
+        } else {
+            e = in[g];
+        }
+    }
+    const int32_t c = have ? e.id[order - 1] : 0;
+    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    V3 pc{0, 0, 0}, nc{0, 0, 1};
+    Pyramid pyr[3][SCALE];
+    float inv_h[3][SCALE];
+    long long tail = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            pyr[j][t] = Pyramid{};
+            inv_h[j][t] = kInf;
+        }
+    if (have) {
+        prim_plane(M, c, pc, nc);
+        for (int j = 0; j < order; ++j) {
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t)
+                pyr[j][t] = unfolded_pyramid(M, I, e.id[j], t, &e.id[j + 1], order - 1 - j, inv_h[j][t]);
+            tail = tail * (long long)M.nprim + (long long)e.id[j];
+        }
+    }
+    {  // this lane's data, for the transposed per-receiver tests (read back by its own wave only)
+        BeamEmitD<SCALE> &d = lds[threadIdx.x];
+        d.I[0] = I.x; d.I[1] = I.y; d.I[2] = I.z;
+        d.pc[0] = pc.x; d.pc[1] = pc.y; d.pc[2] = pc.z;
+        d.nc[0] = nc.x; d.nc[1] = nc.y; d.nc[2] = nc.z;
+        d.side_prev = e.side_prev;
+        d.tx = e.tx;
+        d.pad = 0;
+        d.tail = tail;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) {
+                d.inv_h[j][t] = inv_h[j][t];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    d.pyr[j][t][3 * f] = pyr[j][t].n[f].x;
+                    d.pyr[j][t][3 * f + 1] = pyr[j][t].n[f].y;
+                    d.pyr[j][t][3 * f + 2] = pyr[j][t].n[f].z;
+                }
+            }
+    }
+    __syncthreads();
+    long long npow = 1;
+    for (int j = 0; j < order; ++j) npow *= (long long)M.nprim;
+    const int64_t nclusters = (nrx + 63) / 64;
+    for (int64_t cl = 0; cl < nclusters; ++cl) {
+        // ---- per lane (= prefix): can ANY receiver of the cluster pass?  box (centre, half extents), wave-uniform ----
+        const V3 sc = ld3(boxes + 6 * cl);
+        // half extents, generously padded (rounding of the box and of the tests below)
+        const V3 hx = V3{boxes[6 * cl + 3] * 1.0001f + E, boxes[6 * cl + 4] * 1.0001f + E, boxes[6 * cl + 5] * 1.0001f + E};
+        bool maybe = have;
+        {
+            const V3 w = sc - I;
+            // >= |r - I| for every receiver r of the cluster
+            const float wl = __builtin_sqrtf(dot(w, w)) + __builtin_sqrtf(dot(hx, hx));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j < order) {
+                    bool sep_all = true;
+#pragma unroll
+                    for (int t = 0; t < SCALE; ++t) {
+                        const float thr = -(E + E * (wl * inv_h[j][t]));
+                        bool sep = false;
+#pragma unroll
+                        for (int f = 0; f < 3; ++f) {
+                            const V3 nf = pyr[j][t].n[f];  // max over the box of <x - I, n> = <c - I, n> + <|n|, h>
+                            const float ext = (__builtin_fabsf(nf.x) * hx.x + __builtin_fabsf(nf.y) * hx.y) + __builtin_fabsf(nf.z) * hx.z;
+                            sep = sep || (dot(w, nf) + ext < thr);
+                        }
+                        sep_all = sep_all && sep;
+                    }
+                    maybe = maybe && !sep_all;
+                }
+            }
+            const float dc = dot(sc - pc, nc);
+            const float de = (__builtin_fabsf(nc.x) * hx.x + __builtin_fabsf(nc.y) * hx.y) + __builtin_fabsf(nc.z) * hx.z;
+            const int sb = (dc == dc) ? side_of_range(dc - de, dc + de, 4.0f * E) : 0;
+            maybe = maybe && !(e.side_prev * sb == -1);
+        }
+        unsigned long long todo = __ballot(maybe);
+        if (todo == 0) continue;
+        // ---- transposed: lane = receiver of the cluster, prefix broadcast from LDS ----
+        const int64_t pos = cl * 64 + lane;
+        const bool have_r = pos < nrx;
+        const V3 r = have_r ? ld3(rx_sorted + 3 * pos) : V3{0, 0, 0};
+        const long long ir = have_r ? (long long)rx_index[pos] : 0;
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const BeamEmitD<SCALE> &d = lds[wave * 64 + l];  // wave-uniform address: broadcast reads
+            const V3 dI = V3{d.I[0], d.I[1], d.I[2]};
+            const float dd = dot(r - V3{d.pc[0], d.pc[1], d.pc[2]}, V3{d.nc[0], d.nc[1], d.nc[2]});
+            const int side_r = (dd == dd) ? side_of_range(dd, dd, 4.0f * E) : 0;
+            const V3 w = r - dI;
+            const float wl = __builtin_sqrtf(dot(w, w));
+            bool inside_all = true;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j < order) {
+                    bool inside_any = false;
+#pragma unroll
+                    for (int t = 0; t < SCALE; ++t) {
+                        const float thr = -(E + E * (wl * d.inv_h[j][t]));
+                        bool inside = true;
+#pragma unroll
+                        for (int f = 0; f < 3; ++f)
+                            inside = inside && !(dot(w, V3{d.pyr[j][t][3 * f], d.pyr[j][t][3 * f + 1], d.pyr[j][t][3 * f + 2]}) < thr);
+                        inside_any = inside_any || inside;
+                    }
+                    inside_all = inside_all && inside_any;
+                }
+            }
+            const bool keep = have_r && inside_all && !(d.side_prev * side_r == -1);
+            const unsigned long long vote = __ballot(keep);
+            if (vote) {
+                unsigned long long b0 = 0;
+                const int leader = __builtin_ctzll(vote);
+                if (lane == leader) b0 = atomicAdd(count, (unsigned long long)__popcll(vote));
+                b0 = __shfl(b0, leader, 64);
+                if (keep) {
+                    const unsigned long long slot = b0 + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
+                    if ((int64_t)slot < cap) rows[slot] = ((long long)d.tx * (long long)nrx + ir) * npow + d.tail;
+                }
+            }
+        }
+    }
+}
+
 static BeamMesh beam_mesh(drt_mesh_t m) {
     BeamMesh M;
     M.tv = m->tri_verts;
@@ -956,6 +1128,36 @@ int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t 
         hipLaunchKernelGGL(beam_emit_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
                            reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx, nrx, margin,
                            reinterpret_cast<long long *>(rows_out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev));
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_beam_emit_clustered(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t n_in,
+                                int32_t order, const float *rx_sorted, const int32_t *rx_index, const float *boxes,
+                                int64_t nrx, int64_t ntx, float margin, int64_t *rows_out, int64_t capacity,
+                                int64_t *count_dev, void *stream) {
+    DRT_REQUIRE(mesh && count_dev, "null argument");
+    DRT_REQUIRE(n_in >= 0 && nrx >= 0 && ntx >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
+    DRT_REQUIRE(order >= 1 && order <= 3, "beam pruning covers orders 1..3");
+    const BeamMesh M = beam_mesh(mesh);
+    unsigned __int128 total = (unsigned __int128)(ntx > 0 ? ntx : 1) * (unsigned __int128)(nrx > 0 ? nrx : 1);
+    for (int j = 0; j < order; ++j) total *= (unsigned __int128)(M.nprim > 0 ? M.nprim : 1);
+    DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx * rx * primitives^order does not fit a 62-bit row key");
+    if (n_in == 0 || nrx == 0) return DRT_OK;
+    DRT_REQUIRE(in && rx_sorted && rx_index && boxes && (rows_out || capacity == 0), "null pointer");
+    DRT_REQUIRE(!records || order >= 2, "records address level order-1 prefixes: order >= 2");
+    const dim3 grid((unsigned)ceil_div(n_in, 128));
+    const auto *rec = reinterpret_cast<const unsigned long long *>(records);
+    if (M.scale == 2)
+        hipLaunchKernelGGL(beam_emit_clustered_kernel<2>, grid, dim3(128), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx_sorted, rx_index, boxes,
+                           nrx, margin, reinterpret_cast<long long *>(rows_out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev));
+    else
+        hipLaunchKernelGGL(beam_emit_clustered_kernel<1>, grid, dim3(128), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx_sorted, rx_index, boxes,
+                           nrx, margin, reinterpret_cast<long long *>(rows_out), capacity,
                            reinterpret_cast<unsigned long long *>(count_dev));
     DRT_LAUNCH_CHECK();
     return DRT_OK;

@@ -281,6 +281,44 @@ class AbstractPathTracer:
         return self.trace_path_candidates(scene, cands, types)
 
 
+def _receiver_clusters(rx: torch.Tensor, size: int = 64):
+    """Receivers sorted along a 30-bit Morton curve, cut into clusters of ``size`` consecutive ones:
+    ``(rx_sorted [R,3] f32, rx_index [R] i32, boxes [ceil(R/size),6] f32 = centre + half extents)`` for
+    ``drt_beam_emit_clustered`` (axis-aligned boxes: a receiver grid is flat)."""
+    R = rx.shape[0]
+    r64 = rx.detach().to(torch.float64)
+    lo = r64.min(dim=0).values
+    span = (r64.max(dim=0).values - lo).max().clamp_min(1e-30)  # one scale for all axes: a flat grid clusters in its plane
+    q = ((r64 - lo) / span * 1023.0).to(torch.int64).clamp_(0, 1023)
+
+    def spread(v):  # 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    perm = torch.argsort(code, stable=True)
+    rs = rx.detach()[perm].contiguous()
+    ncl = (R + size - 1) // size
+    pad = ncl * size - R
+    p64 = r64[perm]
+    valid = torch.ones(R, dtype=torch.bool, device=rx.device)
+    if pad:
+        p64 = torch.cat([p64, p64[-1:].expand(pad, 3)])
+        valid = torch.cat([valid, torch.zeros(pad, dtype=torch.bool, device=rx.device)])
+    g = p64.reshape(ncl, size, 3)
+    lo_c, hi_c = g.min(dim=1).values, g.max(dim=1).values
+    centre = 0.5 * (lo_c + hi_c)
+    c32 = centre.to(torch.float32)
+    # half extents around the float32 centre, rounded up
+    half = torch.maximum(hi_c - c32.to(torch.float64), c32.to(torch.float64) - lo_c)
+    h32 = torch.nextafter(half.to(torch.float32), torch.full_like(half, float("inf"), dtype=torch.float32))
+    boxes = torch.cat([c32, h32], dim=1).contiguous()
+    return rs, perm.to(torch.int32).contiguous(), boxes
+
+
 @dataclass
 class ExhaustivePathTracer(AbstractPathTracer):
     """Exhaustive image-method tracer (reference _solvers.py:778-957), same fields and defaults."""
@@ -421,7 +459,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
                           expansion: str = "auto", chunk_entries: int = 1 << 12, max_entries: int = 1 << 28,
                           max_rows: int = 1 << 27,
                           max_survivors: int = 1 << 22, max_paths: int = 1 << 16,
-                          prefix_shard: tuple[int, int] | None = None) -> TracedPaths:
+                          prefix_shard: tuple[int, int] | None = None, emit: str = "auto") -> TracedPaths:
         """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
         enumeration _solvers.py:803-848 and the SAMPLED pruning of the hybrid tracer :1013-1056).
 
@@ -435,6 +473,11 @@ class ExhaustivePathTracer(AbstractPathTracer):
         (``masked_vertices`` order of the exhaustive tracer) and vertex bits are those of
         :meth:`trace_rank_range` over the full space; ``keys`` are ``(tx*num_rx + rx) * n**order +
         sum_j m_j * n**(order-1-j)`` (``n`` primitives, ``m_j`` primitive ids).  Orders 1..3.
+
+        ``emit``: ``"plain"`` (every prefix loops over every receiver), ``"clustered"`` (receivers sorted along
+        a Morton curve in clusters of 64 with bounding boxes; a prefix skips the clusters its pyramids
+        cannot reach and tests the others with lane = receiver) or ``"auto"`` (clustered from 128 receivers
+        on); the same rows either way.
 
         ``prefix_shard=(rank, world)`` keeps the level-1 prefixes (transmitter ``t``, first mirror ``m``) with
         ``(t * n + m) % world == rank``: the multi-GPU split of ``differt_amd.distributed.trace_beam_pruned_sharded``
@@ -527,12 +570,20 @@ class ExhaustivePathTracer(AbstractPathTracer):
         npow = n ** order
         parts = []
         rows_buf = torch.empty(max_rows, dtype=torch.int64, device=dev)
+        if emit not in ("auto", "plain", "clustered"):
+            raise ValueError(f"unknown emit {emit!r}")
+        clusters = _receiver_clusters(rxd) if (emit == "clustered" or (emit == "auto" and nrx >= 128)) else None
 
         def process(src, rec, nsrc):
             """prefixes (+ records of the last expansion) -> rows -> trace; False when `max_rows` was too small."""
             count.zero_()
-            _lib.call("drt_beam_emit", h, ptr(src), ptr(rec), nsrc, order, ptr(rxd), nrx, ntx, margin, ptr(rows_buf),
-                      max_rows, ptr(count), stream())
+            if clusters is None:
+                _lib.call("drt_beam_emit", h, ptr(src), ptr(rec), nsrc, order, ptr(rxd), nrx, ntx, margin, ptr(rows_buf),
+                          max_rows, ptr(count), stream())
+            else:
+                _lib.call("drt_beam_emit_clustered", h, ptr(src), ptr(rec), nsrc, order, ptr(clusters[0]),
+                          ptr(clusters[1]), ptr(clusters[2]), nrx, ntx, margin, ptr(rows_buf), max_rows, ptr(count),
+                          stream())
             r = int(count.item())
             if r > max_rows:
                 return False

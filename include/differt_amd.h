@@ -462,7 +462,8 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
  *                    1 = walk of the mesh LBVH with the box form of the tests (with assume_quads a
  *                    record may repeat -- de-duplicate the sorted rows); 2 = lane per prefix, brute force
  *   drt_beam_finish  records -> level + 1 prefixes (needed between two expansions)
- *   drt_beam_emit    prefixes x receivers -> packed candidate rows
+ *   drt_beam_emit    prefixes x receivers -> packed candidate rows (drt_beam_emit_clustered: the same
+ *                    for many receivers, with cluster-level culling)
  *                    ((tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j)), n = primitives;
  *                    records == NULL: `in` holds level-`order` prefixes (order 1: straight from the
  *                    seed); else `in` holds level-(order-1) prefixes and `records` the last expansion
@@ -486,6 +487,16 @@ int32_t drt_beam_finish(drt_mesh_t mesh, const drt_beam_entry *src, const uint64
 int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t num_in,
                       int32_t order, const float *rx, int64_t num_rx, int64_t num_tx, float margin,
                       int64_t *rows_out, int64_t capacity, int64_t *count_dev, void *stream);
+/* drt_beam_emit for many receivers: `rx_sorted` [num_rx,3] are the receivers in an order that makes 64
+ * consecutive ones spatially compact (e.g. a Morton curve), `rx_index` [num_rx] their indices in the scene's
+ * receiver array (what the rows encode), `boxes` [ceil(num_rx / 64), 6] = (centre, half extents) of an
+ * axis-aligned box around each cluster of 64.  A cluster whose box lies outside a prefix's pyramids / on the
+ * wrong side of its mirror is skipped; the others are tested per receiver with lane = receiver.  Same rows
+ * as drt_beam_emit (as a set). */
+int32_t drt_beam_emit_clustered(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t num_in,
+                                int32_t order, const float *rx_sorted, const int32_t *rx_index, const float *boxes,
+                                int64_t num_rx, int64_t num_tx, float margin, int64_t *rows_out, int64_t capacity,
+                                int64_t *count_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (f4) smoothed ("soft mask") mode -- reference: differt/src/differt/utils.py:70-89

@@ -520,6 +520,37 @@ def test_beam_pruned_prefix_shards_partition_the_result(G, order, world):
         tracer.trace_beam_pruned(scene, order, prefix_shard=(world, world))
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("assume_quads", [False, True])
+def test_beam_pruned_clustered_emit_equals_plain(G, order, assume_quads):
+    """drt_beam_emit_clustered (receivers in Morton clusters of 64 with bounding boxes, lane = receiver for the
+    surviving (prefix, cluster) pairs) returns the rows of drt_beam_emit: identical paths, 150 receivers (a
+    full cluster, a full one and a partial one) on a flat grid plus a few elevated ones."""
+    import synthetic_scenes as S
+
+    V, Tr, c, h = S.manhattan(16, pitch=30.0, seed=11)
+    tx, _ = S.manhattan_tx_rx(c, h, 2, 1, seed=12, pitch=30.0)
+    ext = float(np.abs(V[:, :2]).max()) + 5.0
+    gx, gy = np.meshgrid(np.linspace(-ext, ext, 12), np.linspace(-ext, ext, 12))
+    rx = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, 1.5)], axis=1).astype(np.float32)
+    rx = np.concatenate([rx, np.asarray([[0.0, 0.0, 60.0], [ext, -ext, 35.0], [3.0, 4.0, 20.0], [-ext, 2.0, 80.0],
+                                         [1.0, ext, 15.0], [7.0, -9.0, 45.0]], np.float32)])
+    assert rx.shape[0] == 150
+    mesh = G.Mesh(V, Tr, assume_quads=assume_quads)
+    scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(rx, device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    a = tracer.trace_beam_pruned(scene, order, emit="plain")
+    rows_plain = tracer.last_beam_stats["rows"]
+    b = tracer.trace_beam_pruned(scene, order, emit="clustered")
+    assert tracer.last_beam_stats["rows"] == rows_plain  # the same candidate rows, not just the same survivors
+    assert torch.equal(a.keys, b.keys) and torch.equal(a.objects, b.objects)
+    assert torch.equal(a.vertices.view(torch.int32), b.vertices.view(torch.int32))
+    if order <= 2:
+        assert a.keys.shape[0] > 0
+    with pytest.raises(ValueError):
+        tracer.trace_beam_pruned(scene, order, emit="nope")
+
+
 def test_hybrid_visible_sets_memo_follows_the_end_points(G):
     """num_path_candidates() + trace_rank_range() share one visibility estimate, keyed on the end
     points BY VALUE: moving the transmitter in place must not return the stale sets."""
