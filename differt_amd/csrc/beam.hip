@@ -372,6 +372,12 @@ struct BeamCtx {
     // the per-vertex test of the brute-force kernel for primitive c
     __device__ __forceinline__ bool prim_survives(const BeamMesh &M, int64_t c) const {
         const float *v = M.tv + 9 * c * SCALE;
+        V3 vx[3 * SCALE];
+#pragma unroll
+        for (int vtx = 0; vtx < 3 * SCALE; ++vtx) vx[vtx] = ld3(v + 3 * vtx);
+        return prim_survives_v(vx);
+    }
+    __device__ __forceinline__ bool prim_survives_v(const V3 (&vx)[3 * SCALE]) const {
         float dmin = kInf, dmax = -kInf;
         bool out_face[SCALE][3], out_face0[SCALE][3];
 #pragma unroll
@@ -381,7 +387,7 @@ struct BeamCtx {
         bool nan = false;
 #pragma unroll
         for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
-            const V3 x = ld3(v + 3 * vtx);
+            const V3 x = vx[vtx];
             const float d = dot(x - pm, nm);
             nan = nan || !(d == d);
             dmin = fminf(dmin, d);
@@ -815,6 +821,96 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Expansion with cluster-level culling and transposed survivors (the structure of
+// beam_emit_clustered_kernel): the primitives arrive sorted along a Morton curve (`prim_order`) in clusters
+// of 64 with an axis-aligned box each.  lane = prefix tests each cluster's box with BeamCtx::box_pruned (the
+// box form of the very tests a primitive gets: box pruned => every primitive inside pruned, as in the LBVH
+// walk); the surviving (prefix, cluster) pairs are then tested per primitive with the prefix's context
+// broadcast from LDS and lane = primitive of the cluster.  Same survivors as the other mappings (tested);
+// per prefix the work drops from one 150-instruction test per primitive to one ~60-instruction box test per
+// 64 primitives plus full-lane tests of the clusters its cones actually reach.
+// ---------------------------------------------------------------------------------------------
+template <int SCALE>
+__global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
+    BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in, int level, float E, unsigned long long *__restrict__ out,
+    int64_t cap, unsigned long long *__restrict__ count, const int32_t *__restrict__ prim_order,
+    const float *__restrict__ boxes, int64_t nclusters, int64_t clusters_per_split) {
+    __shared__ BeamCtx<SCALE> lds_ctx[128];
+    __shared__ int32_t lds_m[128];
+    __shared__ unsigned long long wbuf[2][kBeamWaveBuf];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    const bool have = g < n_in;
+    BeamEntry e{};
+    if (have) e = in[g];
+    const int32_t m = have ? e.id[level - 1] : -1;
+    BeamCtx<SCALE> ctx;
+    ctx.E = E;
+    ctx.I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    ctx.pm = V3{0, 0, 0};
+    ctx.nm = V3{0, 0, 1};
+    ctx.inv_h = kInf;
+    ctx.side_prev = e.side_prev;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        ctx.pyr[t] = Pyramid{};
+        ctx.pyr0[t] = Pyramid{};
+        ctx.inv_h0[t] = kInf;
+    }
+    if (have) {
+        prim_plane(M, m, ctx.pm, ctx.nm);
+        const float h = __builtin_fabsf(dot(ctx.I - ctx.pm, ctx.nm));
+        ctx.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) ctx.pyr[t] = make_pyramid(ctx.I, M.tv + 9 * ((int64_t)m * SCALE + t));
+        if (level == 2) {
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) ctx.pyr0[t] = unfolded_pyramid(M, ctx.I, e.id[0], t, &e.id[1], 1, ctx.inv_h0[t]);
+        }
+    }
+    lds_ctx[threadIdx.x] = ctx;  // read back by this lane's own wave only
+    lds_m[threadIdx.x] = m;
+    __syncthreads();
+    const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
+    const int64_t cl_end = (cl_begin + clusters_per_split < nclusters) ? cl_begin + clusters_per_split : nclusters;
+    const unsigned long long gbase = (unsigned long long)((int64_t)blockIdx.x * 128 + wave * 64);
+    int wcount = 0;
+    for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
+        const float *bx = boxes + 6 * cl;  // lo[3], hi[3]: wave-uniform loads
+        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        unsigned long long todo = __ballot(have && !ctx.box_pruned(lo, hi));
+        if (todo == 0) continue;
+        // ---- transposed: lane = primitive of the cluster ----
+        const int64_t pos = cl * 64 + lane;
+        const int32_t p = (pos < M.nprim) ? prim_order[pos] : -1;
+        const bool act = p >= 0 && prim_active(M, p);
+        V3 vx[3 * SCALE];
+#pragma unroll
+        for (int k = 0; k < 3 * SCALE; ++k) vx[k] = act ? ld3(M.tv + 9 * (int64_t)p * SCALE + 3 * k) : V3{0, 0, 0};
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const BeamCtx<SCALE> &cx = lds_ctx[wave * 64 + l];  // wave-uniform address: broadcast reads
+            const bool keep = act && (p != lds_m[wave * 64 + l]) && cx.prim_survives_v(vx);
+            const unsigned long long vote = __ballot(keep);
+            if (vote) {
+                if (keep) {
+                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
+                    wbuf[wave][slot] = ((gbase + (unsigned long long)l) << 32) | (uint32_t)p;
+                }
+                wcount += __popcll(vote);
+                if (wcount > kBeamWaveBuf - 64) {
+                    beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+                    wcount = 0;
+                }
+            }
+        }
+    }
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+}
+
 // beam_emit for MANY receivers (configs[4]: 1024): the receivers arrive sorted along a Morton curve in
 // clusters of 64 with an axis-aligned bounding box each (a receiver grid is flat: a ball would be a poor
 // bound).  lane = prefix as above, but a lane first tests each cluster's box against its pyramids / mirror
@@ -1129,6 +1225,40 @@ int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t 
                            reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx, nrx, margin,
                            reinterpret_cast<long long *>(rows_out), capacity,
                            reinterpret_cast<unsigned long long *>(count_dev));
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+int32_t drt_beam_expand_clustered(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t level,
+                                  float margin, const int32_t *prim_order, const float *cluster_boxes,
+                                  int64_t num_clusters, uint64_t *out, int64_t capacity, int64_t *count_dev,
+                                  void *stream) {
+    DRT_REQUIRE(mesh && count_dev, "null argument");
+    DRT_REQUIRE(n_in >= 0 && capacity >= 0 && margin >= 0.0f && num_clusters >= 0, "bad argument");
+    DRT_REQUIRE(level >= 1 && level <= 2, "expansion goes from level 1 or 2 (orders up to 3)");
+    const BeamMesh M = beam_mesh(mesh);
+    if (n_in == 0 || M.nprim == 0) return DRT_OK;
+    DRT_REQUIRE(in && prim_order && cluster_boxes && (out || capacity == 0), "null pointer");
+    DRT_REQUIRE(num_clusters == ceil_div(M.nprim, (int64_t)64), "one cluster per 64 primitives of prim_order");
+    DRT_REQUIRE(n_in < (1ll << 32), "record format holds 32-bit prefix indices");
+    const int64_t bx = ceil_div(n_in, 128);
+    int64_t by = ceil_div(2048, bx);  // few prefixes: split the cluster range so that the launch fills the chip
+    if (by > num_clusters) by = num_clusters;
+    if (by > 65535) by = 65535;
+    if (by < 1) by = 1;
+    const int64_t cps = ceil_div(num_clusters, by);
+    by = ceil_div(num_clusters, cps);
+    const dim3 grid((unsigned)bx, (unsigned)by);
+    if (M.scale == 2)
+        hipLaunchKernelGGL(beam_expand_clustered_kernel<2>, grid, dim3(128), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                           reinterpret_cast<unsigned long long *>(out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, cluster_boxes, num_clusters, cps);
+    else
+        hipLaunchKernelGGL(beam_expand_clustered_kernel<1>, grid, dim3(128), 0, as_stream(stream), M,
+                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
+                           reinterpret_cast<unsigned long long *>(out), capacity,
+                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, cluster_boxes, num_clusters, cps);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

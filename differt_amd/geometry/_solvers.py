@@ -281,15 +281,12 @@ class AbstractPathTracer:
         return self.trace_path_candidates(scene, cands, types)
 
 
-def _receiver_clusters(rx: torch.Tensor, size: int = 64):
-    """Receivers sorted along a 30-bit Morton curve, cut into clusters of ``size`` consecutive ones:
-    ``(rx_sorted [R,3] f32, rx_index [R] i32, boxes [ceil(R/size),6] f32 = centre + half extents)`` for
-    ``drt_beam_emit_clustered`` (axis-aligned boxes: a receiver grid is flat)."""
-    R = rx.shape[0]
-    r64 = rx.detach().to(torch.float64)
-    lo = r64.min(dim=0).values
-    span = (r64.max(dim=0).values - lo).max().clamp_min(1e-30)  # one scale for all axes: a flat grid clusters in its plane
-    q = ((r64 - lo) / span * 1023.0).to(torch.int64).clamp_(0, 1023)
+def _morton_order(points64: torch.Tensor) -> torch.Tensor:
+    """Permutation that sorts points along a 30-bit Morton curve (one scale for all axes, so that a flat set
+    clusters in its plane)."""
+    lo = points64.min(dim=0).values
+    span = (points64.max(dim=0).values - lo).max().clamp_min(1e-30)
+    q = ((points64 - lo) / span * 1023.0).to(torch.int64).clamp_(0, 1023)
 
     def spread(v):  # 10 bits -> every third bit
         v = (v | (v << 16)) & 0x030000FF
@@ -299,7 +296,42 @@ def _receiver_clusters(rx: torch.Tensor, size: int = 64):
         return v
 
     code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-    perm = torch.argsort(code, stable=True)
+    return torch.argsort(code, stable=True)
+
+
+def _primitive_clusters(mesh, size: int = 64):
+    """``(prim_order [n] i32, boxes [ceil(n/size),6] f32 = lo, hi)`` for ``drt_beam_expand_clustered``:
+    primitives sorted along a Morton curve over their centroids, an axis-aligned box around ALL vertices of
+    every ``size`` consecutive ones (exact float32 min / max of the vertices the kernels read).  Cached on the
+    mesh, keyed like its native handle."""
+    key = (mesh._handle_key(), size)
+    cached = getattr(mesh, "_beam_clusters", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    scale = 2 if mesh.assume_quads else 1
+    tv = mesh.triangle_vertices.detach()  # [T,3,3] float32
+    n = tv.shape[0] // scale
+    pv = tv.reshape(n, 3 * scale, 3)
+    order = _morton_order(pv.to(torch.float64).mean(dim=1))
+    ncl = (n + size - 1) // size
+    pad = ncl * size - n
+    sorted_v = pv[order]
+    if pad:
+        sorted_v = torch.cat([sorted_v, sorted_v[-1:].expand(pad, 3 * scale, 3)])
+    g = sorted_v.reshape(ncl, size * 3 * scale, 3)
+    boxes = torch.cat([g.min(dim=1).values, g.max(dim=1).values], dim=1).to(torch.float32).contiguous()
+    out = (order.to(torch.int32).contiguous(), boxes)
+    mesh._beam_clusters = (key, out)
+    return out
+
+
+def _receiver_clusters(rx: torch.Tensor, size: int = 64):
+    """Receivers sorted along a 30-bit Morton curve, cut into clusters of ``size`` consecutive ones:
+    ``(rx_sorted [R,3] f32, rx_index [R] i32, boxes [ceil(R/size),6] f32 = centre + half extents)`` for
+    ``drt_beam_emit_clustered`` (axis-aligned boxes: a receiver grid is flat)."""
+    R = rx.shape[0]
+    r64 = rx.detach().to(torch.float64)
+    perm = _morton_order(r64)
     rs = rx.detach()[perm].contiguous()
     ncl = (R + size - 1) // size
     pad = ncl * size - R
@@ -512,7 +544,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
         # kernel mapping of the expansion (identical survivors, see drt_beam_expand).  "auto": lane = primitive
         # with wave-level sphere culling for the first expansion (one cone per prefix, few prefixes), lane =
         # prefix for the second one (two cones, ~1e8 prefixes: measured 2.44 s vs 2.91 s on configs[3])
-        modes = {"transposed": (0, 0), "bvh": (1, 1), "prefix": (2, 2), "auto": (0, 2)}
+        modes = {"transposed": (0, 0), "bvh": (1, 1), "prefix": (2, 2), "clustered": (3, 3), "auto": (3, 3)}
         if expansion not in modes:
             raise ValueError(f"unknown expansion {expansion!r}")
         txd, rxd = tx.detach(), rx.detach()
@@ -543,8 +575,13 @@ class ExhaustivePathTracer(AbstractPathTracer):
             """level-`level` prefixes x primitives -> 8-byte (prefix, primitive) records in `out`; returns the
             count, or None when `cap` was too small."""
             count.zero_()
-            _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, modes[expansion][level - 1], ptr(out), cap,
-                      ptr(count), stream())
+            mode = modes[expansion][level - 1]
+            if mode == 3:
+                order_p, boxes_p = _primitive_clusters(mesh)
+                _lib.call("drt_beam_expand_clustered", h, ptr(src), nsrc, level, margin, ptr(order_p), ptr(boxes_p),
+                          boxes_p.shape[0], ptr(out), cap, ptr(count), stream())
+            else:
+                _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, mode, ptr(out), cap, ptr(count), stream())
             c = int(count.item())
             return c if c <= cap else None
 

@@ -715,7 +715,7 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
     bp = tracer.trace_beam_pruned(scene, 3)
     _assert_same_paths(ex, bp)
     st_bvh = dict(tracer.last_beam_stats)
-    for mapping in ("prefix", "bvh"):  # lane per prefix (every pair tested) / walk of the mesh LBVH
+    for mapping in ("prefix", "bvh", "transposed"):  # default "auto" = clustered; lane per prefix / LBVH walk / lane per primitive
         other = tracer.trace_beam_pruned(scene, 3, expansion=mapping)
         _assert_same_paths(ex, other)
         # sphere / box culling are the same tests on a ball / box: identical survivors at every level
@@ -759,7 +759,7 @@ def test_beam_pruned_equals_exhaustive_quads_masks_orders(G, rng, order, assume_
         bp = tracer.trace_beam_pruned(scene, order)
         _assert_same_paths(ex, bp)
         rows_bvh = tracer.last_beam_stats["rows"]
-        for mapping in ("prefix", "bvh"):
+        for mapping in ("prefix", "bvh", "transposed"):
             _assert_same_paths(ex, tracer.trace_beam_pruned(scene, order, expansion=mapping))
             assert tracer.last_beam_stats["rows"] == rows_bvh  # same candidate rows after de-duplication
         if bp.objects.shape[0]:
