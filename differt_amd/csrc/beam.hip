@@ -790,10 +790,14 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
         const int side_r = (d == d) ? side_of_range(d, d, 4.0f * E) : 0;
         const V3 w = r - I;
         const float wl = __builtin_sqrtf(dot(w, w));
-        bool inside_all = true;
+        // the pyramids in turn, earliest mirror first (unfolded farthest from the apex = the narrowest cone);
+        // the wave leaves the receiver as soon as none of its 64 prefixes is still inside (same tests, same
+        // result: a prefix that fails one pyramid is dropped whatever the others say)
+        bool alive = have && !(e.side_prev * side_r == -1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (j < order) {
+                if (!__any(alive)) break;
                 bool inside_any = false;
 #pragma unroll
                 for (int t = 0; t < SCALE; ++t) {
@@ -803,10 +807,10 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
                     for (int f = 0; f < 3; ++f) inside = inside && !(dot(w, pyr[j][t].n[f]) < thr);
                     inside_any = inside_any || inside;
                 }
-                inside_all = inside_all && inside_any;
+                alive = alive && inside_any;
             }
         }
-        const bool keep = have && inside_all && !(e.side_prev * side_r == -1);
+        const bool keep = alive;
         const unsigned long long vote = __ballot(keep);
         if (vote) {
             unsigned long long b0 = 0;
