@@ -745,6 +745,9 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
                                                         int order, const float *__restrict__ rx, int64_t nrx, float E,
                                                         long long *__restrict__ rows, int64_t cap,
                                                         unsigned long long *__restrict__ count) {
+    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int wcount = 0;  // wave-uniform: rows waiting in wbuf[wave]
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool have = g < n_in;
@@ -811,18 +814,22 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
             }
         }
         const bool keep = alive;
+        // rows leave through the wave's LDS staging buffer, one global atomic per FLUSH: rows are sparse (mostly
+        // one lane per ballot), so an atomic per ballot was ~1.5e8 same-address atomics at configs[3]
         const unsigned long long vote = __ballot(keep);
         if (vote) {
-            unsigned long long b0 = 0;
-            const int leader = __builtin_ctzll(vote);
-            if (lane == leader) b0 = atomicAdd(count, (unsigned long long)__popcll(vote));
-            b0 = __shfl(b0, leader, 64);
             if (keep) {
-                const unsigned long long slot = b0 + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
-                if ((int64_t)slot < cap) rows[slot] = ((long long)e.tx * (long long)nrx + (long long)ir) * npow + tail;
+                const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
+                wbuf[wave][slot] = (unsigned long long)(((long long)e.tx * (long long)nrx + (long long)ir) * npow + tail);
+            }
+            wcount += __popcll(vote);
+            if (wcount > kBeamWaveBuf - 64) {
+                beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+                wcount = 0;
             }
         }
     }
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -942,6 +949,8 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
     BeamMesh M, const BeamEntry *__restrict__ in, const unsigned long long *__restrict__ rec, int64_t n_in, int order,
     const float *__restrict__ rx_sorted, const int32_t *__restrict__ rx_index, const float *__restrict__ boxes,
     int64_t nrx, float E, long long *__restrict__ rows, int64_t cap, unsigned long long *__restrict__ count) {
+    __shared__ unsigned long long wbuf[2][kBeamWaveBuf];
+    int wcount = 0;  // wave-uniform: rows waiting in wbuf[wave]
     __shared__ BeamEmitD<SCALE> lds[128];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1073,18 +1082,20 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
             }
             const bool keep = have_r && inside_all && !(d.side_prev * side_r == -1);
             const unsigned long long vote = __ballot(keep);
-            if (vote) {
-                unsigned long long b0 = 0;
-                const int leader = __builtin_ctzll(vote);
-                if (lane == leader) b0 = atomicAdd(count, (unsigned long long)__popcll(vote));
-                b0 = __shfl(b0, leader, 64);
+            if (vote) {  // staged per wave, one global atomic per flush (see beam_emit_kernel)
                 if (keep) {
-                    const unsigned long long slot = b0 + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull));
-                    if ((int64_t)slot < cap) rows[slot] = ((long long)d.tx * (long long)nrx + ir) * npow + d.tail;
+                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
+                    wbuf[wave][slot] = (unsigned long long)(((long long)d.tx * (long long)nrx + ir) * npow + d.tail);
+                }
+                wcount += __popcll(vote);
+                if (wcount > kBeamWaveBuf - 64) {
+                    beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+                    wcount = 0;
                 }
             }
         }
     }
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
 }
 
 static BeamMesh beam_mesh(drt_mesh_t m) {
