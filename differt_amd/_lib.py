@@ -178,7 +178,7 @@ _SIGNATURES = {
     "drt_beam_expand": (_i32, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "drt_beam_finish": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp]),
     "drt_beam_emit": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
-    "drt_beam_expand_clustered": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "drt_beam_expand_clustered": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "drt_beam_emit_clustered": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
     "drt_launch_paths_vjp": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "drt_warp_ray_prep": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
 }
 
 constexpr int kBeamWaveBuf = 192;  // records staged per wave before one flush (>= 128: a flush moves 64+)
+constexpr int kBeamWaveBufBig = 1024;  // the same for kernels that emit ~1e10 records (one atomic per ~960)
 
 // wave-private LDS staging buffer -> output list: ONE global atomic for `n` records
 __device__ __forceinline__ void beam_flush(const unsigned long long *buf, int n, int lane,
@@ -832,13 +833,39 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
 }
 
+// value of lane `l` (wave-uniform index) on every lane, through v_readlane: no LDS round trip, no wait
+__device__ __forceinline__ float lane_bcast(float x, int l) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l));
+}
+__device__ __forceinline__ V3 lane_bcast(V3 v, int l) { return V3{lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)}; }
+template <int SCALE>
+__device__ __forceinline__ BeamCtx<SCALE> lane_bcast(const BeamCtx<SCALE> &c, int l) {
+    BeamCtx<SCALE> o;
+    o.I = lane_bcast(c.I, l);
+    o.pm = lane_bcast(c.pm, l);
+    o.nm = lane_bcast(c.nm, l);
+    o.inv_h = lane_bcast(c.inv_h, l);
+    o.E = c.E;
+    o.side_prev = __builtin_amdgcn_readlane(c.side_prev, l);
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        o.inv_h0[t] = lane_bcast(c.inv_h0[t], l);
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            o.pyr[t].n[f] = lane_bcast(c.pyr[t].n[f], l);
+            o.pyr0[t].n[f] = lane_bcast(c.pyr0[t].n[f], l);
+        }
+    }
+    return o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Expansion with cluster-level culling and transposed survivors (the structure of
 // beam_emit_clustered_kernel): the primitives arrive sorted along a Morton curve (`prim_order`) in clusters
 // of 64 with an axis-aligned box each.  lane = prefix tests each cluster's box with BeamCtx::box_pruned (the
 // box form of the very tests a primitive gets: box pruned => every primitive inside pruned, as in the LBVH
 // walk); the surviving (prefix, cluster) pairs are then tested per primitive with the prefix's context
-// broadcast from LDS and lane = primitive of the cluster.  Same survivors as the other mappings (tested);
+// broadcast lane-to-wave (v_readlane) and lane = primitive of the cluster.  Same survivors as the other mappings (tested);
 // per prefix the work drops from one 150-instruction test per primitive to one ~60-instruction box test per
 // 64 primitives plus full-lane tests of the clusters its cones actually reach.
 // ---------------------------------------------------------------------------------------------
@@ -846,10 +873,11 @@ template <int SCALE>
 __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
     BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in, int level, float E, unsigned long long *__restrict__ out,
     int64_t cap, unsigned long long *__restrict__ count, const int32_t *__restrict__ prim_order,
-    const float *__restrict__ boxes, int64_t nclusters, int64_t clusters_per_split) {
-    __shared__ BeamCtx<SCALE> lds_ctx[128];
-    __shared__ int32_t lds_m[128];
-    __shared__ unsigned long long wbuf[2][kBeamWaveBuf];
+    const float *__restrict__ sorted_vertices, const float *__restrict__ boxes, int64_t nclusters,
+    int64_t clusters_per_split) {
+    // 8 KiB per wave: a flush every ~960 records.  With 192 (~130 per flush) the 8.4e7 flush atomics per step of
+    // configs[3] -- all on ONE address, ~1.75e8/s -- were half of the kernel's time
+    __shared__ unsigned long long wbuf[2][kBeamWaveBufBig];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
@@ -881,30 +909,45 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
             for (int t = 0; t < SCALE; ++t) ctx.pyr0[t] = unfolded_pyramid(M, ctx.I, e.id[0], t, &e.id[1], 1, ctx.inv_h0[t]);
         }
     }
-    lds_ctx[threadIdx.x] = ctx;  // read back by this lane's own wave only
-    lds_m[threadIdx.x] = m;
-    __syncthreads();
     const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
     const int64_t cl_end = (cl_begin + clusters_per_split < nclusters) ? cl_begin + clusters_per_split : nclusters;
     const unsigned long long gbase = (unsigned long long)((int64_t)blockIdx.x * 128 + wave * 64);
     int wcount = 0;
+    // software pipeline: the next cluster's box (scalar loads), primitive id and vertices (sorted copy, no
+    // indirection) are in flight while this cluster is tested -- fetched whether or not the cluster will be
+    // hit (the mesh lives in L2); with the loads issued only after a hit the kernel sat in s_waitcnt
+    float nb[6];
+    int32_t p_next;
+    V3 vx_next[3 * SCALE];
+    auto fetch = [&](int64_t c) {
+        const int64_t cc = (c < cl_end) ? c : cl_end - 1;  // the last trip re-reads its own cluster
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nb[k] = boxes[6 * cc + k];
+        const int64_t pos = cc * 64 + lane;
+        const int64_t pc = (pos < M.nprim) ? pos : M.nprim - 1;
+        p_next = (pos < M.nprim) ? prim_order[pc] : -1;
+#pragma unroll
+        for (int k = 0; k < 3 * SCALE; ++k) vx_next[k] = ld3(sorted_vertices + 9 * pc * SCALE + 3 * k);
+    };
+    if (cl_begin < cl_end) fetch(cl_begin);
     for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
-        const float *bx = boxes + 6 * cl;  // lo[3], hi[3]: wave-uniform loads
-        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        const float lo[3] = {nb[0], nb[1], nb[2]}, hi[3] = {nb[3], nb[4], nb[5]};
+        const int32_t p = p_next;
+        V3 vx[3 * SCALE];
+#pragma unroll
+        for (int k = 0; k < 3 * SCALE; ++k) vx[k] = vx_next[k];
+        fetch(cl + 1);
         unsigned long long todo = __ballot(have && !ctx.box_pruned(lo, hi));
         if (todo == 0) continue;
         // ---- transposed: lane = primitive of the cluster ----
-        const int64_t pos = cl * 64 + lane;
-        const int32_t p = (pos < M.nprim) ? prim_order[pos] : -1;
         const bool act = p >= 0 && prim_active(M, p);
-        V3 vx[3 * SCALE];
-#pragma unroll
-        for (int k = 0; k < 3 * SCALE; ++k) vx[k] = act ? ld3(M.tv + 9 * (int64_t)p * SCALE + 3 * k) : V3{0, 0, 0};
         while (todo) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const BeamCtx<SCALE> &cx = lds_ctx[wave * 64 + l];  // wave-uniform address: broadcast reads
-            const bool keep = act && (p != lds_m[wave * 64 + l]) && cx.prim_survives_v(vx);
+            // the prefix of lane l on every lane: v_readlane of its registers (the LDS broadcast this replaces
+            // left the kernel 76 % of its wave-cycles in s_waitcnt at 20 % VALU issue, profiles/r02/beam.md)
+            const BeamCtx<SCALE> cx = lane_bcast<SCALE>(ctx, l);
+            const bool keep = act && (p != __builtin_amdgcn_readlane(m, l)) && cx.prim_survives_v(vx);
             const unsigned long long vote = __ballot(keep);
             if (vote) {
                 if (keep) {
@@ -912,7 +955,7 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
                     wbuf[wave][slot] = ((gbase + (unsigned long long)l) << 32) | (uint32_t)p;
                 }
                 wcount += __popcll(vote);
-                if (wcount > kBeamWaveBuf - 64) {
+                if (wcount > kBeamWaveBufBig - 64) {
                     beam_flush(wbuf[wave], wcount, lane, out, cap, count);
                     wcount = 0;
                 }
@@ -1245,15 +1288,15 @@ int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t 
 }
 
 int32_t drt_beam_expand_clustered(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t level,
-                                  float margin, const int32_t *prim_order, const float *cluster_boxes,
-                                  int64_t num_clusters, uint64_t *out, int64_t capacity, int64_t *count_dev,
+                                  float margin, const int32_t *prim_order, const float *sorted_vertices,
+                                  const float *cluster_boxes, int64_t num_clusters, uint64_t *out, int64_t capacity, int64_t *count_dev,
                                   void *stream) {
     DRT_REQUIRE(mesh && count_dev, "null argument");
     DRT_REQUIRE(n_in >= 0 && capacity >= 0 && margin >= 0.0f && num_clusters >= 0, "bad argument");
     DRT_REQUIRE(level >= 1 && level <= 2, "expansion goes from level 1 or 2 (orders up to 3)");
     const BeamMesh M = beam_mesh(mesh);
     if (n_in == 0 || M.nprim == 0) return DRT_OK;
-    DRT_REQUIRE(in && prim_order && cluster_boxes && (out || capacity == 0), "null pointer");
+    DRT_REQUIRE(in && prim_order && sorted_vertices && cluster_boxes && (out || capacity == 0), "null pointer");
     DRT_REQUIRE(num_clusters == ceil_div(M.nprim, (int64_t)64), "one cluster per 64 primitives of prim_order");
     DRT_REQUIRE(n_in < (1ll << 32), "record format holds 32-bit prefix indices");
     const int64_t bx = ceil_div(n_in, 128);
@@ -1268,12 +1311,12 @@ int32_t drt_beam_expand_clustered(drt_mesh_t mesh, const drt_beam_entry *in, int
         hipLaunchKernelGGL(beam_expand_clustered_kernel<2>, grid, dim3(128), 0, as_stream(stream), M,
                            reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
                            reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, cluster_boxes, num_clusters, cps);
+                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, sorted_vertices, cluster_boxes, num_clusters, cps);
     else
         hipLaunchKernelGGL(beam_expand_clustered_kernel<1>, grid, dim3(128), 0, as_stream(stream), M,
                            reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
                            reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, cluster_boxes, num_clusters, cps);
+                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, sorted_vertices, cluster_boxes, num_clusters, cps);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

@@ -300,7 +300,8 @@ def _morton_order(points64: torch.Tensor) -> torch.Tensor:
 
 
 def _primitive_clusters(mesh, size: int = 64):
-    """``(prim_order [n] i32, boxes [ceil(n/size),6] f32 = lo, hi)`` for ``drt_beam_expand_clustered``:
+    """``(prim_order [n] i32, boxes [ceil(n/size),6] f32 = lo, hi, sorted_vertices [n,3*scale,3] f32)`` for
+    ``drt_beam_expand_clustered``:
     primitives sorted along a Morton curve over their centroids, an axis-aligned box around ALL vertices of
     every ``size`` consecutive ones (exact float32 min / max of the vertices the kernels read).  Cached on the
     mesh, keyed like its native handle."""
@@ -320,7 +321,7 @@ def _primitive_clusters(mesh, size: int = 64):
         sorted_v = torch.cat([sorted_v, sorted_v[-1:].expand(pad, 3 * scale, 3)])
     g = sorted_v.reshape(ncl, size * 3 * scale, 3)
     boxes = torch.cat([g.min(dim=1).values, g.max(dim=1).values], dim=1).to(torch.float32).contiguous()
-    out = (order.to(torch.int32).contiguous(), boxes)
+    out = (order.to(torch.int32).contiguous(), boxes, pv[order].to(torch.float32).contiguous())
     mesh._beam_clusters = (key, out)
     return out
 
@@ -577,9 +578,9 @@ class ExhaustivePathTracer(AbstractPathTracer):
             count.zero_()
             mode = modes[expansion][level - 1]
             if mode == 3:
-                order_p, boxes_p = _primitive_clusters(mesh)
-                _lib.call("drt_beam_expand_clustered", h, ptr(src), nsrc, level, margin, ptr(order_p), ptr(boxes_p),
-                          boxes_p.shape[0], ptr(out), cap, ptr(count), stream())
+                order_p, boxes_p, sorted_v = _primitive_clusters(mesh)
+                _lib.call("drt_beam_expand_clustered", h, ptr(src), nsrc, level, margin, ptr(order_p), ptr(sorted_v),
+                          ptr(boxes_p), boxes_p.shape[0], ptr(out), cap, ptr(count), stream())
             else:
                 _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, mode, ptr(out), cap, ptr(count), stream())
             c = int(count.item())

@@ -484,12 +484,13 @@ int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_i
                         void *stream);
 /* drt_beam_expand with cluster-level culling: `prim_order` [num_primitives] lists the primitives in an order
  * that makes 64 consecutive ones spatially compact (e.g. a Morton curve over their centroids),
- * `cluster_boxes` [num_clusters = ceil(num_primitives / 64), 6] = (lo[3], hi[3]) bounds ALL vertices of each
+ * `sorted_vertices` [num_primitives, 3 (6 with quads), 3] their vertices in that order (a gather of the
+ * mesh's triangle vertices: the kernel streams it instead of chasing prim_order), `cluster_boxes` [num_clusters = ceil(num_primitives / 64), 6] = (lo[3], hi[3]) bounds ALL vertices of each
  * cluster.  A prefix skips the clusters whose box fails the box form of the primitive tests and tests the
  * others with lane = primitive.  Same records as drt_beam_expand (as a set). */
 int32_t drt_beam_expand_clustered(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t level,
-                                  float margin, const int32_t *prim_order, const float *cluster_boxes,
-                                  int64_t num_clusters, uint64_t *records_out, int64_t capacity,
+                                  float margin, const int32_t *prim_order, const float *sorted_vertices,
+                                  const float *cluster_boxes, int64_t num_clusters, uint64_t *records_out, int64_t capacity,
                                   int64_t *count_dev, void *stream);
 int32_t drt_beam_finish(drt_mesh_t mesh, const drt_beam_entry *src, const uint64_t *records, int64_t num_records,
                         int32_t level, float margin, drt_beam_entry *out, void *stream);
