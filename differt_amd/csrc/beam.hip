@@ -39,6 +39,14 @@
 #pragma clang fp contract(off)
 
 namespace drt {
+// Dot product with fused multiply-adds (3 instructions instead of 5).  The beam tests are necessary
+// conditions with explicit margins, not parity arithmetic: one rounding instead of three per product-sum is
+// only more accurate, and every mapping of the expansion / receiver stage uses this same function, so
+// their survivors stay identical.
+__device__ __forceinline__ float fdot(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+}  // namespace drt
+
+namespace drt {
 
 struct BeamEntry {  // == drt_beam_entry (32 bytes)
     int32_t tx;
@@ -78,7 +86,7 @@ __device__ __forceinline__ int side_of_prim(const BeamMesh &M, int64_t p, V3 pt,
     float dmin = kInf, dmax = -kInf;
     const float *v = M.tv + 9 * p * M.scale;
     for (int i = 0; i < 3 * M.scale; ++i) {
-        const float d = dot(ld3(v + 3 * i) - pt, n);
+        const float d = fdot(ld3(v + 3 * i) - pt, n);
         dmin = fminf(dmin, d);
         dmax = fmaxf(dmax, d);
     }
@@ -93,8 +101,8 @@ struct Pyramid {
 };
 __device__ __forceinline__ V3 face_normal(V3 I, V3 a, V3 b, V3 third) {
     const V3 N = cross(a - I, b - I);
-    const float len = __builtin_sqrtf(dot(N, N));
-    const float s = dot(third - I, N);
+    const float len = __builtin_sqrtf(fdot(N, N));
+    const float s = fdot(third - I, N);
     if (!(len > 0.0f) || !(s == s) || s == 0.0f || !is_finite(len)) return V3{0, 0, 0};
     const float inv = ((s > 0.0f) ? 1.0f : -1.0f) / len;
     return N * inv;
@@ -127,8 +135,8 @@ __device__ __forceinline__ Pyramid unfolded_pyramid(const BeamMesh &M, V3 I, int
     P.n[1] = face_normal(I, v[1], v[2], v[0]);
     P.n[2] = face_normal(I, v[2], v[0], v[1]);
     const V3 c = cross(v[1] - v[0], v[2] - v[0]);
-    const float len = __builtin_sqrtf(dot(c, c));
-    const float h = (len > 0.0f) ? __builtin_fabsf(dot(I - v[0], c)) / len : 0.0f;
+    const float len = __builtin_sqrtf(fdot(c, c));
+    const float h = (len > 0.0f) ? __builtin_fabsf(fdot(I - v[0], c)) / len : 0.0f;
     inv_h = (h > 0.0f) ? 1.0f / h : kInf;
     return P;
 }
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
         prim_plane(M, a, pt, n);
         const V3 t = ld3(tx + 3 * it);
         const V3 I = image_of_vertex(t, pt, n);
-        const float d = dot(t - pt, n);
+        const float d = fdot(t - pt, n);
         e.tx = (int32_t)it;
         e.id[0] = (int32_t)a;
         e.id[1] = e.id[2] = -1;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
     }
     if (have) {
         prim_plane(M, m, pm, nm);
-        const float h = __builtin_fabsf(dot(I - pm, nm));
+        const float h = __builtin_fabsf(fdot(I - pm, nm));
         inv_h = (h > 0.0f) ? 1.0f / h : kInf;
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) pyr[t] = make_pyramid(I, M.tv + 9 * ((int64_t)m * SCALE + t));
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
 #pragma unroll
             for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
                 const V3 x = V3{lds_v[j][vtx][0], lds_v[j][vtx][1], lds_v[j][vtx][2]};
-                const float d = dot(x - pm, nm);
+                const float d = fdot(x - pm, nm);
                 nan = nan || !(d == d);
                 dmin = fminf(dmin, d);
                 dmax = fmaxf(dmax, d);
@@ -275,9 +283,9 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
                     const float thr0 = -(E + E * (wl * inv_h0[t]));
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
-                        const float s = dot(w, pyr[t].n[f]);
+                        const float s = fdot(w, pyr[t].n[f]);
                         out_face[t][f] = out_face[t][f] && (s < thr);  // NaN compares false
-                        const float s0 = dot(w, pyr0[t].n[f]);
+                        const float s0 = fdot(w, pyr0[t].n[f]);
                         out_face0[t][f] = out_face0[t][f] && (s0 < thr0);
                     }
                 }
@@ -341,7 +349,7 @@ struct BeamCtx {
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
                 const V3 n = P[t].n[f];
-                const float smax = dot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
+                const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
                                                 __builtin_fabsf(n.z) * e.z);
                 st = st || (smax < thr);
             }
@@ -356,7 +364,7 @@ struct BeamCtx {
         const V3 e = V3{0.5f * (hi[0] - lo[0]), 0.5f * (hi[1] - lo[1]), 0.5f * (hi[2] - lo[2])};
         if (!(e.x >= 0.0f) || !(e.y >= 0.0f) || !(e.z >= 0.0f)) return false;  // NaN / empty box: keep
         if (side_prev != 0) {
-            const float dc = dot(c - pm, nm);
+            const float dc = fdot(c - pm, nm);
             const float r = (__builtin_fabsf(nm.x) * e.x + __builtin_fabsf(nm.y) * e.y) + __builtin_fabsf(nm.z) * e.z;
             const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, 4.0f * E) : 0;
             if (side_prev * sb == -1) return true;
@@ -389,7 +397,7 @@ struct BeamCtx {
 #pragma unroll
         for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
             const V3 x = vx[vtx];
-            const float d = dot(x - pm, nm);
+            const float d = fdot(x - pm, nm);
             nan = nan || !(d == d);
             dmin = fminf(dmin, d);
             dmax = fmaxf(dmax, d);
@@ -401,8 +409,8 @@ struct BeamCtx {
                 const float thr0 = -(E + E * (wl * inv_h0[t]));
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
-                    out_face[t][f] = out_face[t][f] && (dot(w, pyr[t].n[f]) < thr);
-                    out_face0[t][f] = out_face0[t][f] && (dot(w, pyr0[t].n[f]) < thr0);
+                    out_face[t][f] = out_face[t][f] && (fdot(w, pyr[t].n[f]) < thr);
+                    out_face0[t][f] = out_face0[t][f] && (fdot(w, pyr0[t].n[f]) < thr0);
                 }
             }
         }
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void beam_expand_bvh_kernel(BeamMesh M, const 
     }
     if (have) {
         prim_plane(M, m, ctx.pm, ctx.nm);
-        const float h = __builtin_fabsf(dot(ctx.I - ctx.pm, ctx.nm));
+        const float h = __builtin_fabsf(fdot(ctx.I - ctx.pm, ctx.nm));
         ctx.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) ctx.pyr[t] = make_pyramid(ctx.I, M.tv + 9 * ((int64_t)m * SCALE + t));
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(256) void beam_expand_t_kernel(BeamMesh M, const Be
 #pragma unroll
     for (int k = 0; k < 3 * SCALE; ++k) {
         const V3 dv = vx[k] - sc;
-        r2 = fmaxf(r2, lane_ok ? dot(dv, dv) : 0.0f);
+        r2 = fmaxf(r2, lane_ok ? fdot(dv, dv) : 0.0f);
     }
     // radius rounded up generously (sqrt + a relative pad); NaN geometry -> NaN radius -> never culls
     const float sr = __builtin_sqrtf(wave_max_f(r2)) * 1.0001f + 1e-30f;
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256) void beam_expand_t_kernel(BeamMesh M, const Be
                 const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
                 V3 pm, nm;
                 prim_plane(M, m, pm, nm);
-                const float h = __builtin_fabsf(dot(I - pm, nm));
+                const float h = __builtin_fabsf(fdot(I - pm, nm));
                 d.I[0] = I.x; d.I[1] = I.y; d.I[2] = I.z;
                 d.pm[0] = pm.x; d.pm[1] = pm.y; d.pm[2] = pm.z;
                 d.nm[0] = nm.x; d.nm[1] = nm.y; d.nm[2] = nm.z;
@@ -645,15 +653,15 @@ __global__ __launch_bounds__(256) void beam_expand_t_kernel(BeamMesh M, const Be
                     bool st = false, st0 = false;
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
-                        st = st || (dot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) + sr < thr);
-                        st0 = st0 || (dot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) + sr < thr0);
+                        st = st || (fdot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) + sr < thr);
+                        st0 = st0 || (fdot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) + sr < thr0);
                     }
                     sep = sep && st;
                     sep0 = sep0 && st0;
                 }
                 bool cull = sep || sep0;
                 if (side_prev != 0) {
-                    const float dc = dot(sc - pm, nm);
+                    const float dc = fdot(sc - pm, nm);
                     const int sb = (dc == dc) ? side_of_range(dc - sr, dc + sr, 4.0f * E) : 0;
                     cull = cull || (side_prev * sb == -1);
                 }
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(256) void beam_expand_t_kernel(BeamMesh M, const Be
 #pragma unroll
             for (int k = 0; k < 3 * SCALE; ++k) {
                 const V3 x = vx[k];
-                const float dd = dot(x - pm, nm);
+                const float dd = fdot(x - pm, nm);
                 nan = nan || !(dd == dd);
                 dmin = fminf(dmin, dd);
                 dmax = fmaxf(dmax, dd);
@@ -684,9 +692,9 @@ __global__ __launch_bounds__(256) void beam_expand_t_kernel(BeamMesh M, const Be
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
                         out_face[t][f] = out_face[t][f] &&
-                                         (dot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) < thr);
+                                         (fdot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) < thr);
                         out_face0[t][f] = out_face0[t][f] &&
-                                          (dot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) < thr0);
+                                          (fdot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) < thr0);
                     }
                 }
             }
@@ -790,10 +798,10 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     for (int j = 0; j < order; ++j) npow *= (long long)M.nprim;
     for (int64_t ir = 0; ir < nrx; ++ir) {
         const V3 r = ld3(rx + 3 * ir);  // wave-uniform
-        const float d = dot(r - pc, nc);
+        const float d = fdot(r - pc, nc);
         const int side_r = (d == d) ? side_of_range(d, d, 4.0f * E) : 0;
         const V3 w = r - I;
-        const float wl = __builtin_sqrtf(dot(w, w));
+        const float wl = __builtin_sqrtf(fdot(w, w));
         // the pyramids in turn, earliest mirror first (unfolded farthest from the apex = the narrowest cone);
         // the wave leaves the receiver as soon as none of its 64 prefixes is still inside (same tests, same
         // result: a prefix that fails one pyramid is dropped whatever the others say)
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
                     const float thr = -(E + E * (wl * inv_h[j][t]));
                     bool inside = true;
 #pragma unroll
-                    for (int f = 0; f < 3; ++f) inside = inside && !(dot(w, pyr[j][t].n[f]) < thr);
+                    for (int f = 0; f < 3; ++f) inside = inside && !(fdot(w, pyr[j][t].n[f]) < thr);
                     inside_any = inside_any || inside;
                 }
                 alive = alive && inside_any;
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
     }
     if (have) {
         prim_plane(M, m, ctx.pm, ctx.nm);
-        const float h = __builtin_fabsf(dot(ctx.I - ctx.pm, ctx.nm));
+        const float h = __builtin_fabsf(fdot(ctx.I - ctx.pm, ctx.nm));
         ctx.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) ctx.pyr[t] = make_pyramid(ctx.I, M.tv + 9 * ((int64_t)m * SCALE + t));
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
         {
             const V3 w = sc - I;
             // >= |r - I| for every receiver r of the cluster
-            const float wl = __builtin_sqrtf(dot(w, w)) + __builtin_sqrtf(dot(hx, hx));
+            const float wl = __builtin_sqrtf(fdot(w, w)) + __builtin_sqrtf(fdot(hx, hx));
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (j < order) {
@@ -1078,14 +1086,14 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
                         for (int f = 0; f < 3; ++f) {
                             const V3 nf = pyr[j][t].n[f];  // max over the box of <x - I, n> = <c - I, n> + <|n|, h>
                             const float ext = (__builtin_fabsf(nf.x) * hx.x + __builtin_fabsf(nf.y) * hx.y) + __builtin_fabsf(nf.z) * hx.z;
-                            sep = sep || (dot(w, nf) + ext < thr);
+                            sep = sep || (fdot(w, nf) + ext < thr);
                         }
                         sep_all = sep_all && sep;
                     }
                     maybe = maybe && !sep_all;
                 }
             }
-            const float dc = dot(sc - pc, nc);
+            const float dc = fdot(sc - pc, nc);
             const float de = (__builtin_fabsf(nc.x) * hx.x + __builtin_fabsf(nc.y) * hx.y) + __builtin_fabsf(nc.z) * hx.z;
             const int sb = (dc == dc) ? side_of_range(dc - de, dc + de, 4.0f * E) : 0;
             maybe = maybe && !(e.side_prev * sb == -1);
@@ -1102,10 +1110,10 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
             todo &= todo - 1;
             const BeamEmitD<SCALE> &d = lds[wave * 64 + l];  // wave-uniform address: broadcast reads
             const V3 dI = V3{d.I[0], d.I[1], d.I[2]};
-            const float dd = dot(r - V3{d.pc[0], d.pc[1], d.pc[2]}, V3{d.nc[0], d.nc[1], d.nc[2]});
+            const float dd = fdot(r - V3{d.pc[0], d.pc[1], d.pc[2]}, V3{d.nc[0], d.nc[1], d.nc[2]});
             const int side_r = (dd == dd) ? side_of_range(dd, dd, 4.0f * E) : 0;
             const V3 w = r - dI;
-            const float wl = __builtin_sqrtf(dot(w, w));
+            const float wl = __builtin_sqrtf(fdot(w, w));
             bool inside_all = true;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -1117,7 +1125,7 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
                         bool inside = true;
 #pragma unroll
                         for (int f = 0; f < 3; ++f)
-                            inside = inside && !(dot(w, V3{d.pyr[j][t][3 * f], d.pyr[j][t][3 * f + 1], d.pyr[j][t][3 * f + 2]}) < thr);
+                            inside = inside && !(fdot(w, V3{d.pyr[j][t][3 * f], d.pyr[j][t][3 * f + 1], d.pyr[j][t][3 * f + 2]}) < thr);
                         inside_any = inside_any || inside;
                     }
                     inside_all = inside_all && inside_any;
