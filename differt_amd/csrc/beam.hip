@@ -802,13 +802,15 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     for (int64_t ir = 0; ir < nrx; ++ir) {
         const V3 r = ld3(rx + 3 * ir);  // wave-uniform
         const float d = fdot(r - pc, nc);
-        const int side_r = (d == d) ? side_of_range(d, d, 4.0f * E) : 0;
+        // wrong side of the last mirror: side_prev * d < -4E (side_prev in {-1, 0, +1}; 0 or a NaN distance never
+        // rejects) -- the same decision as side_prev * side_of_range(d, d, 4E) == -1 in one multiply + compare
+        const bool wrong_side = (float)e.side_prev * d < -4.0f * E;
         const V3 w = r - I;
         const float wl = margin_len(w);
         // the pyramids in turn, earliest mirror first (unfolded farthest from the apex = the narrowest cone);
         // the wave leaves the receiver as soon as none of its 64 prefixes is still inside (same tests, same
         // result: a prefix that fails one pyramid is dropped whatever the others say)
-        bool alive = have && !(e.side_prev * side_r == -1);
+        bool alive = have && !wrong_side;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (j < order) {
@@ -1114,7 +1116,7 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
             const BeamEmitD<SCALE> &d = lds[wave * 64 + l];  // wave-uniform address: broadcast reads
             const V3 dI = V3{d.I[0], d.I[1], d.I[2]};
             const float dd = fdot(r - V3{d.pc[0], d.pc[1], d.pc[2]}, V3{d.nc[0], d.nc[1], d.nc[2]});
-            const int side_r = (dd == dd) ? side_of_range(dd, dd, 4.0f * E) : 0;
+            const bool wrong_side = (float)d.side_prev * dd < -4.0f * E;  // as beam_emit_kernel
             const V3 w = r - dI;
             const float wl = margin_len(w);  // as beam_emit_kernel
             bool inside_all = true;
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
                     inside_all = inside_all && inside_any;
                 }
             }
-            const bool keep = have_r && inside_all && !(d.side_prev * side_r == -1);
+            const bool keep = have_r && inside_all && !wrong_side;
             const unsigned long long vote = __ballot(keep);
             if (vote) {  // staged per wave, one global atomic per flush (see beam_emit_kernel)
                 if (keep) {
