@@ -1,0 +1,73 @@
+"""Conservative beam pruning vs the exhaustive tracer on random small cities (with a ground quad, triangles or
+quads, optional masks, transmitters at random heights, 1-3 transmitters x 1-200 receivers, orders 1..3): the
+pruned search must return EXACTLY the exhaustive tracer's valid paths (keys, objects, vertex bits); every few
+cases the other expansion mappings and the other receiver stage are run too and must give the same candidate
+rows.  python scratch/beam_stress.py [seconds]"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import differt_amd.geometry as G  # noqa: E402
+import synthetic_scenes as S  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(77)
+st = {"cases": 0, "exhaustive_candidates": 0, "rows_traced": 0, "valid_paths": 0, "missed": 0, "extra": 0,
+      "vertex_mismatch": 0, "mapping_row_mismatch": 0, "mapping_checks": 0}
+t0 = time.time()
+while time.time() - t0 < budget:
+    boxes = int(rng.integers(3, 40))
+    pitch = float(rng.uniform(18, 45))
+    V, Tr, c, h = S.manhattan(boxes, pitch=pitch, seed=int(rng.integers(1 << 30)))
+    ext = float(np.abs(V[:, :2]).max()) + 10
+    if rng.random() < 0.7:
+        gv = np.array([[-ext, -ext, 0], [ext, -ext, 0], [ext, ext, 0], [-ext, ext, 0]], np.float32)
+        Tr = np.concatenate((Tr, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V)))
+        V = np.concatenate((V, gv))
+    order = int(rng.integers(1, 4))
+    ntx = int(rng.integers(1, 4))
+    nrx = int(rng.choice([1, 3, 8, 40, 130, 200])) if order < 3 else int(rng.choice([1, 3, 8, 20]))
+    tx, rx = S.manhattan_tx_rx(c, h, min(ntx, boxes), nrx, seed=int(rng.integers(1 << 30)), pitch=pitch)
+    tx[:, 2] = rng.uniform(1.5, 70, len(tx))
+    if rng.random() < 0.3:
+        rx[:, 2] = rng.uniform(1.0, 50, len(rx))
+    assume_quads = bool(rng.random() < 0.4)
+    mask = None
+    if rng.random() < 0.3:
+        mask = rng.random(Tr.shape[0]) > 0.15
+        if assume_quads:
+            mask[1::2] = mask[0::2]
+    mesh = G.Mesh(V, Tr, mask=mask, assume_quads=assume_quads)
+    n = mesh.num_primitives
+    if order == 3 and n > 260:
+        order = 2
+    scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    bp = tracer.trace_beam_pruned(scene, order)
+    rows = tracer.last_beam_stats["rows"]
+    a = set(ex.keys.cpu().tolist()) if ex.keys is not None else set()
+    # exhaustive keys are (pair, candidate rank); compare through objects
+    ea = [tuple(o) for o in ex.objects.cpu().tolist()]
+    ba = [tuple(o) for o in bp.objects.cpu().tolist()]
+    st["missed"] += len(set(ea) - set(ba))
+    st["extra"] += len(set(ba) - set(ea))
+    if ea == ba and ex.vertices.shape == bp.vertices.shape:
+        st["vertex_mismatch"] += int((ex.vertices.view(torch.int32) != bp.vertices.view(torch.int32)).any(dim=(-1, -2)).sum())
+    st["cases"] += 1
+    st["exhaustive_candidates"] += len(tx) * len(rx) * n * max(n - 1, 1) ** (order - 1)
+    st["rows_traced"] += rows
+    st["valid_paths"] += len(ea)
+    if st["cases"] % 4 == 0:
+        for kw in ({"expansion": "prefix"}, {"expansion": "transposed"}, {"expansion": "bvh"},
+                   {"emit": "clustered"}, {"emit": "plain"}):
+            other = tracer.trace_beam_pruned(scene, order, **kw)
+            st["mapping_checks"] += 1
+            if tracer.last_beam_stats["rows"] != rows or not torch.equal(other.keys, bp.keys):
+                st["mapping_row_mismatch"] += 1
+st["seconds"] = time.time() - t0
+print(json.dumps(st))

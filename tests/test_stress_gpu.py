@@ -55,6 +55,15 @@ def test_hybrid_candidate_space_stress():
     assert st["object_mismatch_cases"] == 0 and st["vertex_mismatch_cases"] == 0 and st["pairs_not_subset"] == 0, st
 
 
+def test_beam_pruning_vs_exhaustive_stress():
+    """the conservatively pruned search returns exactly the exhaustive tracer's paths, and
+    all expansion mappings / receiver stages agree on the candidate rows."""
+    st = _run("beam_stress.py")
+    assert st["cases"] > 50 and st["valid_paths"] > 0 and st["mapping_checks"] > 0
+    assert st["rows_traced"] < st["exhaustive_candidates"] / 10
+    assert st["missed"] == 0 and st["extra"] == 0 and st["vertex_mismatch"] == 0 and st["mapping_row_mismatch"] == 0, st
+
+
 def test_bvh_vs_brute_force_stress():
     r = subprocess.run([sys.executable, "scratch/bvh_stress.py", "20"], cwd=ROOT, capture_output=True, text=True,
                        timeout=600)
