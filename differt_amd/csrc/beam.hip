@@ -799,8 +799,15 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     }
     long long npow = 1;
     for (int j = 0; j < order; ++j) npow *= (long long)M.nprim;
-    for (int64_t ir = 0; ir < nrx; ++ir) {
-        const V3 r = ld3(rx + 3 * ir);  // wave-uniform
+    // receivers are wave-uniform scalar loads; the next one is in flight during this one's tests (the counters
+    // showed 41 % of the wave-cycles in s_waitcnt with a load + wait per iteration)
+    const float *prx = rx;
+    V3 r_next = ld3(prx);
+    const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
+    for (int ir = 0; ir < nrx32; ++ir) {
+        const V3 r = r_next;
+        prx += (ir + 1 < nrx32) ? 3 : 0;
+        r_next = ld3(prx);
         const float d = fdot(r - pc, nc);
         // wrong side of the last mirror: side_prev * d < -4E (side_prev in {-1, 0, +1}; 0 or a NaN distance never
         // rejects) -- the same decision as side_prev * side_of_range(d, d, 4E) == -1 in one multiply + compare
