@@ -51,8 +51,11 @@ def lib(path: os.PathLike | None = None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    so = Path(path) if path is not None else _HERE / "_build" / "libdiffert_oracle.so"
+    env = os.environ.get("DRT_ORACLE_LIB")  # e.g. the sanitizer build (`make -C oracle sanitize`)
+    so = Path(path) if path is not None else (Path(env) if env else _HERE / "_build" / "libdiffert_oracle.so")
     if not so.exists():
+        if env and path is None:
+            raise FileNotFoundError(f"DRT_ORACLE_LIB={env} does not exist")
         so = build()
     L = C.CDLL(str(so))
     vp, i64, f32, i32 = C.c_void_p, C.c_int64, C.c_float, C.c_int32
