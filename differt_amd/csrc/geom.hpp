@@ -148,7 +148,14 @@ __device__ __forceinline__ uint64_t moller_trumbore_wave(V3 o, V3 d, const TriE 
     const float aa = __builtin_fabsf(a0);
     const uint64_t okm = __builtin_amdgcn_ballot_w64(aa > mt_fast_threshold(eps)) &
                          __builtin_amdgcn_ballot_w64(aa <= 0x1p+126f);
-    if (__builtin_expect(okm == __builtin_amdgcn_read_exec(), 1)) {
+    // A determinant that is EXACTLY zero (segment in the triangle's plane: two mirrors on one wall plane of an
+    // axis-aligned city, 10 % of the waves of configs[2]) is a miss in the reference (a -> inf, f = 0, t = 0 or
+    // NaN, `t > eps` false) and on the fast path alike (rcp(0) = inf, e = NaN, u = NaN: every compare false), so
+    // it need not send the wave to the literal formula; t of such a lane is never used (it is not a hit).
+    bool fast = okm == __builtin_amdgcn_read_exec();
+    if (__builtin_expect(!fast, 0))
+        fast = (okm | __builtin_amdgcn_ballot_w64(aa == 0.0f)) == __builtin_amdgcn_read_exec();
+    if (__builtin_expect(fast, 1)) {
         const float r = __builtin_amdgcn_rcpf(a0);
         const float e = __builtin_fmaf(-a0, r, 1.0f);
         const float f = __builtin_fmaf(e, r, r);
@@ -162,6 +169,9 @@ __device__ __forceinline__ uint64_t moller_trumbore_wave(V3 o, V3 d, const TriE 
         if (WANT_T) *t_out = t;
         return m & __builtin_amdgcn_ballot_w64(t > eps);
     }
+#ifdef DRT_MT_DBG  // scratch instrumentation of trace.hip's debug build
+    DRT_MT_DBG();
+#endif
     const float pt = dot(q, tr.e2);
     const bool zero = (a0 == 0.0f);
     bool hit = (zero ? kInf : aa) > eps;

@@ -21,6 +21,17 @@
 #include <cstring>
 #include <string.h>
 
+#include <hip/hip_runtime.h>
+#ifdef DRT_FILTER_DEBUG  // scratch instrumentation: how often a wave leaves the fast paths (never in the product build)
+namespace drt {
+__device__ unsigned long long drt_dbg_counts[8];
+}
+#define DRT_DBG(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&drt::drt_dbg_counts[i], 1ull); } while (0)
+#define DRT_MT_DBG() DRT_DBG(3)
+#else
+#define DRT_DBG(i) do { } while (0)
+#endif
+
 #include <rocprim/rocprim.hpp>
 
 #include "common.hpp"
@@ -135,6 +146,7 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                         // plus a v_cndmask / v_cmp pair to rebuild the mask)
                         if (__builtin_expect(__builtin_amdgcn_fcmpf(__builtin_fabsf(t), kInf, 4) !=
                                                  __builtin_amdgcn_read_exec(), 0)) {
+                            DRT_DBG(1 + j);
                             cur = backward_step(cur, img[j], m.p[j], m.n[j]);
                         } else {
                             cur = V3{cur.x + dir.x * t, cur.y + dir.y * t, cur.z + dir.z * t};
@@ -146,13 +158,26 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                 uint64_t alive_mask = live_mask;
                 if (K > 0) alive_mask = inside_one_wave<K, QUADS>(m, full, K - 1, a.eps, live_mask);
                 bool alive = false, fin = true;
+                DRT_DBG(0);
+                // Some lane passes the last mirror's test in 9.4 % of the wave-iterations of configs[2]
+                // (scratch/filter_debug.py) -- not rare enough to run all remaining checks for: the other
+                // mirrors' inside tests come next, still as wave masks, and the wave leaves as soon as the mask
+                // is empty (the checks are independent, so their order cannot change the result)
+                if (!DENSE) {
+#pragma unroll
+                    for (int j = K - 2; j >= 0; --j)
+                        if (alive_mask != 0) alive_mask = inside_one_wave<K, QUADS>(m, full, j, a.eps, alive_mask);
+                }
                 if (DENSE || alive_mask != 0) {
+                    DRT_DBG(4);
                     alive = (alive_mask >> lane) & 1ull;
                     fin = path_finite<K>(full);
                     alive = alive && fin;
+                    if (DENSE) {
 #pragma unroll
-                    for (int j = K - 2; j >= 0; --j)
-                        alive = alive && inside_one<K, QUADS>(m, full, j, a.eps);
+                        for (int j = K - 2; j >= 0; --j)
+                            alive = alive && inside_one<K, QUADS>(m, full, j, a.eps);
+                    }
 #pragma unroll
                     for (int j = 0; j < K; ++j)  // IM:443-454
                         alive = alive && same_sign(dot(full[j] - m.p[j], m.n[j]),
@@ -677,6 +702,16 @@ static size_t sort_temp_bytes(int64_t n) {
 }  // namespace drt
 
 using namespace drt;
+#ifdef DRT_FILTER_DEBUG
+extern "C" void drt_debug_counts(unsigned long long *out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(drt::drt_dbg_counts), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(drt::drt_dbg_counts), z, sizeof(z));
+    }
+}
+#endif
 
 extern "C" {
 
