@@ -1,5 +1,6 @@
 """First-hit / any-hit / visibility throughput on the 10k- and 200k-triangle synthetic Manhattan
-meshes: brute-force LDS-tiled kernels vs the LBVH kernels, rays/s.
+meshes: brute-force LDS-tiled kernels vs the LBVH kernels, rays/s; on the 10k mesh
+also the ray-launching users of the LBVH (rows f2 / f3): SBR path launching and the visibility estimate.
 
     python bench_queries.py
 """
@@ -51,6 +52,19 @@ def run(dev=None) -> dict:
         ta = _time(lambda: mesh.ray_intersect_any_triangle(to, td, accel="bvh"))
         res["any_hit_brute_rays_per_s"] = R / tb
         res["any_hit_bvh_rays_per_s"] = R / ta
+        if T <= 50000:  # rows f2 / f3: ray-launching users of the LBVH first hit
+            _, _, c, h = S.manhattan(boxes)
+            tx1, rx4 = S.manhattan_tx_rx(c, h, 1, 4)
+            scene = G.Scene(torch.as_tensor(tx1, device="cuda"), torch.as_tensor(rx4, device="cuda"), mesh)
+            sbr = G.SBRPathLauncher(num_rays=1_000_000, max_dist=1.0)
+            for order in (1, 3):
+                ts = _time(lambda: sbr.launch_paths(scene, order), reps=3)
+                res[f"sbr_order{order}_rays_per_s"] = 1_000_000 / ts
+                res[f"sbr_order{order}_bounces_per_s"] = 1_000_000 * order / ts
+            res["sbr_note"] = "SBRPathLauncher.launch_paths, 1 TX x 4 RX, 1e6 lattice rays, LBVH first hit per bounce"
+            tv = _time(lambda: mesh.triangles_visible_from_vertex(scene.transmitters.reshape(-1, 3), num_rays=1_000_000,
+                                                                  accel="bvh"), reps=3)
+            res["visibility_1e6_rays_s"] = tv
         out[f"manhattan_{T}"] = res
     return out
 
