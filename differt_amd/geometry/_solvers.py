@@ -542,9 +542,9 @@ class ExhaustivePathTracer(AbstractPathTracer):
         ulp = 2.0 ** (int(np.floor(np.log2(mag))) - 23)
         margin = float(kappa) * ulp / float(cos_min) ** order
         h = mesh.handle().h
-        # kernel mapping of the expansion (identical survivors, see drt_beam_expand).  "auto": lane = primitive
-        # with wave-level sphere culling for the first expansion (one cone per prefix, few prefixes), lane =
-        # prefix for the second one (two cones, ~1e8 prefixes: measured 2.44 s vs 2.91 s on configs[3])
+        # kernel mapping of the expansion (identical survivors, see drt_beam_expand).  "auto" = "clustered":
+        # primitives in Morton clusters of 64 with boxes, box test per (prefix, cluster), survivors tested with
+        # lane = primitive (configs[3]: second expansion 2.4 s with lane = prefix, 0.6 s clustered)
         modes = {"transposed": (0, 0), "bvh": (1, 1), "prefix": (2, 2), "clustered": (3, 3), "auto": (3, 3)}
         if expansion not in modes:
             raise ValueError(f"unknown expansion {expansion!r}")

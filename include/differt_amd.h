@@ -458,9 +458,10 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
  *   drt_beam_expand  level-`level` prefixes x primitives -> surviving (prefix index << 32 | primitive)
  *                    records, 8 bytes each                                      -> out[0 .. *count);
  *                    use_bvh selects the mapping (same survivors): 0 = lane per primitive, prefixes
- *                    staged in LDS, wave-level bounding-sphere culling (default, fastest measured);
+ *                    staged in LDS, wave-level bounding-sphere culling;
  *                    1 = walk of the mesh LBVH with the box form of the tests (with assume_quads a
- *                    record may repeat -- de-duplicate the sorted rows); 2 = lane per prefix, brute force
+ *                    record may repeat -- de-duplicate the sorted rows); 2 = lane per prefix, brute force.
+ *                    drt_beam_expand_clustered (below) is the fastest measured and what the Python layer uses
  *   drt_beam_finish  records -> level + 1 prefixes (needed between two expansions)
  *   drt_beam_emit    prefixes x receivers -> packed candidate rows (drt_beam_emit_clustered: the same
  *                    for many receivers, with cluster-level culling)
