@@ -520,7 +520,12 @@ class ExhaustivePathTracer(AbstractPathTracer):
         if self.smoothing_factor is not None:
             raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
         if order == 0:
-            return self.trace_rank_range(scene, 0, max_survivors=max_survivors, max_paths=max_paths)
+            p0 = self.trace_rank_range(scene, 0, max_survivors=max_survivors, max_paths=max_paths)
+            if prefix_shard is not None and int(prefix_shard[0]) != 0:  # line-of-sight paths have no prefix: rank 0 owns them
+                it0 = None if p0.interaction_types is None else p0.interaction_types[:0]
+                p0 = TracedPaths(p0.vertices[:0], p0.objects[:0], p0.mask[:0], it0, self.confidence_threshold,
+                                 None if p0.keys is None else p0.keys[:0])
+            return p0
         if not 1 <= order <= 3:
             raise ValueError("beam pruning covers orders 1..3")
         mesh = scene.mesh
