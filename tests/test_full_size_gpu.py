@@ -231,6 +231,50 @@ def test_cfg4_order3_rank_window(G, manhattan):
     np.testing.assert_array_equal(_np(w.keys), np.flatnonzero(o["mask"].reshape(-1)))
 
 
+def test_cfg4_full_coverage_beam_pruned(G, manhattan):
+    """configs[3] at FULL size: order 3 over all 1.02e15 candidates through the conservatively pruned search
+    (DESIGN.md section 9).  No exhaustive run can cross-check it; what can be checked here: every returned path
+    is valid and bit-identical for the oracle given only its candidate (soundness), the keys are the closed form
+    of the objects in strictly increasing order, the independent sampled per-pair search finds no path the
+    pruned search lacks (it may find fewer), and two prefix shards partition the result."""
+    V, Tr, tx, rx = manhattan
+    n, order = Tr.shape[0], 3
+    scene = G.Scene(tx, rx, G.Mesh(V, Tr))
+    tracer = G.ExhaustivePathTracer(accel="bvh")
+    bp = tracer.trace_beam_pruned(scene, order)
+    st = dict(tracer.last_beam_stats)
+    assert bp.objects.shape[0] >= 50 and st["rows"] < 1e-6 * 1024 * n * (n - 1) ** 2
+    _oracle_revalidate(V, Tr, tx, rx, bp, n ** order, order, n)
+    o = bp.objects.long()
+    keys = (o[:, 0] * rx.shape[0] + o[:, 4]) * n ** 3 + o[:, 1] * n * n + o[:, 2] * n + o[:, 3]
+    assert torch.equal(bp.keys, keys) and bool((keys[1:] > keys[:-1]).all())
+    sampled = G.HybridPathTracer(num_rays=100_000, accel="bvh", sample_triangles=True).trace_pairs(scene, order)
+    have = set(map(tuple, _np(bp.objects).tolist()))
+    assert set(map(tuple, _np(sampled.objects).tolist())) <= have
+    parts = [tracer.trace_beam_pruned(scene, order, prefix_shard=(r, 2)) for r in range(2)]
+    merged = torch.sort(torch.cat([p.keys for p in parts])).values
+    assert torch.equal(merged, bp.keys)
+
+
+def test_cfg5_full_coverage_beam_pruned(G):
+    """configs[4] at FULL size (1 TX x 1024 RX, 200 000 triangles, order 2, 4.1e13 candidates) through the pruned
+    search with the clustered expansion / receiver stage: every path re-validated by the oracle against the whole
+    mesh, the plain receiver stage gives the same rows, fwd + grad finite."""
+    V, Tr, tx, rx = S.cfg5_scene()
+    n, order = Tr.shape[0], 2
+    txg = torch.tensor(tx, device="cuda", requires_grad=True)
+    scene = G.Scene(txg, torch.tensor(rx, device="cuda"), G.Mesh(V, Tr))
+    tracer = G.ExhaustivePathTracer(accel="bvh")
+    bp = tracer.trace_beam_pruned(scene, order)
+    rows = tracer.last_beam_stats["rows"]
+    assert bp.objects.shape[0] >= 50 and rows < 1e-5 * 1024 * n * (n - 1)
+    _oracle_revalidate(V, Tr, tx, rx, bp, n ** order, order, n)
+    plain = tracer.trace_beam_pruned(scene, order, emit="plain", expansion="transposed")
+    assert tracer.last_beam_stats["rows"] == rows and torch.equal(plain.keys, bp.keys)
+    torch.sqrt((torch.diff(bp.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+    assert bool(torch.isfinite(txg.grad).all()) and float(txg.grad.abs().max()) > 0
+
+
 def test_cfg5_200k_triangles(G):
     """configs[4] scene: 20 000 boxes = 200 000 triangles, 1 TX x 1024 RX grid, order 2: first-hit /
     any-hit over the full mesh vs the oracle on sampled rays, and a rank window of the tracer."""
