@@ -153,6 +153,24 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Time-based pre-warm BEFORE the counted warm-up: the metric is steady-state throughput, and the
+    # first tens of milliseconds after an idle period run at a ramping clock (a cold 20-launch window
+    # measured 0.94 ms/step where the same process settles at 0.79 ms).  Launch blocks of 50 until two
+    # consecutive block means agree within 1 %, capped at 1 s of device time.
+    prewarm_ms, prewarm_launches, prev_mean = 0.0, 0, None
+    pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    while prewarm_ms < 1000.0:
+        pe0.record()
+        for _ in range(50):
+            step()
+        pe1.record()
+        pe1.synchronize()
+        blk = pe0.elapsed_time(pe1)
+        prewarm_ms += blk
+        prewarm_launches += 50
+        if prev_mean is not None and abs(blk - prev_mean) <= 0.01 * prev_mean:
+            break
+        prev_mean = blk
     for _ in range(args.warmup):
         step()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -181,13 +199,20 @@ def main() -> None:
         tests_per_step = R * T * world
         algo_bytes = 5 * R * T + 24 * R + 36 * T  # 5 B out/test + inputs once
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch come from a committed counter pass (rocprofv3 --pmc cannot run inside this
+        # process); the record carries a hash of the kernel sources it was collected on, and a record that
+        # no longer describes the tree is flagged instead of being quoted silently
+        traffic, pmc_stale = None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get("mt_dense_kernel_bytes_per_launch")
+                from differt_amd._srchash import is_stale
+
+                rec = json.loads(pmc.read_text())
+                traffic = rec.get("mt_dense_kernel_bytes_per_launch")
+                pmc_stale = is_stale(rec, "dense")
             except Exception:  # noqa: BLE001
-                traffic = None
+                traffic, pmc_stale = None, None
         result = {
             "metric": "ray-triangle tests/s (ray_intersect_triangle dense fwd, 10k random triangles)",
             "value": tests_per_step * args.steps / elapsed,
@@ -195,6 +220,8 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_ms": prewarm_ms,
+            "prewarm_launches": prewarm_launches,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -217,6 +244,8 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)",
+                "pmc_stale": pmc_stale,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
@@ -272,6 +301,42 @@ def main() -> None:
             "hbm_frac": (5 * Rl * T + 24 * Rl + 36 * T) / ((us_graph or us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
         }
 
+    # configs[1] as DiffeRT issues it under leading batch axes: 64 problems of 256 rays x 10k triangles
+    # (own triangle set each) in ONE launch of the batched entry point
+    if rank == 0:
+        try:
+            Bn, Rl = 64, 256
+            ob, db, _ = make_cfg2(Bn * Rl, T, seed=77)
+            tvb = np.stack([make_cfg2(1, T, seed=500 + b)[2] for b in range(Bn)])
+            ob, db, tvb = (torch.as_tensor(x, device=dev) for x in (ob, db, tvb))
+            tb = torch.empty((Bn, Rl, T), dtype=torch.float32, device=dev)
+            hb = torch.empty((Bn, Rl, T), dtype=torch.uint8, device=dev)
+
+            def step_b():
+                lib.call("drt_ray_intersect_triangle_dense_batched", ptr(ob), ptr(db), 3 * Rl, Rl, ptr(tvb), 9 * T, T,
+                         Bn, eps, ptr(tb), ptr(hb), stream())
+
+            for _ in range(20):
+                step_b()
+            nbt = 100
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(nbt):
+                step_b()
+            e1.record()
+            torch.cuda.synchronize()
+            msb = e0.elapsed_time(e1) / nbt
+            bytes_b = Bn * (5 * Rl * T + 24 * Rl + 36 * T)
+            result["cfg2_batched"] = {
+                "problems": Bn, "rays": Rl, "triangles": T, "ms_per_launch": msb,
+                "tests_per_s": Bn * Rl * T / (msb * 1e-3),
+                "hbm_frac": bytes_b / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            }
+            del ob, db, tvb, tb, hb
+        except Exception as exc:  # noqa: BLE001 - an extra leg never costs the headline line
+            result["cfg2_batched"] = {"error": repr(exc)}
+
     if not args.no_paths:  # every rank takes part: the candidate-rank space is sharded over the GPUs
         paths = None
         try:
@@ -296,6 +361,17 @@ def main() -> None:
             sc = {"error": repr(exc)}
         if rank == 0:
             result["strong_scaling"] = sc
+            if world > 1 and isinstance(sc, dict):
+                # the north-star scaling claim (>= 6x at 8 GPUs) is about FIXED total work: surface those
+                # legs at the top level so that a SCALE run shows them without digging (`value` above stays
+                # the weak-scaling dense operator, identical to the single-GPU bench at N = 1)
+                heads = []
+                for leg in ("beam_sharded", "candidate_sharded"):
+                    rec = sc.get(leg)
+                    if isinstance(rec, dict) and rec.get("s_per_step") is not None:
+                        heads.append({"leg": leg, "s_per_step": rec["s_per_step"], "n_gpus": world,
+                                      "scaling": "strong", "valid_paths": rec.get("valid_paths")})
+                result["strong_headline"] = heads
 
     if rank == 0 and not args.no_paths:
         try:

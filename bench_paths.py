@@ -119,12 +119,19 @@ def paths_roofline(order: int, stage: dict | None) -> dict | None:
 
     if not stage or not stage.get("filter_ms"):
         return None
-    pmc = Path(__file__).resolve().parent / "profiles" / "r02" / "pmc_trace_filter.json"
+    root = Path(__file__).resolve().parent / "profiles"
+    # newest committed counter record; it carries a hash of the kernel sources it was collected on
+    pmcs = sorted(root.glob("r*/pmc_trace_filter.json"))
+    pmc = pmcs[-1] if pmcs else root / "r02" / "pmc_trace_filter.json"
     per_cand = None
     occ_per_surv_tri = None
+    pmc_stale = None
     if pmc.exists():
         try:
+            from differt_amd._srchash import is_stale
+
             rec = json.loads(pmc.read_text())
+            pmc_stale = is_stale(rec, "trace_filter")
             per_cand = rec.get("executed_valu_per_candidate", {}).get(str(order))
             occ_per_surv_tri = rec.get("occlusion_valu_per_survivor_triangle")
         except Exception:  # noqa: BLE001
@@ -138,7 +145,8 @@ def paths_roofline(order: int, stage: dict | None) -> dict | None:
         "occlusion_kernel_ms": stage["occlusion_ms"],
         "sort_emit_ms": stage["sort_emit_ms"],
         "executed_valu_per_candidate": per_cand,
-        "executed_valu_source": "profiles/r02/pmc_trace_filter.json (SQ_INSTS_VALU pass, committed)",
+        "executed_valu_source": f"profiles/{pmc.parent.name}/pmc_trace_filter.json (SQ_INSTS_VALU pass, committed)",
+        "pmc_stale": pmc_stale,
         "peak": PEAK_VALU_ISSUE,
         "peak_fma_flops": PEAK_FP32_FMA,
         "unit": "lane-ops/s",

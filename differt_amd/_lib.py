@@ -105,6 +105,7 @@ _SIGNATURES = {
     "drt_device_check": (_i32, []),
     "drt_ray_intersect_triangle_dense": (_i32, [_vp, _vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp]),
     "drt_ray_intersect_triangle_paired": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "drt_ray_intersect_triangle_dense_batched": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
     "drt_ray_intersect_any_triangle": (
         _i32,
         [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _f32, _f32, _vp, _vp],

@@ -38,16 +38,24 @@ __device__ __forceinline__ void atomic_add3f(float *p, V3 v) {
 }
 constexpr int kDenseCols = kDenseThreads * 4;  // triangles per block
 constexpr int kDenseGroup = 8;                 // rays whose hit bytes are staged in LDS together
+// batched launches (drt_ray_intersect_triangle_dense_batched): element strides between two problems
+struct DenseBatch {
+    int64_t ray_stride;  // floats between the ray arrays of consecutive problems (3 R, or 0 = shared rays)
+    int64_t tv_stride;   // floats between their triangle sets (9 T, or 0 = shared triangles)
+};
 constexpr int kDenseStageDwords = 5 * 64 * 4;  // LDS triangle staging per wave: 5 x b128 per lane (32 lanes x 4 triangles x 9 floats = 1152 dwords used)
 
 // Stores with a wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset: the per-row address math
 // stays on the scalar unit.  Nontemporal: measured 0.83 ms vs 0.95 ms for plain stores on the bench
 // shape (profiles/r02/dense_lab.md).
+// gfx9-family hazard: a VMEM store of more than 64 bits followed by a VALU write of its data VGPRs needs
+// one wait state, and LLVM's hazard recogniser does not look inside inline asm -- the `s_nop 0` covers it
+// whatever the scheduler places after the store (one issue cycle per 1-KiB wave store).
 __device__ __forceinline__ void store_nt_b128(char *base, uint32_t off, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(off), "v"(v), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void store_nt_b128(char *base, uint32_t off, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(off), "v"(v), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 
 // Byte offset, inside a row segment of `hd` head bytes + `body` bytes of whole 128-B lines + a
@@ -75,7 +83,14 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(7
 void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
                              const float *__restrict__ tv, int64_t T, float eps,
                              float *__restrict__ t_out, uint8_t *__restrict__ hit_out,
-                             int rays_per_block, int stage_tris) {
+                             int rays_per_block, int stage_tris, DenseBatch nb) {
+    // blockIdx.z = problem of a batched launch (R rays x T triangles each; outputs [B,R,T]): wave-uniform
+    // pointer offsets on the scalar unit, nothing else changes (nb = {0, 0} for the plain operator)
+    ro += (int64_t)blockIdx.z * nb.ray_stride;
+    rd += (int64_t)blockIdx.z * nb.ray_stride;
+    tv += (int64_t)blockIdx.z * nb.tv_stride;
+    t_out += (int64_t)blockIdx.z * R * T;
+    hit_out += (int64_t)blockIdx.z * R * T;
     // one LDS allocation, two uses: triangle staging (20 KiB, start of the block) and then the hit rows
     // of kDenseGroup rays x 2 buffers (16 KiB)
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4 * kDenseStageDwords];
@@ -182,8 +197,10 @@ void mt_dense_aligned_kernel(const float *__restrict__ ro, const float *__restri
         for (int k = 0; k < kDenseGroup / 4; ++k) {
             const int s = wave + 4 * k;  // wave w flushes rows w and w + 4 of the group
             if (s < cnt) {
-                const int64_t A = (r0 + (int64_t)g * kDenseGroup + s) * T + col0;  // first hit byte
-                const uint32_t head = (128u - ((uint32_t)A & 127u)) & 127u;
+                // first hit byte, relative to the problem's rows; the line phase is that of the ADDRESS
+                const int64_t A = (r0 + (int64_t)g * kDenseGroup + s) * T + col0;
+                const uint32_t phase = (uint32_t)(reinterpret_cast<uintptr_t>(hit_out) + (uintptr_t)A) & 127u;
+                const uint32_t head = (128u - phase) & 127u;
                 const uint32_t hd = head < W ? head : W;
                 const uint32_t body = (W - hd) & ~127u;
                 const uint32_t off = line_first_offset((uint32_t)lane * 16u, hd, body);
@@ -203,7 +220,12 @@ template <bool VEC>
 __global__ __launch_bounds__(kDenseThreads) void mt_dense_kernel(
     const float *__restrict__ ro, const float *__restrict__ rd, int64_t R,
     const float *__restrict__ tv, int64_t T, float eps, float *__restrict__ t_out,
-    uint8_t *__restrict__ hit_out, int rays_per_block) {
+    uint8_t *__restrict__ hit_out, int rays_per_block, DenseBatch nb) {
+    ro += (int64_t)blockIdx.z * nb.ray_stride;
+    rd += (int64_t)blockIdx.z * nb.ray_stride;
+    tv += (int64_t)blockIdx.z * nb.tv_stride;
+    t_out += (int64_t)blockIdx.z * R * T;
+    hit_out += (int64_t)blockIdx.z * R * T;
     const int64_t j0 = ((int64_t)blockIdx.y * kDenseThreads + threadIdx.x) * 4;
     if (j0 >= T) return;
     const int64_t r0 = (int64_t)blockIdx.x * rays_per_block;
@@ -550,12 +572,10 @@ using namespace drt;
 
 extern "C" {
 
-int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64_t R,
-                                         const float *tv, int64_t T, float eps, float *t_out,
-                                         uint8_t *hit_out, void *stream) {
-    DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
-    if (R == 0 || T == 0) return DRT_OK;
-    DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
+static int32_t dense_launch(const float *ro, const float *rd, int64_t R, const float *tv, int64_t T, float eps,
+                            float *t_out, uint8_t *hit_out, int64_t B, DenseBatch nb, void *stream) {
+    // with B > 1 every problem's output block starts R*T elements after the previous one: the aligned
+    // kernel needs each of them 16-B aligned (T % 16 == 0 makes R*T a multiple of 16)
     const bool al16 = (T % 16 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(hit_out) & 15) == 0);
     const bool al4 = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(t_out) & 15) == 0) &&
@@ -571,7 +591,7 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
         const long v = e ? atol(e) : 0;
         return (int64_t)(v > 0 ? v : 1280);
     }();
-    int64_t rpb = (R * cols) / target_blocks;
+    int64_t rpb = (R * cols * B) / target_blocks;
     if (rpb < 1) rpb = 1;
     if (rpb > 32) rpb = 32;
     if (al16 && rpb > kDenseGroup) rpb -= rpb % kDenseGroup;  // whole groups: no short trailing group
@@ -579,7 +599,7 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     DRT_REQUIRE(rows < (1ll << 31), "too many rays for one launch");
     // 32-bit byte offsets inside a block's rows: rpb * T * 4 bytes must fit
     DRT_REQUIRE(T <= (1ll << 24), "too many triangles per row for one launch (%lld)", (long long)T);
-    dim3 grid((unsigned)rows, (unsigned)cols);
+    dim3 grid((unsigned)rows, (unsigned)cols, (unsigned)B);
     hipStream_t s = as_stream(stream);
     // coalesced LDS staging of the triangles needs 16-B aligned rows of 4 triangles (experiment hook:
     // DRT_DENSE_STAGE=0 keeps the direct per-lane loads)
@@ -589,18 +609,42 @@ int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64
     }();
     // worth it only when a block walks few rays (configs[1]: 8.0 -> 7.4 us; at 32 rays per block the direct
     // loads hide behind the other blocks' arithmetic and staging costs 1 %: profiles/r02/literal_lab.txt)
-    const int stage = (stage_ok && rpb <= kDenseGroup && (reinterpret_cast<uintptr_t>(tv) & 15) == 0) ? 1 : 0;
+    const int stage = (stage_ok && rpb <= kDenseGroup && (reinterpret_cast<uintptr_t>(tv) & 15) == 0 &&
+                       (nb.tv_stride % 4) == 0) ? 1 : 0;
     if (al16)
         hipLaunchKernelGGL(mt_dense_aligned_kernel, grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T, eps,
-                           t_out, hit_out, (int)rpb, stage);
+                           t_out, hit_out, (int)rpb, stage, nb);
     else if (al4)
         hipLaunchKernelGGL((mt_dense_kernel<true>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
-                           eps, t_out, hit_out, (int)rpb);
+                           eps, t_out, hit_out, (int)rpb, nb);
     else
         hipLaunchKernelGGL((mt_dense_kernel<false>), grid, dim3(kDenseThreads), 0, s, ro, rd, R, tv, T,
-                           eps, t_out, hit_out, (int)rpb);
+                           eps, t_out, hit_out, (int)rpb, nb);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
+}
+
+int32_t drt_ray_intersect_triangle_dense(const float *ro, const float *rd, int64_t R,
+                                         const float *tv, int64_t T, float eps, float *t_out,
+                                         uint8_t *hit_out, void *stream) {
+    DRT_REQUIRE(R >= 0 && T >= 0, "negative size");
+    if (R == 0 || T == 0) return DRT_OK;
+    DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
+    return dense_launch(ro, rd, R, tv, T, eps, t_out, hit_out, 1, DenseBatch{0, 0}, stream);
+}
+
+int32_t drt_ray_intersect_triangle_dense_batched(const float *ro, const float *rd, int64_t ray_batch_stride,
+                                                 int64_t R, const float *tv, int64_t tv_batch_stride, int64_t T,
+                                                 int64_t B, float eps, float *t_out, uint8_t *hit_out,
+                                                 void *stream) {
+    DRT_REQUIRE(R >= 0 && T >= 0 && B >= 0, "negative size");
+    DRT_REQUIRE(ray_batch_stride == 0 || ray_batch_stride == 3 * R, "ray_batch_stride is 0 (shared) or 3 * num_rays");
+    DRT_REQUIRE(tv_batch_stride == 0 || tv_batch_stride == 9 * T, "tv_batch_stride is 0 (shared) or 9 * num_triangles");
+    DRT_REQUIRE(B <= 65535, "at most 65535 problems per launch");
+    if (R == 0 || T == 0 || B == 0) return DRT_OK;
+    DRT_REQUIRE(ro && rd && tv && t_out && hit_out, "null pointer");
+    return dense_launch(ro, rd, R, tv, T, eps, t_out, hit_out, B, DenseBatch{ray_batch_stride, tv_batch_stride},
+                        stream);
 }
 
 int32_t drt_ray_intersect_triangle_paired(const float *ro, const float *rd, const float *tv,

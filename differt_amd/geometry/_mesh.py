@@ -140,16 +140,31 @@ class Mesh:
 
         return (k(self.vertices), k(self.triangles), k(self.mask), bool(self.assume_quads))
 
+    def _handle_is_current(self) -> bool:
+        """The handle keeps STRONG references to the tensors it was snapshotted from and is current only
+        while the mesh still holds those very objects (``is``) at the same in-place version.  An address /
+        version pair alone is not an identity: a fresh tensor from an optimisation step can be allocated
+        where a freed one lived, with version 0 again."""
+        h = self._handle
+        if h is None or getattr(h, "key", None) != self._handle_key():
+            return False
+        return all(a is b for a, b in zip(h.src, (self.vertices, self.triangles, self.mask)))
+
     def handle(self) -> _MeshHandle:
-        key = self._handle_key()
-        if self._handle is None or getattr(self._handle, "key", None) != key:
+        if not self._handle_is_current():
             if self.mask is not None and self.mask.shape[0] != self.triangles.shape[0]:
                 raise ValueError("mask must have one entry per triangle")
             self._handle = _MeshHandle(
                 self.vertices.detach().contiguous(), self.triangles, self.mask, self.assume_quads
             )
-            self._handle.key = key
+            self._handle.key = self._handle_key()
+            self._handle.src = (self.vertices, self.triangles, self.mask)
         return self._handle
+
+    def generation(self) -> int:
+        """Identity of the current device snapshot (changes whenever :meth:`handle` re-snapshots): the key
+        for anything cached per geometry outside the native handle."""
+        return id(self.handle())
 
     # ---- reference properties ----
     @property

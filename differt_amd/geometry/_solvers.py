@@ -760,7 +760,8 @@ class HybridPathTracer(ExhaustivePathTracer):
         # launch the visibility rays twice: memoise the last result on everything it depends on
         # (end points by VALUE: a fresh tensor of an optimisation step may reuse the previous one's memory)
         def key():
-            return (mesh._handle_key(), self.num_rays, self.accel, self.sample_triangles,
+            # the handle object itself (kept alive by the cache entry): a re-snapshot makes a new one
+            return (mesh.handle(), self.num_rays, self.accel, self.sample_triangles,
                     tx.detach().cpu().numpy().tobytes(), rx.detach().cpu().numpy().tobytes())
 
         cached = getattr(self, "_vis_cache", None)

@@ -243,6 +243,21 @@ def ray_intersect_triangle(
             "drt_ray_intersect_triangle_dense",
             ptr(of), ptr(df), of.shape[0], ptr(tvf), T, eps, ptr(t), ptr(hit), stream(),
         )
+    elif nb >= 3 and ob[-1] == 1 and db[-1] == 1 and tvb[-2] == 1 and int(np.prod(batch[:-2], dtype=np.int64)) <= 65535:
+        # the outer form under leading batch axes (`vmap` of configs[1]: o [*L,R,1,3] x tv [*L,1,T,3,3],
+        # docs/source/batch_axes.md:67-80): B = prod(L) independent R x T problems in ONE launch -- a single
+        # 256-ray problem is latency-bound, a batch of them is not
+        lead, R, T = batch[:-2], batch[-2], batch[-1]
+        B = int(np.prod(lead, dtype=np.int64))
+        of = o.reshape(ob[:-1] + (3,)).expand(*lead, R, 3).contiguous()
+        df = d.reshape(db[:-1] + (3,)).expand(*lead, R, 3).contiguous()
+        shared_tv = all(x == 1 for x in tvb[:-2])
+        tvf = (tv.reshape(T, 3, 3) if shared_tv
+               else tv.reshape(tvb[:-2] + (T, 3, 3)).expand(*lead, T, 3, 3)).contiguous()
+        _lib.call(
+            "drt_ray_intersect_triangle_dense_batched",
+            ptr(of), ptr(df), 3 * R, R, ptr(tvf), 0 if shared_tv else 9 * T, T, B, eps, ptr(t), ptr(hit), stream(),
+        )
     else:
         of = o.expand(*batch, 3).contiguous()
         df = d.expand(*batch, 3).contiguous()
@@ -346,7 +361,7 @@ def first_triangle_hit_by_ray(
             ptr(o), ptr(d), R, ptr(tv), T, tvs, ptr(act), acts, eps,
             0 if batch_size is None else int(batch_size), ptr(idx), ptr(t), ptr(ws), R * 8, stream(),
         )
-    if R and torch.is_grad_enabled() and (o.requires_grad or d.requires_grad or tv.requires_grad):
+    if R and T and torch.is_grad_enabled() and (o.requires_grad or d.requires_grad or tv.requires_grad):
         # the reference's t is differentiable (argmin picks one triangle, t = min over the hits,
         # _utils.py:1886-1960): re-evaluate the paired operator on the hit triangle -- the same
         # arithmetic, hence the same bits -- with its VJP attached; misses keep the constant inf

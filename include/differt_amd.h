@@ -60,6 +60,18 @@ int32_t drt_ray_intersect_triangle_dense(const float *ray_origins, const float *
 int32_t drt_ray_intersect_triangle_paired(const float *ray_origins, const float *ray_directions,
                                           const float *triangle_vertices, int64_t n, float epsilon,
                                           float *t_out, uint8_t *hit_out, void *stream);
+/* batched: `num_problems` independent dense problems of num_rays x num_triangles each in ONE launch --
+ * the outer form under leading batch axes (`vmap` of the call above; broadcasting rules of
+ * docs/source/batch_axes.md:67-80).  Problem b reads rays at ray_origins + b * ray_batch_stride
+ * (stride in floats: 3 * num_rays, or 0 = every problem shares the rays) and triangles at
+ * triangle_vertices + b * tv_batch_stride (9 * num_triangles, or 0 = shared); outputs
+ * t [B, R, T] f32 and hit [B, R, T] u8.  Bit-identical to B separate dense calls; a single 256-ray
+ * problem (BASELINE configs[1]) is latency-bound, a batch of them runs at the dense kernel's bandwidth. */
+int32_t drt_ray_intersect_triangle_dense_batched(const float *ray_origins, const float *ray_directions,
+                                                 int64_t ray_batch_stride, int64_t num_rays,
+                                                 const float *triangle_vertices, int64_t tv_batch_stride,
+                                                 int64_t num_triangles, int64_t num_problems, float epsilon,
+                                                 float *t_out, uint8_t *hit_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (a2) ray_intersect_any_triangle -- reference: geometry/_utils.py:1353-1537 (hard mode), and the

@@ -44,6 +44,28 @@ def test_known_answers(G, goldens):
         assert bool(_np((t < 1.0) & hit)[0]) == case["expected"]
 
 
+@pytest.mark.parametrize("B,R,T,shared", [(64, 256, 10000, True), (64, 256, 10000, False), (5, 33, 1023, False),
+                                          (3, 40, 2064, False), (7, 9, 16, True), (2, 300, 1028, False)])
+def test_dense_batched_equals_single_launches(G, rng, B, R, T, shared):
+    """drt_ray_intersect_triangle_dense_batched (configs[1] under leading batch axes,
+    docs/source/batch_axes.md:67-80): B problems in one launch, bit-identical to B single launches and
+    to the oracle, with shared and with per-problem triangle sets, on the aligned and the fallback kernels."""
+    o = (rng.uniform(-1, 1, (B, R, 3)) * 50).astype(np.float32)
+    d = (rng.uniform(-1, 1, (B, R, 3)) * 50).astype(np.float32) - o
+    nb = 1 if shared else B
+    c = (rng.uniform(-1, 1, (nb, T, 1, 3)) * 50).astype(np.float32)
+    tv = (c + np.concatenate([np.zeros((nb, T, 1, 3)), rng.normal(size=(nb, T, 2, 3)) * 2], axis=2)).astype(np.float32)
+    t, hit = G.ray_intersect_triangle(o[:, :, None, :], d[:, :, None, :], tv[:, None])
+    assert t.shape == (B, R, T) and hit.shape == (B, R, T)
+    for b in sorted({0, B // 2, B - 1}):
+        tb = tv[0 if shared else b]
+        t1, h1 = G.ray_intersect_triangle(o[b][:, None, :], d[b][:, None, :], tb)
+        assert torch.equal(t[b].view(torch.int32), t1.view(torch.int32)) and torch.equal(hit[b], h1)
+        et, eh = orc.ray_intersect_triangle_dense(o[b], d[b], tb)
+        np.testing.assert_array_equal(_np(hit[b]), eh)
+        np.testing.assert_array_equal(_np(t[b]).view(np.uint32), et.view(np.uint32))
+
+
 @pytest.mark.parametrize("R,T", [(1, 1), (7, 5), (256, 10000), (33, 1023), (64, 4099), (300, 1028), (3, 16), (5, 1040),
                                  (40, 2064), (2000, 1024)])
 def test_dense_bit_exact(G, rng, R, T):
