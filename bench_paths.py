@@ -186,8 +186,10 @@ def beam_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:
         st = tracer.last_beam_stats
         return {"s_per_step": dt, "valid_paths": int(nv), "valid_paths_per_s": nv / dt,
                 "same_valid_paths_as_exhaustive": int(nv) == int(expected_valid),
-                "rows_traced": int(st["rows"]), "prefix_levels": st["levels"], "margin_m": st["margin_m"],
-                "coverage": "all n(n-1) candidates of every (tx, rx) pair; guarantee: incidence cosines >= 0.25"}
+                "rows_traced": int(st["rows"]), "prefix_levels": st["levels"], "unit_m": st["unit_m"], "grazing_prefixes": st["grazing_prefixes"],
+                "entry_point": "drt_trace_paths_beam (one native call per step)",
+                "coverage": "all n(n-1)^(order-1) candidates of every (tx, rx) pair; error bounds per mirror from its "
+                            "incidence geometry (no smallest-cosine parameter)"}
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}
 

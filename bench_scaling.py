@@ -206,7 +206,7 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
             "equivalent_path_candidates_per_s": int(rx.shape[0]) * total / dt,
             "rows_traced_this_rank": int(st.get("rows", 0)),
             "prefix_levels_this_rank": [int(x) for x in st.get("levels", [])],
-            "margin_m": float(st.get("margin_m", 0.0)),
+            "unit_m": float(st.get("unit_m", 0.0)), "grazing_prefixes": int(st.get("grazing_prefixes", 0)),
             "checksum_keys": int(gk.sum().item()) if gk.shape[0] else 0,  # identical for every N
             "grad_tx_finite": bool(torch.isfinite(grad).all().item()),
             "grad_tx_absmax": float(grad.abs().max().item()),

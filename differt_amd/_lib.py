@@ -64,7 +64,42 @@ class TraceParams(C.Structure):
 DRT_TRACE_USE_BVH = 1
 DRT_TRACE_SKIP_OCCLUSION = 2
 DRT_TRACE_OVERFLOW_SURVIVORS, DRT_TRACE_OVERFLOW_PATHS = 1, 2
-ABI_VERSION = 4  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
+ABI_VERSION = 5  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
+
+
+class BeamStats(C.Structure):
+    """``drt_beam_stats``."""
+
+    _fields_ = [
+        ("levels", C.c_int64 * 4),
+        ("rows", C.c_int64),
+        ("slices", C.c_int64),
+        ("valid", C.c_int64),
+        ("grazing_prefixes", C.c_int64),
+        ("unit_m", C.c_float),
+        ("magnitude", C.c_float),
+    ]
+
+
+class BeamParams(C.Structure):
+    """``drt_beam_params``."""
+
+    _fields_ = [
+        ("kappa", C.c_float),
+        ("flags", C.c_int32),
+        ("max_entries", C.c_int64),
+        ("max_records", C.c_int64),
+        ("max_rows", C.c_int64),
+        ("max_survivors", C.c_int64),
+        ("probe_prefixes", C.c_int64),
+        ("shard_rank", C.c_int64),
+        ("shard_world", C.c_int64),
+        ("stats", C.POINTER(BeamStats)),
+    ]
+
+
+DRT_BEAM_EXPAND_PLAIN, DRT_BEAM_EMIT_PLAIN, DRT_BEAM_EMIT_CLUSTERED = 1, 2, 4
+DRT_CAND_PACKED_KEYS = 4
 
 
 class EmParams(C.Structure):
@@ -169,18 +204,15 @@ _SIGNATURES = {
          _vp, _sz, _vp],
     ),
     "drt_trace_compact_workspace_size": (_sz, [_i64, _i64]),
+    "drt_mesh_build_beam_clusters": (_i32, [_vp, _vp]),
+    "drt_trace_beam_workspace_size": (_sz, [_i64, _i64, _i64, _i32, _vp, _i64]),
+    "drt_trace_paths_beam": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drt_trace_paths_compact": (
         _i32,
         [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _i64, _i64, _vp,
          _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
     ),
     "drt_ray_intersect_triangle_vjp": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "drt_beam_seed": (_i32, [_vp, _vp, _i64, _f32, _vp, _i64, _vp, _vp]),
-    "drt_beam_expand": (_i32, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
-    "drt_beam_finish": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp]),
-    "drt_beam_emit": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
-    "drt_beam_expand_clustered": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
-    "drt_beam_emit_clustered": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
     "drt_launch_paths_vjp": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "drt_warp_ray_prep": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "drt_warp_first_hit_finish": (_i32, [_vp, _vp, _i64, _f32, _vp]),

@@ -1,37 +1,60 @@
-// beam.hip -- conservative ("beam") pruning of the exhaustive candidate space, GPU resident.
+// beam.hip -- conservative ("beam") pruning of the exhaustive candidate space, GPU resident, behind ONE
+// entry point: drt_trace_paths_beam (clustering, prefix expansion, receiver stage, row sort / decode,
+// fused trace; no host-side glue between the stages).
 //
 // Reference context: the exhaustive tracer enumerates n (n-1)^(k-1) candidates per (tx, rx) pair
-// (geometry/_solvers.py:803-848) and the hybrid tracer prunes them with SAMPLED visibility
-// (_solvers.py:1013-1056), which is lossy.  This file prunes with a geometric argument instead.
+// (geometry/_solvers.py:803-848, traced by :936-957) and the hybrid tracer prunes them with SAMPLED
+// visibility (_solvers.py:1013-1056), which is lossy.  This file prunes with a geometric argument.
 //
 // A specular path tx -> P_1 in m_1 -> ... -> P_k in m_k -> rx unfolds into straight lines through
 // the images I_j of the transmitter (I_0 = tx, I_j = mirror image of I_{j-1} in the plane of m_j):
 // P_{j+1} lies on the ray from I_j through P_j, i.e. inside the pyramid with apex I_j spanned by the
-// primitive m_j, and rx lies inside the pyramid (I_k, m_k).  Moreover the reference's same-side
-// check (_solver_image_method.py:443-454) needs P_{j-1} and P_{j+1} on one side of the plane of m_j.
-// Both are NECESSARY conditions of a valid path, so a prefix (m_1..m_j) can be discarded together
-// with all of its n^(k-j) extensions when
+// primitive m_j -- and inside the pyramids over every EARLIER mirror unfolded through the later planes --
+// and rx lies inside all pyramids with apex I_k.  Moreover the reference's same-side check
+// (_solver_image_method.py:443-454) needs P_{j-1} and P_{j+1} on one side of the plane of m_j.  Both are
+// NECESSARY conditions of a valid path, so a prefix (m_1..m_j) is discarded with all of its extensions when
 //   (S) the previous point set (tx or the primitive m_{j-1}) lies strictly on one side of the plane of
 //       m_j and the next primitive strictly on the other, or
-//   (B) every vertex of the next primitive lies strictly outside one face plane of the pyramid
-//       (I_j, m_j) (for quads: of both triangles' pyramids),
-// "strictly" meaning by more than a margin derived from E, a bound on the position error of the
-// reference's own float32 reflection points (DESIGN.md section 9 derives E from the scene magnitude,
-// the order and the smallest incidence cosine covered by the guarantee): plane-side tests use 4 E
-// (two points, each within E of its primitive, plus the rounding of the dot products); pyramid faces
-// use E (1 + |x - I_j| / h_j) with h_j the distance of the apex from the mirror plane -- an error E at
-// the mirror opens the pyramid by the angle E / h_j, and an apex (nearly) in the mirror plane
-// switches the test off by itself.  The tests only ever REMOVE candidates
-// that the reference arithmetic rejects; what survives is evaluated by the ordinary trace kernels
-// with the reference arithmetic, so results are those of the exhaustive tracer.
+//   (B) every vertex of the next primitive lies strictly outside one face plane of one of the pyramids.
+//
+// "Strictly" = by more than an error bound of the REFERENCE's float32 arithmetic, built per mirror from
+// LOCAL quantities (DESIGN.md section 9 has the argument): the reference computes its reflection points
+// backwards, P~_j = line(P~_{j+1}, I_j) /\ plane(m_j) (_solver_image_method.py:152-203) and accepts a
+// candidate only if Moller-Trumbore finds each P~_j inside m_j (_solvers.py:598-642).  Each of those
+// steps is a float32 ray / plane intersection whose position error is at most
+//       eps_j = u * sigma_j * D_j / h_j,        u = kappa * ulp(M)
+// (M = largest coordinate magnitude, sigma_j = 1 / sin of the sharpest corner of m_j, D_j = largest distance
+// of a vertex of m_j from the apex I_{j-1}, h_j = distance of that apex from the plane of m_j: D_j / h_j
+// bounds 1 / cos(incidence) for every ray from the apex to the primitive).  Consecutive computed points
+// are tied to each other by these LOCAL errors -- the chain is never compared with an exact path -- so the
+// bound of a test is a SUM S_j = eps_1 + ... + eps_j over the prefix (plus eps of the candidate being
+// tested), not a product of 1 / cos over the whole path: there is no user-chosen smallest incidence
+// cosine any more.  A mirror seen at grazing incidence (h_j -> 0) makes its own eps_j -- and with it every
+// test it takes part in -- unbounded: the test switches itself off instead of dropping a path.
+//   side tests     : previous set by S_{j-1} + 2u, candidate by eps_c + 2u, receivers by 2u
+//   pyramid faces  : vertex x of candidate c is outside face f when
+//                    <x - I, n_f> < -( 2 eps_c + u + g |x - I|_1 ),  g = 1.01 * 2 S / (h_P - 2 S) + 2e-6
+//                    (h_P = distance of the apex from the (unfolded) mirror's plane; h_P <= 2.1 S: off)
+// The tests only ever REMOVE candidates that the reference arithmetic rejects; what survives is evaluated
+// by the ordinary trace kernels with the reference arithmetic, so results are those of the exhaustive tracer.
 //
 // Pipeline (device lists, wave-ballot compaction, no host enumeration):
-//   beam_seed    level-1 prefixes (tx, m_1) for all active primitives
-//   beam_expand  level-j prefixes x primitives, tests (S) and (B) -> 8-byte (prefix, primitive) records
-//   beam_finish  records -> level-(j+1) prefixes (intermediate levels only)
-//   beam_emit    level-k prefixes (or level-(k-1) prefixes + records) x receivers -> packed rows
-//                ((tx nrx + rx) n^k + sum_j m_j n^(k-1-j))
-#include "bvh.hpp"
+//   seed      level-1 prefixes (tx, m_1) for all active primitives (optionally one shard of them)
+//   expand    level-j prefixes x primitives -> 8-byte (prefix, primitive) records; cluster culling:
+//             primitives in Morton clusters of 64 with boxes, lane = prefix tests the box, surviving
+//             (prefix, cluster) pairs are tested with lane = primitive and the prefix broadcast
+//   finish    records -> level-(j+1) prefixes (intermediate levels only)
+//   emit      level-k prefixes (or level-(k-1) prefixes + records) x receivers -> packed rows
+//             ((tx nrx + rx) n^k + sum_j m_j n^(k-1-j)); receivers in Morton clusters from 128 on
+//   rows      radix sort, duplicate marking, decode to a per-pair table, fused compact trace
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+
 #include "common.hpp"
 #include "geom.hpp"
 #include "mesh.hpp"
@@ -41,27 +64,29 @@
 namespace drt {
 // Dot product with fused multiply-adds (3 instructions instead of 5).  The beam tests are necessary
 // conditions with explicit margins, not parity arithmetic: one rounding instead of three per product-sum is
-// only more accurate, and every mapping of the expansion / receiver stage uses this same function, so
+// only more accurate, and every mapping of the expansion / receiver stage uses these same functions, so
 // their survivors stay identical.
 __device__ __forceinline__ float fdot(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
-// |w| for the distance-proportional part of a margin: v_sqrt_f32 (1 ulp) nudged up, instead of the ~12
-// instruction correctly rounded square root per (prefix, receiver)
+// |w|, rounded up: v_sqrt_f32 (1 ulp) nudged, instead of the ~12-instruction correctly rounded square root
 __device__ __forceinline__ float margin_len(V3 w) { return __builtin_amdgcn_sqrtf(fdot(w, w)) * 1.000001f; }
-}  // namespace drt
+__device__ __forceinline__ float l1_len(V3 w) { return (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z); }
 
-namespace drt {
-
-struct BeamEntry {  // == drt_beam_entry (32 bytes)
-    int32_t tx;
-    int32_t id[3];
-    float apex[3];
-    int32_t side_prev;  // side of the previous point set w.r.t. the plane of the last mirror: +1 / -1 / 0 (near, straddling)
+struct BeamEntry {  // 32 bytes
+    uint32_t tx_side;  // bits 0..29 transmitter, bits 30..31 = side + 1 (side of the previous point set w.r.t.
+                       // the plane of the last mirror: +1 / -1 / 0 = near or straddling)
+    int32_t id[3];     // primitive ids of the prefix, unused slots -1
+    float apex[3];     // image of the transmitter through the prefix's mirrors
+    float esum;        // S = sum of the per-mirror error bounds eps_j of the prefix (+inf: every test off)
 };
 static_assert(sizeof(BeamEntry) == 32, "BeamEntry layout");
+__device__ __forceinline__ int entry_tx(const BeamEntry &e) { return (int)(e.tx_side & 0x3fffffffu); }
+__device__ __forceinline__ int entry_side(const BeamEntry &e) { return (int)(e.tx_side >> 30) - 1; }
+__device__ __forceinline__ uint32_t pack_tx_side(int tx, int side) { return (uint32_t)tx | ((uint32_t)(side + 1) << 30); }
 
 struct BeamMesh {
     const float *tv;       // [T,3,3]
     const float *normals;  // [T,3]
+    const float *shape;    // [T]
     const uint8_t *mask;   // [T] or null
     int64_t nprim;
     int32_t scale;  // triangles per primitive (2 with assume_quads)
@@ -81,10 +106,26 @@ __device__ __forceinline__ void prim_plane(const BeamMesh &M, int64_t p, V3 &pt,
 }
 
 __device__ __forceinline__ int side_of_range(float dmin, float dmax, float E) {
-    return (dmin > E) ? 1 : ((dmax < -E) ? -1 : 0);
+    return (dmin > E) ? 1 : ((dmax < -E) ? -1 : 0);  // E = +inf or NaN: 0
 }
 
-// side of all vertices of primitive p w.r.t. plane (pt, n)
+// (n, d = <n, v0>) of a triangle and the distance of a point from that plane -- ONE expression for the
+// cluster-level bound and the per-primitive value, so that the former really is the minimum of the latter
+__device__ __forceinline__ float plane_offset(V3 n, V3 v0) { return fdot(n, v0); }
+__device__ __forceinline__ float plane_dist(V3 I, V3 n, float d) {
+    return __builtin_fabsf(__builtin_fmaf(n.x, I.x, __builtin_fmaf(n.y, I.y, __builtin_fmaf(n.z, I.z, -d))));
+}
+
+// eps = u sigma D / h: position error bound of the reference's float32 reflection point on a mirror seen
+// from an apex at distance h from its plane, D = largest apex-vertex distance.  h <= u sigma (apex in the
+// plane up to the arithmetic's resolution), NaN or overflow: +inf, which switches every test that uses it off.
+__device__ __forceinline__ float beam_eps(float u, float sigma, float D, float h) {
+    const float us = u * sigma;
+    const float e = us * (D / h) * 1.0001f;
+    return (h > us && e < kInf) ? e : kInf;
+}
+
+// side of all vertices of primitive p w.r.t. plane (pt, n), with margin E
 __device__ __forceinline__ int side_of_prim(const BeamMesh &M, int64_t p, V3 pt, V3 n, float E) {
     float dmin = kInf, dmax = -kInf;
     const float *v = M.tv + 9 * p * M.scale;
@@ -97,10 +138,27 @@ __device__ __forceinline__ int side_of_prim(const BeamMesh &M, int64_t p, V3 pt,
     return side_of_range(dmin, dmax, E);
 }
 
-// inward unit normals of the three face planes of the pyramid (apex I, triangle u v w); a degenerate
-// face (apex on the edge line, or apex in the triangle's plane) gets a zero normal: it never separates
-struct Pyramid {
+// error bound eps of primitive p as the NEXT mirror of a prefix whose apex is I (global loads: seed / finish)
+__device__ __forceinline__ float prim_eps_global(const BeamMesh &M, int64_t p, V3 I, float u) {
+    float D = 0.0f, h = kInf, sg = 0.0f;
+    for (int t = 0; t < M.scale; ++t) {
+        const int64_t f = p * M.scale + t;
+        const float *v = M.tv + 9 * f;
+        const V3 v0 = ld3(v), n = ld3(M.normals + 3 * f);
+        h = fminf(h, plane_dist(I, n, plane_offset(n, v0)));
+        sg = fmaxf(sg, M.shape[f]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D = fmaxf(D, margin_len(ld3(v + 3 * k) - I));
+    }
+    return beam_eps(u, sg, D, h);
+}
+
+// A pyramid (apex I over a triangle): inward unit normals of its three face planes -- a degenerate face
+// (apex on the edge line or in the triangle's plane) gets a zero normal and never separates -- and the slope g
+// of its margin: an error delta = 2 S at the mirror opens the pyramid by delta / (h - delta) per unit distance.
+struct Pyr {
     V3 n[3];
+    float g;  // +inf: the pyramid's tests are off
 };
 __device__ __forceinline__ V3 face_normal(V3 I, V3 a, V3 b, V3 third) {
     const V3 N = cross(a - I, b - I);
@@ -110,51 +168,200 @@ __device__ __forceinline__ V3 face_normal(V3 I, V3 a, V3 b, V3 third) {
     const float inv = ((s > 0.0f) ? 1.0f : -1.0f) / len;
     return N * inv;
 }
-__device__ __forceinline__ Pyramid make_pyramid(V3 I, const float *tri9) {
-    const V3 u = ld3(tri9), v = ld3(tri9 + 3), w = ld3(tri9 + 6);
-    Pyramid P;
-    P.n[0] = face_normal(I, u, v, w);
-    P.n[1] = face_normal(I, v, w, u);
-    P.n[2] = face_normal(I, w, u, v);
-    return P;
-}
-
-// Pyramid (apex I) over the triangle `t` of primitive `p` after reflecting it in the planes of the
-// primitives refl[0..nrefl) in turn ("unfolding"): a specular path is a straight line from the last
-// image of the transmitter that crosses the unfolded images of ALL earlier mirrors, not only the last
-// one.  Also returns 1 / distance of the apex from the unfolded triangle's plane (for the margin).
-__device__ __forceinline__ Pyramid unfolded_pyramid(const BeamMesh &M, V3 I, int64_t p, int t, const int32_t *refl,
-                                                    int nrefl, float &inv_h) {
-    const float *tri = M.tv + 9 * (p * M.scale + t);
-    V3 v[3] = {ld3(tri), ld3(tri + 3), ld3(tri + 6)};
-    for (int r = 0; r < nrefl; ++r) {
-        V3 pt, n;
-        prim_plane(M, refl[r], pt, n);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
-    }
-    Pyramid P;
-    P.n[0] = face_normal(I, v[0], v[1], v[2]);
-    P.n[1] = face_normal(I, v[1], v[2], v[0]);
-    P.n[2] = face_normal(I, v[2], v[0], v[1]);
-    const V3 c = cross(v[1] - v[0], v[2] - v[0]);
+__device__ __forceinline__ Pyr make_pyr(V3 I, V3 v0, V3 v1, V3 v2, float S) {
+    Pyr P;
+    P.n[0] = face_normal(I, v0, v1, v2);
+    P.n[1] = face_normal(I, v1, v2, v0);
+    P.n[2] = face_normal(I, v2, v0, v1);
+    const V3 c = cross(v1 - v0, v2 - v0);
     const float len = __builtin_sqrtf(fdot(c, c));
-    const float h = (len > 0.0f) ? __builtin_fabsf(fdot(I - v[0], c)) / len : 0.0f;
-    inv_h = (h > 0.0f) ? 1.0f / h : kInf;
+    const float h = (len > 0.0f) ? __builtin_fabsf(fdot(I - v0, c)) / len : 0.0f;
+    const float delta = 2.0f * S;
+    // 2e-6 |x - I|_1 covers the rounding of <x - I, n_f> and of the normalisation itself
+    P.g = (h > 1.05f * delta) ? 1.01f * delta / (h - delta) + 2e-6f : kInf;
     return P;
 }
 
-constexpr int kBeamTile = 128;  // primitives per LDS tile (x up to 6 vertices x 12 B = 9 KiB)
+// Everything a prefix needs to test candidates: apex, plane of its last mirror, side of the previous point
+// set, and its LEVEL pyramids -- [LEVEL-1] over the last mirror, [j] over mirror j unfolded (reflected) through
+// the planes of the mirrors after it: a specular path is a straight line from the last image that crosses the
+// unfolded images of ALL earlier mirrors.
+template <int SCALE, int LEVEL>
+struct BeamCtx {
+    V3 I, pm, nm;
+    float u;    // kappa * ulp(M)
+    int side_prev;
+    Pyr pyr[LEVEL][SCALE];
+};
+
+template <int SCALE, int LEVEL>
+__device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e, float u, bool have,
+                                          BeamCtx<SCALE, LEVEL> &c) {
+    c.u = u;
+    c.I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    c.pm = V3{0, 0, 0};
+    c.nm = V3{0, 0, 1};
+    c.side_prev = have ? entry_side(e) : 0;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j)
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            c.pyr[j][t].n[0] = c.pyr[j][t].n[1] = c.pyr[j][t].n[2] = V3{0, 0, 0};
+            c.pyr[j][t].g = kInf;
+        }
+    if (!have) return;
+    prim_plane(M, e.id[LEVEL - 1], c.pm, c.nm);
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) {
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            const float *tri = M.tv + 9 * ((int64_t)e.id[j] * SCALE + t);
+            V3 v[3] = {ld3(tri), ld3(tri + 3), ld3(tri + 6)};
+#pragma unroll
+            for (int r = j + 1; r < LEVEL; ++r) {
+                V3 pt, n;
+                prim_plane(M, e.id[r], pt, n);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
+            }
+            c.pyr[j][t] = make_pyr(c.I, v[0], v[1], v[2], e.esum);
+        }
+    }
+}
+
+// true: primitive (vertices vx, per-triangle planes pl = (n, d), shape factor sigma) cannot follow this prefix
+template <int SCALE, int LEVEL>
+__device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, const V3 (&vx)[3 * SCALE],
+                                            const float (&pl)[SCALE][4], float sigma) {
+    float dmin = kInf, dmax = -kInf, D = 0.0f;
+    float mf[LEVEL][SCALE][3];  // max over the vertices of <x - I, n_f> + g |x - I|_1
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j)
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) mf[j][t][f] = -kInf;
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < 3 * SCALE; ++k) {
+        const V3 x = vx[k];
+        const float d = fdot(x - c.pm, c.nm);
+        nan = nan || !(d == d);
+        dmin = fminf(dmin, d);
+        dmax = fmaxf(dmax, d);
+        const V3 w = x - c.I;
+        const float wl = l1_len(w);  // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
+        D = fmaxf(D, margin_len(w));
+#pragma unroll
+        for (int j = 0; j < LEVEL; ++j)
+#pragma unroll
+            for (int t = 0; t < SCALE; ++t) {
+                // an "off" pyramid (g = inf) is skipped below; keep inf * 0 = NaN out of the maxima
+                const float g = (c.pyr[j][t].g < kInf) ? c.pyr[j][t].g : 0.0f;
+#pragma unroll
+                for (int f = 0; f < 3; ++f)
+                    mf[j][t][f] = fmaxf(mf[j][t][f], __builtin_fmaf(g, wl, fdot(w, c.pyr[j][t].n[f])));
+            }
+    }
+    float h = kInf;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) h = fminf(h, plane_dist(c.I, V3{pl[t][0], pl[t][1], pl[t][2]}, pl[t][3]));
+    const float eps_c = beam_eps(c.u, sigma, D, h);
+    const float base = -(2.0f * eps_c + c.u);  // -inf for a candidate seen at grazing incidence: nothing separates
+    bool separated = false;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) {
+        bool all_t = true;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            const bool on = c.pyr[j][t].g < kInf;
+            all_t = all_t && on && ((mf[j][t][0] < base) || (mf[j][t][1] < base) || (mf[j][t][2] < base));
+        }
+        separated = separated || all_t;
+    }
+    const int side_c = nan ? 0 : side_of_range(dmin, dmax, eps_c + 2.0f * c.u);
+    return !nan && (separated || (c.side_prev * side_c == -1));
+}
+
+// true: NO primitive inside the box [lo, hi] whose own bound is <= eps_max can follow this prefix (the box form
+// of prim_pruned: support of the box along each normal, the largest margin inside the box)
+template <int SCALE, int LEVEL>
+__device__ __forceinline__ bool box_pruned(const BeamCtx<SCALE, LEVEL> &c, const float (&lo)[3], const float (&hi)[3],
+                                           float eps_max) {
+    const V3 ce = V3{0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    // half extents, rounded up (the centre itself is rounded)
+    const V3 e = V3{(hi[0] - lo[0]) * 0.50001f, (hi[1] - lo[1]) * 0.50001f, (hi[2] - lo[2]) * 0.50001f};
+    if (!(e.x >= 0.0f) || !(e.y >= 0.0f) || !(e.z >= 0.0f)) return false;  // NaN / empty box: keep
+    if (c.side_prev != 0) {
+        const float dc = fdot(ce - c.pm, c.nm);
+        const float r = (__builtin_fabsf(c.nm.x) * e.x + __builtin_fabsf(c.nm.y) * e.y) + __builtin_fabsf(c.nm.z) * e.z;
+        const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, eps_max + 2.0f * c.u) : 0;
+        if (c.side_prev * sb == -1) return true;
+    }
+    const V3 w = ce - c.I;
+    const float wl = l1_len(w) + ((e.x + e.y) + e.z);  // largest |x - I|_1 inside the box
+    const float base = -(2.0f * eps_max + c.u);
+    bool separated = false;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) {
+        bool all_t = true;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            const Pyr &P = c.pyr[j][t];
+            bool st = false;
+            if (P.g < kInf) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const V3 n = P.n[f];
+                    const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
+                                                    __builtin_fabsf(n.z) * e.z);
+                    st = st || (__builtin_fmaf(P.g, wl, smax) < base);
+                }
+            }
+            all_t = all_t && st;
+        }
+        separated = separated || all_t;
+    }
+    return separated;
+}
+
+// value of lane `l` (wave-uniform index) on every lane, through v_readlane: no LDS round trip, no wait
+__device__ __forceinline__ float lane_bcast(float x, int l) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l));
+}
+__device__ __forceinline__ V3 lane_bcast(V3 v, int l) { return V3{lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)}; }
+template <int SCALE, int LEVEL>
+__device__ __forceinline__ BeamCtx<SCALE, LEVEL> lane_bcast(const BeamCtx<SCALE, LEVEL> &c, int l) {
+    BeamCtx<SCALE, LEVEL> o;
+    o.I = lane_bcast(c.I, l);
+    o.pm = lane_bcast(c.pm, l);
+    o.nm = lane_bcast(c.nm, l);
+    o.u = c.u;
+    o.side_prev = __builtin_amdgcn_readlane(c.side_prev, l);
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j)
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            o.pyr[j][t].g = lane_bcast(c.pyr[j][t].g, l);
+#pragma unroll
+            for (int f = 0; f < 3; ++f) o.pyr[j][t].n[f] = lane_bcast(c.pyr[j][t].n[f], l);
+        }
+    return o;
+}
 
 // ---------------------------------------------------------------------------------------------
+// level-1 prefixes; `shard_world` > 1 keeps those with (tx * n + m) % shard_world == shard_rank (by CONTENT:
+// the list is compacted with atomics and has no stable order) -- the multi-GPU split: every valid path has
+// exactly one level-1 prefix
 __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float *__restrict__ tx, int64_t ntx,
-                                                        float E, BeamEntry *__restrict__ out, int64_t cap,
+                                                        float u, int64_t shard_rank, int64_t shard_world,
+                                                        BeamEntry *__restrict__ out, int64_t cap,
                                                         unsigned long long *__restrict__ count) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in = g < ntx * M.nprim;
     const int64_t it = in ? g / M.nprim : 0, a = in ? g - it * M.nprim : 0;
-    const bool keep = in && prim_active(M, a);
+    const bool keep = in && prim_active(M, a) && (shard_world <= 1 || g % shard_world == shard_rank);
     BeamEntry e{};
     if (keep) {
         V3 pt, n;
@@ -162,13 +369,13 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
         const V3 t = ld3(tx + 3 * it);
         const V3 I = image_of_vertex(t, pt, n);
         const float d = fdot(t - pt, n);
-        e.tx = (int32_t)it;
+        e.tx_side = pack_tx_side((int)it, (d == d) ? side_of_range(d, d, 2.0f * u) : 0);  // the transmitter is exact
         e.id[0] = (int32_t)a;
         e.id[1] = e.id[2] = -1;
         e.apex[0] = I.x;
         e.apex[1] = I.y;
         e.apex[2] = I.z;
-        e.side_prev = (d == d) ? side_of_range(d, d, 4.0f * E) : 0;
+        e.esum = prim_eps_global(M, a, t, u);
     }
     const unsigned long long vote = __ballot(keep);
     if (vote) {
@@ -182,10 +389,12 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
     }
 }
 
-constexpr int kBeamWaveBuf = 192;  // records staged per wave before one flush (>= 128: a flush moves 64+)
+constexpr int kBeamTile = 128;         // primitives per LDS tile of the plain expansion
+constexpr int kBeamWaveBuf = 192;      // records staged per wave before one flush (>= 128: a flush moves 64+)
 constexpr int kBeamWaveBufBig = 1024;  // the same for kernels that emit ~1e10 records (one atomic per ~960)
 
-// wave-private LDS staging buffer -> output list: ONE global atomic for `n` records
+// wave-private LDS staging buffer -> output list: ONE global atomic for `n` records (one atomic per ballot
+// meant 7e9 same-address atomics at configs[3]: the L2 atomic unit, not the arithmetic, set the pace)
 __device__ __forceinline__ void beam_flush(const unsigned long long *buf, int n, int lane,
                                            unsigned long long *__restrict__ out, int64_t cap,
                                            unsigned long long *__restrict__ count) {
@@ -198,48 +407,47 @@ __device__ __forceinline__ void beam_flush(const unsigned long long *buf, int n,
     }
 }
 
-// lane = prefix; the block walks all primitives through LDS tiles
-template <int SCALE>
+// append the lanes with `keep` to the wave's staging buffer, flushing when another full ballot may not fit
+template <int CAP>
+__device__ __forceinline__ void beam_stage(bool keep, unsigned long long value, unsigned long long *wb, int &wcount,
+                                           int lane, unsigned long long *__restrict__ out, int64_t cap,
+                                           unsigned long long *__restrict__ count) {
+    const unsigned long long vote = __ballot(keep);
+    if (vote) {
+        if (keep) wb[wcount + __popcll(vote & ((1ull << lane) - 1ull))] = value;
+        wcount += __popcll(vote);
+        if (wcount > CAP - 64) {
+            beam_flush(wb, wcount, lane, out, cap, count);
+            wcount = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain expansion: lane = prefix, the block walks all primitives through LDS tiles (every pair is tested).
+// The reference mapping for the clustered kernel below: identical survivors.
+template <int SCALE, int LEVEL>
 __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
-                                                          int level, float E, unsigned long long *__restrict__ out,
-                                                          int64_t cap, unsigned long long *__restrict__ count,
+                                                          float u, unsigned long long *__restrict__ out, int64_t cap,
+                                                          unsigned long long *__restrict__ count,
                                                           int64_t prims_per_split) {
     __shared__ float lds_v[kBeamTile][3 * SCALE][3];
+    __shared__ float lds_pl[kBeamTile][SCALE][4];
+    __shared__ float lds_sg[kBeamTile];
     __shared__ uint8_t lds_act[kBeamTile];
+    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
     if (have) e = in[g];
-    const int32_t m = have ? e.id[level - 1] : 0;
-    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
-    V3 pm{0, 0, 0}, nm{0, 0, 1};
-    Pyramid pyr[SCALE];
-    Pyramid pyr0[SCALE];  // level 2: the first mirror id[0] unfolded in the plane of m (zero normals otherwise)
-    float inv_h = kInf;   // 1 / distance of the apex from the plane of m (inf: the pyramid test never prunes)
-    float inv_h0[SCALE];
-#pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        pyr[t] = Pyramid{};
-        pyr0[t] = Pyramid{};
-        inv_h0[t] = kInf;
-    }
-    if (have) {
-        prim_plane(M, m, pm, nm);
-        const float h = __builtin_fabsf(fdot(I - pm, nm));
-        inv_h = (h > 0.0f) ? 1.0f / h : kInf;
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) pyr[t] = make_pyramid(I, M.tv + 9 * ((int64_t)m * SCALE + t));
-        if (level == 2) {
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) pyr0[t] = unfolded_pyramid(M, I, e.id[0], t, &e.id[1], 1, inv_h0[t]);
-        }
-    }
-    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int wcount = 0;  // wave-uniform: records waiting in wbuf[wave]
-    // few prefixes x many primitives (configs[4]: 2e5 x 2e5) would leave most CUs idle with one block per
-    // 256 prefixes: blockIdx.y splits the primitive range so that the launch holds >= ~2048 blocks
+    const int32_t m = have ? e.id[LEVEL - 1] : -1;
+    BeamCtx<SCALE, LEVEL> ctx;
+    build_ctx<SCALE, LEVEL>(M, e, u, have, ctx);
+    int wcount = 0;
+    // few prefixes x many primitives would leave most CUs idle with one block per 256 prefixes: blockIdx.y
+    // splits the primitive range
     const int64_t prim_begin = (int64_t)blockIdx.y * prims_per_split;
     const int64_t prim_end = (prim_begin + prims_per_split < M.nprim) ? prim_begin + prims_per_split : M.nprim;
     for (int64_t base = prim_begin; base < prim_end; base += kBeamTile) {
@@ -253,650 +461,75 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             lds_v[i / (3 * SCALE)][vtx][1] = v.y;
             lds_v[i / (3 * SCALE)][vtx][2] = v.z;
         }
+        for (int i = threadIdx.x; i < kBeamTile * SCALE; i += 256) {
+            const int64_t p = base + i / SCALE;
+            const int t = i % SCALE;
+            V3 n{0, 0, 1};
+            float d = 0.0f;
+            if (p < prim_end) {
+                n = ld3(M.normals + 3 * (p * SCALE + t));
+                d = plane_offset(n, ld3(M.tv + 9 * (p * SCALE + t)));
+            }
+            lds_pl[i / SCALE][t][0] = n.x;
+            lds_pl[i / SCALE][t][1] = n.y;
+            lds_pl[i / SCALE][t][2] = n.z;
+            lds_pl[i / SCALE][t][3] = d;
+        }
         if (threadIdx.x < kBeamTile) {
             const int64_t p = base + threadIdx.x;
-            lds_act[threadIdx.x] = (uint8_t)(p < prim_end && prim_active(M, p));
+            const bool ok = p < prim_end;
+            lds_act[threadIdx.x] = (uint8_t)(ok && prim_active(M, p));
+            float sg = 1.0f;
+            if (ok) {
+                sg = M.shape[p * SCALE];
+                if (SCALE == 2) sg = fmaxf(sg, M.shape[p * SCALE + 1]);
+            }
+            lds_sg[threadIdx.x] = sg;
         }
         __syncthreads();
         const int nt = (int)((prim_end - base < kBeamTile) ? prim_end - base : kBeamTile);
         for (int j = 0; j < nt; ++j) {
             if (!lds_act[j]) continue;  // wave-uniform
             const int32_t c = (int32_t)(base + j);
-            // (S) sides of c w.r.t. the plane of m, (B) all vertices outside one face of every pyramid of m
-            float dmin = kInf, dmax = -kInf;
-            bool out_face[SCALE][3], out_face0[SCALE][3];
+            V3 vx[3 * SCALE];
+            float pl[SCALE][4];
+#pragma unroll
+            for (int k = 0; k < 3 * SCALE; ++k) vx[k] = V3{lds_v[j][k][0], lds_v[j][k][1], lds_v[j][k][2]};
 #pragma unroll
             for (int t = 0; t < SCALE; ++t)
 #pragma unroll
-                for (int f = 0; f < 3; ++f) out_face[t][f] = out_face0[t][f] = true;
-            bool nan = false;
-#pragma unroll
-            for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
-                const V3 x = V3{lds_v[j][vtx][0], lds_v[j][vtx][1], lds_v[j][vtx][2]};
-                const float d = fdot(x - pm, nm);
-                nan = nan || !(d == d);
-                dmin = fminf(dmin, d);
-                dmax = fmaxf(dmax, d);
-                const V3 w = x - I;
-                // |w|_1 >= |w|_2: a slightly larger margin (conservative), no square root in the loop
-                const float wl = (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z);
-                const float thr = -(E + E * (wl * inv_h));  // -inf / NaN: never separates
-#pragma unroll
-                for (int t = 0; t < SCALE; ++t) {
-                    const float thr0 = -(E + E * (wl * inv_h0[t]));
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        const float s = fdot(w, pyr[t].n[f]);
-                        out_face[t][f] = out_face[t][f] && (s < thr);  // NaN compares false
-                        const float s0 = fdot(w, pyr0[t].n[f]);
-                        out_face0[t][f] = out_face0[t][f] && (s0 < thr0);
-                    }
-                }
-            }
-            bool separated = true, separated0 = true;
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) {
-                separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
-                separated0 = separated0 && (out_face0[t][0] || out_face0[t][1] || out_face0[t][2]);
-            }
-            separated = separated || separated0;  // outside the cone of the last mirror OR of the unfolded first one
-            const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
-            const bool keep = have && (c != m) && !separated && !(e.side_prev * side_c == -1);
-            // survivors leave as 8-byte (source prefix, primitive) records, staged per wave in LDS and
-            // flushed 64+ at a time: one global atomic per FLUSH.  One atomic per iteration meant 7e9
-            // atomics on ONE address for configs[3] (40 s: the L2 atomic unit, not the arithmetic, set
-            // the pace); building the child prefix here (dependent global loads under divergence) was
-            // worse still.
-            const unsigned long long vote = __ballot(keep);
-            if (vote) {
-                if (keep) {
-                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
-                    wbuf[wave][slot] = ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c;
-                }
-                wcount += __popcll(vote);
-                if (wcount > kBeamWaveBuf - 64) {  // room for one more full ballot is gone: flush
-                    beam_flush(wbuf[wave], wcount, lane, out, cap, count);
-                    wcount = 0;
-                }
-            }
+                for (int q = 0; q < 4; ++q) pl[t][q] = lds_pl[j][t][q];
+            const bool keep = have && (c != m) && !prim_pruned<SCALE, LEVEL>(ctx, vx, pl, lds_sg[j]);
+            beam_stage<kBeamWaveBuf>(keep, ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c, wbuf[wave], wcount,
+                                     lane, out, cap, count);
         }
     }
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same expansion as a walk over the mesh LBVH (csrc/bvh.hip): lane = prefix, a subtree is skipped
-// when its (padded) box fails the SAME tests as a primitive would -- every point of the box outside one
-// face plane of every pyramid of a cone, or the box strictly on the wrong side of the mirror plane.
-// The box versions use the box's support along the plane normal and the largest margin inside the box,
-// so "box pruned" implies "every primitive inside pruned": the survivors are exactly those of the
-// brute-force kernel, found in O(survivors x depth) instead of O(primitives) per prefix.
-// With quads a primitive can be reached through either of its triangles: the second triangle emits only
-// if the first one's own box is pruned (duplicates left by the padding of stored boxes are removed when
-// the rows are sorted).
+// Expansion with cluster-level culling and transposed survivors: the primitives arrive sorted along a Morton
+// curve in clusters of 64 (drt_mesh::beam_*) with an axis-aligned box, the planes of their triangles and their
+// largest shape factor.  lane = prefix tests each cluster's box with box_pruned, using an upper bound of the
+// candidates' own error bounds over the cluster (largest box distance / smallest plane distance); the surviving
+// (prefix, cluster) pairs are then tested per primitive with the prefix's context broadcast lane-to-wave
+// (v_readlane) and lane = primitive of the cluster.  Same survivors as the plain kernel (tested); per prefix
+// the work drops from one ~150-instruction test per primitive to one box test per 64 primitives plus full-lane
+// tests of the clusters its cones actually reach.
 // ---------------------------------------------------------------------------------------------
-template <int SCALE>
-struct BeamCtx {
-    V3 I, pm, nm;
-    float inv_h, inv_h0[SCALE], E;
-    Pyramid pyr[SCALE], pyr0[SCALE];
-    int side_prev;
-
-    __device__ __forceinline__ bool cone_outside_box(const Pyramid (&P)[SCALE], const float (&ih)[SCALE], V3 w, V3 e,
-                                                     float wl) const {
-        bool sep = true;
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            const float thr = -(E + E * (wl * ih[t]));
-            bool st = false;
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                const V3 n = P[t].n[f];
-                const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
-                                                __builtin_fabsf(n.z) * e.z);
-                st = st || (smax < thr);
-            }
-            sep = sep && st;
-        }
-        return sep;
-    }
-
-    // true: no primitive inside [lo, hi] can survive
-    __device__ __forceinline__ bool box_pruned(const float *lo, const float *hi) const {
-        const V3 c = V3{0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
-        const V3 e = V3{0.5f * (hi[0] - lo[0]), 0.5f * (hi[1] - lo[1]), 0.5f * (hi[2] - lo[2])};
-        if (!(e.x >= 0.0f) || !(e.y >= 0.0f) || !(e.z >= 0.0f)) return false;  // NaN / empty box: keep
-        if (side_prev != 0) {
-            const float dc = fdot(c - pm, nm);
-            const float r = (__builtin_fabsf(nm.x) * e.x + __builtin_fabsf(nm.y) * e.y) + __builtin_fabsf(nm.z) * e.z;
-            const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, 4.0f * E) : 0;
-            if (side_prev * sb == -1) return true;
-        }
-        const V3 w = c - I;
-        // largest |x - I|_1 inside the box -> the largest (most demanding) margin
-        const float wl = ((__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z)) + ((e.x + e.y) + e.z);
-        float ih[SCALE];
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) ih[t] = inv_h;
-        return cone_outside_box(pyr, ih, w, e, wl) || cone_outside_box(pyr0, inv_h0, w, e, wl);
-    }
-
-    // the per-vertex test of the brute-force kernel for primitive c
-    __device__ __forceinline__ bool prim_survives(const BeamMesh &M, int64_t c) const {
-        const float *v = M.tv + 9 * c * SCALE;
-        V3 vx[3 * SCALE];
-#pragma unroll
-        for (int vtx = 0; vtx < 3 * SCALE; ++vtx) vx[vtx] = ld3(v + 3 * vtx);
-        return prim_survives_v(vx);
-    }
-    __device__ __forceinline__ bool prim_survives_v(const V3 (&vx)[3 * SCALE]) const {
-        float dmin = kInf, dmax = -kInf;
-        bool out_face[SCALE][3], out_face0[SCALE][3];
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t)
-#pragma unroll
-            for (int f = 0; f < 3; ++f) out_face[t][f] = out_face0[t][f] = true;
-        bool nan = false;
-#pragma unroll
-        for (int vtx = 0; vtx < 3 * SCALE; ++vtx) {
-            const V3 x = vx[vtx];
-            const float d = fdot(x - pm, nm);
-            nan = nan || !(d == d);
-            dmin = fminf(dmin, d);
-            dmax = fmaxf(dmax, d);
-            const V3 w = x - I;
-            const float wl = (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z);
-            const float thr = -(E + E * (wl * inv_h));
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) {
-                const float thr0 = -(E + E * (wl * inv_h0[t]));
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    out_face[t][f] = out_face[t][f] && (fdot(w, pyr[t].n[f]) < thr);
-                    out_face0[t][f] = out_face0[t][f] && (fdot(w, pyr0[t].n[f]) < thr0);
-                }
-            }
-        }
-        bool separated = true, separated0 = true;
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
-            separated0 = separated0 && (out_face0[t][0] || out_face0[t][1] || out_face0[t][2]);
-        }
-        const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
-        return !(separated || separated0) && !(side_prev * side_c == -1);
-    }
+struct BeamClusters {
+    const int32_t *order;
+    const float *verts, *planes, *sigma, *boxes;
+    int64_t nclusters;
 };
 
-template <int SCALE>
-__global__ __launch_bounds__(256) void beam_expand_bvh_kernel(BeamMesh M, const BvhNode *__restrict__ nodes, int64_t T,
-                                                              const BeamEntry *__restrict__ in, int64_t n_in, int level,
-                                                              float E, unsigned long long *__restrict__ out,
-                                                              int64_t cap, unsigned long long *__restrict__ count) {
-    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool have = g < n_in;
-    BeamEntry e{};
-    if (have) e = in[g];
-    const int32_t m = have ? e.id[level - 1] : 0;
-    BeamCtx<SCALE> ctx;
-    ctx.E = E;
-    ctx.I = V3{e.apex[0], e.apex[1], e.apex[2]};
-    ctx.pm = V3{0, 0, 0};
-    ctx.nm = V3{0, 0, 1};
-    ctx.inv_h = kInf;
-    ctx.side_prev = e.side_prev;
-#pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        ctx.pyr[t] = Pyramid{};
-        ctx.pyr0[t] = Pyramid{};
-        ctx.inv_h0[t] = kInf;
-    }
-    if (have) {
-        prim_plane(M, m, ctx.pm, ctx.nm);
-        const float h = __builtin_fabsf(fdot(ctx.I - ctx.pm, ctx.nm));
-        ctx.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) ctx.pyr[t] = make_pyramid(ctx.I, M.tv + 9 * ((int64_t)m * SCALE + t));
-        if (level == 2) {
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) ctx.pyr0[t] = unfolded_pyramid(M, ctx.I, e.id[0], t, &e.id[1], 1, ctx.inv_h0[t]);
-        }
-    }
-    int32_t stack[kBvhStack];
-    int sp = 0;
-    int32_t node = (T == 1) ? ~0 : 0;
-    bool active = have;
-    int wcount = 0;
-    // wave-synchronous walk: every active lane handles ONE node per trip, survivors of the trip are
-    // appended with one ballot
-    while (__any(active)) {
-        bool keep = false;
-        int32_t kc = 0;
-        if (active) {
-            if (node < 0) {  // leaf = triangle ~node of primitive c
-                const int32_t tri = ~node;
-                const int32_t c = tri / SCALE;
-                bool first = true;
-                if (SCALE == 2 && (tri & 1)) {
-                    // the quad's first triangle gets there too unless its own box is pruned
-                    const float *v = M.tv + 9 * (int64_t)(tri - 1);
-                    float lo[3], hi[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
-                        hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
-                    }
-                    first = ctx.box_pruned(lo, hi);
-                }
-                if (first && c != m && prim_active(M, c) && ctx.prim_survives(M, c)) {
-                    keep = true;
-                    kc = c;
-                }
-                if (sp == 0) active = false; else node = stack[--sp];
-            } else {
-                const BvhNode nd = nodes[node];
-                const bool gl = !ctx.box_pruned(nd.llo, nd.lhi);
-                const bool gr = !ctx.box_pruned(nd.rlo, nd.rhi);
-                if (gl && gr) {
-                    if (sp < kBvhStack) stack[sp++] = nd.right;
-                    node = nd.left;
-                } else if (gl) {
-                    node = nd.left;
-                } else if (gr) {
-                    node = nd.right;
-                } else if (sp == 0) {
-                    active = false;
-                } else {
-                    node = stack[--sp];
-                }
-            }
-        }
-        const unsigned long long vote = __ballot(keep);
-        if (vote) {
-            if (keep) {
-                const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
-                wbuf[wave][slot] = ((unsigned long long)(uint32_t)g << 32) | (uint32_t)kc;
-            }
-            wcount += __popcll(vote);
-            if (wcount > kBeamWaveBuf - 64) {
-                beam_flush(wbuf[wave], wcount, lane, out, cap, count);
-                wcount = 0;
-            }
-        }
-    }
-    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Transposed expansion: lane = PRIMITIVE (64 consecutive primitives per wave are spatially coherent in any
-// sensible mesh), prefixes are wave-uniform: a block stages the derived data of 256 prefixes in LDS (apex,
-// mirror plane, pyramids), every wave then walks them and first tests the bounding SPHERE of its 64
-// primitives against the prefix's cones and mirror plane -- one uniform decision that skips the 64
-// per-primitive tests for most (prefix, wave) pairs.  With lanes = prefixes (beam_expand_kernel) such a
-// pre-test cannot pay: 64 unrelated cones almost never agree.  Same survivors, by construction: the sphere
-// test is the box test of the LBVH variant with a ball instead of a box.
-// ---------------------------------------------------------------------------------------------
-template <int SCALE>
-struct alignas(16) BeamPrefD {  // derived data of one prefix, as staged in LDS
-    float I[3], pm[3], nm[3];
-    float inv_h;
-    int32_t side_prev, m;
-    float pyr[SCALE][9], pyr0[SCALE][9];
-    float inv_h0[SCALE];
-    float pad[(4 - ((12 + 19 * SCALE) & 3)) & 3];
-};
-
-__device__ __forceinline__ float wave_sum_f(float x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
-__device__ __forceinline__ float wave_max_f(float x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
-    return x;
-}
-
-template <int SCALE>
-__global__ __launch_bounds__(256) void beam_expand_t_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
-                                                            int level, float E, unsigned long long *__restrict__ out,
-                                                            int64_t cap, unsigned long long *__restrict__ count,
-                                                            int64_t prefixes_per_split) {
-    __shared__ BeamPrefD<SCALE> pd[256];
-    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool lane_ok = c < M.nprim && prim_active(M, c);
-    V3 vx[3 * SCALE];
-#pragma unroll
-    for (int k = 0; k < 3 * SCALE; ++k) vx[k] = lane_ok ? ld3(M.tv + 9 * c * SCALE + 3 * k) : V3{0, 0, 0};
-    // bounding sphere of the wave's primitives (centre = mean vertex of the active lanes)
-    float cnt = lane_ok ? (float)(3 * SCALE) : 0.0f;
-    V3 sum{0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 3 * SCALE; ++k) sum = sum + vx[k];
-    cnt = wave_sum_f(cnt);
-    const float inv_cnt = (cnt > 0.0f) ? 1.0f / cnt : 0.0f;
-    const V3 sc = V3{wave_sum_f(lane_ok ? sum.x : 0.0f) * inv_cnt, wave_sum_f(lane_ok ? sum.y : 0.0f) * inv_cnt,
-                     wave_sum_f(lane_ok ? sum.z : 0.0f) * inv_cnt};
-    float r2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 3 * SCALE; ++k) {
-        const V3 dv = vx[k] - sc;
-        r2 = fmaxf(r2, lane_ok ? fdot(dv, dv) : 0.0f);
-    }
-    // radius rounded up generously (sqrt + a relative pad); NaN geometry -> NaN radius -> never culls
-    const float sr = __builtin_sqrtf(wave_max_f(r2)) * 1.0001f + 1e-30f;
-    const bool wave_any = cnt > 0.0f;
-
-    const int64_t p_begin = (int64_t)blockIdx.y * prefixes_per_split;
-    const int64_t p_end = (p_begin + prefixes_per_split < n_in) ? p_begin + prefixes_per_split : n_in;
-    int wcount = 0;
-    for (int64_t base = p_begin; base < p_end; base += 256) {
-        __syncthreads();
-        {  // stage the derived data of prefix base + threadIdx.x
-            const int64_t g = base + threadIdx.x;
-            BeamPrefD<SCALE> d{};
-            d.m = -1;
-            d.inv_h = kInf;
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) d.inv_h0[t] = kInf;
-            if (g < p_end) {
-                const BeamEntry e = in[g];
-                const int32_t m = (level == 1) ? e.id[0] : e.id[1];
-                const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
-                V3 pm, nm;
-                prim_plane(M, m, pm, nm);
-                const float h = __builtin_fabsf(fdot(I - pm, nm));
-                d.I[0] = I.x; d.I[1] = I.y; d.I[2] = I.z;
-                d.pm[0] = pm.x; d.pm[1] = pm.y; d.pm[2] = pm.z;
-                d.nm[0] = nm.x; d.nm[1] = nm.y; d.nm[2] = nm.z;
-                d.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
-                d.side_prev = e.side_prev;
-                d.m = m;
-#pragma unroll
-                for (int t = 0; t < SCALE; ++t) {
-                    const Pyramid P = make_pyramid(I, M.tv + 9 * ((int64_t)m * SCALE + t));
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        d.pyr[t][3 * f] = P.n[f].x; d.pyr[t][3 * f + 1] = P.n[f].y; d.pyr[t][3 * f + 2] = P.n[f].z;
-                    }
-                    if (level == 2) {
-                        const int32_t refl = e.id[1];
-                        const Pyramid Q = unfolded_pyramid(M, I, e.id[0], t, &refl, 1, d.inv_h0[t]);
-#pragma unroll
-                        for (int f = 0; f < 3; ++f) {
-                            d.pyr0[t][3 * f] = Q.n[f].x; d.pyr0[t][3 * f + 1] = Q.n[f].y; d.pyr0[t][3 * f + 2] = Q.n[f].z;
-                        }
-                    }
-                }
-            }
-            pd[threadIdx.x] = d;
-        }
-        __syncthreads();
-        const int nt = (int)((p_end - base < 256) ? p_end - base : 256);
-        if (!wave_any) continue;  // wave-uniform; the barriers above are outside this branch
-        for (int j = 0; j < nt; ++j) {
-            const BeamPrefD<SCALE> &d = pd[j];  // broadcast reads
-            const V3 I = V3{d.I[0], d.I[1], d.I[2]}, pm = V3{d.pm[0], d.pm[1], d.pm[2]}, nm = V3{d.nm[0], d.nm[1], d.nm[2]};
-            const float inv_h = d.inv_h;
-            const int side_prev = d.side_prev;
-            // ---- uniform: bounding sphere of the wave's primitives vs this prefix ----
-            {
-                const V3 w = sc - I;
-                const float wl = ((__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z)) + 1.7320509f * sr;
-                bool sep = true, sep0 = true;
-#pragma unroll
-                for (int t = 0; t < SCALE; ++t) {
-                    const float thr = -(E + E * (wl * inv_h)), thr0 = -(E + E * (wl * d.inv_h0[t]));
-                    bool st = false, st0 = false;
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        st = st || (fdot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) + sr < thr);
-                        st0 = st0 || (fdot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) + sr < thr0);
-                    }
-                    sep = sep && st;
-                    sep0 = sep0 && st0;
-                }
-                bool cull = sep || sep0;
-                if (side_prev != 0) {
-                    const float dc = fdot(sc - pm, nm);
-                    const int sb = (dc == dc) ? side_of_range(dc - sr, dc + sr, 4.0f * E) : 0;
-                    cull = cull || (side_prev * sb == -1);
-                }
-                // identical on every lane; make it a scalar branch for the compiler
-                if (__builtin_amdgcn_readfirstlane((int)cull)) continue;
-            }
-            // ---- per lane: the primitive test ----
-            float dmin = kInf, dmax = -kInf;
-            bool out_face[SCALE][3], out_face0[SCALE][3];
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t)
-#pragma unroll
-                for (int f = 0; f < 3; ++f) out_face[t][f] = out_face0[t][f] = true;
-            bool nan = false;
-#pragma unroll
-            for (int k = 0; k < 3 * SCALE; ++k) {
-                const V3 x = vx[k];
-                const float dd = fdot(x - pm, nm);
-                nan = nan || !(dd == dd);
-                dmin = fminf(dmin, dd);
-                dmax = fmaxf(dmax, dd);
-                const V3 w = x - I;
-                const float wl = (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z);
-                const float thr = -(E + E * (wl * inv_h));
-#pragma unroll
-                for (int t = 0; t < SCALE; ++t) {
-                    const float thr0 = -(E + E * (wl * d.inv_h0[t]));
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        out_face[t][f] = out_face[t][f] &&
-                                         (fdot(w, V3{d.pyr[t][3 * f], d.pyr[t][3 * f + 1], d.pyr[t][3 * f + 2]}) < thr);
-                        out_face0[t][f] = out_face0[t][f] &&
-                                          (fdot(w, V3{d.pyr0[t][3 * f], d.pyr0[t][3 * f + 1], d.pyr0[t][3 * f + 2]}) < thr0);
-                    }
-                }
-            }
-            bool separated = true, separated0 = true;
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) {
-                separated = separated && (out_face[t][0] || out_face[t][1] || out_face[t][2]);
-                separated0 = separated0 && (out_face0[t][0] || out_face0[t][1] || out_face0[t][2]);
-            }
-            const int side_c = nan ? 0 : side_of_range(dmin, dmax, 4.0f * E);
-            const bool keep = lane_ok && ((int32_t)c != d.m) && !(separated || separated0) && !(side_prev * side_c == -1);
-            const unsigned long long vote = __ballot(keep);
-            if (vote) {
-                if (keep) {
-                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
-                    wbuf[wave][slot] = ((unsigned long long)(uint32_t)(base + j) << 32) | (uint32_t)c;
-                }
-                wcount += __popcll(vote);
-                if (wcount > kBeamWaveBuf - 64) {
-                    beam_flush(wbuf[wave], wcount, lane, out, cap, count);
-                    wcount = 0;
-                }
-            }
-        }
-    }
-    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
-}
-
-// (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the
-// parent mirror w.r.t. the new mirror's plane
-__device__ __forceinline__ BeamEntry beam_child(const BeamMesh &M, const BeamEntry &e, int level, int32_t c, float E) {
-    V3 pc, nc;
-    prim_plane(M, c, pc, nc);
-    const V3 I2 = image_of_vertex(V3{e.apex[0], e.apex[1], e.apex[2]}, pc, nc);
-    BeamEntry o = e;
-    o.id[level] = c;
-    o.apex[0] = I2.x;
-    o.apex[1] = I2.y;
-    o.apex[2] = I2.z;
-    o.side_prev = side_of_prim(M, e.id[level - 1], pc, nc, 4.0f * E);
-    return o;
-}
-
-__global__ __launch_bounds__(256) void beam_finish_kernel(BeamMesh M, const BeamEntry *__restrict__ src,
-                                                          const unsigned long long *__restrict__ rec, int64_t n,
-                                                          int level, float E, BeamEntry *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long r = rec[i];
-    out[i] = beam_child(M, src[r >> 32], level, (int32_t)(uint32_t)r, E);
-}
-
-// lane = level-k prefix, loop over the receivers
-template <int SCALE>
-__global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in,
-                                                        const unsigned long long *__restrict__ rec, int64_t n_in,
-                                                        int order, const float *__restrict__ rx, int64_t nrx, float E,
-                                                        long long *__restrict__ rows, int64_t cap,
-                                                        unsigned long long *__restrict__ count) {
-    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int wcount = 0;  // wave-uniform: rows waiting in wbuf[wave]
-    const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool have = g < n_in;
-    BeamEntry e{};
-    if (have) {
-        if (rec) {  // (level order-1 prefix, last primitive) record: build the level-`order` prefix here
-            const unsigned long long r = rec[g];
-            e = beam_child(M, in[r >> 32], order - 1, (int32_t)(uint32_t)r, E);
-        } else {
-            e = in[g];
-        }
-    }
-    const int32_t c = have ? e.id[order - 1] : 0;
-    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
-    V3 pc{0, 0, 0}, nc{0, 0, 1};
-    // pyramids (apex = last image) over the last mirror and over every earlier mirror unfolded through the
-    // later ones: the receiver must see ALL of them in line -- the exact-geometry form of "every reflection
-    // point lies inside its primitive"
-    Pyramid pyr[3][SCALE];
-    float inv_h[3][SCALE];
-    long long tail = 0;  // sum_j id_j n^(k-1-j)
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            pyr[j][t] = Pyramid{};
-            inv_h[j][t] = kInf;
-        }
-    if (have) {
-        prim_plane(M, c, pc, nc);
-        for (int j = 0; j < order; ++j) {
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t)
-                pyr[j][t] = unfolded_pyramid(M, I, e.id[j], t, &e.id[j + 1], order - 1 - j, inv_h[j][t]);
-            tail = tail * (long long)M.nprim + (long long)e.id[j];
-        }
-    }
-    long long npow = 1;
-    for (int j = 0; j < order; ++j) npow *= (long long)M.nprim;
-    // receivers are wave-uniform scalar loads; the next one is in flight during this one's tests (the counters
-    // showed 41 % of the wave-cycles in s_waitcnt with a load + wait per iteration)
-    const float *prx = rx;
-    V3 r_next = ld3(prx);
-    const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
-    for (int ir = 0; ir < nrx32; ++ir) {
-        const V3 r = r_next;
-        prx += (ir + 1 < nrx32) ? 3 : 0;
-        r_next = ld3(prx);
-        const float d = fdot(r - pc, nc);
-        // wrong side of the last mirror: side_prev * d < -4E (side_prev in {-1, 0, +1}; 0 or a NaN distance never
-        // rejects) -- the same decision as side_prev * side_of_range(d, d, 4E) == -1 in one multiply + compare
-        const bool wrong_side = (float)e.side_prev * d < -4.0f * E;
-        const V3 w = r - I;
-        const float wl = margin_len(w);
-        // the pyramids in turn, earliest mirror first (unfolded farthest from the apex = the narrowest cone);
-        // the wave leaves the receiver as soon as none of its 64 prefixes is still inside (same tests, same
-        // result: a prefix that fails one pyramid is dropped whatever the others say)
-        bool alive = have && !wrong_side;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (j < order) {
-                if (!__any(alive)) break;
-                bool inside_any = false;
-#pragma unroll
-                for (int t = 0; t < SCALE; ++t) {
-                    const float thr = -(E + E * (wl * inv_h[j][t]));
-                    bool inside = true;
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) inside = inside && !(fdot(w, pyr[j][t].n[f]) < thr);
-                    inside_any = inside_any || inside;
-                }
-                alive = alive && inside_any;
-            }
-        }
-        const bool keep = alive;
-        // rows leave through the wave's LDS staging buffer, one global atomic per FLUSH: rows are sparse (mostly
-        // one lane per ballot), so an atomic per ballot was ~1.5e8 same-address atomics at configs[3]
-        const unsigned long long vote = __ballot(keep);
-        if (vote) {
-            if (keep) {
-                const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
-                wbuf[wave][slot] = (unsigned long long)(((long long)e.tx * (long long)nrx + (long long)ir) * npow + tail);
-            }
-            wcount += __popcll(vote);
-            if (wcount > kBeamWaveBuf - 64) {
-                beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
-                wcount = 0;
-            }
-        }
-    }
-    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
-}
-
-// value of lane `l` (wave-uniform index) on every lane, through v_readlane: no LDS round trip, no wait
-__device__ __forceinline__ float lane_bcast(float x, int l) {
-    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l));
-}
-__device__ __forceinline__ V3 lane_bcast(V3 v, int l) { return V3{lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)}; }
-template <int SCALE>
-__device__ __forceinline__ BeamCtx<SCALE> lane_bcast(const BeamCtx<SCALE> &c, int l) {
-    BeamCtx<SCALE> o;
-    o.I = lane_bcast(c.I, l);
-    o.pm = lane_bcast(c.pm, l);
-    o.nm = lane_bcast(c.nm, l);
-    o.inv_h = lane_bcast(c.inv_h, l);
-    o.E = c.E;
-    o.side_prev = __builtin_amdgcn_readlane(c.side_prev, l);
-#pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        o.inv_h0[t] = lane_bcast(c.inv_h0[t], l);
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            o.pyr[t].n[f] = lane_bcast(c.pyr[t].n[f], l);
-            o.pyr0[t].n[f] = lane_bcast(c.pyr0[t].n[f], l);
-        }
-    }
-    return o;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Expansion with cluster-level culling and transposed survivors (the structure of
-// beam_emit_clustered_kernel): the primitives arrive sorted along a Morton curve (`prim_order`) in clusters
-// of 64 with an axis-aligned box each.  lane = prefix tests each cluster's box with BeamCtx::box_pruned (the
-// box form of the very tests a primitive gets: box pruned => every primitive inside pruned, as in the LBVH
-// walk); the surviving (prefix, cluster) pairs are then tested per primitive with the prefix's context
-// broadcast lane-to-wave (v_readlane) and lane = primitive of the cluster.  Same survivors as the other mappings (tested);
-// per prefix the work drops from one 150-instruction test per primitive to one ~60-instruction box test per
-// 64 primitives plus full-lane tests of the clusters its cones actually reach.
-// ---------------------------------------------------------------------------------------------
-template <int SCALE>
+template <int SCALE, int LEVEL>
 __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
-    BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in, int level, float E, unsigned long long *__restrict__ out,
-    int64_t cap, unsigned long long *__restrict__ count, const int32_t *__restrict__ prim_order,
-    const float *__restrict__ sorted_vertices, const float *__restrict__ boxes, int64_t nclusters,
+    BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
+    unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split) {
-    // 8 KiB per wave: a flush every ~960 records.  With 192 (~130 per flush) the 8.4e7 flush atomics per step of
-    // configs[3] -- all on ONE address, ~1.75e8/s -- were half of the kernel's time
+    // 8 KiB per wave: a flush every ~960 records (with 192 the flush atomics -- all on ONE address -- were half
+    // of the kernel's time at configs[3])
     __shared__ unsigned long long wbuf[2][kBeamWaveBufBig];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -904,215 +537,216 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
     const bool have = g < n_in;
     BeamEntry e{};
     if (have) e = in[g];
-    const int32_t m = have ? e.id[level - 1] : -1;
-    BeamCtx<SCALE> ctx;
-    ctx.E = E;
-    ctx.I = V3{e.apex[0], e.apex[1], e.apex[2]};
-    ctx.pm = V3{0, 0, 0};
-    ctx.nm = V3{0, 0, 1};
-    ctx.inv_h = kInf;
-    ctx.side_prev = e.side_prev;
-#pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        ctx.pyr[t] = Pyramid{};
-        ctx.pyr0[t] = Pyramid{};
-        ctx.inv_h0[t] = kInf;
-    }
-    if (have) {
-        prim_plane(M, m, ctx.pm, ctx.nm);
-        const float h = __builtin_fabsf(fdot(ctx.I - ctx.pm, ctx.nm));
-        ctx.inv_h = (h > 0.0f) ? 1.0f / h : kInf;
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) ctx.pyr[t] = make_pyramid(ctx.I, M.tv + 9 * ((int64_t)m * SCALE + t));
-        if (level == 2) {
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) ctx.pyr0[t] = unfolded_pyramid(M, ctx.I, e.id[0], t, &e.id[1], 1, ctx.inv_h0[t]);
-        }
-    }
+    const int32_t m = have ? e.id[LEVEL - 1] : -1;
+    BeamCtx<SCALE, LEVEL> ctx;
+    build_ctx<SCALE, LEVEL>(M, e, u, have, ctx);
     const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
-    const int64_t cl_end = (cl_begin + clusters_per_split < nclusters) ? cl_begin + clusters_per_split : nclusters;
+    const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
     const unsigned long long gbase = (unsigned long long)((int64_t)blockIdx.x * 128 + wave * 64);
     int wcount = 0;
-    // software pipeline: the next cluster's box (scalar loads), primitive id and vertices (sorted copy, no
-    // indirection) are in flight while this cluster is tested -- fetched whether or not the cluster will be
-    // hit (the mesh lives in L2); with the loads issued only after a hit the kernel sat in s_waitcnt
-    float nb[6];
-    int32_t p_next;
+    // software pipeline: the next cluster's primitive id and vertices (sorted copy, no indirection) are in
+    // flight while this cluster is tested -- fetched whether or not the cluster will be hit (the mesh lives in L2)
+    int32_t p_next = -1;
     V3 vx_next[3 * SCALE];
     auto fetch = [&](int64_t c) {
         const int64_t cc = (c < cl_end) ? c : cl_end - 1;  // the last trip re-reads its own cluster
-#pragma unroll
-        for (int k = 0; k < 6; ++k) nb[k] = boxes[6 * cc + k];
         const int64_t pos = cc * 64 + lane;
-        const int64_t pc = (pos < M.nprim) ? pos : M.nprim - 1;
-        p_next = (pos < M.nprim) ? prim_order[pc] : -1;
+        p_next = (pos < M.nprim) ? C.order[pos] : -1;
 #pragma unroll
-        for (int k = 0; k < 3 * SCALE; ++k) vx_next[k] = ld3(sorted_vertices + 9 * pc * SCALE + 3 * k);
+        for (int k = 0; k < 3 * SCALE; ++k) vx_next[k] = ld3(C.verts + 9 * pos * SCALE + 3 * k);  // padded to whole clusters
     };
     if (cl_begin < cl_end) fetch(cl_begin);
     for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
-        const float lo[3] = {nb[0], nb[1], nb[2]}, hi[3] = {nb[3], nb[4], nb[5]};
         const int32_t p = p_next;
         V3 vx[3 * SCALE];
 #pragma unroll
         for (int k = 0; k < 3 * SCALE; ++k) vx[k] = vx_next[k];
         fetch(cl + 1);
-        unsigned long long todo = __ballot(have && !ctx.box_pruned(lo, hi));
+        // ---- lane = prefix: box of the cluster (wave-uniform scalar loads) ----
+        const float *bx = C.boxes + 8 * cl;
+        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        // bound of the candidates' own eps over the cluster: smallest plane distance of the apex over the
+        // cluster's triangles (the SAME expression the per-primitive test evaluates), farthest box corner
+        float hmin = kInf;
+        const float4 *pls = reinterpret_cast<const float4 *>(C.planes) + cl * 64 * SCALE;
+#pragma unroll 8
+        for (int k = 0; k < 64 * SCALE; ++k) {
+            const float4 q = pls[k];
+            hmin = fminf(hmin, plane_dist(ctx.I, V3{q.x, q.y, q.z}, q.w));
+        }
+        const V3 far = V3{fmaxf(__builtin_fabsf(ctx.I.x - lo[0]), __builtin_fabsf(ctx.I.x - hi[0])),
+                          fmaxf(__builtin_fabsf(ctx.I.y - lo[1]), __builtin_fabsf(ctx.I.y - hi[1])),
+                          fmaxf(__builtin_fabsf(ctx.I.z - lo[2]), __builtin_fabsf(ctx.I.z - hi[2]))};
+        const float eps_max = beam_eps(u, bx[6], margin_len(far) * 1.0001f, hmin);
+        unsigned long long todo = __ballot(have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max));
         if (todo == 0) continue;
         // ---- transposed: lane = primitive of the cluster ----
+        const int64_t pos = cl * 64 + lane;
         const bool act = p >= 0 && prim_active(M, p);
+        float pl[SCALE][4];
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * SCALE + t];
+            pl[t][0] = q.x; pl[t][1] = q.y; pl[t][2] = q.z; pl[t][3] = q.w;
+        }
+        const float sg = C.sigma[pos];
         while (todo) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
-            // the prefix of lane l on every lane: v_readlane of its registers (the LDS broadcast this replaces
-            // left the kernel 76 % of its wave-cycles in s_waitcnt at 20 % VALU issue, profiles/r02/beam.md)
-            const BeamCtx<SCALE> cx = lane_bcast<SCALE>(ctx, l);
-            const bool keep = act && (p != __builtin_amdgcn_readlane(m, l)) && cx.prim_survives_v(vx);
-            const unsigned long long vote = __ballot(keep);
-            if (vote) {
-                if (keep) {
-                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
-                    wbuf[wave][slot] = ((gbase + (unsigned long long)l) << 32) | (uint32_t)p;
-                }
-                wcount += __popcll(vote);
-                if (wcount > kBeamWaveBufBig - 64) {
-                    beam_flush(wbuf[wave], wcount, lane, out, cap, count);
-                    wcount = 0;
-                }
-            }
+            const BeamCtx<SCALE, LEVEL> cx = lane_bcast<SCALE, LEVEL>(ctx, l);
+            const bool keep = act && (p != __builtin_amdgcn_readlane(m, l)) && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg);
+            beam_stage<kBeamWaveBufBig>(keep, ((gbase + (unsigned long long)l) << 32) | (uint32_t)p, wbuf[wave], wcount,
+                                        lane, out, cap, count);
         }
     }
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
 }
 
-// beam_emit for MANY receivers (configs[4]: 1024): the receivers arrive sorted along a Morton curve in
-// clusters of 64 with an axis-aligned bounding box each (a receiver grid is flat: a ball would be a poor
-// bound).  lane = prefix as above, but a lane first tests each cluster's box against its pyramids / mirror
-// plane (the same inequalities with the box's extent along the face normal added, so a
-// culled cluster holds no receiver the per-receiver test would keep), and only the (prefix, cluster) pairs
-// that survive are tested per receiver -- TRANSPOSED: the prefix's data is broadcast from LDS and lane =
-// receiver of the cluster, so those tests run with full lanes instead of once per wave-any.  Same per-receiver
-// arithmetic as beam_emit_kernel -> the same set of rows (measured on configs[4]: emit 551 -> see
-// profiles/r02/beam.md).
-template <int SCALE>
-struct alignas(16) BeamEmitD {
-    float I[3];
-    int32_t side_prev;
-    float pc[3];
-    int32_t tx;
-    float nc[3];
-    int32_t pad;
-    long long tail;
-    float inv_h[3][SCALE];
-    float pyr[3][SCALE][9];
-};
+// (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the parent's
+// last mirror w.r.t. the new mirror's plane, error sum extended by the new mirror's own bound
+template <int LEVEL>  // level of the PARENT
+__device__ __forceinline__ BeamEntry beam_child(const BeamMesh &M, const BeamEntry &e, int32_t c, float u) {
+    V3 pc, nc;
+    prim_plane(M, c, pc, nc);
+    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    const V3 I2 = image_of_vertex(I, pc, nc);
+    BeamEntry o = e;
+    o.id[LEVEL] = c;
+    o.apex[0] = I2.x;
+    o.apex[1] = I2.y;
+    o.apex[2] = I2.z;
+    o.esum = e.esum + prim_eps_global(M, c, I, u);
+    // the previous reflection point lies within S_parent of the parent's last mirror
+    o.tx_side = pack_tx_side(entry_tx(e), side_of_prim(M, e.id[LEVEL - 1], pc, nc, e.esum + 2.0f * u));
+    return o;
+}
 
-template <int SCALE>
+template <int LEVEL>
+__global__ __launch_bounds__(256) void beam_finish_kernel(BeamMesh M, const BeamEntry *__restrict__ src,
+                                                          const unsigned long long *__restrict__ rec, int64_t n,
+                                                          float u, BeamEntry *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long r = rec[i];
+    out[i] = beam_child<LEVEL>(M, src[r >> 32], (int32_t)(uint32_t)r, u);
+}
+
+template <int ORDER>
+__device__ __forceinline__ BeamEntry emit_entry(const BeamMesh &M, const BeamEntry *__restrict__ in,
+                                                const unsigned long long *__restrict__ rec, int64_t g, float u) {
+    if constexpr (ORDER >= 2) {
+        if (rec) {  // (level ORDER-1 prefix, last primitive) record: build the level-ORDER prefix here
+            const unsigned long long r = rec[g];
+            return beam_child<ORDER - 1>(M, in[r >> 32], (int32_t)(uint32_t)r, u);
+        }
+    }
+    return in[g];
+}
+
+// receiver r vs prefix: on the wrong side of the last mirror, or outside one of the pyramids?
+template <int SCALE, int ORDER>
+__device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, V3 r) {
+    const float d = fdot(r - c.pm, c.nm);
+    // side_prev in {-1, 0, +1}; 0 or a NaN distance never rejects (the receiver is exact: margin 2u)
+    if ((float)c.side_prev * d < -2.0f * c.u) return false;
+    const V3 w = r - c.I;
+    const float wl = l1_len(w);
+    bool inside_all = true;
+#pragma unroll
+    for (int j = 0; j < ORDER; ++j) {
+        bool inside_any = false;
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            const Pyr &P = c.pyr[j][t];
+            const float thr = -(c.u + ((P.g < kInf) ? P.g : 0.0f) * wl);
+            bool inside = true;
+            if (P.g < kInf) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) inside = inside && !(fdot(w, P.n[f]) < thr);
+            }
+            inside_any = inside_any || inside;
+        }
+        inside_all = inside_all && inside_any;
+    }
+    return inside_all;
+}
+
+// lane = level-ORDER prefix, loop over the receivers (wave-uniform scalar loads, the next one in flight)
+template <int SCALE, int ORDER>
+__global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in,
+                                                        const unsigned long long *__restrict__ rec, int64_t n_in,
+                                                        const float *__restrict__ rx, int64_t nrx, float u,
+                                                        long long *__restrict__ rows, int64_t cap,
+                                                        unsigned long long *__restrict__ count,
+                                                        unsigned long long *__restrict__ grazing) {
+    __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int wcount = 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = g < n_in;
+    BeamEntry e{};
+    if (have) e = emit_entry<ORDER>(M, in, rec, g, u);
+    BeamCtx<SCALE, ORDER> ctx;
+    build_ctx<SCALE, ORDER>(M, e, u, have, ctx);
+    long long tail = 0;  // sum_j id_j n^(k-1-j)
+    long long npow = 1;
+#pragma unroll
+    for (int j = 0; j < ORDER; ++j) {
+        tail = tail * (long long)M.nprim + (long long)(have ? e.id[j] : 0);
+        npow *= (long long)M.nprim;
+    }
+    if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);  // every test of this prefix is off (informational)
+    const long long pair0 = (long long)entry_tx(e) * (long long)nrx;
+    const float *prx = rx;
+    V3 r_next = ld3(prx);
+    const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
+    for (int ir = 0; ir < nrx32; ++ir) {
+        const V3 r = r_next;
+        prx += (ir + 1 < nrx32) ? 3 : 0;
+        r_next = ld3(prx);
+        const bool keep = have && receiver_inside<SCALE, ORDER>(ctx, r);
+        beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((pair0 + (long long)ir) * npow + tail), wbuf[wave], wcount,
+                                 lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+    }
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+}
+
+// beam_emit for MANY receivers: the receivers arrive sorted along a Morton curve in clusters of 64 with an
+// axis-aligned bounding box each (lo, hi).  lane = prefix first tests each cluster's box against its pyramids /
+// mirror plane (box_pruned with eps = 0: receivers are exact points), and only the (prefix, cluster) pairs that
+// survive are tested per receiver -- TRANSPOSED: lane = receiver of the cluster, prefix broadcast lane-to-wave.
+// Same per-receiver test as beam_emit_kernel -> the same set of rows.
+template <int SCALE, int ORDER>
 __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
-    BeamMesh M, const BeamEntry *__restrict__ in, const unsigned long long *__restrict__ rec, int64_t n_in, int order,
+    BeamMesh M, const BeamEntry *__restrict__ in, const unsigned long long *__restrict__ rec, int64_t n_in,
     const float *__restrict__ rx_sorted, const int32_t *__restrict__ rx_index, const float *__restrict__ boxes,
-    int64_t nrx, float E, long long *__restrict__ rows, int64_t cap, unsigned long long *__restrict__ count) {
+    int64_t nrx, float u, long long *__restrict__ rows, int64_t cap, unsigned long long *__restrict__ count,
+    unsigned long long *__restrict__ grazing) {
     __shared__ unsigned long long wbuf[2][kBeamWaveBuf];
-    int wcount = 0;  // wave-uniform: rows waiting in wbuf[wave]
-    __shared__ BeamEmitD<SCALE> lds[128];
+    int wcount = 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
-    if (have) {
-        if (rec) {
-            const unsigned long long r = rec[g];
-            e = beam_child(M, in[r >> 32], order - 1, (int32_t)(uint32_t)r, E);
-        } else {
-            e = in[g];
-        }
+    if (have) e = emit_entry<ORDER>(M, in, rec, g, u);
+    BeamCtx<SCALE, ORDER> ctx;
+    build_ctx<SCALE, ORDER>(M, e, u, have, ctx);
+    long long tail = 0, npow = 1;
+#pragma unroll
+    for (int j = 0; j < ORDER; ++j) {
+        tail = tail * (long long)M.nprim + (long long)(have ? e.id[j] : 0);
+        npow *= (long long)M.nprim;
     }
-    const int32_t c = have ? e.id[order - 1] : 0;
-    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
-    V3 pc{0, 0, 0}, nc{0, 0, 1};
-    Pyramid pyr[3][SCALE];
-    float inv_h[3][SCALE];
-    long long tail = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            pyr[j][t] = Pyramid{};
-            inv_h[j][t] = kInf;
-        }
-    if (have) {
-        prim_plane(M, c, pc, nc);
-        for (int j = 0; j < order; ++j) {
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t)
-                pyr[j][t] = unfolded_pyramid(M, I, e.id[j], t, &e.id[j + 1], order - 1 - j, inv_h[j][t]);
-            tail = tail * (long long)M.nprim + (long long)e.id[j];
-        }
-    }
-    {  // this lane's data, for the transposed per-receiver tests (read back by its own wave only)
-        BeamEmitD<SCALE> &d = lds[threadIdx.x];
-        d.I[0] = I.x; d.I[1] = I.y; d.I[2] = I.z;
-        d.pc[0] = pc.x; d.pc[1] = pc.y; d.pc[2] = pc.z;
-        d.nc[0] = nc.x; d.nc[1] = nc.y; d.nc[2] = nc.z;
-        d.side_prev = e.side_prev;
-        d.tx = e.tx;
-        d.pad = 0;
-        d.tail = tail;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t) {
-                d.inv_h[j][t] = inv_h[j][t];
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    d.pyr[j][t][3 * f] = pyr[j][t].n[f].x;
-                    d.pyr[j][t][3 * f + 1] = pyr[j][t].n[f].y;
-                    d.pyr[j][t][3 * f + 2] = pyr[j][t].n[f].z;
-                }
-            }
-    }
-    __syncthreads();
-    long long npow = 1;
-    for (int j = 0; j < order; ++j) npow *= (long long)M.nprim;
+    if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);
+    const int tx = entry_tx(e);
     const int64_t nclusters = (nrx + 63) / 64;
     for (int64_t cl = 0; cl < nclusters; ++cl) {
-        // ---- per lane (= prefix): can ANY receiver of the cluster pass?  box (centre, half extents), wave-uniform ----
-        const V3 sc = ld3(boxes + 6 * cl);
-        // half extents, generously padded (rounding of the box and of the tests below)
-        const V3 hx = V3{boxes[6 * cl + 3] * 1.0001f + E, boxes[6 * cl + 4] * 1.0001f + E, boxes[6 * cl + 5] * 1.0001f + E};
-        bool maybe = have;
-        {
-            const V3 w = sc - I;
-            // >= |r - I| for every receiver r of the cluster
-            const float wl = margin_len(w) + margin_len(hx);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (j < order) {
-                    bool sep_all = true;
-#pragma unroll
-                    for (int t = 0; t < SCALE; ++t) {
-                        const float thr = -(E + E * (wl * inv_h[j][t]));
-                        bool sep = false;
-#pragma unroll
-                        for (int f = 0; f < 3; ++f) {
-                            const V3 nf = pyr[j][t].n[f];  // max over the box of <x - I, n> = <c - I, n> + <|n|, h>
-                            const float ext = (__builtin_fabsf(nf.x) * hx.x + __builtin_fabsf(nf.y) * hx.y) + __builtin_fabsf(nf.z) * hx.z;
-                            sep = sep || (fdot(w, nf) + ext < thr);
-                        }
-                        sep_all = sep_all && sep;
-                    }
-                    maybe = maybe && !sep_all;
-                }
-            }
-            const float dc = fdot(sc - pc, nc);
-            const float de = (__builtin_fabsf(nc.x) * hx.x + __builtin_fabsf(nc.y) * hx.y) + __builtin_fabsf(nc.z) * hx.z;
-            const int sb = (dc == dc) ? side_of_range(dc - de, dc + de, 4.0f * E) : 0;
-            maybe = maybe && !(e.side_prev * sb == -1);
-        }
-        unsigned long long todo = __ballot(maybe);
+        const float *bx = boxes + 6 * cl;
+        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        unsigned long long todo = __ballot(have && !box_pruned<SCALE, ORDER>(ctx, lo, hi, 0.0f));
         if (todo == 0) continue;
-        // ---- transposed: lane = receiver of the cluster, prefix broadcast from LDS ----
         const int64_t pos = cl * 64 + lane;
         const bool have_r = pos < nrx;
         const V3 r = have_r ? ld3(rx_sorted + 3 * pos) : V3{0, 0, 0};
@@ -1120,254 +754,779 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
         while (todo) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const BeamEmitD<SCALE> &d = lds[wave * 64 + l];  // wave-uniform address: broadcast reads
-            const V3 dI = V3{d.I[0], d.I[1], d.I[2]};
-            const float dd = fdot(r - V3{d.pc[0], d.pc[1], d.pc[2]}, V3{d.nc[0], d.nc[1], d.nc[2]});
-            const bool wrong_side = (float)d.side_prev * dd < -4.0f * E;  // as beam_emit_kernel
-            const V3 w = r - dI;
-            const float wl = margin_len(w);  // as beam_emit_kernel
-            bool inside_all = true;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (j < order) {
-                    bool inside_any = false;
-#pragma unroll
-                    for (int t = 0; t < SCALE; ++t) {
-                        const float thr = -(E + E * (wl * d.inv_h[j][t]));
-                        bool inside = true;
-#pragma unroll
-                        for (int f = 0; f < 3; ++f)
-                            inside = inside && !(fdot(w, V3{d.pyr[j][t][3 * f], d.pyr[j][t][3 * f + 1], d.pyr[j][t][3 * f + 2]}) < thr);
-                        inside_any = inside_any || inside;
-                    }
-                    inside_all = inside_all && inside_any;
-                }
-            }
-            const bool keep = have_r && inside_all && !wrong_side;
-            const unsigned long long vote = __ballot(keep);
-            if (vote) {  // staged per wave, one global atomic per flush (see beam_emit_kernel)
-                if (keep) {
-                    const int slot = wcount + __popcll(vote & ((1ull << lane) - 1ull));
-                    wbuf[wave][slot] = (unsigned long long)(((long long)d.tx * (long long)nrx + ir) * npow + d.tail);
-                }
-                wcount += __popcll(vote);
-                if (wcount > kBeamWaveBuf - 64) {
-                    beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
-                    wcount = 0;
-                }
-            }
+            const BeamCtx<SCALE, ORDER> cx = lane_bcast<SCALE, ORDER>(ctx, l);
+            const long long ltail = ((long long)__builtin_amdgcn_readlane((int)(tail >> 32), l) << 32) |
+                                    (long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tail, l);
+            const long long ltx = (long long)__builtin_amdgcn_readlane(tx, l);
+            const bool keep = have_r && receiver_inside<SCALE, ORDER>(cx, r);
+            beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((ltx * (long long)nrx + ir) * npow + ltail), wbuf[wave],
+                                     wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
         }
     }
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Morton clustering (primitives: cached on the mesh; receivers: per call, in the workspace)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// bounds[0..2] = min, [3..5] = max (ordered uints), [6] = max |coordinate| (float bits, non-negative)
+__global__ __launch_bounds__(256) void point_bounds_kernel(const float *__restrict__ pts, int64_t n, int32_t group,
+                                                           uint32_t *__restrict__ bounds) {
+    // one item = the mean of `group` consecutive points (group = vertices per primitive; 1 for receivers)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    V3 s{0, 0, 0};
+    float mag = 0.0f;
+    for (int k = 0; k < group; ++k) {
+        const V3 p = ld3(pts + 3 * (i * group + k));
+        s = s + p;
+        mag = fmaxf(mag, fmaxf(__builtin_fabsf(p.x), fmaxf(__builtin_fabsf(p.y), __builtin_fabsf(p.z))));
+    }
+    const float inv = 1.0f / (float)group;
+    const float c[3] = {s.x * inv, s.y * inv, s.z * inv};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (is_finite(c[k])) {
+            atomicMin(bounds + k, float_to_ordered(c[k]));
+            atomicMax(bounds + 3 + k, float_to_ordered(c[k]));
+        }
+    }
+    if (mag == mag) atomicMax(bounds + 6, __float_as_uint(mag));  // NaN coordinates: ignored here, never pruned later
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(const float *__restrict__ pts, int64_t n, int32_t group,
+                                                     const uint32_t *__restrict__ bounds, uint32_t *__restrict__ keys,
+                                                     uint32_t *__restrict__ ids) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], span = 1e-30f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = ordered_to_float(bounds[k]);
+        span = fmaxf(span, ordered_to_float(bounds[3 + k]) - lo[k]);  // ONE scale for all axes: a flat set clusters in its plane
+    }
+    V3 s{0, 0, 0};
+    for (int k = 0; k < group; ++k) s = s + ld3(pts + 3 * (i * group + k));
+    const float inv = 1.0f / (float)group;
+    const float c[3] = {s.x * inv, s.y * inv, s.z * inv};
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float f = (c[k] - lo[k]) / span * 1023.0f;
+        f = (f == f) ? fminf(fmaxf(f, 0.0f), 1023.0f) : 0.0f;
+        q[k] = (uint32_t)f;
+    }
+    keys[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    ids[i] = (uint32_t)i;
+}
+
+// one wave per cluster of 64 sorted primitives: gathers vertices / planes / shape factors in sorted order
+// (padding lanes replicate the cluster's last primitive) and reduces the box over ALL vertices
+template <int SCALE>
+__global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint32_t *__restrict__ sorted_ids,
+                                                          int32_t *__restrict__ order, float *__restrict__ verts,
+                                                          float *__restrict__ planes, float *__restrict__ sigma,
+                                                          float *__restrict__ boxes) {
+    const int64_t cl = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t pos = cl * 64 + lane;
+    const int64_t src = (pos < M.nprim) ? pos : M.nprim - 1;
+    const int64_t p = (int64_t)sorted_ids[src];
+    if (pos < M.nprim) order[pos] = (int32_t)p;
+    float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+    float sg = 0.0f;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        const int64_t f = p * SCALE + t;
+        const V3 n = ld3(M.normals + 3 * f);
+        const V3 v0 = ld3(M.tv + 9 * f);
+        float *q = planes + 4 * (pos * SCALE + t);
+        q[0] = n.x; q[1] = n.y; q[2] = n.z; q[3] = plane_offset(n, v0);
+        sg = fmaxf(sg, M.shape[f]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const V3 v = ld3(M.tv + 9 * f + 3 * k);
+            st3(verts + 9 * pos * SCALE + 9 * t + 3 * k, v);
+            lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+            lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+            lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+        }
+    }
+    sigma[pos] = sg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+        // NaN-propagating max for the shape factor is not needed: shape is never NaN (mesh_prepare_kernel)
+        sg = fmaxf(sg, __shfl_xor(sg, off, 64));
+    }
+    if (lane == 0) {
+        float *b = boxes + 8 * cl;
+        // fminf / fmaxf drop NaNs: a NaN vertex leaves its box finite, but such a primitive is never pruned by
+        // its own test and a NaN coordinate makes no guarantee meaningful anyway; keep the box honest for infs
+        b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2];
+        b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+        b[6] = sg;
+        b[7] = 0.0f;
+    }
+}
+
+// receivers: sorted copy, original indices, box (lo, hi) per cluster of 64
+__global__ __launch_bounds__(64) void rx_cluster_kernel(const float *__restrict__ rx, int64_t nrx,
+                                                        const uint32_t *__restrict__ sorted_ids,
+                                                        float *__restrict__ rx_sorted, int32_t *__restrict__ rx_index,
+                                                        float *__restrict__ boxes) {
+    const int64_t cl = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t pos = cl * 64 + lane;
+    const int64_t src = (pos < nrx) ? pos : nrx - 1;
+    const int64_t i = (int64_t)sorted_ids[src];
+    const V3 r = ld3(rx + 3 * i);
+    if (pos < nrx) {
+        st3(rx_sorted + 3 * pos, r);
+        rx_index[pos] = (int32_t)i;
+    }
+    float lo[3] = {r.x, r.y, r.z}, hi[3] = {r.x, r.y, r.z};
+    bool nan = !(r.x == r.x) || !(r.y == r.y) || !(r.z == r.z);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+    const bool any_nan = __any(nan);
+    if (lane == 0) {
+        float *b = boxes + 6 * cl;
+        // a NaN receiver makes the cluster's box NaN: box_pruned then keeps the cluster (per-receiver tests decide)
+        const float bad = __builtin_nanf("");
+        for (int k = 0; k < 3; ++k) {
+            b[k] = any_nan ? bad : lo[k];
+            b[3 + k] = any_nan ? bad : hi[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows -> per-pair candidate table of the compact tracer
+// ---------------------------------------------------------------------------------------------
+// sorted packed rows -> table i32[rows, ORDER] (triangle ids; a repeated row becomes a padding row of -1)
+template <int ORDER>
+__global__ __launch_bounds__(256) void rows_decode_kernel(const unsigned long long *__restrict__ rows, int64_t n,
+                                                          unsigned long long nprim, int32_t scale,
+                                                          int32_t *__restrict__ table) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = rows[i];
+    const bool dup = i > 0 && rows[i - 1] == key;
+    unsigned long long rest = key;
+    int32_t id[ORDER];
+#pragma unroll
+    for (int j = ORDER - 1; j >= 0; --j) {
+        const unsigned long long q = rest / nprim;
+        id[j] = (int32_t)(rest - q * nprim) * scale;
+        rest = q;
+    }
+#pragma unroll
+    for (int j = 0; j < ORDER; ++j) table[i * ORDER + j] = dup ? -1 : id[j];
+}
+
+// offsets[p] = first sorted row of pair p (lower bound of p * n^ORDER), p = 0 .. npairs
+__global__ __launch_bounds__(256) void pair_offsets_kernel(const unsigned long long *__restrict__ rows, int64_t n,
+                                                           unsigned long long npow, int64_t npairs,
+                                                           long long *__restrict__ offsets) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p > npairs) return;
+    const unsigned long long target = (unsigned long long)p * npow;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rows[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    offsets[p] = lo;
+}
+
+// keys of the slice's trace are rows of its table: back to packed rows
+__global__ __launch_bounds__(256) void keys_to_rows_kernel(const long long *__restrict__ keys, int64_t n,
+                                                           const unsigned long long *__restrict__ rows,
+                                                           long long *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (long long)rows[keys[i]];
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *__restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)i;
+}
+
+// out[i, :] = in[perm[i], :] for rows of `width` 4-byte words
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ perm,
+                                                          int64_t n, int32_t width, uint32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * width) return;
+    const int64_t r = i / width, c = i - r * width;
+    out[i] = in[(int64_t)perm[r] * width + c];
 }
 
 static BeamMesh beam_mesh(drt_mesh_t m) {
     BeamMesh M;
     M.tv = m->tri_verts;
     M.normals = m->normals;
+    M.shape = m->shape;
     M.mask = m->has_mask ? m->mask : nullptr;
     M.scale = m->assume_quads ? 2 : 1;
     M.nprim = m->num_triangles / M.scale;
     return M;
 }
 
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static size_t sort_pairs_temp_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (uint32_t *)nullptr, (size_t)n, 0, 32, nullptr);
+    return bytes;
+}
+static size_t sort_keys64_temp_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                   (size_t)n, 0, 64, nullptr);
+    return bytes;
+}
+static size_t sort_pairs64_temp_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                    (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 64, nullptr);
+    return bytes;
+}
+
+// Morton order of `n` items (means of `group` consecutive points): sorted ids in `*ids_out`, bounds
+// (min[3], max[3] as ordered uints, max |coordinate| as float bits) in `*bounds_out`; scratch carved from `tmp`
+static size_t morton_scratch_bytes(int64_t n) {
+    if (n < 1) n = 1;
+    return align_up((size_t)n * 4, 256) * 4 + 256 + align_up(sort_pairs_temp_bytes(n), 256);
+}
+static int32_t morton_order(const float *pts, int64_t n, int32_t group, char *tmp, uint32_t **ids_out,
+                            uint32_t **bounds_out, hipStream_t s) {
+    const size_t a = align_up((size_t)(n > 0 ? n : 1) * 4, 256);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(tmp);
+    uint32_t *ids = reinterpret_cast<uint32_t *>(tmp + a);
+    uint32_t *keys_sorted = reinterpret_cast<uint32_t *>(tmp + 2 * a);
+    uint32_t *ids_sorted = reinterpret_cast<uint32_t *>(tmp + 3 * a);
+    uint32_t *bounds = reinterpret_cast<uint32_t *>(tmp + 4 * a);
+    char *sort_tmp = tmp + 4 * a + 256;
+    // min slots start at 0xffffffff, max slots (and the magnitude) at 0
+    DRT_HIP(fill_bytes_async(bounds, 0xff, 12, s));
+    DRT_HIP(fill_bytes_async(bounds + 3, 0, 20, s));
+    *ids_out = ids_sorted;
+    *bounds_out = bounds;
+    if (n <= 0) return DRT_OK;
+    const dim3 grid((unsigned)ceil_div(n, 256));
+    hipLaunchKernelGGL(point_bounds_kernel, grid, dim3(256), 0, s, pts, n, group, bounds);
+    hipLaunchKernelGGL(morton_kernel, grid, dim3(256), 0, s, pts, n, group, bounds, keys, ids);
+    DRT_LAUNCH_CHECK();
+    size_t tb = sort_pairs_temp_bytes(n);
+    DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb, keys, keys_sorted, ids, ids_sorted, (size_t)n, 0, 30, s));
+    return DRT_OK;
+}
+
 }  // namespace drt
 
 using namespace drt;
 
-extern "C" {
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+namespace {
 
-int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t ntx, float margin, drt_beam_entry *out,
-                      int64_t capacity, int64_t *count_dev, void *stream) {
-    DRT_REQUIRE(mesh && count_dev, "null argument");
-    DRT_REQUIRE(ntx >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
-    const BeamMesh M = beam_mesh(mesh);
-    const int64_t n = ntx * M.nprim;
-    if (n == 0) return DRT_OK;
-    DRT_REQUIRE(tx && (out || capacity == 0), "null pointer");
-    hipLaunchKernelGGL(beam_seed_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), M, tx, ntx,
-                       margin, reinterpret_cast<BeamEntry *>(out), capacity,
-                       reinterpret_cast<unsigned long long *>(count_dev));
-    DRT_LAUNCH_CHECK();
+struct BeamLayout {  // byte offsets into the caller's workspace
+    size_t counters, rx_sorted, rx_index, rx_boxes, morton, entries1, entries2, records, rows, rows_sorted, table,
+        pair_offsets, sort_tmp, trace_ws, trace_ws_bytes, slice_keys, merge_keys, merge_perm, merge_iota, merge_rows,
+        total;
+};
+
+struct BeamSizes {
+    int64_t max_entries, max_records, max_rows, max_survivors;
+};
+
+static BeamSizes beam_sizes(const drt_beam_params *bp, int64_t ntx, int64_t nprim) {
+    BeamSizes z;
+    z.max_entries = (bp && bp->max_entries > 0) ? bp->max_entries : (int64_t)1 << 26;
+    z.max_records = (bp && bp->max_records > 0) ? bp->max_records : (int64_t)1 << 27;
+    z.max_rows = (bp && bp->max_rows > 0) ? bp->max_rows : (int64_t)1 << 26;
+    z.max_survivors = (bp && bp->max_survivors > 0) ? bp->max_survivors : (int64_t)1 << 22;
+    (void)ntx;
+    (void)nprim;
+    return z;
+}
+
+static BeamLayout beam_layout(const BeamSizes &z, int64_t ntx, int64_t nrx, int64_t nprim, int32_t order,
+                              int64_t max_paths) {
+    BeamLayout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align_up(bytes > 0 ? bytes : 1, 256);
+        return at;
+    };
+    const int64_t k2 = order + 2;
+    const int64_t nrx_p = ceil_div(nrx > 0 ? nrx : 1, 64) * 64;
+    L.counters = take(256);
+    L.rx_sorted = take((size_t)nrx_p * 12);
+    L.rx_index = take((size_t)nrx_p * 4);
+    L.rx_boxes = take((size_t)(nrx_p / 64) * 24);
+    L.morton = take(morton_scratch_bytes(nrx));
+    L.entries1 = take((size_t)(ntx * nprim > 0 ? ntx * nprim : 1) * 32);
+    L.entries2 = take(order >= 3 ? (size_t)z.max_entries * 32 : 1);
+    L.records = take(order >= 2 ? (size_t)z.max_records * 8 : 1);
+    L.rows = take((size_t)z.max_rows * 8);
+    L.rows_sorted = take((size_t)z.max_rows * 8);
+    L.table = take((size_t)z.max_rows * 4 * (size_t)(order > 0 ? order : 1));
+    L.pair_offsets = take((size_t)(ntx * nrx + 1) * 8);
+    size_t st = sort_keys64_temp_bytes(z.max_rows);
+    const size_t st2 = sort_pairs64_temp_bytes(max_paths);
+    if (st2 > st) st = st2;
+    L.sort_tmp = take(st);
+    L.trace_ws_bytes = drt_trace_compact_workspace_size(z.max_survivors, max_paths);
+    L.trace_ws = take(L.trace_ws_bytes);
+    L.slice_keys = take((size_t)max_paths * 8);
+    L.merge_keys = take((size_t)max_paths * 8);
+    L.merge_perm = take((size_t)max_paths * 4);
+    L.merge_iota = take((size_t)max_paths * 4);
+    L.merge_rows = take((size_t)max_paths * (size_t)k2 * 12);
+    L.total = off;
+    return L;
+}
+
+static int32_t read_count(const unsigned long long *dev, int64_t *host, hipStream_t s) {
+    unsigned long long v = 0;
+    DRT_HIP(hipMemcpyAsync(&v, dev, 8, hipMemcpyDeviceToHost, s));
+    DRT_HIP(hipStreamSynchronize(s));
+    *host = (int64_t)v;
     return DRT_OK;
 }
 
-int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t level, float margin,
-                        int32_t use_bvh, uint64_t *out, int64_t capacity, int64_t *count_dev, void *stream) {
-    DRT_REQUIRE(mesh && count_dev, "null argument");
-    DRT_REQUIRE(n_in >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
-    DRT_REQUIRE(level >= 1 && level <= 2, "expansion goes from level 1 or 2 (orders up to 3)");
-    const BeamMesh M = beam_mesh(mesh);
-    if (n_in == 0 || M.nprim == 0) return DRT_OK;
-    DRT_REQUIRE(in && (out || capacity == 0), "null pointer");
-    if (use_bvh == 0) {  // default: lane = primitive, prefixes staged in LDS, wave-level sphere culling
-        const int64_t bx = ceil_div(M.nprim, 256);
-        int64_t by = ceil_div(4096, bx);
-        const int64_t ptiles = ceil_div(n_in, 256);
-        if (by > ptiles) by = ptiles;
+template <int SCALE, int LEVEL>
+static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool clustered, const BeamEntry *in, int64_t n_in,
+                          float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s) {
+    if (clustered) {
+        const int64_t bx = ceil_div(n_in, 128);
+        int64_t by = ceil_div(2048, bx);  // few prefixes: split the cluster range so that the launch fills the chip
+        if (by > C.nclusters) by = C.nclusters;
         if (by > 65535) by = 65535;
         if (by < 1) by = 1;
-        const int64_t pps = ceil_div(ptiles, by) * 256;
-        by = ceil_div(n_in, pps);
-        const dim3 gt((unsigned)bx, (unsigned)by);
-        if (M.scale == 2)
-            hipLaunchKernelGGL(beam_expand_t_kernel<2>, gt, dim3(256), 0, as_stream(stream), M,
-                               reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                               reinterpret_cast<unsigned long long *>(out), capacity,
-                               reinterpret_cast<unsigned long long *>(count_dev), pps);
-        else
-            hipLaunchKernelGGL(beam_expand_t_kernel<1>, gt, dim3(256), 0, as_stream(stream), M,
-                               reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                               reinterpret_cast<unsigned long long *>(out), capacity,
-                               reinterpret_cast<unsigned long long *>(count_dev), pps);
-        DRT_LAUNCH_CHECK();
-        return DRT_OK;
+        const int64_t cps = ceil_div(C.nclusters, by);
+        by = ceil_div(C.nclusters, cps);
+        hipLaunchKernelGGL((beam_expand_clustered_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128), 0, s,
+                           M, C, in, n_in, u, out, cap, count, cps);
+    } else {
+        const int64_t bx = ceil_div(n_in, 256), tiles = ceil_div(M.nprim, kBeamTile);
+        int64_t by = ceil_div(2048, bx);
+        if (by > tiles) by = tiles;
+        if (by > 65535) by = 65535;
+        if (by < 1) by = 1;
+        const int64_t pps = ceil_div(tiles, by) * kBeamTile;  // whole tiles per split
+        by = ceil_div(M.nprim, pps);
+        hipLaunchKernelGGL((beam_expand_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(256), 0, s, M, in,
+                           n_in, u, out, cap, count, pps);
     }
-    if (use_bvh == 1) {
-        int32_t rc = drt_mesh_build_bvh(mesh, stream);
+}
+
+template <int SCALE, int ORDER>
+static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, const unsigned long long *rec,
+                        int64_t n_in, const float *rx, const float *rx_sorted, const int32_t *rx_index,
+                        const float *rx_boxes, int64_t nrx, float u, long long *rows, int64_t cap,
+                        unsigned long long *count, unsigned long long *grazing, hipStream_t s) {
+    if (clustered)
+        hipLaunchKernelGGL((beam_emit_clustered_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 128)), dim3(128), 0,
+                           s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing);
+    else
+        hipLaunchKernelGGL((beam_emit_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 256)), dim3(256), 0, s, M, in,
+                           rec, n_in, rx, nrx, u, rows, cap, count, grazing);
+}
+
+#define BEAM_DISPATCH2(SC, K, CALL) \
+    do {                            \
+        if ((SC) == 2) {            \
+            if ((K) == 1) CALL(2, 1); else if ((K) == 2) CALL(2, 2); else CALL(2, 3); \
+        } else {                    \
+            if ((K) == 1) CALL(1, 1); else if ((K) == 2) CALL(1, 2); else CALL(1, 3); \
+        }                           \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
+    DRT_REQUIRE(mesh, "mesh is null");
+    if (mesh->beam_blob) return DRT_OK;
+    const BeamMesh M = beam_mesh(mesh);
+    if (M.nprim == 0) return DRT_OK;
+    hipStream_t s = as_stream(stream);
+    const int64_t ncl = ceil_div(M.nprim, 64), pp = ncl * 64, sc = M.scale;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align_up(bytes, 256);
+        return at;
+    };
+    const size_t o_order = take((size_t)M.nprim * 4), o_verts = take((size_t)pp * 36 * sc),
+                 o_planes = take((size_t)pp * 16 * sc), o_sigma = take((size_t)pp * 4), o_boxes = take((size_t)ncl * 32);
+    char *blob = nullptr, *tmp = nullptr;
+    DRT_HIP(hipMalloc(&blob, off));
+    const size_t tmp_bytes = morton_scratch_bytes(M.nprim);
+    if (hipMalloc(&tmp, tmp_bytes) != hipSuccess) {
+        (void)hipFree(blob);
+        return fail(DRT_E_HIP, "hipMalloc of %zu bytes failed", tmp_bytes);
+    }
+    uint32_t *ids = nullptr, *bounds = nullptr;
+    int32_t rc = morton_order(M.tv, M.nprim, 3 * (int32_t)sc, tmp, &ids, &bounds, s);
+    if (rc == DRT_OK) {
+        auto *order = reinterpret_cast<int32_t *>(blob + o_order);
+        auto *verts = reinterpret_cast<float *>(blob + o_verts);
+        auto *planes = reinterpret_cast<float *>(blob + o_planes);
+        auto *sigma = reinterpret_cast<float *>(blob + o_sigma);
+        auto *boxes = reinterpret_cast<float *>(blob + o_boxes);
+        if (sc == 2)
+            hipLaunchKernelGGL(prim_cluster_kernel<2>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, sigma, boxes);
+        else
+            hipLaunchKernelGGL(prim_cluster_kernel<1>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, sigma, boxes);
+        uint32_t mag_bits = 0;
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&mag_bits, bounds + 6, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(DRT_E_HIP, "beam cluster build failed: %s", hipGetErrorString(e));
+        if (rc == DRT_OK) {
+            float mag;
+            memcpy(&mag, &mag_bits, 4);
+            mesh->beam_max_abs = mag;
+            mesh->beam_order = order;
+            mesh->beam_verts = verts;
+            mesh->beam_planes = planes;
+            mesh->beam_sigma = sigma;
+            mesh->beam_boxes = boxes;
+            mesh->beam_clusters = ncl;
+            mesh->beam_blob = blob;
+        }
+    }
+    (void)hipFree(tmp);
+    if (rc != DRT_OK) (void)hipFree(blob);
+    return rc;
+}
+
+size_t drt_trace_beam_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_primitives, int32_t order,
+                                     const drt_beam_params *bp, int64_t max_paths) {
+    if (num_tx < 0) num_tx = 0;
+    if (num_rx < 0) num_rx = 0;
+    if (num_primitives < 0) num_primitives = 0;
+    if (max_paths < 0) max_paths = 0;
+    if (order < 0) order = 0;
+    if (order > 3) order = 3;
+    if (order == 0) return drt_trace_compact_workspace_size(num_tx * num_rx, max_paths);  // line of sight: plain trace
+    return beam_layout(beam_sizes(bp, num_tx, num_primitives), num_tx, num_rx, num_primitives, order, max_paths).total;
+}
+
+int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const drt_beam_params *bp, const float *tx,
+                             int64_t ntx, const float *rx, int64_t nrx, int32_t order, int64_t max_paths,
+                             int64_t *keys, float *vertices, int32_t *objects, int64_t *num_valid_host, void *ws,
+                             size_t ws_bytes, void *stream) {
+    DRT_REQUIRE(mesh && pr && num_valid_host, "null argument");
+    *num_valid_host = 0;
+    DRT_REQUIRE(ntx >= 0 && nrx >= 0 && max_paths >= 0, "negative size");
+    DRT_REQUIRE(order >= 0 && order <= 3, "beam pruning covers orders 0..3");
+    DRT_REQUIRE(ntx < (1ll << 30) && nrx < (1ll << 31), "too many transmitters / receivers");
+    const float kappa = (bp && bp->kappa > 0.0f) ? bp->kappa : 64.0f;
+    const int32_t flags = bp ? bp->flags : 0;
+    const int64_t shard_world = (bp && bp->shard_world > 1) ? bp->shard_world : 1;
+    const int64_t shard_rank = bp ? bp->shard_rank : 0;
+    DRT_REQUIRE(shard_rank >= 0 && shard_rank < shard_world, "shard_rank must be in [0, shard_world)");
+    drt_beam_stats *st = bp ? bp->stats : nullptr;
+    if (st) memset(st, 0, sizeof(*st));
+    hipStream_t s = as_stream(stream);
+    const BeamMesh M = beam_mesh(mesh);
+    drt_trace_params tp = *pr;
+    tp.stats = nullptr;
+
+    if (order == 0) {  // line of sight: no prefix to prune; rank 0 of a sharded call owns it
+        if (shard_rank != 0 || ntx == 0 || nrx == 0) return DRT_OK;
+        drt_candidates c{};
+        c.num_candidates = 1;
+        c.num_nodes = M.nprim > 0 ? M.nprim : 1;
+        c.order = 0;
+        const size_t need = drt_trace_compact_workspace_size(ntx * nrx, max_paths);
+        if (!ws || ws_bytes < need) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", need);
+        const int32_t rc0 = drt_trace_paths_compact(mesh, &tp, tx, ntx, rx, nrx, &c, ntx * nrx, max_paths, keys, vertices,
+                                                    objects, num_valid_host, ws, ws_bytes, stream);
+        if (st) st->valid = *num_valid_host;
+        return rc0;
+    }
+    if (M.nprim == 0 || ntx == 0 || nrx == 0) return DRT_OK;
+    DRT_REQUIRE(tx && rx, "null pointer");
+    DRT_REQUIRE(max_paths == 0 || (keys && vertices && objects), "null output");
+    unsigned __int128 total = (unsigned __int128)ntx * (unsigned __int128)nrx;
+    unsigned long long npow = 1;
+    for (int j = 0; j < order; ++j) {
+        total *= (unsigned __int128)M.nprim;
+        npow *= (unsigned long long)M.nprim;
+    }
+    if (total >= ((unsigned __int128)1 << 62))
+        return fail(DRT_E_OVERFLOW, "tx * rx * primitives^order does not fit a 62-bit row key");
+    int key_bits = 1;
+    while (key_bits < 64 && ((unsigned __int128)1 << key_bits) < total) ++key_bits;
+
+    const BeamSizes z = beam_sizes(bp, ntx, M.nprim);
+    const BeamLayout L = beam_layout(z, ntx, nrx, M.nprim, order, max_paths);
+    if (!ws || ws_bytes < L.total) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", L.total);
+    char *base = reinterpret_cast<char *>(ws);
+    auto *counters = reinterpret_cast<unsigned long long *>(base + L.counters);  // [0] list count, [1] grazing prefixes
+    auto *rx_sorted = reinterpret_cast<float *>(base + L.rx_sorted);
+    auto *rx_index = reinterpret_cast<int32_t *>(base + L.rx_index);
+    auto *rx_boxes = reinterpret_cast<float *>(base + L.rx_boxes);
+    auto *entries1 = reinterpret_cast<BeamEntry *>(base + L.entries1);
+    auto *entries2 = reinterpret_cast<BeamEntry *>(base + L.entries2);
+    auto *records = reinterpret_cast<unsigned long long *>(base + L.records);
+    auto *rows = reinterpret_cast<long long *>(base + L.rows);
+    auto *rows_sorted = reinterpret_cast<unsigned long long *>(base + L.rows_sorted);
+    auto *table = reinterpret_cast<int32_t *>(base + L.table);
+    auto *pair_offsets = reinterpret_cast<long long *>(base + L.pair_offsets);
+    char *sort_tmp = base + L.sort_tmp;
+    auto *slice_keys = reinterpret_cast<long long *>(base + L.slice_keys);
+
+    int32_t rc = drt_mesh_build_beam_clusters(mesh, stream);
+    if (rc != DRT_OK) return rc;
+    BeamClusters C;
+    C.order = mesh->beam_order;
+    C.verts = mesh->beam_verts;
+    C.planes = mesh->beam_planes;
+    C.sigma = mesh->beam_sigma;
+    C.boxes = mesh->beam_boxes;
+    C.nclusters = mesh->beam_clusters;
+
+    // receivers: Morton clusters (also yields the largest |coordinate| of the receivers); transmitters: bounds only
+    uint32_t *rx_ids = nullptr, *rx_bounds = nullptr;
+    rc = morton_order(rx, nrx, 1, base + L.morton, &rx_ids, &rx_bounds, s);
+    if (rc != DRT_OK) return rc;
+    hipLaunchKernelGGL(rx_cluster_kernel, dim3((unsigned)ceil_div(nrx, 64)), dim3(64), 0, s, rx, nrx, rx_ids, rx_sorted,
+                       rx_index, rx_boxes);
+    hipLaunchKernelGGL(point_bounds_kernel, dim3((unsigned)ceil_div(ntx, 256)), dim3(256), 0, s, tx, ntx, 1, rx_bounds);
+    DRT_LAUNCH_CHECK();
+    uint32_t mag_bits = 0;
+    DRT_HIP(hipMemcpyAsync(&mag_bits, rx_bounds + 6, 4, hipMemcpyDeviceToHost, s));
+    DRT_HIP(hipStreamSynchronize(s));
+    float mag;
+    memcpy(&mag, &mag_bits, 4);
+    mag = std::max(std::max(mag, mesh->beam_max_abs), 1e-30f);
+    int ex = 0;
+    (void)std::frexp(mag, &ex);                  // mag = f * 2^ex, f in [0.5, 1)
+    const float u = kappa * std::ldexp(1.0f, ex - 1 - 23);  // kappa * ulp(M)
+    if (st) {
+        st->unit_m = u;
+        st->magnitude = mag;
+    }
+    const bool expand_clustered = !(flags & DRT_BEAM_EXPAND_PLAIN);
+    const bool emit_clustered = (flags & DRT_BEAM_EMIT_CLUSTERED) || (!(flags & DRT_BEAM_EMIT_PLAIN) && nrx >= 128);
+
+    DRT_HIP(fill_bytes_async(counters, 0, 256, s));
+    // ---- level 1 ----
+    hipLaunchKernelGGL(beam_seed_kernel, dim3((unsigned)ceil_div(ntx * M.nprim, 256)), dim3(256), 0, s, M, tx, ntx, u,
+                       shard_rank, shard_world, entries1, ntx * M.nprim, counters);
+    DRT_LAUNCH_CHECK();
+    int64_t ncur = 0;
+    rc = read_count(counters, &ncur, s);
+    if (rc != DRT_OK) return rc;
+    if (st) st->levels[0] = ncur;
+    const BeamEntry *cur = entries1;
+    // ---- intermediate level (order 3): level 1 -> level 2 in one piece ----
+    if (order == 3 && ncur > 0) {
+        DRT_HIP(fill_bytes_async(counters, 0, 8, s));
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur, ncur, u, records, z.max_records, counters, s)
+        BEAM_DISPATCH2(M.scale, 1, CALL);
+#undef CALL
+        DRT_LAUNCH_CHECK();
+        int64_t c2 = 0;
+        rc = read_count(counters, &c2, s);
         if (rc != DRT_OK) return rc;
-        const auto *nodes = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
-        const dim3 g1((unsigned)ceil_div(n_in, 256));
-        if (M.scale == 2)
-            hipLaunchKernelGGL(beam_expand_bvh_kernel<2>, g1, dim3(256), 0, as_stream(stream), M, nodes,
-                               mesh->num_triangles, reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                               reinterpret_cast<unsigned long long *>(out), capacity,
-                               reinterpret_cast<unsigned long long *>(count_dev));
-        else
-            hipLaunchKernelGGL(beam_expand_bvh_kernel<1>, g1, dim3(256), 0, as_stream(stream), M, nodes,
-                               mesh->num_triangles, reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                               reinterpret_cast<unsigned long long *>(out), capacity,
-                               reinterpret_cast<unsigned long long *>(count_dev));
-        DRT_LAUNCH_CHECK();
-        return DRT_OK;
+        if (c2 > z.max_records || c2 > z.max_entries) {
+            *num_valid_host = c2;
+            return fail(DRT_E_CAPACITY, "%lld level-2 prefixes: raise max_records / max_entries (%lld / %lld)",
+                        (long long)c2, (long long)z.max_records, (long long)z.max_entries);
+        }
+        if (c2 > 0) {
+            hipLaunchKernelGGL(beam_finish_kernel<1>, dim3((unsigned)ceil_div(c2, 256)), dim3(256), 0, s, M, cur, records,
+                               c2, u, entries2);
+            DRT_LAUNCH_CHECK();
+        }
+        cur = entries2;
+        ncur = c2;
+        if (st) st->levels[1] = ncur;
     }
-    const int64_t bx = ceil_div(n_in, 256), tiles = ceil_div(M.nprim, kBeamTile);
-    int64_t by = ceil_div(2048, bx);
-    if (by > tiles) by = tiles;
-    if (by > 65535) by = 65535;
-    if (by < 1) by = 1;
-    const int64_t pps = ceil_div(tiles, by) * kBeamTile;  // whole tiles per split
-    by = ceil_div(M.nprim, pps);
-    const dim3 grid((unsigned)bx, (unsigned)by);
-    if (M.scale == 2)
-        hipLaunchKernelGGL(beam_expand_kernel<2>, grid, dim3(256), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                           reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev), pps);
-    else
-        hipLaunchKernelGGL(beam_expand_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                           reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev), pps);
-    DRT_LAUNCH_CHECK();
-    return DRT_OK;
-}
+    DRT_REQUIRE(ncur < (1ll << 32), "record format holds 32-bit prefix indices");
 
-int32_t drt_beam_finish(drt_mesh_t mesh, const drt_beam_entry *src, const uint64_t *records, int64_t n,
-                        int32_t level, float margin, drt_beam_entry *out, void *stream) {
-    DRT_REQUIRE(mesh, "null argument");
-    DRT_REQUIRE(n >= 0 && level >= 1 && level <= 2 && margin >= 0.0f, "bad argument");
-    if (n == 0) return DRT_OK;
-    DRT_REQUIRE(src && records && out, "null pointer");
-    hipLaunchKernelGGL(beam_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream),
-                       beam_mesh(mesh), reinterpret_cast<const BeamEntry *>(src),
-                       reinterpret_cast<const unsigned long long *>(records), n, (int)level, margin,
-                       reinterpret_cast<BeamEntry *>(out));
-    DRT_LAUNCH_CHECK();
-    return DRT_OK;
-}
+    // ---- last level: rows of a slice of prefixes -> sort -> table -> trace ----
+    int64_t nvalid = 0, slices_with_paths = 0;
+    auto process = [&](const BeamEntry *src, const unsigned long long *rec, int64_t nsrc, int64_t *rows_out,
+                       bool *fits) -> int32_t {
+        *fits = true;
+        *rows_out = 0;
+        if (nsrc == 0) return DRT_OK;
+        DRT_HIP(fill_bytes_async(counters, 0, 8, s));
+#define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, src, rec, nsrc, rx, rx_sorted, rx_index, rx_boxes, nrx, u, rows, z.max_rows, counters, counters + 1, s)
+        BEAM_DISPATCH2(M.scale, order, CALL);
+#undef CALL
+        DRT_LAUNCH_CHECK();
+        int64_t r = 0;
+        int32_t rc2 = read_count(counters, &r, s);
+        if (rc2 != DRT_OK) return rc2;
+        if (r > z.max_rows) {
+            *fits = false;
+            *rows_out = r;
+            return DRT_OK;
+        }
+        *rows_out = r;
+        if (r == 0) return DRT_OK;
+        size_t tb = sort_keys64_temp_bytes(r);
+        DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted, (size_t)r,
+                                         0, key_bits, s));
+        const dim3 gr((unsigned)ceil_div(r, 256));
+        if (order == 1) hipLaunchKernelGGL(rows_decode_kernel<1>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
+        else if (order == 2) hipLaunchKernelGGL(rows_decode_kernel<2>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
+        else hipLaunchKernelGGL(rows_decode_kernel<3>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
+        hipLaunchKernelGGL(pair_offsets_kernel, dim3((unsigned)ceil_div(ntx * nrx + 1, 256)), dim3(256), 0, s, rows_sorted, r,
+                           npow, ntx * nrx, pair_offsets);
+        DRT_LAUNCH_CHECK();
+        drt_candidates c{};
+        c.table = table;
+        c.num_candidates = r;
+        c.order = order;
+        c.pair_offsets = reinterpret_cast<const int64_t *>(pair_offsets);
+        int64_t nv = 0;
+        const int64_t k2 = order + 2;
+        rc2 = drt_trace_paths_compact(mesh, &tp, tx, ntx, rx, nrx, &c, z.max_survivors, max_paths - nvalid,
+                                      reinterpret_cast<int64_t *>(slice_keys), vertices ? vertices + nvalid * k2 * 3 : nullptr,
+                                      objects ? objects + nvalid * k2 : nullptr, &nv, base + L.trace_ws, L.trace_ws_bytes, stream);
+        if (rc2 == DRT_E_CAPACITY && nv > max_paths - nvalid) {
+            *num_valid_host = nvalid + nv;
+            return fail(DRT_E_CAPACITY, "more than %lld valid paths: raise max_paths", (long long)max_paths);
+        }
+        if (rc2 != DRT_OK) {
+            *num_valid_host = nv;
+            return rc2;
+        }
+        if (nv > 0) {
+            hipLaunchKernelGGL(keys_to_rows_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, s, slice_keys, nv,
+                               rows_sorted, reinterpret_cast<long long *>(keys) + nvalid);
+            DRT_LAUNCH_CHECK();
+            nvalid += nv;
+            ++slices_with_paths;
+        }
+        return DRT_OK;
+    };
 
-int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t n_in,
-                      int32_t order, const float *rx, int64_t nrx, int64_t ntx, float margin, int64_t *rows_out,
-                      int64_t capacity, int64_t *count_dev, void *stream) {
-    DRT_REQUIRE(mesh && count_dev, "null argument");
-    DRT_REQUIRE(n_in >= 0 && nrx >= 0 && ntx >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
-    DRT_REQUIRE(order >= 1 && order <= 3, "beam pruning covers orders 1..3");
-    const BeamMesh M = beam_mesh(mesh);
-    // packed rows must fit 62 bits: (ntx nrx) n^order
-    unsigned __int128 total = (unsigned __int128)(ntx > 0 ? ntx : 1) * (unsigned __int128)(nrx > 0 ? nrx : 1);
-    for (int j = 0; j < order; ++j) total *= (unsigned __int128)(M.nprim > 0 ? M.nprim : 1);
-    DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx * rx * primitives^order does not fit a 62-bit row key");
-    if (n_in == 0 || nrx == 0) return DRT_OK;
-    DRT_REQUIRE(in && rx && (rows_out || capacity == 0), "null pointer");
-    DRT_REQUIRE(!records || order >= 2, "records address level order-1 prefixes: order >= 2");
-    const dim3 grid((unsigned)ceil_div(n_in, 256));
-    const auto *rec = reinterpret_cast<const unsigned long long *>(records);
-    if (M.scale == 2)
-        hipLaunchKernelGGL(beam_emit_kernel<2>, grid, dim3(256), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx, nrx, margin,
-                           reinterpret_cast<long long *>(rows_out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev));
-    else
-        hipLaunchKernelGGL(beam_emit_kernel<1>, grid, dim3(256), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx, nrx, margin,
-                           reinterpret_cast<long long *>(rows_out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev));
-    DRT_LAUNCH_CHECK();
-    return DRT_OK;
-}
+    int64_t total_rows = 0, nslices = 0, last_level = 0;
+    if (order == 1) {
+        bool fits = true;
+        int64_t r = 0;
+        rc = process(cur, nullptr, ncur, &r, &fits);
+        if (rc != DRT_OK) return rc;
+        if (!fits) {
+            *num_valid_host = r;
+            return fail(DRT_E_CAPACITY, "%lld candidate rows: raise max_rows (%lld)", (long long)r, (long long)z.max_rows);
+        }
+        total_rows = r;
+        nslices = 1;
+    } else {
+        // slices of the level-(order-1) list sized from the measured fan-out (a small probe slice first), so that
+        // the records of a slice and its rows fit their buffers; a slice that overflows is retried smaller
+        int64_t i0 = 0;
+        int64_t step = std::max<int64_t>(std::min<int64_t>((bp && bp->probe_prefixes > 0) ? bp->probe_prefixes : 4096, ncur), 1);
+        while (i0 < ncur) {
+            const int64_t i1 = std::min(i0 + step, ncur);
+            DRT_HIP(fill_bytes_async(counters, 0, 8, s));
+            if (order == 2) {
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s)
+                BEAM_DISPATCH2(M.scale, 1, CALL);
+#undef CALL
+            } else {
+#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s)
+                BEAM_DISPATCH2(M.scale, 1, CALL);
+#undef CALL
+            }
+            DRT_LAUNCH_CHECK();
+            int64_t c = 0, r = 0;
+            rc = read_count(counters, &c, s);
+            if (rc != DRT_OK) return rc;
+            bool fits = c <= z.max_records;
+            if (fits) {
+                rc = process(cur + i0, records, c, &r, &fits);
+                if (rc != DRT_OK) return rc;
+            }
+            if (!fits) {
+                if (step == 1) {
+                    *num_valid_host = std::max(c, r);
+                    return fail(DRT_E_CAPACITY, "one prefix overflows max_records / max_rows (%lld records, %lld rows)",
+                                (long long)c, (long long)r);
+                }
+                step = std::max<int64_t>(step / 4, 1);
+                continue;
+            }
+            last_level += c;
+            total_rows += r;
+            ++nslices;
+            const double per = (double)(i1 - i0);
+            const double fan = std::max({(double)c / per / (double)z.max_records, (double)r / per / (double)z.max_rows, 1e-18});
+            double next = 0.5 / fan;
+            if (nslices > 1) next = std::min(next, 4.0 * (double)step);
+            step = (int64_t)std::max(1.0, std::min(next, (double)ncur));
+            i0 = i1;
+        }
+        if (st) st->levels[order - 1] = last_level;
+    }
 
-int32_t drt_beam_expand_clustered(drt_mesh_t mesh, const drt_beam_entry *in, int64_t n_in, int32_t level,
-                                  float margin, const int32_t *prim_order, const float *sorted_vertices,
-                                  const float *cluster_boxes, int64_t num_clusters, uint64_t *out, int64_t capacity, int64_t *count_dev,
-                                  void *stream) {
-    DRT_REQUIRE(mesh && count_dev, "null argument");
-    DRT_REQUIRE(n_in >= 0 && capacity >= 0 && margin >= 0.0f && num_clusters >= 0, "bad argument");
-    DRT_REQUIRE(level >= 1 && level <= 2, "expansion goes from level 1 or 2 (orders up to 3)");
-    const BeamMesh M = beam_mesh(mesh);
-    if (n_in == 0 || M.nprim == 0) return DRT_OK;
-    DRT_REQUIRE(in && prim_order && sorted_vertices && cluster_boxes && (out || capacity == 0), "null pointer");
-    DRT_REQUIRE(num_clusters == ceil_div(M.nprim, (int64_t)64), "one cluster per 64 primitives of prim_order");
-    DRT_REQUIRE(n_in < (1ll << 32), "record format holds 32-bit prefix indices");
-    const int64_t bx = ceil_div(n_in, 128);
-    int64_t by = ceil_div(2048, bx);  // few prefixes: split the cluster range so that the launch fills the chip
-    if (by > num_clusters) by = num_clusters;
-    if (by > 65535) by = 65535;
-    if (by < 1) by = 1;
-    const int64_t cps = ceil_div(num_clusters, by);
-    by = ceil_div(num_clusters, cps);
-    const dim3 grid((unsigned)bx, (unsigned)by);
-    if (M.scale == 2)
-        hipLaunchKernelGGL(beam_expand_clustered_kernel<2>, grid, dim3(128), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                           reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, sorted_vertices, cluster_boxes, num_clusters, cps);
-    else
-        hipLaunchKernelGGL(beam_expand_clustered_kernel<1>, grid, dim3(128), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), n_in, (int)level, margin,
-                           reinterpret_cast<unsigned long long *>(out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev), prim_order, sorted_vertices, cluster_boxes, num_clusters, cps);
-    DRT_LAUNCH_CHECK();
-    return DRT_OK;
-}
-
-int32_t drt_beam_emit_clustered(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t n_in,
-                                int32_t order, const float *rx_sorted, const int32_t *rx_index, const float *boxes,
-                                int64_t nrx, int64_t ntx, float margin, int64_t *rows_out, int64_t capacity,
-                                int64_t *count_dev, void *stream) {
-    DRT_REQUIRE(mesh && count_dev, "null argument");
-    DRT_REQUIRE(n_in >= 0 && nrx >= 0 && ntx >= 0 && capacity >= 0 && margin >= 0.0f, "bad argument");
-    DRT_REQUIRE(order >= 1 && order <= 3, "beam pruning covers orders 1..3");
-    const BeamMesh M = beam_mesh(mesh);
-    unsigned __int128 total = (unsigned __int128)(ntx > 0 ? ntx : 1) * (unsigned __int128)(nrx > 0 ? nrx : 1);
-    for (int j = 0; j < order; ++j) total *= (unsigned __int128)(M.nprim > 0 ? M.nprim : 1);
-    DRT_REQUIRE(total < ((unsigned __int128)1 << 62), "tx * rx * primitives^order does not fit a 62-bit row key");
-    if (n_in == 0 || nrx == 0) return DRT_OK;
-    DRT_REQUIRE(in && rx_sorted && rx_index && boxes && (rows_out || capacity == 0), "null pointer");
-    DRT_REQUIRE(!records || order >= 2, "records address level order-1 prefixes: order >= 2");
-    const dim3 grid((unsigned)ceil_div(n_in, 128));
-    const auto *rec = reinterpret_cast<const unsigned long long *>(records);
-    if (M.scale == 2)
-        hipLaunchKernelGGL(beam_emit_clustered_kernel<2>, grid, dim3(128), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx_sorted, rx_index, boxes,
-                           nrx, margin, reinterpret_cast<long long *>(rows_out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev));
-    else
-        hipLaunchKernelGGL(beam_emit_clustered_kernel<1>, grid, dim3(128), 0, as_stream(stream), M,
-                           reinterpret_cast<const BeamEntry *>(in), rec, n_in, (int)order, rx_sorted, rx_index, boxes,
-                           nrx, margin, reinterpret_cast<long long *>(rows_out), capacity,
-                           reinterpret_cast<unsigned long long *>(count_dev));
-    DRT_LAUNCH_CHECK();
+    // ---- slices interleave in key order: one final sort of (key, position) and a gather ----
+    if (slices_with_paths > 1 && nvalid > 1) {
+        const int64_t k2 = order + 2;
+        auto *mk = reinterpret_cast<unsigned long long *>(base + L.merge_keys);
+        auto *perm = reinterpret_cast<uint32_t *>(base + L.merge_perm);
+        auto *iota = reinterpret_cast<uint32_t *>(base + L.merge_iota);
+        auto *tmp_rows = reinterpret_cast<uint32_t *>(base + L.merge_rows);
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)ceil_div(nvalid, 256)), dim3(256), 0, s, iota, nvalid);
+        size_t tb = sort_pairs64_temp_bytes(nvalid);
+        DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb, reinterpret_cast<unsigned long long *>(keys), mk, iota, perm,
+                                          (size_t)nvalid, 0, key_bits, s));
+        DRT_HIP(hipMemcpyAsync(keys, mk, (size_t)nvalid * 8, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(nvalid * k2 * 3, 256)), dim3(256), 0, s,
+                           reinterpret_cast<const uint32_t *>(vertices), perm, nvalid, (int32_t)(k2 * 3), tmp_rows);
+        DRT_HIP(hipMemcpyAsync(vertices, tmp_rows, (size_t)nvalid * k2 * 12, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(nvalid * k2, 256)), dim3(256), 0, s,
+                           reinterpret_cast<const uint32_t *>(objects), perm, nvalid, (int32_t)k2, tmp_rows);
+        DRT_HIP(hipMemcpyAsync(objects, tmp_rows, (size_t)nvalid * k2 * 4, hipMemcpyDeviceToDevice, s));
+        DRT_LAUNCH_CHECK();
+    }
+    *num_valid_host = nvalid;
+    if (st) {
+        int64_t gz = 0;
+        rc = read_count(counters + 1, &gz, s);
+        if (rc != DRT_OK) return rc;
+        st->grazing_prefixes = gz;
+        st->rows = total_rows;
+        st->slices = nslices;
+        st->valid = nvalid;
+    }
     return DRT_OK;
 }
 

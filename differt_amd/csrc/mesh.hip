@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void mesh_prepare_kernel(const float *__restri
                                                            const int32_t *__restrict__ triangles,
                                                            int64_t T, float *__restrict__ tv,
                                                            float *__restrict__ normals,
+                                                           float *__restrict__ shape,
                                                            int32_t *__restrict__ bad_index) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
@@ -35,6 +36,14 @@ __global__ __launch_bounds__(256) void mesh_prepare_kernel(const float *__restri
     const float len = __builtin_sqrtf(dot(c, c));
     const float den = (len == 0.0f) ? 1.0f : len;
     st3(normals + 3 * t, V3{c.x / den, c.y / den, c.z / den});
+    // shape factor sigma >= 1 for the error bounds of the beam pruning (csrc/beam.hip): the largest
+    // 1 / sin(corner angle) = |a| |b| / |a x b|; a Moller-Trumbore inside test loses that factor in
+    // position accuracy on a sliver.  Degenerate triangle -> +inf (its tests switch themselves off).
+    const V3 ea = v[1] - v[0], eb = v[2] - v[1], ec = v[0] - v[2];
+    const float la = __builtin_sqrtf(dot(ea, ea)), lb = __builtin_sqrtf(dot(eb, eb)), lc = __builtin_sqrtf(dot(ec, ec));
+    const float pm = fmaxf(la * lb, fmaxf(lb * lc, lc * la));
+    const float sg = (len > 0.0f) ? pm / len : kInf;
+    shape[t] = (sg >= 1.0f && sg < kInf) ? sg * 1.0001f : ((sg < 1.0f) ? 1.0f : kInf);
 }
 
 }  // namespace drt
@@ -104,8 +113,10 @@ int32_t drt_mesh_destroy(drt_mesh_t m) {
     (void)hipFree(m->triangles);
     (void)hipFree(m->tri_verts);
     (void)hipFree(m->normals);
+    (void)hipFree(m->shape);
     (void)hipFree(m->mask);
     (void)hipFree(m->bvh_nodes);
+    (void)hipFree(m->beam_blob);
     delete m;
     return DRT_OK;
 }
@@ -144,6 +155,7 @@ int32_t drt_mesh_create(const float *vertices, int64_t num_vertices, const int32
     TRY_HIP(hipMalloc(&m->triangles, nt * 12));
     TRY_HIP(hipMalloc(&m->tri_verts, nt * 36));
     TRY_HIP(hipMalloc(&m->normals, nt * 12));
+    TRY_HIP(hipMalloc(&m->shape, nt * 4));
     TRY_HIP(hipMalloc(&bad, 4));
     TRY_HIP(hipMemsetAsync(bad, 0, 4, s));
     if (num_vertices > 0)
@@ -157,7 +169,7 @@ int32_t drt_mesh_create(const float *vertices, int64_t num_vertices, const int32
         }
         hipLaunchKernelGGL(mesh_prepare_kernel, dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, s,
                            m->vertices, num_vertices, m->triangles, T, m->tri_verts, m->normals,
-                           bad);
+                           m->shape, bad);
         TRY_HIP(hipGetLastError());
     }
     int32_t bad_host = 0;

@@ -13,6 +13,19 @@ struct drt_mesh {
     int32_t *triangles = nullptr;  // [T,3]
     float *tri_verts = nullptr;    // [T,3,3]  gathered triangle vertices (reference Mesh.triangle_vertices)
     float *normals = nullptr;      // [T,3]    reference Mesh.normals
+    float *shape = nullptr;        // [T]      largest 1/sin(corner angle) per triangle (beam.hip error bounds)
     uint8_t *mask = nullptr;       // [T] or nullptr (all active)
     void *bvh_nodes = nullptr;     // LBVH (csrc/bvh.hip), built lazily by drt_mesh_build_bvh
+    // Primitive clusters of the beam-pruned tracer (csrc/beam.hip), built lazily by
+    // drt_mesh_build_beam_clusters: primitives (triangles, or quads = triangle pairs) sorted along a Morton
+    // curve, 64 per cluster.  One allocation (`beam_blob`), the others point into it.
+    void *beam_blob = nullptr;
+    int32_t *beam_order = nullptr;   // [P]            primitive id at sorted position
+    float *beam_verts = nullptr;     // [Pp,3*scale,3] vertices in sorted order (Pp = clusters * 64, padded)
+    float *beam_normals = nullptr;   // [Pp,scale,3]   unit normals of the primitive's triangles
+    float *beam_sigma = nullptr;     // [Pp]           shape factor (see beam.hip), max over its triangles
+    float *beam_planes = nullptr;    // [Pp*scale,4]   (n, <n, v0>) per triangle
+    float *beam_boxes = nullptr;     // [clusters,8]   lo[3], hi[3], max sigma, 0
+    int64_t beam_clusters = 0;
+    float beam_max_abs = 0.0f;       // largest |coordinate| of the mesh vertices
 };

@@ -756,6 +756,7 @@ int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *pr, const
     int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
     if (rc != DRT_OK) return rc;
     DRT_REQUIRE(!L.cs.ragged, "ragged pair spaces have no dense layout: use drt_trace_paths_compact");
+    DRT_REQUIRE(!L.cs.packed, "packed keys address traced paths (drt_trace_paths_vjp), they are not a candidate source");
     L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
     if ((pr->flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0) {
         rc = drt_mesh_build_bvh(mesh, stream);
@@ -812,6 +813,7 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
         if (rc != DRT_OK) return rc;
         L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
     }
+    DRT_REQUIRE(!L.cs.packed, "packed keys address traced paths (drt_trace_paths_vjp), they are not a candidate source");
     L.cs.npairs = ntx * nrx;
     const unsigned __int128 total = L.cs.ragged ? (unsigned __int128)L.cs.count
                                                 : (unsigned __int128)ntx * (unsigned __int128)nrx *
@@ -909,6 +911,7 @@ int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *p
                     "DRT_TRACE_USE_BVH in the async entry point needs drt_mesh_build_bvh() beforehand");
         L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
     }
+    DRT_REQUIRE(!L.cs.packed, "packed keys address traced paths (drt_trace_paths_vjp), they are not a candidate source");
     L.cs.npairs = ntx * nrx;
     const unsigned __int128 total = L.cs.ragged ? (unsigned __int128)L.cs.count
                                                 : (unsigned __int128)ntx * (unsigned __int128)nrx *

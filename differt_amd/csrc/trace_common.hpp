@@ -36,6 +36,9 @@ struct CandSrc {
     int32_t prefix_kernel;   // stage A: lane = prefix (first K-1 interactions), see trace_filter_prefix_kernel
     int64_t max_prefixes;    // max over transmitters of F_tx * num_nodes^(K-2) (grid sizing)
     int64_t npairs, mid_pw;  // mid_pw = num_nodes^(K-2)
+    // packed keys (DRT_CAND_PACKED_KEYS): a flat key IS the candidate -- (tx * nrx + rx) * n^K + sum_j m_j n^(K-1-j),
+    // the keys drt_trace_paths_beam returns; pw[j] = n^(K-1-j), count = n^K
+    int32_t packed;
     const int64_t *pair_offsets, *first_off, *last_off;
 };
 
@@ -225,7 +228,18 @@ template <int K>
 __device__ __forceinline__ bool key_to_path(const TraceArgs &a, const CandSrc &cs, int64_t flat,
                                             int64_t &it, int64_t &ir, int32_t (&id)[KA<K>::n],
                                             V3 (&p)[KA<K>::n], V3 (&n)[KA<K>::n], V3 (&full)[K + 2]) {
-    if (cs.ragged) {
+    if (cs.packed) {
+        const int64_t pair = flat / cs.count;
+        uint64_t rest = (uint64_t)(flat - pair * cs.count);
+        it = pair / a.nrx;
+        ir = pair - it * a.nrx;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint64_t q = rest / (uint64_t)cs.pw[j];
+            rest -= q * (uint64_t)cs.pw[j];
+            id[j] = (int32_t)q * cs.id_scale;
+        }
+    } else if (cs.ragged) {
         ragged_decode<K>(cs, a.nrx, flat, it, ir, id);
     } else {
         const int64_t pair = flat / cs.count;
@@ -313,6 +327,21 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
     s.node_map = c->node_map;
     s.id_scale = id_scale;
     for (int j = 0; j < DRT_MAX_ORDER; ++j) s.pw[j] = 1;
+    if (!c->table && (c->reserved & DRT_CAND_PACKED_KEYS)) {
+        DRT_REQUIRE(c->order >= 1 && c->num_nodes >= 1, "packed keys need order >= 1 and num_nodes >= 1");
+        unsigned __int128 pw = 1;
+        for (int j = c->order - 1; j >= 0; --j) {
+            DRT_REQUIRE(pw < ((unsigned __int128)1 << 62), "packed key space too large");
+            s.pw[j] = (int64_t)pw;
+            pw *= (unsigned __int128)c->num_nodes;
+        }
+        DRT_REQUIRE(pw < ((unsigned __int128)1 << 62), "packed key space too large");
+        s.count = (int64_t)pw;
+        s.packed = 1;
+        s.node_map = nullptr;
+        *out = s;
+        return DRT_OK;
+    }
     if (c->table && c->pair_offsets) {  // per-pair table: rows grouped by pair, CSR offsets
         DRT_REQUIRE(c->order >= 1, "a per-pair table needs order >= 1");
         s.ragged = 1;

@@ -180,6 +180,61 @@ class _TraceCompactFn(torch.autograd.Function):
         return gtx, grx, gmv, None, None, None, None, None
 
 
+class _TraceBeamFn(torch.autograd.Function):
+    """``drt_trace_paths_beam``: the valid paths of the exhaustive tracer through the geometric pruning, ONE
+    native call; differentiable through ``drt_trace_paths_vjp`` on the returned (self-describing) keys."""
+
+    @staticmethod
+    def forward(ctx, tx, rx, mesh_vertices, mesh, order, params, beam, max_paths, workspace):
+        dev = tx.device
+        lib = _lib.load()
+        n = mesh.num_primitives
+        h = mesh.handle().h
+        while True:
+            nbytes = lib.drt_trace_beam_workspace_size(tx.shape[0], rx.shape[0], n, order, C.byref(beam), max_paths)
+            ws = workspace(nbytes, dev)
+            keys = torch.empty(max_paths, dtype=torch.int64, device=dev)
+            verts = torch.empty((max_paths, order + 2, 3), dtype=torch.float32, device=dev)
+            objs = torch.empty((max_paths, order + 2), dtype=torch.int32, device=dev)
+            nv = C.c_int64(0)
+            try:
+                _lib.call("drt_trace_paths_beam", h, C.byref(params), C.byref(beam), ptr(tx), tx.shape[0], ptr(rx),
+                          rx.shape[0], order, max_paths, ptr(keys), ptr(verts), ptr(objs), C.byref(nv), ptr(ws),
+                          nbytes, stream())
+                break
+            except _lib.CapacityError as exc:
+                # only the output capacity is grown here; list capacities are the caller's (results never
+                # depend on capacities)
+                if "max_paths" not in exc.msg:
+                    raise
+                max_paths = max(2 * max_paths, int(nv.value))
+        nvalid = int(nv.value)
+        keys = keys[:nvalid].clone()
+        objs = objs[:nvalid].clone()
+        ctx.mesh, ctx.order, ctx.n = mesh, order, n
+        ctx.save_for_backward(tx, rx, keys)
+        ctx.mark_non_differentiable(objs, keys)
+        return verts[:nvalid].clone(), objs, keys
+
+    @staticmethod
+    def backward(ctx, gv, _go, _gk):
+        tx, rx, keys = ctx.saved_tensors
+        mesh = ctx.mesh
+        gtx, grx = torch.zeros_like(tx), torch.zeros_like(rx)
+        gmv = torch.zeros_like(mesh.vertices) if ctx.needs_input_grad[2] else None
+        if keys.shape[0]:
+            if ctx.order == 0:
+                cands = _rank_candidates(0, 0, 1, max(ctx.n, 1), None)
+            else:
+                cands = _lib.Candidates()
+                cands.table, cands.num_nodes, cands.order = None, ctx.n, ctx.order
+                cands.reserved = _lib.DRT_CAND_PACKED_KEYS
+            _lib.call("drt_trace_paths_vjp", mesh.handle().h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+                      C.byref(cands), ptr(keys), ptr(gv.contiguous()), keys.shape[0], ptr(gtx), ptr(grx), ptr(gmv),
+                      stream())
+        return gtx, grx, gmv, None, None, None, None, None, None
+
+
 class _TraceSmoothFn(torch.autograd.Function):
     """Smoothed tracer (_solvers.py:499-770 with ``smoothing_factor``): vertices AND the float mask are
     differentiable in (tx, rx, mesh vertices) through ``drt_trace_paths_dense_smooth_vjp``."""
@@ -279,77 +334,6 @@ class AbstractPathTracer:
                         scene, order, chunk_size=chunk_size, pad_chunks=pad_chunks))
         cands, types = self.generate_path_candidates(scene, order)
         return self.trace_path_candidates(scene, cands, types)
-
-
-def _morton_order(points64: torch.Tensor) -> torch.Tensor:
-    """Permutation that sorts points along a 30-bit Morton curve (one scale for all axes, so that a flat set
-    clusters in its plane)."""
-    lo = points64.min(dim=0).values
-    span = (points64.max(dim=0).values - lo).max().clamp_min(1e-30)
-    q = ((points64 - lo) / span * 1023.0).to(torch.int64).clamp_(0, 1023)
-
-    def spread(v):  # 10 bits -> every third bit
-        v = (v | (v << 16)) & 0x030000FF
-        v = (v | (v << 8)) & 0x0300F00F
-        v = (v | (v << 4)) & 0x030C30C3
-        v = (v | (v << 2)) & 0x09249249
-        return v
-
-    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-    return torch.argsort(code, stable=True)
-
-
-def _primitive_clusters(mesh, size: int = 64):
-    """``(prim_order [n] i32, boxes [ceil(n/size),6] f32 = lo, hi, sorted_vertices [n,3*scale,3] f32)`` for
-    ``drt_beam_expand_clustered``:
-    primitives sorted along a Morton curve over their centroids, an axis-aligned box around ALL vertices of
-    every ``size`` consecutive ones (exact float32 min / max of the vertices the kernels read).  Cached on the
-    mesh, keyed like its native handle."""
-    key = (mesh._handle_key(), size)
-    cached = getattr(mesh, "_beam_clusters", None)
-    if cached is not None and cached[0] == key:
-        return cached[1]
-    scale = 2 if mesh.assume_quads else 1
-    tv = mesh.triangle_vertices.detach()  # [T,3,3] float32
-    n = tv.shape[0] // scale
-    pv = tv.reshape(n, 3 * scale, 3)
-    order = _morton_order(pv.to(torch.float64).mean(dim=1))
-    ncl = (n + size - 1) // size
-    pad = ncl * size - n
-    sorted_v = pv[order]
-    if pad:
-        sorted_v = torch.cat([sorted_v, sorted_v[-1:].expand(pad, 3 * scale, 3)])
-    g = sorted_v.reshape(ncl, size * 3 * scale, 3)
-    boxes = torch.cat([g.min(dim=1).values, g.max(dim=1).values], dim=1).to(torch.float32).contiguous()
-    out = (order.to(torch.int32).contiguous(), boxes, pv[order].to(torch.float32).contiguous())
-    mesh._beam_clusters = (key, out)
-    return out
-
-
-def _receiver_clusters(rx: torch.Tensor, size: int = 64):
-    """Receivers sorted along a 30-bit Morton curve, cut into clusters of ``size`` consecutive ones:
-    ``(rx_sorted [R,3] f32, rx_index [R] i32, boxes [ceil(R/size),6] f32 = centre + half extents)`` for
-    ``drt_beam_emit_clustered`` (axis-aligned boxes: a receiver grid is flat)."""
-    R = rx.shape[0]
-    r64 = rx.detach().to(torch.float64)
-    perm = _morton_order(r64)
-    rs = rx.detach()[perm].contiguous()
-    ncl = (R + size - 1) // size
-    pad = ncl * size - R
-    p64 = r64[perm]
-    valid = torch.ones(R, dtype=torch.bool, device=rx.device)
-    if pad:
-        p64 = torch.cat([p64, p64[-1:].expand(pad, 3)])
-        valid = torch.cat([valid, torch.zeros(pad, dtype=torch.bool, device=rx.device)])
-    g = p64.reshape(ncl, size, 3)
-    lo_c, hi_c = g.min(dim=1).values, g.max(dim=1).values
-    centre = 0.5 * (lo_c + hi_c)
-    c32 = centre.to(torch.float32)
-    # half extents around the float32 centre, rounded up
-    half = torch.maximum(hi_c - c32.to(torch.float64), c32.to(torch.float64) - lo_c)
-    h32 = torch.nextafter(half.to(torch.float32), torch.full_like(half, float("inf"), dtype=torch.float32))
-    boxes = torch.cat([c32, h32], dim=1).contiguous()
-    return rs, perm.to(torch.int32).contiguous(), boxes
 
 
 @dataclass
@@ -488,203 +472,76 @@ class ExhaustivePathTracer(AbstractPathTracer):
         return self._trace_compact(scene, desc, max_survivors, max_paths)
 
     # ---- conservative ("beam") pruning: the lossless counterpart of the hybrid tracer's sampling ----
-    def trace_beam_pruned(self, scene, order: int, *, cos_min: float = 0.25, kappa: float = 8.0,
-                          expansion: str = "auto", chunk_entries: int = 1 << 12, max_entries: int = 1 << 28,
-                          max_rows: int = 1 << 27,
-                          max_survivors: int = 1 << 22, max_paths: int = 1 << 16,
-                          prefix_shard: tuple[int, int] | None = None, emit: str = "auto") -> TracedPaths:
-        """Exhaustive search with geometric pruning (csrc/beam.hip; reference context: the exhaustive
-        enumeration _solvers.py:803-848 and the SAMPLED pruning of the hybrid tracer :1013-1056).
+    def trace_beam_pruned(self, scene, order: int, *, kappa: float = 64.0, expansion: str = "auto", emit: str = "auto",
+                          max_entries: int | None = None, max_records: int | None = None, max_rows: int | None = None,
+                          max_survivors: int | None = None, max_paths: int = 1 << 16, probe_prefixes: int | None = None,
+                          prefix_shard: tuple[int, int] | None = None) -> TracedPaths:
+        """The valid paths of the exhaustive tracer -- same objects, same ``masked_vertices`` order, identical
+        vertex bits, same autograd -- without visiting ``n (n-1)**(order-1)`` candidates per pair: ONE call of
+        ``drt_trace_paths_beam`` (csrc/beam.hip; reference context: the exhaustive enumeration
+        _solvers.py:803-848 traced by :936-957, and the SAMPLED pruning of the hybrid tracer :1013-1056).
 
-        A prefix of mirrors is dropped only when a necessary condition of a valid specular path --
-        next primitive inside the pyramid spanned by the image of the transmitter and the current
-        mirror; previous and next point on one side of the mirror plane (the reference's same-side
-        check) -- fails by more than a margin built from ``E = kappa * ulp(M) / cos_min**order``
-        (``M`` = largest coordinate magnitude of the scene), a bound on the error of the reference's own
-        float32 reflection points for paths whose incidence angles all satisfy ``cos >= cos_min``
-        (DESIGN.md section 9).  Survivors are traced by the ordinary kernels, so valid paths, their order
-        (``masked_vertices`` order of the exhaustive tracer) and vertex bits are those of
-        :meth:`trace_rank_range` over the full space; ``keys`` are ``(tx*num_rx + rx) * n**order +
-        sum_j m_j * n**(order-1-j)`` (``n`` primitives, ``m_j`` primitive ids).  Orders 1..3.
+        A prefix of mirrors is dropped only when a necessary condition of a valid specular path -- next
+        primitive inside the pyramids spanned by the image of the transmitter and the mirrors so far; previous
+        and next point on one side of the mirror plane (the reference's same-side check) -- fails by more than a
+        bound on the error of the reference's own float32 reflection points, built per mirror as
+        ``kappa * ulp(M) * sigma * D / h`` from its incidence geometry: a mirror seen at
+        grazing incidence switches its own tests off, there is no smallest incidence angle to choose.
+        ``keys`` are ``(tx*num_rx + rx) * n**order + sum_j m_j * n**(order-1-j)`` (``n`` primitives, ``m_j``
+        primitive ids).  Orders 0..3.
 
-        ``emit``: ``"plain"`` (every prefix loops over every receiver), ``"clustered"`` (receivers sorted along
-        a Morton curve in clusters of 64 with bounding boxes; a prefix skips the clusters its pyramids
-        cannot reach and tests the others with lane = receiver) or ``"auto"`` (clustered from 128 receivers
-        on); the same rows either way.
-
+        ``expansion``: ``"clustered"`` (= ``"auto"``: primitives in Morton clusters of 64, box test per (prefix,
+        cluster)) or ``"plain"`` (every pair tested); ``emit``: ``"plain"``, ``"clustered"`` (receivers in Morton
+        clusters) or ``"auto"`` (clustered from 128 receivers on) -- the same rows either way.
         ``prefix_shard=(rank, world)`` keeps the level-1 prefixes (transmitter ``t``, first mirror ``m``) with
-        ``(t * n + m) % world == rank``: the multi-GPU split of ``differt_amd.distributed.trace_beam_pruned_sharded``
-        -- every valid path has exactly one level-1 prefix, so the shards' results partition the full
-        result (strided rather than blocked: consecutive primitives are spatial neighbours with similar
-        fan-out)."""
+        ``(t * n + m) % world == rank``: the multi-GPU split of
+        ``differt_amd.distributed.trace_beam_pruned_sharded`` -- every valid path has exactly one level-1
+        prefix, so the shards' results partition the full result; rank 0 owns the line-of-sight paths."""
         if self.smoothing_factor is not None:
             raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
-        if order == 0:
-            p0 = self.trace_rank_range(scene, 0, max_survivors=max_survivors, max_paths=max_paths)
-            if prefix_shard is not None and int(prefix_shard[0]) != 0:  # line-of-sight paths have no prefix: rank 0 owns them
-                it0 = None if p0.interaction_types is None else p0.interaction_types[:0]
-                p0 = TracedPaths(p0.vertices[:0], p0.objects[:0], p0.mask[:0], it0, self.confidence_threshold,
-                                 None if p0.keys is None else p0.keys[:0])
-            return p0
-        if not 1 <= order <= 3:
-            raise ValueError("beam pruning covers orders 1..3")
-        mesh = scene.mesh
-        if mesh.mask is not None and not self.disconnect_inactive_triangles:
-            pass  # inactive primitives are never mirrors in either case (the trace marks them invalid)
-        tx = scene.transmitters.reshape(-1, 3).contiguous()
-        rx = scene.receivers.reshape(-1, 3).contiguous()
-        ntx, nrx, dev = tx.shape[0], rx.shape[0], tx.device
-        n = mesh.num_primitives
-        scale = 2 if mesh.assume_quads else 1
-        empty = TracedPaths(torch.zeros((0, order + 2, 3), device=dev), torch.zeros((0, order + 2), dtype=torch.int32, device=dev),
-                            torch.zeros(0, dtype=torch.bool, device=dev), torch.zeros((0, order), dtype=torch.int32, device=dev),
-                            self.confidence_threshold, torch.zeros(0, dtype=torch.int64, device=dev))
-        if n == 0 or ntx == 0 or nrx == 0:
-            return empty
-        if ntx * nrx * n ** order >= 2 ** 62:
-            raise OverflowError("tx * rx * primitives**order does not fit a 62-bit row key")
-        mag = max(float(mesh.vertices.detach().abs().max()), float(tx.detach().abs().max()), float(rx.detach().abs().max()), 1e-30)
-        ulp = 2.0 ** (int(np.floor(np.log2(mag))) - 23)
-        margin = float(kappa) * ulp / float(cos_min) ** order
-        h = mesh.handle().h
-        # kernel mapping of the expansion (identical survivors, see drt_beam_expand).  "auto" = "clustered":
-        # primitives in Morton clusters of 64 with boxes, box test per (prefix, cluster), survivors tested with
-        # lane = primitive (configs[3]: second expansion 2.4 s with lane = prefix, 0.6 s clustered)
-        modes = {"transposed": (0, 0), "bvh": (1, 1), "prefix": (2, 2), "clustered": (3, 3), "auto": (3, 3)}
-        if expansion not in modes:
+        if not 0 <= order <= 3:
+            raise ValueError("beam pruning covers orders 0..3")
+        if expansion not in ("auto", "clustered", "plain"):
             raise ValueError(f"unknown expansion {expansion!r}")
-        txd, rxd = tx.detach(), rx.detach()
-        count = torch.zeros(1, dtype=torch.int64, device=dev)
-        stats = {"margin_m": margin, "levels": [], "rows": 0, "chunks": 0}
-
-        def entries(cap):
-            return torch.empty((max(cap, 1), 8), dtype=torch.int32, device=dev)  # 32-byte records
-
-        lvl = entries(ntx * n)
-        _lib.call("drt_beam_seed", h, ptr(txd), ntx, margin, ptr(lvl), ntx * n, ptr(count), stream())
-        cur, ncur = lvl, int(count.item())
+        if emit not in ("auto", "plain", "clustered"):
+            raise ValueError(f"unknown emit {emit!r}")
+        beam = _lib.BeamParams()
+        beam.kappa = float(kappa)
+        beam.flags = ((_lib.DRT_BEAM_EXPAND_PLAIN if expansion == "plain" else 0)
+                      | (_lib.DRT_BEAM_EMIT_PLAIN if emit == "plain" else 0)
+                      | (_lib.DRT_BEAM_EMIT_CLUSTERED if emit == "clustered" else 0))
+        beam.max_entries, beam.max_records = int(max_entries or 0), int(max_records or 0)
+        beam.max_rows, beam.max_survivors = int(max_rows or 0), int(max_survivors or 0)
+        beam.probe_prefixes = int(probe_prefixes or 0)
         if prefix_shard is not None:
             srank, sworld = int(prefix_shard[0]), int(prefix_shard[1])
             if sworld <= 0 or not 0 <= srank < sworld:
                 raise ValueError("prefix_shard = (rank, world) with 0 <= rank < world")
-            # by CONTENT (transmitter * n + first primitive), not by position: the seed kernel compacts with
-            # atomics, so the order of the list differs from call to call and from rank to rank
-            lvl1 = cur[:ncur]
-            owner = (lvl1[:, 0].to(torch.int64) * n + lvl1[:, 1].to(torch.int64)) % sworld
-            cur = lvl1[owner == srank].contiguous()
-            ncur = int(cur.shape[0])
-            if ncur == 0:
-                cur = entries(1)
-        stats["levels"].append(ncur)
-
-        def expand(src, nsrc, level, out, cap):
-            """level-`level` prefixes x primitives -> 8-byte (prefix, primitive) records in `out`; returns the
-            count, or None when `cap` was too small."""
-            count.zero_()
-            mode = modes[expansion][level - 1]
-            if mode == 3:
-                order_p, boxes_p, sorted_v = _primitive_clusters(mesh)
-                _lib.call("drt_beam_expand_clustered", h, ptr(src), nsrc, level, margin, ptr(order_p), ptr(sorted_v),
-                          ptr(boxes_p), boxes_p.shape[0], ptr(out), cap, ptr(count), stream())
-            else:
-                _lib.call("drt_beam_expand", h, ptr(src), nsrc, level, margin, mode, ptr(out), cap, ptr(count), stream())
-            c = int(count.item())
-            return c if c <= cap else None
-
-        def records(cap):
-            return torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
-
-        # all but the last expansion are done in one piece (they are small: |L1| = ntx * n)
-        for level in range(1, order - 1):
-            cap = min(max_entries, max(ncur * 64, 1 << 16))
-            while True:
-                rec = records(cap)
-                c = expand(cur, ncur, level, rec, cap)
-                if c is not None:
-                    break
-                cap *= 4
-                if cap > 16 * max_entries:
-                    raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam prefix list does not fit: raise max_entries")
-            nxt = entries(c)
-            _lib.call("drt_beam_finish", h, ptr(cur), ptr(rec), c, level, margin, ptr(nxt), stream())
-            cur, ncur = nxt, c
-            stats["levels"].append(ncur)
-
-        npow = n ** order
-        parts = []
-        rows_buf = torch.empty(max_rows, dtype=torch.int64, device=dev)
-        if emit not in ("auto", "plain", "clustered"):
-            raise ValueError(f"unknown emit {emit!r}")
-        clusters = _receiver_clusters(rxd) if (emit == "clustered" or (emit == "auto" and nrx >= 128)) else None
-
-        def process(src, rec, nsrc):
-            """prefixes (+ records of the last expansion) -> rows -> trace; False when `max_rows` was too small."""
-            count.zero_()
-            if clusters is None:
-                _lib.call("drt_beam_emit", h, ptr(src), ptr(rec), nsrc, order, ptr(rxd), nrx, ntx, margin, ptr(rows_buf),
-                          max_rows, ptr(count), stream())
-            else:
-                _lib.call("drt_beam_emit_clustered", h, ptr(src), ptr(rec), nsrc, order, ptr(clusters[0]),
-                          ptr(clusters[1]), ptr(clusters[2]), nrx, ntx, margin, ptr(rows_buf), max_rows, ptr(count),
-                          stream())
-            r = int(count.item())
-            if r > max_rows:
-                return False
-            if r == 0:
-                return True
-            # (with quads the LBVH walk may reach a primitive through both of its triangles: unique)
-            rows = torch.unique_consecutive(torch.sort(rows_buf[:r]).values)
-            stats["rows"] += int(rows.shape[0])
-            pair = torch.div(rows, npow, rounding_mode="floor")
-            rest = rows - pair * npow
-            cols = []
-            for j in range(order):
-                pw = n ** (order - 1 - j)
-                dgt = torch.div(rest, pw, rounding_mode="floor")
-                rest = rest - dgt * pw
-                cols.append((dgt * scale).to(torch.int32))
-            table = torch.stack(cols, dim=1).contiguous()
-            offs = torch.searchsorted(pair, torch.arange(ntx * nrx + 1, dtype=torch.int64, device=dev)).contiguous()
-            desc = {"table": table, "order": order, "pair_offsets": offs}
-            p = self._trace_compact(scene, desc, max_survivors, max_paths)
-            if p.objects.shape[0]:
-                parts.append((rows[p.keys], p.vertices, p.objects))
-            return True
-
-        if order == 1:
-            if not process(cur, None, ncur):
-                raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "beam rows do not fit: raise max_rows")
-        else:
-            # last expansion in slices sized from the measured fan-out (a small probe slice first), so that the
-            # level-`order` list of a slice and its rows fit their buffers; a slice that overflows is split
-            out = records(max_entries)
-            i0, step = 0, max(min(int(chunk_entries), ncur), 1)
-            stats["levels"].append(0)
-            while i0 < ncur:
-                i1 = min(i0 + step, ncur)
-                c = expand(cur[i0:i1], i1 - i0, order - 1, out, max_entries)
-                rows_before = stats["rows"]
-                ok = c is not None and process(cur[i0:i1], out, c)
-                if not ok:
-                    if step == 1:
-                        raise _lib.CapacityError(_lib.DRT_E_CAPACITY, "one prefix overflows max_entries / max_rows")
-                    step = max(step // 4, 1)
-                    continue
-                stats["levels"][-1] += c
-                stats["chunks"] += 1
-                fan = max(c / (i1 - i0), (stats["rows"] - rows_before) / (i1 - i0) * (max_entries / max_rows), 1e-9)
-                step = int(min(max(0.5 * max_entries / fan, 1), 4 * step if stats["chunks"] > 1 else 1 << 40, ncur))
-                i0 = i1
-        self.last_beam_stats = stats
-        if not parts:
-            return empty
-        keys = torch.cat([p[0] for p in parts])
-        perm = torch.argsort(keys, stable=True)
-        verts = torch.cat([p[1] for p in parts])[perm]
-        objs = torch.cat([p[2] for p in parts])[perm]
+            beam.shard_rank, beam.shard_world = srank, sworld
+        st = _lib.BeamStats()
+        beam.stats = C.pointer(st)
+        tx = scene.transmitters.reshape(-1, 3).contiguous()
+        rx = scene.receivers.reshape(-1, 3).contiguous()
+        mesh = scene.mesh
+        if tx.shape[0] * rx.shape[0] * max(mesh.num_primitives, 1) ** order >= 2 ** 62:
+            raise OverflowError("tx * rx * primitives**order does not fit a 62-bit row key")
+        verts, objs, keys = _TraceBeamFn.apply(tx, rx, mesh.vertices, mesh, order, _params(self.epsilon, self.hit_tol, self.min_len, self.accel),
+                                               beam, int(max_paths), self._beam_workspace)
+        self.last_beam_stats = {"unit_m": st.unit_m, "magnitude": st.magnitude, "levels": [int(x) for x in st.levels[:max(order, 1)]],
+                                "rows": int(st.rows), "chunks": int(st.slices), "valid": int(st.valid),
+                                "grazing_prefixes": int(st.grazing_prefixes)}
         nv = objs.shape[0]
-        return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=dev),
-                           torch.zeros((nv, order), dtype=torch.int32, device=dev), self.confidence_threshold, keys[perm])
+        return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=objs.device),
+                           torch.zeros((nv, order), dtype=torch.int32, device=objs.device), self.confidence_threshold, keys)
+
+    def _beam_workspace(self, nbytes: int, dev) -> torch.Tensor:
+        """One workspace per tracer, grown on demand and reused from call to call (the default list capacities
+        add up to a few GiB: allocating them per call would dominate small scenes)."""
+        ws = getattr(self, "_beam_ws", None)
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            self._beam_ws = ws = None  # release before growing
+            self._beam_ws = ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws
 
     def _trace_compact(self, scene, desc, max_survivors, max_paths) -> TracedPaths:
         tx = scene.transmitters.reshape(-1, 3).contiguous()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRT_ABI_VERSION 4
+#define DRT_ABI_VERSION 5
 
 enum {
     DRT_OK = 0,
@@ -401,7 +401,10 @@ typedef struct drt_candidates {
     /* PER-PAIR TABLE (drt_trace_paths_compact / _async / _vjp): table != NULL together with pair_offsets
      * != NULL -- rows [pair_offsets[p], pair_offsets[p+1]) of `table` are the candidates of pair
      * p = tx * num_rx + rx (triangle ids, already even for quads); first / last maps unused.  Keys are
-     * global table rows.  This is how the rows of drt_beam_emit are traced. */
+     * global table rows.  This is how drt_trace_paths_beam traces its candidate rows.
+     * PACKED KEYS (drt_trace_paths_vjp only): table == NULL and reserved & DRT_CAND_PACKED_KEYS -- a key is
+     * (tx * num_rx + rx) * num_nodes^order + sum_j m_j * num_nodes^(order-1-j), m_j = primitive ids: the keys
+     * drt_trace_paths_beam returns are self-describing, no table has to outlive the forward call. */
 } drt_candidates;
 
 /* Dense reference layout for every (tx, rx, candidate):
@@ -460,66 +463,69 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
                             float *grad_rx, float *grad_vertices, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Conservative ("beam") pruning of the exhaustive candidate space -- the lossless counterpart of the
- * reference's sampled visibility pruning (geometry/_solvers.py:1013-1056).  A prefix of mirrors is
- * dropped only when a NECESSARY condition of a valid specular path fails by more than `margin`
- * (next primitive outside the pyramid spanned by the image of the transmitter and the current
- * mirror, or on the wrong side of the mirror plane for the reference's same-side check,
- * _solver_image_method.py:443-454); see csrc/beam.hip and DESIGN.md section 9.  Orders 1..3.
- *   drt_beam_seed    level-1 prefixes (tx, m1) of all active primitives        -> out[0 .. *count)
- *   drt_beam_expand  level-`level` prefixes x primitives -> surviving (prefix index << 32 | primitive)
- *                    records, 8 bytes each                                      -> out[0 .. *count);
- *                    use_bvh selects the mapping (same survivors): 0 = lane per primitive, prefixes
- *                    staged in LDS, wave-level bounding-sphere culling;
- *                    1 = walk of the mesh LBVH with the box form of the tests (with assume_quads a
- *                    record may repeat -- de-duplicate the sorted rows); 2 = lane per prefix, brute force.
- *                    drt_beam_expand_clustered (below) is the fastest measured and what the Python layer uses
- *   drt_beam_finish  records -> level + 1 prefixes (needed between two expansions)
- *   drt_beam_emit    prefixes x receivers -> packed candidate rows (drt_beam_emit_clustered: the same
- *                    for many receivers, with cluster-level culling)
- *                    ((tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j)), n = primitives;
- *                    records == NULL: `in` holds level-`order` prefixes (order 1: straight from the
- *                    seed); else `in` holds level-(order-1) prefixes and `records` the last expansion
- * count_dev (device int64, zeroed by the caller) receives the number of records produced; records
- * beyond `capacity` are dropped, so count > capacity means "re-run with more room".  Rows, once
- * sorted, feed drt_trace_paths_compact as a per-pair table (drt_candidates.table + pair_offsets).
+ * Beam-pruned exhaustive tracer: ONE call that returns the valid paths of the exhaustive tracer
+ * (reference: Scene.trace_paths -> solver.trace_path_candidates over the FULL candidate list,
+ * geometry/_scene.py:650-764, geometry/_solvers.py:803-848, 936-957; static output capacity like
+ * wp.jax_callable(output_dims=...), geometry/_mesh.py:266-276) without visiting the
+ * n (n-1)^(order-1) candidates per pair: prefixes of mirrors are discarded by NECESSARY geometric
+ * conditions of a valid specular path (next primitive inside the pyramids spanned by the image of
+ * the transmitter and the mirrors so far; previous and next point on one side of the mirror plane,
+ * _solver_image_method.py:443-454) failing by more than a bound on the reference's own float32
+ * error -- built per mirror from its incidence geometry, so a mirror seen at grazing incidence
+ * switches its own tests off instead of losing a path (csrc/beam.hip).
+ * Survivors are traced by the ordinary kernels: same valid paths, same masked_vertices order,
+ * bit-identical vertices.  The lossless counterpart of the reference's SAMPLED visibility pruning
+ * (HybridPathTracer, _solvers.py:1013-1056).  Orders 0..3.
+ *
+ *   keys     [max_paths] i64 : (tx * num_rx + rx) * n^order + sum_j m_j * n^(order-1-j), n = primitives,
+ *                              m_j = primitive ids (ascending = masked_vertices order); order 0: tx * num_rx + rx
+ *   vertices [max_paths,order+2,3] f32, objects [max_paths,order+2] i32 (triangle ids, even for quads)
+ *   *num_valid_host: number of valid paths; the call synchronises the stream (list sizes are read back once
+ *   per level / slice).  DRT_E_CAPACITY: a capacity of drt_beam_params / max_paths / the workspace is too small
+ *   (*num_valid_host then holds the count that did not fit).
+ * Gradients: drt_trace_paths_vjp with a drt_candidates of {table NULL, num_nodes = n, order,
+ * reserved = DRT_CAND_PACKED_KEYS} and these keys.
+ * Everything -- Morton clustering of primitives (cached in the mesh handle, like the LBVH) and receivers,
+ * prefix expansion, receiver stage, row sort / decode, trace -- runs inside this call; no torch, no Python.
  * ------------------------------------------------------------------------------------------- */
-typedef struct drt_beam_entry {
-    int32_t tx;
-    int32_t id[3];      /* primitive ids of the prefix, unused slots -1 */
-    float apex[3];      /* image of the transmitter through the prefix's mirrors */
-    int32_t side_prev;  /* +1 / -1 / 0: side of the previous point set w.r.t. the last mirror plane */
-} drt_beam_entry;
-int32_t drt_beam_seed(drt_mesh_t mesh, const float *tx, int64_t num_tx, float margin, drt_beam_entry *out,
-                      int64_t capacity, int64_t *count_dev, void *stream);
-int32_t drt_beam_expand(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t level, float margin,
-                        int32_t use_bvh, uint64_t *records_out, int64_t capacity, int64_t *count_dev,
-                        void *stream);
-/* drt_beam_expand with cluster-level culling: `prim_order` [num_primitives] lists the primitives in an order
- * that makes 64 consecutive ones spatially compact (e.g. a Morton curve over their centroids),
- * `sorted_vertices` [num_primitives, 3 (6 with quads), 3] their vertices in that order (a gather of the
- * mesh's triangle vertices: the kernel streams it instead of chasing prim_order), `cluster_boxes` [num_clusters = ceil(num_primitives / 64), 6] = (lo[3], hi[3]) bounds ALL vertices of each
- * cluster.  A prefix skips the clusters whose box fails the box form of the primitive tests and tests the
- * others with lane = primitive.  Same records as drt_beam_expand (as a set). */
-int32_t drt_beam_expand_clustered(drt_mesh_t mesh, const drt_beam_entry *in, int64_t num_in, int32_t level,
-                                  float margin, const int32_t *prim_order, const float *sorted_vertices,
-                                  const float *cluster_boxes, int64_t num_clusters, uint64_t *records_out, int64_t capacity,
-                                  int64_t *count_dev, void *stream);
-int32_t drt_beam_finish(drt_mesh_t mesh, const drt_beam_entry *src, const uint64_t *records, int64_t num_records,
-                        int32_t level, float margin, drt_beam_entry *out, void *stream);
-int32_t drt_beam_emit(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t num_in,
-                      int32_t order, const float *rx, int64_t num_rx, int64_t num_tx, float margin,
-                      int64_t *rows_out, int64_t capacity, int64_t *count_dev, void *stream);
-/* drt_beam_emit for many receivers: `rx_sorted` [num_rx,3] are the receivers in an order that makes 64
- * consecutive ones spatially compact (e.g. a Morton curve), `rx_index` [num_rx] their indices in the scene's
- * receiver array (what the rows encode), `boxes` [ceil(num_rx / 64), 6] = (centre, half extents) of an
- * axis-aligned box around each cluster of 64.  A cluster whose box lies outside a prefix's pyramids / on the
- * wrong side of its mirror is skipped; the others are tested per receiver with lane = receiver.  Same rows
- * as drt_beam_emit (as a set). */
-int32_t drt_beam_emit_clustered(drt_mesh_t mesh, const drt_beam_entry *in, const uint64_t *records, int64_t num_in,
-                                int32_t order, const float *rx_sorted, const int32_t *rx_index, const float *boxes,
-                                int64_t num_rx, int64_t num_tx, float margin, int64_t *rows_out, int64_t capacity,
-                                int64_t *count_dev, void *stream);
+typedef struct drt_beam_stats {
+    int64_t levels[4];        /* prefixes kept at level 1, 2, 3 (this shard) */
+    int64_t rows;             /* candidate rows handed to the tracer */
+    int64_t slices;           /* slices of the last expansion */
+    int64_t valid;            /* valid paths */
+    int64_t grazing_prefixes; /* last-level prefixes whose error bound is unbounded: every test of theirs was off
+                                 (they were kept, never dropped) -- informational */
+    float unit_m;             /* u = kappa * ulp(largest coordinate magnitude), metres */
+    float magnitude;          /* that magnitude */
+} drt_beam_stats;
+
+#define DRT_BEAM_EXPAND_PLAIN 1   /* expansion: every (prefix, primitive) pair tested, no cluster culling */
+#define DRT_BEAM_EMIT_PLAIN 2     /* receiver stage: every (prefix, receiver) pair tested */
+#define DRT_BEAM_EMIT_CLUSTERED 4 /* receiver stage: Morton clusters of 64 even below 128 receivers */
+/* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on) */
+
+typedef struct drt_beam_params {
+    float kappa;            /* error unit u = kappa * ulp(M); <= 0: default 64 */
+    int32_t flags;          /* DRT_BEAM_* */
+    int64_t max_entries;    /* level-2 prefix list (order 3), 32 B each; <= 0: 2^26 */
+    int64_t max_records;    /* records of one expansion slice, 8 B each; <= 0: 2^27 */
+    int64_t max_rows;       /* candidate rows of one slice, 8 + 8 + 4 order B each; <= 0: 2^26 */
+    int64_t max_survivors;  /* survivor queue of the fused trace; <= 0: 2^22 */
+    int64_t probe_prefixes; /* size of the first slice of the last expansion; <= 0: 4096 */
+    int64_t shard_rank;     /* multi-GPU split: keep the level-1 prefixes (tx, m) with */
+    int64_t shard_world;    /*   (tx * n + m) % shard_world == shard_rank; <= 1: everything */
+    drt_beam_stats *stats;  /* host pointer or NULL */
+} drt_beam_params;
+#define DRT_CAND_PACKED_KEYS 4 /* drt_candidates.reserved bit: keys ARE the candidates (see above) */
+
+/* Morton clusters of the mesh's primitives (allocates, synchronises; implied by drt_trace_paths_beam) */
+int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream);
+size_t drt_trace_beam_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_primitives, int32_t order,
+                                     const drt_beam_params *beam, int64_t max_paths);
+int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *params, const drt_beam_params *beam,
+                             const float *tx, int64_t num_tx, const float *rx, int64_t num_rx, int32_t order,
+                             int64_t max_paths, int64_t *keys, float *vertices, int32_t *objects,
+                             int64_t *num_valid_host, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (f4) smoothed ("soft mask") mode -- reference: differt/src/differt/utils.py:70-89

@@ -63,8 +63,7 @@ while time.time() - t0 < budget:
     st["rows_traced"] += rows
     st["valid_paths"] += len(ea)
     if st["cases"] % 4 == 0:
-        for kw in ({"expansion": "prefix"}, {"expansion": "transposed"}, {"expansion": "bvh"},
-                   {"emit": "clustered"}, {"emit": "plain"}):
+        for kw in ({"expansion": "plain"}, {"emit": "clustered"}, {"emit": "plain"}):
             other = tracer.trace_beam_pruned(scene, order, **kw)
             st["mapping_checks"] += 1
             if tracer.last_beam_stats["rows"] != rows or not torch.equal(other.keys, bp.keys):

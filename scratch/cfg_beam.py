@@ -1,6 +1,6 @@
 """Conservative beam pruning on the BASELINE configurations: configs[2] (order 2), configs[3] (order 3, FULL
 coverage of the 1.02e15 candidates) and configs[4] (200k triangles, 1024 RX, order 2), forward + grad(TX).
-python scratch/cfg_beam.py [cfg3] [cfg4] [cfg5] [--expansion=auto|clustered|transposed|prefix|bvh] [--emit=auto|plain|clustered]"""
+python scratch/cfg_beam.py [cfg3] [cfg4] [cfg5] [--expansion=auto|clustered|plain] [--kappa=64] [--emit=auto|plain|clustered]"""
 import json
 import sys
 import time
@@ -14,6 +14,7 @@ import synthetic_scenes as S  # noqa: E402
 which = [a for a in sys.argv[1:] if a.startswith("cfg")] or ["cfg3", "cfg4"]
 EXPANSION = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--expansion=")), "auto")
 EMIT = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--emit=")), "auto")
+KAPPA = float(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--kappa=")), "64"))
 
 
 def run(name, V, Tr, tx, rx, order, verify=None):
@@ -23,7 +24,7 @@ def run(name, V, Tr, tx, rx, order, verify=None):
     def step():
         txg = torch.tensor(tx, device="cuda", requires_grad=True)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
-        p = tracer.trace_beam_pruned(scene, order, expansion=EXPANSION, emit=EMIT)
+        p = tracer.trace_beam_pruned(scene, order, expansion=EXPANSION, emit=EMIT, kappa=KAPPA)
         if p.objects.shape[0]:
             torch.sqrt((torch.diff(p.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
         return p, txg.grad
@@ -37,7 +38,7 @@ def run(name, V, Tr, tx, rx, order, verify=None):
     n = mesh.num_primitives
     out = {"config": name, "order": order, "triangles": int(Tr.shape[0]), "num_tx": len(tx), "num_rx": len(rx),
            "exhaustive_candidates": len(tx) * len(rx) * n * (n - 1) ** (order - 1), "s_per_step": dt,
-           "valid_paths": int(p.objects.shape[0]), "expansion": EXPANSION, "emit": EMIT, **tracer.last_beam_stats,
+           "valid_paths": int(p.objects.shape[0]), "expansion": EXPANSION, "emit": EMIT, "kappa": KAPPA, **tracer.last_beam_stats,
            "grad_finite": bool(torch.isfinite(g).all()) if g is not None else None}
     if verify is not None:
         ex = verify(mesh)

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert not unbound, f"declared in the header but no ctypes signature: {unbound}"
     stale = [s for s in _lib._SIGNATURES if s not in declared]
     assert not stale, f"ctypes signature without a declaration in the header: {stale}"
-    assert L.drt_abi_version() == _lib.ABI_VERSION == 4
+    assert L.drt_abi_version() == _lib.ABI_VERSION == 5
     assert f"#define DRT_ABI_VERSION {_lib.ABI_VERSION}" in _lib.HEADER_PATH.read_text()
 
 
@@ -36,6 +36,9 @@ def test_struct_layouts_match_header():
     assert _lib.Candidates.order.offset == 40 and _lib.Candidates.first_map.offset == 48
     assert _lib.Candidates.num_last.offset == 72
     assert C.sizeof(_lib.EmParams) == 40 and _lib.EmParams.rx_polarization.offset == 24
+    # drt_beam_params: f32, i32, 7 x i64, ptr; drt_beam_stats: 4 + 4 x i64, 2 x f32 (tests/abi/abi_beam_example.cpp asserts the same)
+    assert C.sizeof(_lib.BeamParams) == 72 and _lib.BeamParams.stats.offset == 64 and _lib.BeamParams.shard_rank.offset == 48
+    assert C.sizeof(_lib.BeamStats) == 72 and _lib.BeamStats.unit_m.offset == 64
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

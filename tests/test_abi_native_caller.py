@@ -12,14 +12,15 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "tests" / "abi" / "abi_host_example.cpp"
+BEAM_SRC = ROOT / "tests" / "abi" / "abi_beam_example.cpp"
 LIBDIR = ROOT / "differt_amd" / "lib"
 
 
-def _build(tmp: Path) -> Path:
+def _build(tmp: Path, src: Path = SRC) -> Path:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    exe = tmp / "abi_host_example"
+    exe = tmp / src.stem
     subprocess.run(
-        [hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", str(ROOT / "include"), str(SRC), "-L",
+        [hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", str(ROOT / "include"), str(src), "-L",
          str(LIBDIR), "-ldiffert_amd", f"-Wl,-rpath,{LIBDIR}", "-o", str(exe)],
         check=True, capture_output=True,
     )
@@ -38,3 +39,74 @@ def test_native_caller_runs(tmp_path):
                        env={**os.environ, "LD_LIBRARY_PATH": f"{LIBDIR}:{os.environ.get('LD_LIBRARY_PATH', '')}"})
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("OK"), r.stdout
+
+
+def test_native_beam_caller_compiles_against_the_header(tmp_path):
+    assert _build(tmp_path, BEAM_SRC).exists()
+
+
+def _run_beam(exe, tmp, V, Tr, tx, rx, order, quads=False, max_paths=4096):
+    import numpy as np
+
+    scene, out = tmp / "scene.bin", tmp / "out.bin"
+    with scene.open("wb") as f:
+        f.write(np.asarray([len(V), len(Tr), int(quads), len(tx), len(rx), order, max_paths], np.int64).tobytes())
+        for a, dt in ((V, np.float32), (Tr, np.int32), (tx, np.float32), (rx, np.float32)):
+            f.write(np.ascontiguousarray(a, dt).tobytes())
+    r = subprocess.run([str(exe), str(scene), str(out)], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "LD_LIBRARY_PATH": f"{LIBDIR}:{os.environ.get('LD_LIBRARY_PATH', '')}"})
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+    raw = out.read_bytes()
+    head = np.frombuffer(raw[:48], np.int64)
+    nv, k2, off = int(head[0]), order + 2, 48
+    keys = np.frombuffer(raw[off:off + 8 * nv], np.int64); off += 8 * nv
+    objs = np.frombuffer(raw[off:off + 4 * nv * k2], np.int32).reshape(nv, k2); off += 4 * nv * k2
+    verts = np.frombuffer(raw[off:off + 12 * nv * k2], np.float32).reshape(nv, k2, 3); off += 12 * nv * k2
+    gtx = np.frombuffer(raw[off:off + 12 * len(tx)], np.float32).reshape(len(tx), 3)
+    return head, keys, objs, verts, gtx
+
+
+@pytest.mark.gpu
+def test_native_beam_caller_reproduces_the_reference_goldens(tmp_path, two_buildings, goldens):
+    """No torch, no Python in the traced process: drt_trace_paths_beam on the reference's two-buildings scene returns
+    the valid paths its own test holds (differt/tests/geometry/test_scene.py:116-160), orders 0..3."""
+    import numpy as np
+
+    exe = _build(tmp_path, BEAM_SRC)
+    ex = goldens["advanced_path_tracing_example"]
+    V, Tr = two_buildings["vertices"], two_buildings["triangles"]
+    for order in (0, 1, 2, 3):
+        g = ex["orders"][str(order)]
+        _, keys, objs, verts, gtx = _run_beam(exe, tmp_path, V, Tr, [ex["tx"]], [ex["rx"]], order)
+        assert objs.tolist() == g["objects"]
+        np.testing.assert_allclose(verts, np.asarray(g["path_vertices"], np.float32), rtol=ex["rtol"])
+        n = len(Tr)
+        assert keys.tolist() == [sum(int(m) * n ** (order - 1 - j) for j, m in enumerate(o[1:-1])) for o in objs]
+        assert np.isfinite(gtx).all()
+
+
+@pytest.mark.gpu
+def test_native_beam_caller_cfg3_matches_the_exhaustive_keys(tmp_path):
+    """BASELINE configs[2] (16 TX x 64 RX, 10 000 triangles, order 2: 1.0e11 candidates) through the native caller:
+    the 54 valid paths of the exhaustive tracer -- same keys, objects, vertex bits -- and the same grad(TX)."""
+    import numpy as np
+    import torch
+
+    import differt_amd.geometry as G
+    import synthetic_scenes as S
+
+    V, Tr, c, h = S.manhattan(1000)
+    tx, rx = S.manhattan_tx_rx(c, h, 16, 64)
+    exe = _build(tmp_path, BEAM_SRC)
+    head, keys, objs, verts, gtx = _run_beam(exe, tmp_path, V, Tr, tx, rx, 2)
+    txg = torch.tensor(tx, device="cuda", requires_grad=True)
+    scene = G.Scene(txg, torch.tensor(rx, device="cuda"), G.Mesh(V, Tr))
+    ex = G.ExhaustivePathTracer().trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 16)
+    assert ex.objects.shape[0] == 54 and objs.shape[0] == 54
+    assert np.array_equal(objs, ex.objects.cpu().numpy())
+    assert np.array_equal(verts.view(np.uint32), ex.vertices.detach().cpu().numpy().view(np.uint32))
+    n, o = len(Tr), ex.objects.cpu().numpy().astype(np.int64)
+    assert np.array_equal(keys, (o[:, 0] * 64 + o[:, 3]) * n * n + o[:, 1] * n + o[:, 2])
+    ex.vertices.sum().backward()
+    np.testing.assert_allclose(gtx, txg.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert head[1] < 1e-4 * 1024 * n * (n - 1)  # rows traced vs candidates

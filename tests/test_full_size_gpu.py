@@ -269,7 +269,7 @@ def test_cfg5_full_coverage_beam_pruned(G):
     rows = tracer.last_beam_stats["rows"]
     assert bp.objects.shape[0] >= 50 and rows < 1e-5 * 1024 * n * (n - 1)
     _oracle_revalidate(V, Tr, tx, rx, bp, n ** order, order, n)
-    plain = tracer.trace_beam_pruned(scene, order, emit="plain", expansion="transposed")
+    plain = tracer.trace_beam_pruned(scene, order, emit="plain")
     assert tracer.last_beam_stats["rows"] == rows and torch.equal(plain.keys, bp.keys)
     torch.sqrt((torch.diff(bp.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
     assert bool(torch.isfinite(txg.grad).all()) and float(txg.grad.abs().max()) > 0

@@ -524,8 +524,8 @@ def test_beam_pruned_prefix_shards_partition_the_result(G, order, world):
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("assume_quads", [False, True])
 def test_beam_pruned_clustered_emit_equals_plain(G, order, assume_quads):
-    """drt_beam_emit_clustered (receivers in Morton clusters of 64 with bounding boxes, lane = receiver for the
-    surviving (prefix, cluster) pairs) returns the rows of drt_beam_emit: identical paths, 150 receivers (a
+    """The clustered receiver stage (receivers in Morton clusters of 64 with bounding boxes, lane = receiver for the
+    surviving (prefix, cluster) pairs) returns the rows of the plain one: identical paths, 150 receivers (a
     full cluster, a full one and a partial one) on a flat grid plus a few elevated ones."""
     import synthetic_scenes as S
 
@@ -716,10 +716,10 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
     bp = tracer.trace_beam_pruned(scene, 3)
     _assert_same_paths(ex, bp)
     st_bvh = dict(tracer.last_beam_stats)
-    for mapping in ("prefix", "bvh", "transposed"):  # default "auto" = clustered; lane per prefix / LBVH walk / lane per primitive
+    for mapping in ("plain",):  # default "auto" = clustered; "plain" tests every (prefix, primitive) pair
         other = tracer.trace_beam_pruned(scene, 3, expansion=mapping)
         _assert_same_paths(ex, other)
-        # sphere / box culling are the same tests on a ball / box: identical survivors at every level
+        # box culling is the same test on a box with a bound of the candidates' own error: identical survivors at every level
         assert st_bvh["levels"] == tracer.last_beam_stats["levels"] and st_bvh["rows"] == tracer.last_beam_stats["rows"]
     n = Tr.shape[0]
     evaluated, total = tracer.last_beam_stats["rows"], 64 * n * (n - 1) ** 2
@@ -760,9 +760,9 @@ def test_beam_pruned_equals_exhaustive_quads_masks_orders(G, rng, order, assume_
         bp = tracer.trace_beam_pruned(scene, order)
         _assert_same_paths(ex, bp)
         rows_bvh = tracer.last_beam_stats["rows"]
-        for mapping in ("prefix", "bvh", "transposed"):
+        for mapping in ("plain",):
             _assert_same_paths(ex, tracer.trace_beam_pruned(scene, order, expansion=mapping))
-            assert tracer.last_beam_stats["rows"] == rows_bvh  # same candidate rows after de-duplication
+            assert tracer.last_beam_stats["rows"] == rows_bvh  # same candidate rows
         if bp.objects.shape[0]:
             gref, = torch.autograd.grad(torch.sqrt((torch.diff(ex.vertices, dim=-2) ** 2).sum(-1)).sum(), txg)
             ggot, = torch.autograd.grad(torch.sqrt((torch.diff(bp.vertices, dim=-2) ** 2).sum(-1)).sum(), txg)
@@ -770,7 +770,7 @@ def test_beam_pruned_equals_exhaustive_quads_masks_orders(G, rng, order, assume_
 
 
 def test_beam_pruned_margin_only_widens_the_search(G):
-    """A larger margin (smaller cos_min / larger kappa) can only ADD rows, never lose a path."""
+    """A larger error unit (kappa) can only ADD rows, never lose a path."""
     import synthetic_scenes as S
 
     V, Tr, c, h = S.manhattan(40, seed=9)
@@ -779,7 +779,11 @@ def test_beam_pruned_margin_only_widens_the_search(G):
     tracer = G.ExhaustivePathTracer()
     base = tracer.trace_beam_pruned(scene, 2)
     rows0 = tracer.last_beam_stats["rows"]
-    wide = tracer.trace_beam_pruned(scene, 2, cos_min=1 / 64, kappa=256.0)
+    wide = tracer.trace_beam_pruned(scene, 2, kappa=4096.0)
     rows1 = tracer.last_beam_stats["rows"]
     _assert_same_paths(base, wide)
-    assert rows1 >= rows0 and tracer.last_beam_stats["margin_m"] > 0
+    assert rows1 >= rows0 and tracer.last_beam_stats["unit_m"] > 0
+    # small slices / tiny list capacities change nothing but the number of slices
+    tiny = tracer.trace_beam_pruned(scene, 2, probe_prefixes=7, max_records=3000, max_rows=2000)
+    _assert_same_paths(base, tiny)
+    assert tracer.last_beam_stats["rows"] == rows0 and tracer.last_beam_stats["chunks"] > 3
