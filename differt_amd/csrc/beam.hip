@@ -154,31 +154,35 @@ __device__ __forceinline__ float prim_eps_global(const BeamMesh &M, int64_t p, V
 }
 
 // A pyramid (apex I over a triangle): inward unit normals of its three face planes -- a degenerate face
-// (apex on the edge line or in the triangle's plane) gets a zero normal and never separates -- and the slope g
-// of its margin: an error delta = 2 S at the mirror opens the pyramid by delta / (h - delta) per unit distance.
+// (apex on the edge line or in the triangle's plane) gets a zero normal and never separates -- and, per face,
+// the slope g of its margin.  Seen from the apex, the reference's decisions about this mirror are uncertain by a
+// LATERAL distance delta (the along-ray error of a reflection point, which incidence amplifies, does not move
+// the line apex -> point): a line through the apex that passes within delta of the face's edge makes an angle
+// of at most delta / (rho - delta) with the face plane, rho = distance of the apex from the EDGE LINE.
 struct Pyr {
     V3 n[3];
-    float g;  // +inf: the pyramid's tests are off
+    float g[3];  // +inf: the face's test is off (apex within the arithmetic's resolution of the edge line)
 };
-__device__ __forceinline__ V3 face_normal(V3 I, V3 a, V3 b, V3 third) {
+__device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, float delta, V3 &n_out, float &g_out) {
     const V3 N = cross(a - I, b - I);
     const float len = __builtin_sqrtf(fdot(N, N));
     const float s = fdot(third - I, N);
-    if (!(len > 0.0f) || !(s == s) || s == 0.0f || !is_finite(len)) return V3{0, 0, 0};
-    const float inv = ((s > 0.0f) ? 1.0f : -1.0f) / len;
-    return N * inv;
-}
-__device__ __forceinline__ Pyr make_pyr(V3 I, V3 v0, V3 v1, V3 v2, float S) {
-    Pyr P;
-    P.n[0] = face_normal(I, v0, v1, v2);
-    P.n[1] = face_normal(I, v1, v2, v0);
-    P.n[2] = face_normal(I, v2, v0, v1);
-    const V3 c = cross(v1 - v0, v2 - v0);
-    const float len = __builtin_sqrtf(fdot(c, c));
-    const float h = (len > 0.0f) ? __builtin_fabsf(fdot(I - v0, c)) / len : 0.0f;
-    const float delta = 2.0f * S;
+    const V3 e = b - a;
+    const float el = __builtin_sqrtf(fdot(e, e));
+    const float rho = (el > 0.0f) ? len / el : 0.0f;
     // 2e-6 |x - I|_1 covers the rounding of <x - I, n_f> and of the normalisation itself
-    P.g = (h > 1.05f * delta) ? 1.01f * delta / (h - delta) + 2e-6f : kInf;
+    g_out = (rho > 1.05f * delta) ? 1.01f * delta / (rho - delta) + 2e-6f : kInf;
+    if (!(len > 0.0f) || !(s == s) || s == 0.0f || !is_finite(len)) {
+        n_out = V3{0, 0, 0};
+        return;
+    }
+    n_out = N * (((s > 0.0f) ? 1.0f : -1.0f) / len);
+}
+__device__ __forceinline__ Pyr make_pyr(V3 I, V3 v0, V3 v1, V3 v2, float delta) {
+    Pyr P;
+    pyr_face(I, v0, v1, v2, delta, P.n[0], P.g[0]);
+    pyr_face(I, v1, v2, v0, delta, P.n[1], P.g[1]);
+    pyr_face(I, v2, v0, v1, delta, P.n[2], P.g[2]);
     return P;
 }
 
@@ -207,10 +211,20 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
             c.pyr[j][t].n[0] = c.pyr[j][t].n[1] = c.pyr[j][t].n[2] = V3{0, 0, 0};
-            c.pyr[j][t].g = kInf;
+            c.pyr[j][t].g[0] = c.pyr[j][t].g[1] = c.pyr[j][t].g[2] = kInf;
         }
     if (!have) return;
     prim_plane(M, e.id[LEVEL - 1], c.pm, c.nm);
+    // lateral tolerance of the prefix: u sigma per mirror (Moller-Trumbore's edge tests + the lateral rounding of
+    // the reflection points), summed over the mirrors the unfolding passes; doubled (both end points of a segment)
+    float lat = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) {
+        float sg = M.shape[(int64_t)e.id[j] * SCALE];
+        if (SCALE == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * SCALE + 1]);
+        lat += u * sg;
+    }
+    const float delta = 2.0f * lat;  // +inf for a degenerate mirror: every face off
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
 #pragma unroll
@@ -224,7 +238,7 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
 #pragma unroll
                 for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
             }
-            c.pyr[j][t] = make_pyr(c.I, v[0], v[1], v[2], e.esum);
+            c.pyr[j][t] = make_pyr(c.I, v[0], v[1], v[2], delta);
         }
     }
 }
@@ -256,11 +270,12 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
         for (int j = 0; j < LEVEL; ++j)
 #pragma unroll
             for (int t = 0; t < SCALE; ++t) {
-                // an "off" pyramid (g = inf) is skipped below; keep inf * 0 = NaN out of the maxima
-                const float g = (c.pyr[j][t].g < kInf) ? c.pyr[j][t].g : 0.0f;
 #pragma unroll
-                for (int f = 0; f < 3; ++f)
+                for (int f = 0; f < 3; ++f) {
+                    // an "off" face (g = inf) is skipped below; keep inf * 0 = NaN out of the maxima
+                    const float g = (c.pyr[j][t].g[f] < kInf) ? c.pyr[j][t].g[f] : 0.0f;
                     mf[j][t][f] = fmaxf(mf[j][t][f], __builtin_fmaf(g, wl, fdot(w, c.pyr[j][t].n[f])));
+                }
             }
     }
     float h = kInf;
@@ -274,8 +289,9 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
         bool all_t = true;
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
-            const bool on = c.pyr[j][t].g < kInf;
-            all_t = all_t && on && ((mf[j][t][0] < base) || (mf[j][t][1] < base) || (mf[j][t][2] < base));
+            const Pyr &P = c.pyr[j][t];
+            all_t = all_t && ((P.g[0] < kInf && mf[j][t][0] < base) || (P.g[1] < kInf && mf[j][t][1] < base) ||
+                              (P.g[2] < kInf && mf[j][t][2] < base));
         }
         separated = separated || all_t;
     }
@@ -309,14 +325,12 @@ __device__ __forceinline__ bool box_pruned(const BeamCtx<SCALE, LEVEL> &c, const
         for (int t = 0; t < SCALE; ++t) {
             const Pyr &P = c.pyr[j][t];
             bool st = false;
-            if (P.g < kInf) {
 #pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    const V3 n = P.n[f];
-                    const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
-                                                    __builtin_fabsf(n.z) * e.z);
-                    st = st || (__builtin_fmaf(P.g, wl, smax) < base);
-                }
+            for (int f = 0; f < 3; ++f) {
+                const V3 n = P.n[f];
+                const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
+                                                __builtin_fabsf(n.z) * e.z);
+                st = st || (P.g[f] < kInf && __builtin_fmaf(P.g[f], wl, smax) < base);
             }
             all_t = all_t && st;
         }
@@ -342,9 +356,11 @@ __device__ __forceinline__ BeamCtx<SCALE, LEVEL> lane_bcast(const BeamCtx<SCALE,
     for (int j = 0; j < LEVEL; ++j)
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
-            o.pyr[j][t].g = lane_bcast(c.pyr[j][t].g, l);
 #pragma unroll
-            for (int f = 0; f < 3; ++f) o.pyr[j][t].n[f] = lane_bcast(c.pyr[j][t].n[f], l);
+            for (int f = 0; f < 3; ++f) {
+                o.pyr[j][t].g[f] = lane_bcast(c.pyr[j][t].g[f], l);
+                o.pyr[j][t].n[f] = lane_bcast(c.pyr[j][t].n[f], l);
+            }
         }
     return o;
 }
@@ -658,12 +674,10 @@ __device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, 
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
             const Pyr &P = c.pyr[j][t];
-            const float thr = -(c.u + ((P.g < kInf) ? P.g : 0.0f) * wl);
             bool inside = true;
-            if (P.g < kInf) {
 #pragma unroll
-                for (int f = 0; f < 3; ++f) inside = inside && !(fdot(w, P.n[f]) < thr);
-            }
+            for (int f = 0; f < 3; ++f)
+                inside = inside && !(P.g[f] < kInf && __builtin_fmaf(P.g[f], wl, fdot(w, P.n[f])) < -c.u);
             inside_any = inside_any || inside;
         }
         inside_all = inside_all && inside_any;
