@@ -1364,31 +1364,6 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     rc = read_count(counters, &ncur, s);
     if (rc != DRT_OK) return rc;
     if (st) st->levels[0] = ncur;
-    const BeamEntry *cur = entries1;
-    // ---- intermediate level (order 3): level 1 -> level 2 in one piece ----
-    if (order == 3 && ncur > 0) {
-        DRT_HIP(fill_bytes_async(counters, 0, 8, s));
-#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur, ncur, u, records, z.max_records, counters, s)
-        BEAM_DISPATCH2(M.scale, 1, CALL);
-#undef CALL
-        DRT_LAUNCH_CHECK();
-        int64_t c2 = 0;
-        rc = read_count(counters, &c2, s);
-        if (rc != DRT_OK) return rc;
-        if (c2 > z.max_records || c2 > z.max_entries) {
-            *num_valid_host = c2;
-            return fail(DRT_E_CAPACITY, "%lld level-2 prefixes: raise max_records / max_entries (%lld / %lld)",
-                        (long long)c2, (long long)z.max_records, (long long)z.max_entries);
-        }
-        if (c2 > 0) {
-            hipLaunchKernelGGL(beam_finish_kernel<1>, dim3((unsigned)ceil_div(c2, 256)), dim3(256), 0, s, M, cur, records,
-                               c2, u, entries2);
-            DRT_LAUNCH_CHECK();
-        }
-        cur = entries2;
-        ncur = c2;
-        if (st) st->levels[1] = ncur;
-    }
     DRT_REQUIRE(ncur < (1ll << 32), "record format holds 32-bit prefix indices");
 
     // ---- last level: rows of a slice of prefixes -> sort -> table -> trace ----
@@ -1406,12 +1381,11 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         int64_t r = 0;
         int32_t rc2 = read_count(counters, &r, s);
         if (rc2 != DRT_OK) return rc2;
+        *rows_out = r;
         if (r > z.max_rows) {
             *fits = false;
-            *rows_out = r;
             return DRT_OK;
         }
-        *rows_out = r;
         if (r == 0) return DRT_OK;
         size_t tb = sort_keys64_temp_bytes(r);
         DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted, (size_t)r,
@@ -1451,23 +1425,15 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         return DRT_OK;
     };
 
-    int64_t total_rows = 0, nslices = 0, last_level = 0;
-    if (order == 1) {
-        bool fits = true;
-        int64_t r = 0;
-        rc = process(cur, nullptr, ncur, &r, &fits);
-        if (rc != DRT_OK) return rc;
-        if (!fits) {
-            *num_valid_host = r;
-            return fail(DRT_E_CAPACITY, "%lld candidate rows: raise max_rows (%lld)", (long long)r, (long long)z.max_rows);
-        }
-        total_rows = r;
-        nslices = 1;
-    } else {
-        // slices of the level-(order-1) list sized from the measured fan-out (a small probe slice first), so that
-        // the records of a slice and its rows fit their buffers; a slice that overflows is retried smaller
+    int64_t total_rows = 0, nslices = 0;
+    // the last expansion of the list `cur` (level order-1) in slices sized from the measured fan-out (a small probe
+    // slice first), so that the records of a slice and its rows fit their buffers; a slice that overflows is
+    // retried smaller.  LEVEL = order - 1.
+    int64_t step_hint = (bp && bp->probe_prefixes > 0) ? bp->probe_prefixes : 4096;  // carried from list to list
+    int64_t done = 0;
+    auto last_expansion = [&](const BeamEntry *cur, int64_t ncur, int64_t *records_total) -> int32_t {
         int64_t i0 = 0;
-        int64_t step = std::max<int64_t>(std::min<int64_t>((bp && bp->probe_prefixes > 0) ? bp->probe_prefixes : 4096, ncur), 1);
+        int64_t step = std::max<int64_t>(std::min<int64_t>(step_hint, ncur), 1);
         while (i0 < ncur) {
             const int64_t i1 = std::min(i0 + step, ncur);
             DRT_HIP(fill_bytes_async(counters, 0, 8, s));
@@ -1482,12 +1448,12 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             }
             DRT_LAUNCH_CHECK();
             int64_t c = 0, r = 0;
-            rc = read_count(counters, &c, s);
-            if (rc != DRT_OK) return rc;
+            int32_t rc2 = read_count(counters, &c, s);
+            if (rc2 != DRT_OK) return rc2;
             bool fits = c <= z.max_records;
             if (fits) {
-                rc = process(cur + i0, records, c, &r, &fits);
-                if (rc != DRT_OK) return rc;
+                rc2 = process(cur + i0, records, c, &r, &fits);
+                if (rc2 != DRT_OK) return rc2;
             }
             if (!fits) {
                 if (step == 1) {
@@ -1498,17 +1464,81 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
                 step = std::max<int64_t>(step / 4, 1);
                 continue;
             }
-            last_level += c;
+            *records_total += c;
             total_rows += r;
             ++nslices;
+            ++done;
             const double per = (double)(i1 - i0);
             const double fan = std::max({(double)c / per / (double)z.max_records, (double)r / per / (double)z.max_rows, 1e-18});
             double next = 0.5 / fan;
-            if (nslices > 1) next = std::min(next, 4.0 * (double)step);
+            if (done > 1) next = std::min(next, 4.0 * (double)step);
+            step_hint = (int64_t)std::max(1.0, std::min(next, 4e18));
+            step = std::min<int64_t>(step_hint, ncur);
+            i0 = i1;
+        }
+        return DRT_OK;
+    };
+
+    if (order == 1) {
+        bool fits = true;
+        int64_t r = 0;
+        rc = process(entries1, nullptr, ncur, &r, &fits);
+        if (rc != DRT_OK) return rc;
+        if (!fits) {
+            *num_valid_host = r;
+            return fail(DRT_E_CAPACITY, "%lld candidate rows: raise max_rows (%lld)", (long long)r, (long long)z.max_rows);
+        }
+        total_rows = r;
+        nslices = 1;
+    } else if (order == 2) {
+        int64_t last = 0;
+        rc = last_expansion(entries1, ncur, &last);
+        if (rc != DRT_OK) return rc;
+        if (st) st->levels[1] = last;
+    } else {
+        // order 3: the level-1 list in slices whose level-2 lists fit max_entries (sized from the measured fan-out
+        // like the inner slices), each level-2 list then through the last expansion
+        int64_t i0 = 0, level2 = 0, level3 = 0, outer_done = 0;
+        const int64_t cap2 = std::min(z.max_entries, z.max_records);
+        int64_t step = std::max<int64_t>(std::min<int64_t>(1024, ncur), 1);
+        while (i0 < ncur) {
+            const int64_t i1 = std::min(i0 + step, ncur);
+            DRT_HIP(fill_bytes_async(counters, 0, 8, s));
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, entries1 + i0, i1 - i0, u, records, cap2, counters, s)
+            BEAM_DISPATCH2(M.scale, 1, CALL);
+#undef CALL
+            DRT_LAUNCH_CHECK();
+            int64_t c2 = 0;
+            rc = read_count(counters, &c2, s);
+            if (rc != DRT_OK) return rc;
+            if (c2 > cap2) {
+                if (step == 1) {
+                    *num_valid_host = c2;
+                    return fail(DRT_E_CAPACITY, "one level-1 prefix has %lld children: raise max_records / max_entries",
+                                (long long)c2);
+                }
+                step = std::max<int64_t>(step / 4, 1);
+                continue;
+            }
+            if (c2 > 0) {
+                hipLaunchKernelGGL(beam_finish_kernel<1>, dim3((unsigned)ceil_div(c2, 256)), dim3(256), 0, s, M, entries1 + i0,
+                                   records, c2, u, entries2);
+                DRT_LAUNCH_CHECK();
+                rc = last_expansion(entries2, c2, &level3);
+                if (rc != DRT_OK) return rc;
+            }
+            level2 += c2;
+            ++outer_done;
+            const double fan = std::max((double)c2 / (double)(i1 - i0) / (double)cap2, 1e-18);
+            double next = 0.7 / fan;
+            if (outer_done > 1) next = std::min(next, 8.0 * (double)step);
             step = (int64_t)std::max(1.0, std::min(next, (double)ncur));
             i0 = i1;
         }
-        if (st) st->levels[order - 1] = last_level;
+        if (st) {
+            st->levels[1] = level2;
+            st->levels[2] = level3;
+        }
     }
 
     // ---- slices interleave in key order: one final sort of (key, position) and a gather ----
