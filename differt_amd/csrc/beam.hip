@@ -121,7 +121,7 @@ __device__ __forceinline__ float plane_dist(V3 I, V3 n, float d) {
 // plane up to the arithmetic's resolution), NaN or overflow: +inf, which switches every test that uses it off.
 __device__ __forceinline__ float beam_eps(float u, float sigma, float D, float h) {
     const float us = u * sigma;
-    const float e = us * (D / h) * 1.0001f;
+    const float e = us * (D * __builtin_amdgcn_rcpf(h)) * 1.0001f;  // v_rcp_f32: 1 ulp, inside the 1.0001
     return (h > us && e < kInf) ? e : kInf;
 }
 
@@ -161,22 +161,28 @@ __device__ __forceinline__ float prim_eps_global(const BeamMesh &M, int64_t p, V
 // of at most delta / (rho - delta) with the face plane, rho = distance of the apex from the EDGE LINE.
 struct Pyr {
     V3 n[3];
-    float g[3];  // +inf: the face's test is off (apex within the arithmetic's resolution of the edge line)
+    float g[3];  // a face whose test is off (apex within the arithmetic's resolution of the edge line, degenerate
+                 // face, unbounded tolerance) has n = 0 and g = 0: its value <x - I, n> + g |x - I| is 0, never below a
+                 // negative threshold -- no guard compare anywhere
 };
+// three-way minimum / maximum that IGNORE NaN operands (v_min3_f32 / v_max3_f32): a NaN never separates
+__device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, float delta, V3 &n_out, float &g_out) {
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded forms (~12 instructions each, five per face,
+    // three faces per pyramid, up to three pyramids per prefix): these are margins, and the 2e-6 |x - I|_1 in the
+    // slope covers the rounding of the normalisation and of <x - I, n_f>; rho is rounded DOWN by the 0.9999
     const V3 N = cross(a - I, b - I);
-    const float len = __builtin_sqrtf(fdot(N, N));
+    const float len = __builtin_amdgcn_sqrtf(fdot(N, N));
     const float s = fdot(third - I, N);
     const V3 e = b - a;
-    const float el = __builtin_sqrtf(fdot(e, e));
-    const float rho = (el > 0.0f) ? len / el : 0.0f;
-    // 2e-6 |x - I|_1 covers the rounding of <x - I, n_f> and of the normalisation itself
-    g_out = (rho > 1.05f * delta) ? 1.01f * delta / (rho - delta) + 2e-6f : kInf;
-    if (!(len > 0.0f) || !(s == s) || s == 0.0f || !is_finite(len)) {
-        n_out = V3{0, 0, 0};
-        return;
-    }
-    n_out = N * (((s > 0.0f) ? 1.0f : -1.0f) / len);
+    const float el = __builtin_amdgcn_sqrtf(fdot(e, e));
+    const float rho = (el > 0.0f) ? 0.9999f * len * __builtin_amdgcn_rcpf(el) : 0.0f;
+    const float g = 1.0101f * delta * __builtin_amdgcn_rcpf(rho - delta) + 2e-6f;
+    const bool on = (rho > 1.05f * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
+    const float inv = __builtin_amdgcn_rcpf(len);
+    const float sc = on ? ((s > 0.0f) ? inv : -inv) : 0.0f;
+    n_out = on ? N * sc : V3{0, 0, 0};  // (0 * inf = NaN for a huge N: the select, not the product, zeroes it)
+    g_out = on ? g : 0.0f;
 }
 __device__ __forceinline__ Pyr make_pyr(V3 I, V3 v0, V3 v1, V3 v2, float delta) {
     Pyr P;
@@ -211,7 +217,7 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
             c.pyr[j][t].n[0] = c.pyr[j][t].n[1] = c.pyr[j][t].n[2] = V3{0, 0, 0};
-            c.pyr[j][t].g[0] = c.pyr[j][t].g[1] = c.pyr[j][t].g[2] = kInf;
+            c.pyr[j][t].g[0] = c.pyr[j][t].g[1] = c.pyr[j][t].g[2] = 0.0f;
         }
     if (!have) return;
     prim_plane(M, e.id[LEVEL - 1], c.pm, c.nm);
@@ -247,7 +253,7 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
 template <int SCALE, int LEVEL>
 __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, const V3 (&vx)[3 * SCALE],
                                             const float (&pl)[SCALE][4], float sigma) {
-    float dmin = kInf, dmax = -kInf, D = 0.0f;
+    float dmin = kInf, dmax = -kInf, D2 = 0.0f;
     float mf[LEVEL][SCALE][3];  // max over the vertices of <x - I, n_f> + g |x - I|_1
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j)
@@ -260,42 +266,41 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
     for (int k = 0; k < 3 * SCALE; ++k) {
         const V3 x = vx[k];
         const float d = fdot(x - c.pm, c.nm);
-        nan = nan || !(d == d);
         dmin = fminf(dmin, d);
         dmax = fmaxf(dmax, d);
         const V3 w = x - c.I;
         const float wl = l1_len(w);  // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
-        D = fmaxf(D, margin_len(w));
+        const float chk = d + wl;    // NaN vertex, plane or apex (the maxima below ignore NaNs): never prune
+        nan = nan || !(chk == chk);
+        D2 = fmaxf(D2, fdot(w, w));
 #pragma unroll
         for (int j = 0; j < LEVEL; ++j)
 #pragma unroll
-            for (int t = 0; t < SCALE; ++t) {
+            for (int t = 0; t < SCALE; ++t)
 #pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    // an "off" face (g = inf) is skipped below; keep inf * 0 = NaN out of the maxima
-                    const float g = (c.pyr[j][t].g[f] < kInf) ? c.pyr[j][t].g[f] : 0.0f;
-                    mf[j][t][f] = fmaxf(mf[j][t][f], __builtin_fmaf(g, wl, fdot(w, c.pyr[j][t].n[f])));
-                }
-            }
+                for (int f = 0; f < 3; ++f)
+                    mf[j][t][f] = fmaxf(mf[j][t][f], __builtin_fmaf(c.pyr[j][t].g[f], wl, fdot(w, c.pyr[j][t].n[f])));
     }
     float h = kInf;
 #pragma unroll
     for (int t = 0; t < SCALE; ++t) h = fminf(h, plane_dist(c.I, V3{pl[t][0], pl[t][1], pl[t][2]}, pl[t][3]));
-    const float eps_c = beam_eps(c.u, sigma, D, h);
+#ifdef BEAM_LAB_NO_PRIM_EPS
+    const float eps_c = 0.0f * (sigma + D2 + h);
+#else
+    const float eps_c = beam_eps(c.u, sigma, __builtin_amdgcn_sqrtf(D2) * 1.000001f, h);
+#endif
     const float base = -(2.0f * eps_c + c.u);  // -inf for a candidate seen at grazing incidence: nothing separates
+    // separated by a pyramid: for EACH of the mirror's triangles SOME face has all vertices outside, i.e. the
+    // smallest of its three maxima is below the threshold; (a NaN vertex: `nan` below keeps the primitive)
     bool separated = false;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
-        bool all_t = true;
+        float worst = -kInf;  // max over the triangles of min over the faces
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            const Pyr &P = c.pyr[j][t];
-            all_t = all_t && ((P.g[0] < kInf && mf[j][t][0] < base) || (P.g[1] < kInf && mf[j][t][1] < base) ||
-                              (P.g[2] < kInf && mf[j][t][2] < base));
-        }
-        separated = separated || all_t;
+        for (int t = 0; t < SCALE; ++t) worst = fmaxf(worst, min3f(mf[j][t][0], mf[j][t][1], mf[j][t][2]));
+        separated = separated || (worst < base);
     }
-    const int side_c = nan ? 0 : side_of_range(dmin, dmax, eps_c + 2.0f * c.u);
+    const int side_c = side_of_range(dmin, dmax, eps_c + 2.0f * c.u);
     return !nan && (separated || (c.side_prev * side_c == -1));
 }
 
@@ -324,15 +329,15 @@ __device__ __forceinline__ bool box_pruned(const BeamCtx<SCALE, LEVEL> &c, const
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
             const Pyr &P = c.pyr[j][t];
-            bool st = false;
+            float v[3];
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
                 const V3 n = P.n[f];
                 const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
                                                 __builtin_fabsf(n.z) * e.z);
-                st = st || (P.g[f] < kInf && __builtin_fmaf(P.g[f], wl, smax) < base);
+                v[f] = __builtin_fmaf(P.g[f], wl, smax);
             }
-            all_t = all_t && st;
+            all_t = all_t && (min3f(v[0], v[1], v[2]) < base);
         }
         separated = separated || all_t;
     }
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
 // ---------------------------------------------------------------------------------------------
 struct BeamClusters {
     const int32_t *order;
-    const float *verts, *planes, *sigma, *boxes;
+    const float *verts, *planes, *uplanes, *sigma, *boxes;
     int64_t nclusters;
 };
 
@@ -547,6 +552,11 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
     // 8 KiB per wave: a flush every ~960 records (with 192 the flush atomics -- all on ONE address -- were half
     // of the kernel's time at configs[3])
     __shared__ unsigned long long wbuf[2][kBeamWaveBufBig];
+    // the cluster's triangle planes, staged per wave: lane k brings plane k with one coalesced load (in flight one
+    // cluster ahead), the 64 prefixes of the wave then read them back as LDS broadcasts.  As 64 scalar loads per
+    // (wave, cluster) this loop was half of the kernel's time (profiles/r03/beam.md): 157 KiB of planes per wave
+    // do not live in the 16-KiB scalar cache
+    __shared__ __attribute__((aligned(16))) float4 lds_planes[2][64 * SCALE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
@@ -564,19 +574,31 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
     // flight while this cluster is tested -- fetched whether or not the cluster will be hit (the mesh lives in L2)
     int32_t p_next = -1;
     V3 vx_next[3 * SCALE];
+    float4 pl_next[SCALE], uq_next[SCALE];
     auto fetch = [&](int64_t c) {
         const int64_t cc = (c < cl_end) ? c : cl_end - 1;  // the last trip re-reads its own cluster
         const int64_t pos = cc * 64 + lane;
         p_next = (pos < M.nprim) ? C.order[pos] : -1;
 #pragma unroll
         for (int k = 0; k < 3 * SCALE; ++k) vx_next[k] = ld3(C.verts + 9 * pos * SCALE + 3 * k);  // padded to whole clusters
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            pl_next[t] = reinterpret_cast<const float4 *>(C.planes)[pos * SCALE + t];
+            uq_next[t] = reinterpret_cast<const float4 *>(C.uplanes)[pos * SCALE + t];
+        }
     };
     if (cl_begin < cl_end) fetch(cl_begin);
     for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
         const int32_t p = p_next;
         V3 vx[3 * SCALE];
+        float pl[SCALE][4];
 #pragma unroll
         for (int k = 0; k < 3 * SCALE; ++k) vx[k] = vx_next[k];
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            pl[t][0] = pl_next[t].x; pl[t][1] = pl_next[t].y; pl[t][2] = pl_next[t].z; pl[t][3] = pl_next[t].w;
+            lds_planes[wave][lane * SCALE + t] = uq_next[t];  // wave-private: ordered by the wave's own LDS queue
+        }
         fetch(cl + 1);
         // ---- lane = prefix: box of the cluster (wave-uniform scalar loads) ----
         const float *bx = C.boxes + 8 * cl;
@@ -584,27 +606,38 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
         // bound of the candidates' own eps over the cluster: smallest plane distance of the apex over the
         // cluster's triangles (the SAME expression the per-primitive test evaluates), farthest box corner
         float hmin = kInf;
-        const float4 *pls = reinterpret_cast<const float4 *>(C.planes) + cl * 64 * SCALE;
+#ifndef BEAM_LAB_NO_HMIN
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the LDS writes above precede the reads below
+        __builtin_amdgcn_wave_barrier();
+        // non-negative floats order like their bit patterns, NaN patterns lie above +inf: an unsigned integer minimum
+        // is fminf here, without the NaN-quieting and unordered-compare code the float form expands to (measured:
+        // that expansion, a branch per two planes, made this loop half of the kernel)
+        uint32_t hbits = 0x7f800000u;
+        const int nplanes = __builtin_amdgcn_readfirstlane((int)bx[7]);  // distinct planes of the cluster, first in the list
 #pragma unroll 8
-        for (int k = 0; k < 64 * SCALE; ++k) {
-            const float4 q = pls[k];
-            hmin = fminf(hmin, plane_dist(ctx.I, V3{q.x, q.y, q.z}, q.w));
+        for (int k = 0; k < nplanes; ++k) {
+            const float4 q = lds_planes[wave][k];  // same address on every lane: broadcast
+            float sd = __builtin_fmaf(q.x, ctx.I.x, __builtin_fmaf(q.y, ctx.I.y, __builtin_fmaf(q.z, ctx.I.z, -q.w)));
+            asm volatile("" : "+v"(sd));  // keeps the compiler from pairing planes into v_pk_fma_f32 + v_mov shuffles
+            const uint32_t b = __float_as_uint(sd) & 0x7fffffffu;
+            hbits = (b < hbits) ? b : hbits;
         }
+        hmin = __uint_as_float(hbits);
+        __builtin_amdgcn_wave_barrier();  // reads done before the next cluster's writes
+#endif
         const V3 far = V3{fmaxf(__builtin_fabsf(ctx.I.x - lo[0]), __builtin_fabsf(ctx.I.x - hi[0])),
                           fmaxf(__builtin_fabsf(ctx.I.y - lo[1]), __builtin_fabsf(ctx.I.y - hi[1])),
                           fmaxf(__builtin_fabsf(ctx.I.z - lo[2]), __builtin_fabsf(ctx.I.z - hi[2]))};
+#ifdef BEAM_LAB_NO_HMIN
+        const float eps_max = 0.0f;
+#else
         const float eps_max = beam_eps(u, bx[6], margin_len(far) * 1.0001f, hmin);
+#endif
         unsigned long long todo = __ballot(have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max));
         if (todo == 0) continue;
         // ---- transposed: lane = primitive of the cluster ----
         const int64_t pos = cl * 64 + lane;
         const bool act = p >= 0 && prim_active(M, p);
-        float pl[SCALE][4];
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * SCALE + t];
-            pl[t][0] = q.x; pl[t][1] = q.y; pl[t][2] = q.z; pl[t][3] = q.w;
-        }
         const float sg = C.sigma[pos];
         while (todo) {
             const int l = __builtin_ctzll(todo);
@@ -659,30 +692,31 @@ __device__ __forceinline__ BeamEntry emit_entry(const BeamMesh &M, const BeamEnt
     return in[g];
 }
 
-// receiver r vs prefix: on the wrong side of the last mirror, or outside one of the pyramids?
-template <int SCALE, int ORDER>
-__device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, V3 r) {
+// receiver r vs prefix: on the wrong side of the last mirror, or outside one of the pyramids?  The pyramids in
+// turn, earliest mirror first (unfolded farthest from the apex = the narrowest cone); with WAVE_EXIT the wave leaves
+// the receiver as soon as none of its 64 lanes is still inside (same tests, same result: a lane that fails one
+// pyramid is dropped whatever the others say).
+template <int SCALE, int ORDER, bool WAVE_EXIT>
+__device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, V3 r, bool lane_on) {
     const float d = fdot(r - c.pm, c.nm);
     // side_prev in {-1, 0, +1}; 0 or a NaN distance never rejects (the receiver is exact: margin 2u)
-    if ((float)c.side_prev * d < -2.0f * c.u) return false;
+    bool alive = lane_on && !((float)c.side_prev * d < -2.0f * c.u);
     const V3 w = r - c.I;
     const float wl = l1_len(w);
-    bool inside_all = true;
 #pragma unroll
     for (int j = 0; j < ORDER; ++j) {
+        if (WAVE_EXIT && !__any(alive)) return false;
         bool inside_any = false;
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
             const Pyr &P = c.pyr[j][t];
-            bool inside = true;
-#pragma unroll
-            for (int f = 0; f < 3; ++f)
-                inside = inside && !(P.g[f] < kInf && __builtin_fmaf(P.g[f], wl, fdot(w, P.n[f])) < -c.u);
-            inside_any = inside_any || inside;
+            const float lowest = min3f(__builtin_fmaf(P.g[0], wl, fdot(w, P.n[0])), __builtin_fmaf(P.g[1], wl, fdot(w, P.n[1])),
+                                       __builtin_fmaf(P.g[2], wl, fdot(w, P.n[2])));
+            inside_any = inside_any || !(lowest < -c.u);
         }
-        inside_all = inside_all && inside_any;
+        alive = alive && inside_any;
     }
-    return inside_all;
+    return alive;
 }
 
 // lane = level-ORDER prefix, loop over the receivers (wave-uniform scalar loads, the next one in flight)
@@ -719,7 +753,7 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
         const V3 r = r_next;
         prx += (ir + 1 < nrx32) ? 3 : 0;
         r_next = ld3(prx);
-        const bool keep = have && receiver_inside<SCALE, ORDER>(ctx, r);
+        const bool keep = receiver_inside<SCALE, ORDER, true>(ctx, r, have);
         beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((pair0 + (long long)ir) * npow + tail), wbuf[wave], wcount,
                                  lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
     }
@@ -772,7 +806,7 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
             const long long ltail = ((long long)__builtin_amdgcn_readlane((int)(tail >> 32), l) << 32) |
                                     (long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tail, l);
             const long long ltx = (long long)__builtin_amdgcn_readlane(tx, l);
-            const bool keep = have_r && receiver_inside<SCALE, ORDER>(cx, r);
+            const bool keep = receiver_inside<SCALE, ORDER, true>(cx, r, have_r);
             beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((ltx * (long long)nrx + ir) * npow + ltail), wbuf[wave],
                                      wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
         }
@@ -847,8 +881,8 @@ __global__ __launch_bounds__(256) void morton_kernel(const float *__restrict__ p
 template <int SCALE>
 __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint32_t *__restrict__ sorted_ids,
                                                           int32_t *__restrict__ order, float *__restrict__ verts,
-                                                          float *__restrict__ planes, float *__restrict__ sigma,
-                                                          float *__restrict__ boxes) {
+                                                          float *__restrict__ planes, float *__restrict__ uplanes,
+                                                          float *__restrict__ sigma, float *__restrict__ boxes) {
     const int64_t cl = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t pos = cl * 64 + lane;
@@ -857,13 +891,15 @@ __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint
     if (pos < M.nprim) order[pos] = (int32_t)p;
     float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
     float sg = 0.0f;
+    float myq[SCALE][4];
 #pragma unroll
     for (int t = 0; t < SCALE; ++t) {
         const int64_t f = p * SCALE + t;
         const V3 n = ld3(M.normals + 3 * f);
         const V3 v0 = ld3(M.tv + 9 * f);
         float *q = planes + 4 * (pos * SCALE + t);
-        q[0] = n.x; q[1] = n.y; q[2] = n.z; q[3] = plane_offset(n, v0);
+        myq[t][0] = n.x; myq[t][1] = n.y; myq[t][2] = n.z; myq[t][3] = plane_offset(n, v0);
+        q[0] = myq[t][0]; q[1] = myq[t][1]; q[2] = myq[t][2]; q[3] = myq[t][3];
         sg = fmaxf(sg, M.shape[f]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -875,6 +911,37 @@ __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint
         }
     }
     sigma[pos] = sg;
+    // DISTINCT planes of the cluster, compacted to the front of `uplanes` (the two triangles of a box face, the
+    // faces of one wall line ... share a plane bit for bit): the expansion's bound of the candidates' own error
+    // needs the smallest plane distance of an apex over the cluster, one evaluation per distinct plane.  A
+    // non-finite plane makes the cluster's shape factor +inf (never box-pruned).
+    int ndistinct = 0;
+    bool bad_plane = false;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        const float qx = myq[t][0], qy = myq[t][1], qz = myq[t][2], qw = myq[t][3];
+        bad_plane = bad_plane || !is_finite(qx) || !is_finite(qy) || !is_finite(qz) || !is_finite(qw);
+        bool dup = false;
+        for (int l = 0; l < 64; ++l) {
+#pragma unroll
+            for (int t2 = 0; t2 < SCALE; ++t2) {
+                const float ox = __shfl(myq[t2][0], l, 64), oy = __shfl(myq[t2][1], l, 64);
+                const float oz = __shfl(myq[t2][2], l, 64), ow = __shfl(myq[t2][3], l, 64);
+                // list order: (triangle t of every lane) before (triangle t + 1 of every lane)
+                const bool earlier = (t2 * 64 + l) < (t * 64 + lane);
+                // the same plane, or the same plane with the opposite orientation (the distance is an absolute value)
+                const bool same = (ox == qx && oy == qy && oz == qz && ow == qw) || (ox == -qx && oy == -qy && oz == -qz && ow == -qw);
+                dup = dup || (earlier && same);
+            }
+        }
+        const unsigned long long keepm = __ballot(!dup);
+        if (!dup) {
+            float *o = uplanes + 4 * (cl * 64 * SCALE + ndistinct + __popcll(keepm & ((1ull << lane) - 1ull)));
+            o[0] = qx; o[1] = qy; o[2] = qz; o[3] = qw;
+        }
+        ndistinct += __popcll(keepm);
+    }
+    if (__any(bad_plane)) sg = kInf;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -892,7 +959,7 @@ __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint
         b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2];
         b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
         b[6] = sg;
-        b[7] = 0.0f;
+        b[7] = (float)ndistinct;
     }
 }
 
@@ -1200,7 +1267,8 @@ int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
         return at;
     };
     const size_t o_order = take((size_t)M.nprim * 4), o_verts = take((size_t)pp * 36 * sc),
-                 o_planes = take((size_t)pp * 16 * sc), o_sigma = take((size_t)pp * 4), o_boxes = take((size_t)ncl * 32);
+                 o_planes = take((size_t)pp * 16 * sc), o_uplanes = take((size_t)pp * 16 * sc),
+                 o_sigma = take((size_t)pp * 4), o_boxes = take((size_t)ncl * 32);
     char *blob = nullptr, *tmp = nullptr;
     DRT_HIP(hipMalloc(&blob, off));
     const size_t tmp_bytes = morton_scratch_bytes(M.nprim);
@@ -1214,12 +1282,13 @@ int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
         auto *order = reinterpret_cast<int32_t *>(blob + o_order);
         auto *verts = reinterpret_cast<float *>(blob + o_verts);
         auto *planes = reinterpret_cast<float *>(blob + o_planes);
+        auto *uplanes = reinterpret_cast<float *>(blob + o_uplanes);
         auto *sigma = reinterpret_cast<float *>(blob + o_sigma);
         auto *boxes = reinterpret_cast<float *>(blob + o_boxes);
         if (sc == 2)
-            hipLaunchKernelGGL(prim_cluster_kernel<2>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, sigma, boxes);
+            hipLaunchKernelGGL(prim_cluster_kernel<2>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes);
         else
-            hipLaunchKernelGGL(prim_cluster_kernel<1>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, sigma, boxes);
+            hipLaunchKernelGGL(prim_cluster_kernel<1>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes);
         uint32_t mag_bits = 0;
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&mag_bits, bounds + 6, 4, hipMemcpyDeviceToHost, s);
@@ -1232,6 +1301,7 @@ int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
             mesh->beam_order = order;
             mesh->beam_verts = verts;
             mesh->beam_planes = planes;
+            mesh->beam_uplanes = uplanes;
             mesh->beam_sigma = sigma;
             mesh->beam_boxes = boxes;
             mesh->beam_clusters = ncl;
@@ -1327,6 +1397,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     C.order = mesh->beam_order;
     C.verts = mesh->beam_verts;
     C.planes = mesh->beam_planes;
+    C.uplanes = mesh->beam_uplanes;
     C.sigma = mesh->beam_sigma;
     C.boxes = mesh->beam_boxes;
     C.nclusters = mesh->beam_clusters;

@@ -25,7 +25,8 @@ struct drt_mesh {
     float *beam_normals = nullptr;   // [Pp,scale,3]   unit normals of the primitive's triangles
     float *beam_sigma = nullptr;     // [Pp]           shape factor (see beam.hip), max over its triangles
     float *beam_planes = nullptr;    // [Pp*scale,4]   (n, <n, v0>) per triangle
-    float *beam_boxes = nullptr;     // [clusters,8]   lo[3], hi[3], max sigma, 0
+    float *beam_uplanes = nullptr;   // [Pp*scale,4]   per cluster: its DISTINCT planes first (count in beam_boxes[.,7])
+    float *beam_boxes = nullptr;     // [clusters,8]   lo[3], hi[3], max sigma, number of distinct planes
     int64_t beam_clusters = 0;
     float beam_max_abs = 0.0f;       // largest |coordinate| of the mesh vertices
 };
