@@ -63,6 +63,7 @@ class TraceParams(C.Structure):
 
 DRT_TRACE_USE_BVH = 1
 DRT_TRACE_SKIP_OCCLUSION = 2
+DRT_TRACE_DETERMINISTIC_GRAD = 4
 DRT_TRACE_OVERFLOW_SURVIVORS, DRT_TRACE_OVERFLOW_PATHS = 1, 2
 ABI_VERSION = 5  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
 
@@ -204,6 +205,17 @@ _SIGNATURES = {
          _vp, _sz, _vp],
     ),
     "drt_trace_compact_workspace_size": (_sz, [_i64, _i64]),
+    "drt_comm_unique_id": (_i32, [_vp]),
+    "drt_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
+    "drt_comm_destroy": (_i32, [_vp]),
+    "drt_comm_rank": (_i32, [_vp]),
+    "drt_comm_world": (_i32, [_vp]),
+    "drt_allreduce_min_u64": (_i32, [_vp, _vp, _i64, _vp]),
+    "drt_allreduce_max_u8": (_i32, [_vp, _vp, _i64, _vp]),
+    "drt_allreduce_sum_f32": (_i32, [_vp, _vp, _i64, _vp]),
+    "drt_allgather_bytes": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "drt_trace_vjp_workspace_size": (_sz, [_i64, _i32]),
+    "drt_trace_paths_vjp_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drt_mesh_build_beam_clusters": (_i32, [_vp, _vp]),
     "drt_trace_beam_workspace_size": (_sz, [_i64, _i64, _i64, _i32, _vp, _i64]),
     "drt_trace_paths_beam": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -259,7 +271,7 @@ _SIGNATURES = {
 }
 
 # functions whose int32 result is NOT a status code
-_NOT_STATUS = {"drt_abi_version", "drt_mesh_has_bvh"}
+_NOT_STATUS = {"drt_abi_version", "drt_mesh_has_bvh", "drt_comm_rank", "drt_comm_world"}
 
 _LIB = None
 

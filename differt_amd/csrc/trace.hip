@@ -585,6 +585,92 @@ __global__ __launch_bounds__(256) void trace_vjp_kernel(
     if (g_rx) atomic_add3(g_rx + 3 * ir, rx_bar);
 }
 
+// Deterministic variant (DRT_TRACE_DETERMINISTIC_GRAD, SURVEY.md section 7 hard part 6): float atomics add in
+// arrival order, so two runs differ in the last bits.  Here every path WRITES its contributions -- slot 0 its
+// transmitter's, slot 1 its receiver's, slots 2.. the three vertices of each mirror -- next to a 64-bit
+// destination key (space << 40 | index; all ones = nothing); a STABLE radix sort groups them by destination with the
+// path order kept inside a group, and one lane per group adds them up in that fixed order.
+template <int K>
+__global__ __launch_bounds__(256) void trace_vjp_contrib_kernel(
+    TraceArgs a, CandSrc cs, const float *__restrict__ mesh_vertices, const int32_t *__restrict__ mesh_triangles,
+    const long long *__restrict__ keys, const float *__restrict__ cot, int64_t num, int want_tx, int want_rx,
+    int want_vertices, unsigned long long *__restrict__ dest, uint32_t *__restrict__ slot_ids,
+    float *__restrict__ vecs) {
+    constexpr int S = 2 + 3 * K;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= num) return;
+    unsigned long long dk[S];
+    V3 dv[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+        dk[q] = ~0ull;
+        dv[q] = V3{0, 0, 0};
+    }
+    int64_t it, ir;
+    int32_t id[KA<K>::n];
+    V3 p[KA<K>::n], n[KA<K>::n], full[K + 2];
+    const long long key = keys[i];
+    if (key >= 0 && key_to_path<K>(a, cs, key, it, ir, id, p, n, full) && path_finite<K>(full)) {
+        const float *g = cot + i * (K + 2) * 3;
+        V3 tx_bar = ld3(g), rx_bar = ld3(g + 3 * (K + 1));
+        if constexpr (K > 0) {
+            V3 gp[KA<K>::n], pb[KA<K>::n], nb[KA<K>::n], fb, tb;
+#pragma unroll
+            for (int j = 0; j < K; ++j) gp[j] = ld3(g + 3 * (j + 1));
+            image_chain_vjp<KA<K>::n>(full[0], full[K + 1], p, n, gp, fb, tb, pb, nb);
+            tx_bar = tx_bar + fb;
+            rx_bar = rx_bar + tb;
+            if (want_vertices) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    int32_t vi[3];
+                    V3 vv[3];
+                    mirror_vjp_contrib(mesh_vertices, mesh_triangles, id[j], pb[j], nb[j], vi, vv);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dk[2 + 3 * j + k] = (2ull << 40) | (unsigned long long)(uint32_t)vi[k];
+                        dv[2 + 3 * j + k] = vv[k];
+                    }
+                }
+            }
+        }
+        if (want_tx) {
+            dk[0] = (unsigned long long)it;
+            dv[0] = tx_bar;
+        }
+        if (want_rx) {
+            dk[1] = (1ull << 40) | (unsigned long long)ir;
+            dv[1] = rx_bar;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+        const int64_t slot = i * S + q;
+        dest[slot] = dk[q];
+        slot_ids[slot] = (uint32_t)slot;
+        st3(vecs + 3 * slot, dv[q]);
+    }
+}
+
+__global__ __launch_bounds__(256) void trace_vjp_reduce_kernel(const unsigned long long *__restrict__ dest_sorted,
+                                                               const uint32_t *__restrict__ slots_sorted,
+                                                               const float *__restrict__ vecs, int64_t n,
+                                                               float *__restrict__ g_tx, float *__restrict__ g_rx,
+                                                               float *__restrict__ g_vertices) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long d = dest_sorted[i];
+    if (d == ~0ull || (i > 0 && dest_sorted[i - 1] == d)) return;  // not the head of a group
+    V3 acc = ld3(vecs + 3 * (int64_t)slots_sorted[i]);
+    for (int64_t j = i + 1; j < n && dest_sorted[j] == d; ++j) acc = acc + ld3(vecs + 3 * (int64_t)slots_sorted[j]);
+    const int space = (int)(d >> 40);
+    float *out = ((space == 0) ? g_tx : ((space == 1) ? g_rx : g_vertices)) + 3 * (int64_t)(d & 0xffffffffffull);
+    // gradients are ACCUMULATED into the caller's buffers: the group's only writer adds its total
+    out[0] += acc.x;
+    out[1] += acc.y;
+    out[2] += acc.z;
+}
+
 // (a12) GPU-resident candidate table
 template <int K>
 __global__ __launch_bounds__(256) void candidates_fill_kernel(CandSrc cs, int32_t *__restrict__ out) {
@@ -983,6 +1069,68 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t ntx, const
                        cot, num, g_tx, g_rx, g_vertices)
     DRT_ORDER_SWITCH(k, CALL)
 #undef CALL
+    DRT_LAUNCH_CHECK();
+    return DRT_OK;
+}
+
+static size_t vjp_sort_temp_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                    (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 42, nullptr);
+    return bytes;
+}
+
+size_t drt_trace_vjp_workspace_size(int64_t num_paths, int32_t order) {
+    if (num_paths < 0) num_paths = 0;
+    if (order < 0) order = 0;
+    const int64_t n = num_paths * (2 + 3 * (int64_t)order);
+    return 256 + 2 * align_up((size_t)n * 8, 256) + 2 * align_up((size_t)n * 4, 256) + align_up((size_t)n * 12, 256) +
+           align_up(vjp_sort_temp_bytes(n), 256);
+}
+
+int32_t drt_trace_paths_vjp_ex(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx, int64_t ntx,
+                               const float *rx, int64_t nrx, const drt_candidates *cands, const int64_t *keys,
+                               const float *cot, int64_t num, float *g_tx, float *g_rx, float *g_vertices, void *ws,
+                               size_t ws_bytes, void *stream) {
+    if (!pr || !(pr->flags & DRT_TRACE_DETERMINISTIC_GRAD))
+        return drt_trace_paths_vjp(mesh, tx, ntx, rx, nrx, cands, keys, cot, num, g_tx, g_rx, g_vertices, stream);
+    DRT_REQUIRE(mesh && cands, "null argument");
+    DRT_REQUIRE(num >= 0, "negative size");
+    if (num == 0) return DRT_OK;
+    DRT_REQUIRE(tx && rx && keys && cot, "null pointer");
+    Launch L;
+    L.s = as_stream(stream);
+    L.quads = mesh->assume_quads != 0;
+    int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
+    if (rc != DRT_OK) return rc;
+    L.cs.npairs = ntx * nrx;
+    L.a = make_args(mesh, nullptr, tx, ntx, rx, nrx);
+    const int k = cands->order;
+    const int64_t n = num * (2 + 3 * (int64_t)k);
+    DRT_REQUIRE(n < (1ll << 32), "too many gradient contributions for one call");
+    const size_t need = drt_trace_vjp_workspace_size(num, k);
+    if (!ws || ws_bytes < need) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", need);
+    char *base = reinterpret_cast<char *>(ws);
+    const size_t a8 = align_up((size_t)n * 8, 256), a4 = align_up((size_t)n * 4, 256);
+    auto *dest = reinterpret_cast<unsigned long long *>(base);
+    auto *dest_sorted = reinterpret_cast<unsigned long long *>(base + a8);
+    auto *slots = reinterpret_cast<uint32_t *>(base + 2 * a8);
+    auto *slots_sorted = reinterpret_cast<uint32_t *>(base + 2 * a8 + a4);
+    auto *vecs = reinterpret_cast<float *>(base + 2 * a8 + 2 * a4);
+    char *sort_tmp = base + 2 * a8 + 2 * a4 + align_up((size_t)n * 12, 256);
+#define CALL(K)                                                                                                       \
+    hipLaunchKernelGGL(trace_vjp_contrib_kernel<K>, dim3((unsigned)ceil_div(num, 256)), dim3(256), 0, L.s, L.a, L.cs,  \
+                       mesh->vertices, mesh->triangles, reinterpret_cast<const long long *>(keys), cot, num,         \
+                       g_tx ? 1 : 0, g_rx ? 1 : 0, g_vertices ? 1 : 0, dest, slots, vecs)
+    DRT_ORDER_SWITCH(k, CALL)
+#undef CALL
+    DRT_LAUNCH_CHECK();
+    size_t tb = vjp_sort_temp_bytes(n);
+    // radix sort is stable: inside a destination the slots stay in path order
+    DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb, dest, dest_sorted, slots, slots_sorted, (size_t)n, 0, 42, L.s));
+    hipLaunchKernelGGL(trace_vjp_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, L.s, dest_sorted,
+                       slots_sorted, vecs, n, g_tx, g_rx, g_vertices);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

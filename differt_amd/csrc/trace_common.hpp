@@ -277,10 +277,10 @@ __device__ __forceinline__ void atomic_add3(float *p, V3 v) {
 
 // Reverse of "mirror point = v0 of triangle `tri`, mirror normal = normalize((v1-v0) x (v2-v1))"
 // (_mesh.py:950-956): scatters the cotangents (p_bar, n_bar) of one mirror into the mesh vertices.
-__device__ __forceinline__ void mirror_vjp_to_mesh(const float *__restrict__ mesh_vertices,
-                                                   const int32_t *__restrict__ mesh_triangles,
-                                                   int64_t tri, V3 p_bar, V3 n_bar,
-                                                   float *__restrict__ g_vertices) {
+// the three (vertex index, cotangent) contributions of one mirror
+__device__ __forceinline__ void mirror_vjp_contrib(const float *__restrict__ mesh_vertices,
+                                                   const int32_t *__restrict__ mesh_triangles, int64_t tri, V3 p_bar,
+                                                   V3 n_bar, int32_t (&idx)[3], V3 (&vec)[3]) {
     const int32_t i0 = mesh_triangles[3 * tri], i1 = mesh_triangles[3 * tri + 1],
                   i2 = mesh_triangles[3 * tri + 2];
     const V3 v0 = ld3(mesh_vertices + 3 * (int64_t)i0), v1 = ld3(mesh_vertices + 3 * (int64_t)i1),
@@ -298,9 +298,21 @@ __device__ __forceinline__ void mirror_vjp_to_mesh(const float *__restrict__ mes
     }
     const V3 ea_bar = cross(eb, cbar);  // c = ea x eb
     const V3 eb_bar = cross(cbar, ea);
-    atomic_add3(g_vertices + 3 * (int64_t)i0, p_bar - ea_bar);
-    atomic_add3(g_vertices + 3 * (int64_t)i1, ea_bar - eb_bar);
-    atomic_add3(g_vertices + 3 * (int64_t)i2, eb_bar);
+    idx[0] = i0; idx[1] = i1; idx[2] = i2;
+    vec[0] = p_bar - ea_bar;
+    vec[1] = ea_bar - eb_bar;
+    vec[2] = eb_bar;
+}
+
+__device__ __forceinline__ void mirror_vjp_to_mesh(const float *__restrict__ mesh_vertices,
+                                                   const int32_t *__restrict__ mesh_triangles,
+                                                   int64_t tri, V3 p_bar, V3 n_bar,
+                                                   float *__restrict__ g_vertices) {
+    int32_t idx[3];
+    V3 vec[3];
+    mirror_vjp_contrib(mesh_vertices, mesh_triangles, tri, p_bar, n_bar, idx, vec);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomic_add3(g_vertices + 3 * (int64_t)idx[k], vec[k]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -33,6 +33,8 @@ __all__ = [
     "shard_interval",
     "trace_rank_range_sharded",
     "trace_beam_pruned_sharded",
+    "NativeComm",
+    "native_comm",
 ]
 
 
@@ -43,6 +45,93 @@ def shard_interval(total: int, world_size: int, rank: int) -> tuple[int, int]:
     base, rem = divmod(total, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+class NativeComm:
+    """``drt_comm_t``: the path's collectives straight on RCCL (csrc/comm.hip), no torch.distributed in the data
+    path.  ``unique_id`` (128 bytes from :meth:`unique_id` on rank 0) reaches the other ranks out of band."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        import ctypes as C
+
+        from . import _lib
+
+        self._lib, self.h = _lib, C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.call("drt_comm_init", buf, int(rank), int(world), C.byref(self.h))
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _lib
+
+        buf = (C.c_uint8 * 128)()
+        _lib.call("drt_comm_unique_id", buf)
+        return bytes(buf)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self._lib.call("drt_comm_destroy", self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def _call(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        from ._tensors import ptr, stream
+
+        assert t.is_contiguous()
+        self._lib.call(name, self.h, ptr(t), t.numel(), stream())
+        return t
+
+    def allreduce_min_u64(self, keys_i64: torch.Tensor) -> torch.Tensor:
+        """In place; the tensor holds UNSIGNED 64-bit keys in an int64 container."""
+        return self._call("drt_allreduce_min_u64", keys_i64)
+
+    def allreduce_max_u8(self, flags: torch.Tensor) -> torch.Tensor:
+        return self._call("drt_allreduce_max_u8", flags)
+
+    def allreduce_sum_f32(self, x: torch.Tensor) -> torch.Tensor:
+        return self._call("drt_allreduce_sum_f32", x)
+
+    def allgather_bytes(self, send: torch.Tensor) -> torch.Tensor:
+        from ._tensors import ptr, stream
+
+        send = send.contiguous()
+        nbytes = send.numel() * send.element_size()
+        recv = torch.empty((self.world, *send.shape), dtype=send.dtype, device=send.device)
+        self._lib.call("drt_allgather_bytes", self.h, ptr(send), ptr(recv), nbytes, stream())
+        return recv
+
+
+_NATIVE: dict = {}
+
+
+def native_comm(group=None) -> NativeComm | None:
+    """The native communicator of ``group`` when ``DRT_COMM=rccl`` (created on first use: rank 0 draws the id,
+    torch.distributed's broadcast carries its 128 bytes -- rendezvous only, never the data path)."""
+    import os
+
+    if os.environ.get("DRT_COMM", "").lower() != "rccl":
+        return None
+    world, rank = _world(group)
+    if world == 1:
+        return None
+    key = id(group)
+    if key not in _NATIVE:
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.tensor(list(NativeComm.unique_id()), dtype=torch.uint8, device=dev)
+        dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        _NATIVE[key] = NativeComm(bytes(idt.cpu().tolist()), rank, world)
+    return _NATIVE[key]
 
 
 def _world(group) -> tuple[int, int]:
@@ -94,7 +183,11 @@ def allreduce_grads(*grads: torch.Tensor, group=None) -> None:
     if world == 1 or not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    nc = native_comm(group)
+    if nc is not None and flat.dtype == torch.float32 and flat.is_cuda:
+        nc.allreduce_sum_f32(flat)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for g in grads:
         g.copy_(flat[off: off + g.numel()].reshape(g.shape))
@@ -106,7 +199,15 @@ def reduce_first_hit(packed_keys: torch.Tensor, group=None) -> torch.Tensor:
     sign bit flipped (so that signed MIN == unsigned MIN; RCCL has no uint64 MIN on every build)."""
     world, _ = _world(group)
     if world > 1:
-        dist.all_reduce(packed_keys, op=dist.ReduceOp.MIN, group=group)
+        nc = native_comm(group)
+        if nc is not None and packed_keys.is_cuda:
+            # the native path reduces UNSIGNED keys: undo / redo the sign-bit flip of the torch path around it
+            flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=packed_keys.device)
+            packed_keys.bitwise_xor_(flip)
+            nc.allreduce_min_u64(packed_keys)
+            packed_keys.bitwise_xor_(flip)
+        else:
+            dist.all_reduce(packed_keys, op=dist.ReduceOp.MIN, group=group)
     return packed_keys
 
 
@@ -115,7 +216,11 @@ def reduce_any_hit(blocked: torch.Tensor, group=None) -> torch.Tensor:
     occludes one of its segments."""
     world, _ = _world(group)
     if world > 1:
-        dist.all_reduce(blocked, op=dist.ReduceOp.MAX, group=group)
+        nc = native_comm(group)
+        if nc is not None and blocked.is_cuda and blocked.dtype == torch.uint8:
+            nc.allreduce_max_u8(blocked)
+        else:
+            dist.all_reduce(blocked, op=dist.ReduceOp.MAX, group=group)
     return blocked
 
 

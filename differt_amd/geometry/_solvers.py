@@ -35,15 +35,31 @@ __all__ = [
 ]
 
 
-def _params(epsilon, hit_tol, min_len, accel=None, skip_occlusion: bool = False) -> _lib.TraceParams:
+def _params(epsilon, hit_tol, min_len, accel=None, skip_occlusion: bool = False,
+            deterministic_grad: bool = False) -> _lib.TraceParams:
     if accel not in (None, "bvh"):
         raise ValueError(f"unknown accel {accel!r}")
     return _lib.TraceParams(
         10.0 * F32_EPS if epsilon is None else float(epsilon),   # _utils.py:1257-1259
         100.0 * F32_EPS if hit_tol is None else float(hit_tol),  # _utils.py:1418-1420
         10.0 * F32_EPS if min_len is None else float(min_len),   # _solvers.py:514-516
-        (_lib.DRT_TRACE_USE_BVH if accel == "bvh" else 0) | (_lib.DRT_TRACE_SKIP_OCCLUSION if skip_occlusion else 0),
+        (_lib.DRT_TRACE_USE_BVH if accel == "bvh" else 0) | (_lib.DRT_TRACE_SKIP_OCCLUSION if skip_occlusion else 0)
+        | (_lib.DRT_TRACE_DETERMINISTIC_GRAD if deterministic_grad else 0),
     )
+
+
+def _paths_vjp(mesh, params, tx, rx, cands, keys, gv, n: int, order: int, gtx, grx, gmv) -> None:
+    """``drt_trace_paths_vjp``, or its deterministic form (stable sort + ordered sums instead of float atomics) when
+    ``params`` carries ``DRT_TRACE_DETERMINISTIC_GRAD``."""
+    h = mesh.handle().h
+    if params is not None and (params.flags & _lib.DRT_TRACE_DETERMINISTIC_GRAD):
+        nbytes = _lib.load().drt_trace_vjp_workspace_size(n, order)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=tx.device)
+        _lib.call("drt_trace_paths_vjp_ex", h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+                  C.byref(cands), ptr(keys), ptr(gv), n, ptr(gtx), ptr(grx), ptr(gmv), ptr(ws), nbytes, stream())
+    else:
+        _lib.call("drt_trace_paths_vjp", h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0], C.byref(cands), ptr(keys),
+                  ptr(gv), n, ptr(gtx), ptr(grx), ptr(gmv), stream())
 
 
 def _table_candidates(table: torch.Tensor) -> _lib.Candidates:
@@ -96,7 +112,7 @@ class _TraceDenseFn(torch.autograd.Function):
             cands = _table_candidates(table)
             _lib.call("drt_trace_paths_dense", mesh.handle().h, C.byref(params), ptr(tx), ntx, ptr(rx),
                       nrx, C.byref(cands), ptr(verts), ptr(objs), ptr(mask), ptr(ws), nbytes, stream())
-        ctx.mesh, ctx.table = mesh, table
+        ctx.mesh, ctx.table, ctx.params = mesh, table, params
         ctx.save_for_backward(tx, rx)
         ctx.mark_non_differentiable(objs, mask)
         return verts, objs, mask
@@ -110,10 +126,8 @@ class _TraceDenseFn(torch.autograd.Function):
         gmv = torch.zeros_like(mesh.vertices) if ctx.needs_input_grad[2] else None
         if n:
             keys = torch.arange(n, dtype=torch.int64, device=tx.device)
-            cands = _table_candidates(table)
-            _lib.call("drt_trace_paths_vjp", mesh.handle().h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
-                      C.byref(cands), ptr(keys), ptr(gv.contiguous()), n, ptr(gtx), ptr(grx), ptr(gmv),
-                      stream())
+            _paths_vjp(mesh, ctx.params, tx, rx, _table_candidates(table), keys, gv.contiguous(), n, table.shape[1],
+                       gtx, grx, gmv)
         return gtx, grx, gmv, None, None, None
 
 
@@ -158,7 +172,7 @@ class _TraceCompactFn(torch.autograd.Function):
                 else:
                     max_paths = max(2 * max_paths, need)
         n = int(nv.value)
-        ctx.mesh, ctx.make_cands = mesh, make_cands
+        ctx.mesh, ctx.make_cands, ctx.params, ctx.order = mesh, make_cands, params, order
         keys = keys[:n].clone()
         ctx.save_for_backward(tx, rx, keys)
         objs = objs[:n].clone()
@@ -173,10 +187,7 @@ class _TraceCompactFn(torch.autograd.Function):
         gmv = torch.zeros_like(mesh.vertices) if ctx.needs_input_grad[2] else None
         n = keys.shape[0]
         if n:
-            cands = ctx.make_cands()
-            _lib.call("drt_trace_paths_vjp", mesh.handle().h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
-                      C.byref(cands), ptr(keys), ptr(gv.contiguous()), n, ptr(gtx), ptr(grx), ptr(gmv),
-                      stream())
+            _paths_vjp(mesh, ctx.params, tx, rx, ctx.make_cands(), keys, gv.contiguous(), n, ctx.order, gtx, grx, gmv)
         return gtx, grx, gmv, None, None, None, None, None
 
 
@@ -211,7 +222,7 @@ class _TraceBeamFn(torch.autograd.Function):
         nvalid = int(nv.value)
         keys = keys[:nvalid].clone()
         objs = objs[:nvalid].clone()
-        ctx.mesh, ctx.order, ctx.n = mesh, order, n
+        ctx.mesh, ctx.order, ctx.n, ctx.params = mesh, order, n, params
         ctx.save_for_backward(tx, rx, keys)
         ctx.mark_non_differentiable(objs, keys)
         return verts[:nvalid].clone(), objs, keys
@@ -229,9 +240,7 @@ class _TraceBeamFn(torch.autograd.Function):
                 cands = _lib.Candidates()
                 cands.table, cands.num_nodes, cands.order = None, ctx.n, ctx.order
                 cands.reserved = _lib.DRT_CAND_PACKED_KEYS
-            _lib.call("drt_trace_paths_vjp", mesh.handle().h, ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
-                      C.byref(cands), ptr(keys), ptr(gv.contiguous()), keys.shape[0], ptr(gtx), ptr(grx), ptr(gmv),
-                      stream())
+            _paths_vjp(mesh, ctx.params, tx, rx, cands, keys, gv.contiguous(), keys.shape[0], ctx.order, gtx, grx, gmv)
         return gtx, grx, gmv, None, None, None, None, None, None
 
 
@@ -351,6 +360,10 @@ class ExhaustivePathTracer(AbstractPathTracer):
     accel: str | None = None
     """MI355X extension: ``"bvh"`` makes the occlusion stage walk the mesh LBVH (O(log T) per segment,
     like the reference's Warp path) instead of testing every triangle."""
+    deterministic_grad: bool = False
+    """MI355X extension (SURVEY.md section 7, hard part 6): gradients of the traced vertices are summed in a fixed
+    order (``DRT_TRACE_DETERMINISTIC_GRAD``: stable sort by destination + ordered sums) instead of float atomics --
+    bit-identical from run to run, a few kernel launches slower."""
     collect_stats: bool = False
     """Fill :attr:`last_stats` (``drt_trace_stats``: candidates / survivors / valid paths and the
     HIP-event time of the filter, occlusion and sort+emit stages) on every compact trace; costs two
@@ -525,7 +538,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
         mesh = scene.mesh
         if tx.shape[0] * rx.shape[0] * max(mesh.num_primitives, 1) ** order >= 2 ** 62:
             raise OverflowError("tx * rx * primitives**order does not fit a 62-bit row key")
-        verts, objs, keys = _TraceBeamFn.apply(tx, rx, mesh.vertices, mesh, order, _params(self.epsilon, self.hit_tol, self.min_len, self.accel),
+        verts, objs, keys = _TraceBeamFn.apply(tx, rx, mesh.vertices, mesh, order, _params(self.epsilon, self.hit_tol, self.min_len, self.accel, deterministic_grad=self.deterministic_grad),
                                                beam, int(max_paths), self._beam_workspace)
         self.last_beam_stats = {"unit_m": st.unit_m, "magnitude": st.magnitude, "levels": [int(x) for x in st.levels[:max(order, 1)]],
                                 "rows": int(st.rows), "chunks": int(st.slices), "valid": int(st.valid),
@@ -547,7 +560,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
         tx = scene.transmitters.reshape(-1, 3).contiguous()
         rx = scene.receivers.reshape(-1, 3).contiguous()
         params = _params(self.epsilon, self.hit_tol, self.min_len, self.accel,
-                         skip_occlusion=bool(getattr(self, "_skip_occlusion", False)))
+                         skip_occlusion=bool(getattr(self, "_skip_occlusion", False)),
+                         deterministic_grad=self.deterministic_grad)
         st = None
         if self.collect_stats:
             st = _lib.TraceStats()

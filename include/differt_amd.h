@@ -462,6 +462,18 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
                             const float *vertices_cotangent, int64_t num_paths, float *grad_tx,
                             float *grad_rx, float *grad_vertices, void *stream);
 
+/* The same VJP with an option for run-to-run REPRODUCIBLE gradients (hard part 6): with
+ * DRT_TRACE_DETERMINISTIC_GRAD in params->flags every path writes its contributions, a stable sort groups them by
+ * destination (transmitter / receiver / mesh vertex) and each group is summed in path order by one lane -- no
+ * float atomics, bit-identical from run to run (and within rounding of the atomic version).  Without the
+ * flag (or params == NULL) this is drt_trace_paths_vjp and the workspace is not touched. */
+#define DRT_TRACE_DETERMINISTIC_GRAD 4
+size_t drt_trace_vjp_workspace_size(int64_t num_paths, int32_t order);
+int32_t drt_trace_paths_vjp_ex(drt_mesh_t mesh, const drt_trace_params *params, const float *tx, int64_t num_tx,
+                               const float *rx, int64_t num_rx, const drt_candidates *cands, const int64_t *keys,
+                               const float *vertices_cotangent, int64_t num_paths, float *grad_tx, float *grad_rx,
+                               float *grad_vertices, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Beam-pruned exhaustive tracer: ONE call that returns the valid paths of the exhaustive tracer
  * (reference: Scene.trace_paths -> solver.trace_path_candidates over the FULL candidate list,
@@ -526,6 +538,29 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *params, co
                              const float *tx, int64_t num_tx, const float *rx, int64_t num_rx, int32_t order,
                              int64_t max_paths, int64_t *keys, float *vertices, int32_t *objects,
                              int64_t *num_valid_host, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (e) collectives of the path on RCCL, no torch in the process.  One process per
+ * GPU; rank 0 draws an id (drt_comm_unique_id) and hands its 128 bytes to the other ranks out of band (the
+ * host's rendezvous: a file, MPI, torch.distributed's store ...); every rank then calls drt_comm_init with
+ * ITS device current.  Collectives are in place, on the caller's stream, asynchronous.
+ *   drt_allreduce_min_u64 : packed first-hit keys of drt_first_hit_keys (triangle-block sharding), 8 B per ray
+ *   drt_allreduce_max_u8  : blocked flags of the triangle-block tracer, 1 B per surviving candidate
+ *   drt_allreduce_sum_f32 : gradients w.r.t. transmitters / receivers / mesh vertices
+ *   drt_allgather_bytes   : fixed-size blocks (counts, then padded compact records); recv = world * bytes_per_rank
+ * librccl.so is opened on first use (DRT_E_UNSUPPORTED when it cannot be): no link-time dependency.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct drt_comm *drt_comm_t;
+#define DRT_COMM_ID_BYTES 128
+int32_t drt_comm_unique_id(uint8_t *id_out_host /* [DRT_COMM_ID_BYTES] */);
+int32_t drt_comm_init(const uint8_t *unique_id_host, int32_t rank, int32_t world, drt_comm_t *comm_out);
+int32_t drt_comm_destroy(drt_comm_t comm);
+int32_t drt_comm_rank(drt_comm_t comm);
+int32_t drt_comm_world(drt_comm_t comm);
+int32_t drt_allreduce_min_u64(drt_comm_t comm, uint64_t *buf, int64_t n, void *stream);
+int32_t drt_allreduce_max_u8(drt_comm_t comm, uint8_t *buf, int64_t n, void *stream);
+int32_t drt_allreduce_sum_f32(drt_comm_t comm, float *buf, int64_t n, void *stream);
+int32_t drt_allgather_bytes(drt_comm_t comm, const void *send, void *recv, int64_t bytes_per_rank, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (f4) smoothed ("soft mask") mode -- reference: differt/src/differt/utils.py:70-89
