@@ -281,7 +281,7 @@ class _TraceSmoothFn(torch.autograd.Function):
 
 def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, interaction_types=None, *,
                            epsilon, hit_tol, min_len, smoothing_factor, confidence_threshold,
-                           batch_size, accel=None) -> TracedPaths:
+                           batch_size, accel=None, deterministic_grad: bool = False) -> TracedPaths:
     """Reference ``_trace_path_candidates`` (_solvers.py:499-770), dense layout
     ``[num_tx, num_rx, num_candidates, ...]``; ``smoothing_factor`` switches to the float-mask mode
     (:599-713), whose blocked term uses the pure operator with ``batch_size`` tiles (:665-674)."""
@@ -294,7 +294,8 @@ def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, inte
             float(smoothing_factor), 0 if batch_size is None else int(batch_size))
     else:
         verts, objs, mask = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table,
-                                                _params(epsilon, hit_tol, min_len, accel))
+                                                _params(epsilon, hit_tol, min_len, accel,
+                                                        deterministic_grad=deterministic_grad))
     if interaction_types is None:  # _solvers.py:751-762
         it = torch.zeros(objs.shape[:-1] + (table.shape[1],), dtype=torch.int32, device=objs.device)
     else:
@@ -443,7 +444,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
             path_candidates, interaction_types, epsilon=self.epsilon, hit_tol=self.hit_tol,
             min_len=self.min_len, smoothing_factor=self.smoothing_factor,
             confidence_threshold=self.confidence_threshold, batch_size=self.batch_size,
-            accel=self.accel,
+            accel=self.accel, deterministic_grad=self.deterministic_grad,
         )
 
     def num_path_candidates(self, scene, order: int) -> int:
