@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256) void radix_tree_kernel(const uint64_t *__restr
     const int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
     const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
     const bool left_leaf = (lo == gamma), right_leaf = (hi == gamma + 1);
+    nodes[i].first = (uint32_t)lo;  // this node's leaves: sorted positions [lo, hi]
+    nodes[i].last = (uint32_t)hi;
     nodes[i].left = left_leaf ? ~(int32_t)gamma : (int32_t)gamma;
     nodes[i].right = right_leaf ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
     if (left_leaf) parent_leaf[gamma] = (int32_t)i; else parent_internal[gamma] = (int32_t)i;
@@ -172,120 +174,51 @@ __global__ __launch_bounds__(256) void refit_kernel(int64_t n, const uint32_t *_
     }
 }
 
-constexpr int kStack = 64;
-
 template <bool FIRST>
 __global__ __launch_bounds__(256) void bvh_query_kernel(
-    const BvhNode *__restrict__ nodes, int64_t T, const float *__restrict__ tv,
-    const uint8_t *__restrict__ mask, const float *__restrict__ ro, const float *__restrict__ rd,
-    int64_t R, float eps, float thr, TileTieB tt, uint8_t *__restrict__ any_out,
+    const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids, int64_t T,
+    const float *__restrict__ tv, const uint8_t *__restrict__ mask, const float *__restrict__ ro,
+    const float *__restrict__ rd, int64_t R, float eps, float thr, TileTieB tt, uint8_t *__restrict__ any_out,
     int32_t *__restrict__ idx_out, float *__restrict__ t_out) {
+    DRT_BVH_LDS_STACK(lds_stack, 256);
+    int32_t *col = &lds_stack[0][threadIdx.x];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= R) return;
-    const RayPrep ray = prep_ray(ld3(ro + 3 * r), ld3(rd + 3 * r));
-    bool any = false;
-    uint64_t best = ~0ull;
-    float best_t = FIRST ? kInf : thr;  // boxes entered after this parameter cannot matter
-    int32_t stack[kStack];
-    int sp = 0;
-    int32_t node = 0;
-    // T == 1: the single triangle is tested directly
-    if (T == 1) node = ~0;
-    for (;;) {
-        if (node < 0) {
-            const int64_t j = ~node;
-            float t;
-            const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) &&
-                           (!mask || mask[j]);
-            if (FIRST) {
-                if (h && is_finite(t)) {
-                    const uint64_t k = first_hit_key_b(t, j, tt);
-                    if (k < best) { best = k; best_t = t; }
-                }
-            } else if (h && (t < thr)) {
-                any = true;
-                break;
-            }
-        } else {
-            const BvhNode nd = nodes[node];
-            float l0, l1, r0, r1;
-            slab(ray, nd.llo, nd.lhi, l0, l1);
-            slab(ray, nd.rlo, nd.rhi, r0, r1);
-            const bool hl = (l0 <= l1) && (l1 >= 0.0f) && (l0 <= best_t);
-            const bool hr = (r0 <= r1) && (r1 >= 0.0f) && (r0 <= best_t);
-            if (hl && hr) {
-                const bool left_first = l0 <= r0;
-                const int32_t nearc = left_first ? nd.left : nd.right;
-                const int32_t farc = left_first ? nd.right : nd.left;
-                if (sp < kStack) stack[sp++] = farc;
-                node = nearc;
-                continue;
-            }
-            if (hl) { node = nd.left; continue; }
-            if (hr) { node = nd.right; continue; }
-        }
-        if (sp == 0) break;
-        node = stack[--sp];
-    }
+    const V3 o = ld3(ro + 3 * r), d = ld3(rd + 3 * r);
     if (FIRST) {
-        if (best == ~0ull) {
-            idx_out[r] = -1;
-            t_out[r] = kInf;
-        } else {
-            const uint64_t tie = best & 0xffffffffull;
-            const int64_t tile = tt.ntiles - 1 - (int64_t)(tie / (uint64_t)tt.bs);
-            idx_out[r] = (int32_t)(tile * tt.bs + (int64_t)(tie % (uint64_t)tt.bs));
-            t_out[r] = ordered_to_float((uint32_t)(best >> 32));
-        }
+        int32_t idx;
+        float t;
+        decode_first_hit(bvh_first_hit<256>(nodes, leaf_ids, T, tv, mask, o, d, eps, tt, col), tt, idx, t);
+        idx_out[r] = idx;
+        t_out[r] = t;
     } else {
-        any_out[r] = (uint8_t)any;
+        any_out[r] = (uint8_t)bvh_any_hit<256>(nodes, leaf_ids, T, tv, mask, o, d, eps, thr, col);
     }
 }
 
 // visibility (reference geometry/_mesh.py:3164-3253): lane = lattice ray, closest hit through the BVH
 // with the tie rule of first_triangle_hit_by_ray(batch_size=None): lowest index among equal t.
 __global__ __launch_bounds__(256) void bvh_visibility_kernel(
-    const BvhNode *__restrict__ nodes, int64_t T, const float *__restrict__ tv,
-    const uint8_t *__restrict__ mask, const float *__restrict__ view,
+    const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids, int64_t T,
+    const float *__restrict__ tv, const uint8_t *__restrict__ mask, const float *__restrict__ view,
     const float *__restrict__ frusta, int64_t num_rays, float eps, uint8_t *__restrict__ visible) {
+    DRT_BVH_LDS_STACK(lds_stack, 256);
+    int32_t *col = &lds_stack[0][threadIdx.x];
     const int64_t b = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= num_rays) return;
     const RayPrep ray = prep_ray(ld3(view + 3 * b), lattice_direction(i, num_rays, frusta + 6 * b));
     float best_t = kInf;
     int64_t best_j = -1;
-    int32_t stack[kStack];
-    int sp = 0;
-    int32_t node = (T == 1) ? ~0 : 0;
-    for (;;) {
-        if (node < 0) {
-            const int64_t j = ~node;
-            float t;
-            const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) &&
-                           (!mask || mask[j]);
-            if (h && is_finite(t) && (t < best_t || (t == best_t && j < best_j))) {
-                best_t = t;
-                best_j = j;
-            }
-        } else {
-            const BvhNode nd = nodes[node];
-            float l0, l1, r0, r1;
-            slab(ray, nd.llo, nd.lhi, l0, l1);
-            slab(ray, nd.rlo, nd.rhi, r0, r1);
-            const bool hl = (l0 <= l1) && (l1 >= 0.0f) && (l0 <= best_t);
-            const bool hr = (r0 <= r1) && (r1 >= 0.0f) && (r0 <= best_t);
-            if (hl && hr) {
-                const bool left_first = l0 <= r0;
-                if (sp < kStack) stack[sp++] = left_first ? nd.right : nd.left;
-                node = left_first ? nd.left : nd.right;
-                continue;
-            }
-            if (hl) { node = nd.left; continue; }
-            if (hr) { node = nd.right; continue; }
+    bvh_walk<256, true>(nodes, leaf_ids, T, ray, best_t, col, [&](int64_t j) {
+        float t;
+        const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) && (!mask || mask[j]);
+        if (h && is_finite(t) && (t < best_t || (t == best_t && j < best_j))) {
+            best_t = t;
+            best_j = j;
         }
-        if (sp == 0) break;
-        node = stack[--sp];
-    }
+        return false;
+    });
     if (best_j >= 0) visible[b * T + best_j] = 1;
 }
 
@@ -302,9 +235,11 @@ __global__ __launch_bounds__(256) void fill_miss_kernel(int64_t R, int32_t *__re
 // visible when the segment viewpoint -> sample is not blocked by any OTHER active triangle before the
 // sample (t < 1 - 1e-4).  ORs into `visible`.
 __global__ __launch_bounds__(256) void bvh_visibility_samples_kernel(
-    const BvhNode *__restrict__ nodes, int64_t T, const float *__restrict__ tv, const uint8_t *__restrict__ mask,
-    const float *__restrict__ view, float eps, uint8_t *__restrict__ visible) {
+    const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids, int64_t T, const float *__restrict__ tv,
+    const uint8_t *__restrict__ mask, const float *__restrict__ view, float eps, uint8_t *__restrict__ visible) {
     constexpr int kSamples = 7;
+    DRT_BVH_LDS_STACK(lds_stack, 256);
+    int32_t *col = &lds_stack[0][threadIdx.x];
     const int64_t b = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= T * kSamples) return;
@@ -322,37 +257,13 @@ __global__ __launch_bounds__(256) void bvh_visibility_samples_kernel(
     const RayPrep ray = prep_ray(o, p - o);
     const float thr = 1.0f - 1e-4f;
     bool blocked = false;
-    int32_t stack[kStack];
-    int sp = 0;
-    int32_t node = (T == 1) ? ~0 : 0;
-    for (;;) {
-        if (node < 0) {
-            const int64_t j = ~node;
-            if (j != tri && (!mask || mask[j])) {
-                float t;
-                if (moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) && t < thr) {
-                    blocked = true;
-                    break;
-                }
-            }
-        } else {
-            const BvhNode nd = nodes[node];
-            float l0, l1, r0, r1;
-            slab(ray, nd.llo, nd.lhi, l0, l1);
-            slab(ray, nd.rlo, nd.rhi, r0, r1);
-            const bool hl = (l0 <= l1) && (l1 >= 0.0f) && (l0 <= thr);
-            const bool hr = (r0 <= r1) && (r1 >= 0.0f) && (r0 <= thr);
-            if (hl && hr) {
-                if (sp < kStack) stack[sp++] = nd.right;
-                node = nd.left;
-                continue;
-            }
-            if (hl) { node = nd.left; continue; }
-            if (hr) { node = nd.right; continue; }
+    bvh_walk<256, false>(nodes, leaf_ids, T, ray, thr, col, [&](int64_t j) {
+        if (j != tri && (!mask || mask[j])) {
+            float t;
+            if (moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) && t < thr) blocked = true;
         }
-        if (sp == 0) break;
-        node = stack[--sp];
-    }
+        return blocked;
+    });
     if (!blocked) visible[b * T + tri] = 1;
 }
 
@@ -377,7 +288,7 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
     void *tmp = nullptr;
     auto cleanup = [&]() {
         (void)hipFree(tri_boxes); (void)hipFree(node_boxes); (void)hipFree(keys);
-        (void)hipFree(keys_sorted); (void)hipFree(ids); (void)hipFree(ids_sorted); (void)hipFree(scene);
+        (void)hipFree(keys_sorted); (void)hipFree(ids); (void)hipFree(scene);
         (void)hipFree(flags); (void)hipFree(par_int); (void)hipFree(par_leaf); (void)hipFree(tmp);
     };
 #define TRY_HIP(expr)                                                                    \
@@ -386,6 +297,7 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
         if (_e != hipSuccess) {                                                          \
             cleanup();                                                                   \
             (void)hipFree(nodes);                                                        \
+            (void)hipFree(ids_sorted);                                                   \
             return fail(DRT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
         }                                                                                \
     } while (0)
@@ -425,6 +337,11 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
     TRY_HIP(hipStreamSynchronize(s));
 #undef TRY_HIP
     cleanup();
+    if (T == 1) {  // no sort ran: the single leaf is position 0
+        const uint32_t zero = 0;
+        (void)hipMemcpy(ids_sorted, &zero, 4, hipMemcpyHostToDevice);
+    }
+    m->bvh_leaf_ids = ids_sorted;
     m->bvh_nodes = nodes;
     return DRT_OK;
 }
@@ -447,7 +364,7 @@ int32_t drt_mesh_ray_intersect_any_triangle(drt_mesh_t m, const float *ro, const
     if (rc != DRT_OK) return rc;
     const TileTieB tt = make_tie_b(m->num_triangles, 0);
     hipLaunchKernelGGL(bvh_query_kernel<false>, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s,
-                       reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->num_triangles, m->tri_verts,
+                       reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->bvh_leaf_ids, m->num_triangles, m->tri_verts,
                        m->has_mask ? m->mask : nullptr, ro, rd, R, epsilon, 1.0f - hit_tol, tt, out,
                        (int32_t *)nullptr, (float *)nullptr);
     DRT_LAUNCH_CHECK();
@@ -465,7 +382,7 @@ int32_t drt_mesh_triangles_visible_samples(drt_mesh_t m, const float *vertices, 
     int32_t rc = drt_mesh_build_bvh(m, stream);
     if (rc != DRT_OK) return rc;
     hipLaunchKernelGGL(bvh_visibility_samples_kernel, dim3((unsigned)ceil_div(T * 7, 256), (unsigned)B), dim3(256), 0,
-                       as_stream(stream), reinterpret_cast<const BvhNode *>(m->bvh_nodes), T, m->tri_verts,
+                       as_stream(stream), reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->bvh_leaf_ids, T, m->tri_verts,
                        m->has_mask ? m->mask : nullptr, vertices, epsilon, visible_inout);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
@@ -489,7 +406,7 @@ int32_t drt_mesh_triangles_visible_from_vertex(drt_mesh_t m, const float *vertic
     launch_frustum_kernel(vertices, B, m->tri_verts, T, mask, frustum_workspace, s);
     DRT_LAUNCH_CHECK();
     hipLaunchKernelGGL(bvh_visibility_kernel, dim3((unsigned)ceil_div(num_rays, 256), (unsigned)B),
-                       dim3(256), 0, s, reinterpret_cast<const BvhNode *>(m->bvh_nodes), T, m->tri_verts,
+                       dim3(256), 0, s, reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->bvh_leaf_ids, T, m->tri_verts,
                        mask, vertices, frustum_workspace, num_rays, epsilon, visible_out);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
@@ -513,7 +430,7 @@ int32_t drt_mesh_first_triangle_hit_by_ray(drt_mesh_t m, const float *ro, const 
     if (rc != DRT_OK) return rc;
     const TileTieB tt = make_tie_b(m->num_triangles, batch_size);
     hipLaunchKernelGGL(bvh_query_kernel<true>, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s,
-                       reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->num_triangles, m->tri_verts,
+                       reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->bvh_leaf_ids, m->num_triangles, m->tri_verts,
                        m->has_mask ? m->mask : nullptr, ro, rd, R, epsilon, 0.0f, tt,
                        (uint8_t *)nullptr, idx, t);
     DRT_LAUNCH_CHECK();

@@ -14,11 +14,13 @@
 namespace drt {
 
 __global__ __launch_bounds__(256) void launch_paths_kernel(
-    const BvhNode *__restrict__ nodes, int64_t T, const float *__restrict__ tv,
-    const float *__restrict__ normals, const uint8_t *__restrict__ mask,
+    const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids, int64_t T,
+    const float *__restrict__ tv, const float *__restrict__ normals, const uint8_t *__restrict__ mask,
     const float *__restrict__ ro, const float *__restrict__ rd, int64_t ntx, int64_t num_rays,
     const float *__restrict__ rx, int64_t nrx, int order, float eps, TileTieB tt, float max_dist,
     int32_t *__restrict__ tri_out, float *__restrict__ vert_out, uint8_t *__restrict__ masks_out) {
+    DRT_BVH_LDS_STACK(lds_stack, 256);
+    int32_t *col = &lds_stack[0][threadIdx.x];
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= ntx * num_rays) return;
     const int64_t it = g / num_rays, i = g - it * num_rays;
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void launch_paths_kernel(
     for (int b = 0; b <= order; ++b) {
         int32_t tri = -1;
         float t_hit = kInf;
-        if (T > 0) decode_first_hit(bvh_first_hit(nodes, T, tv, mask, o, d, eps, tt), tt, tri, t_hit);
+        if (T > 0) decode_first_hit(bvh_first_hit<256>(nodes, leaf_ids, T, tv, mask, o, d, eps, tt, col), tt, tri, t_hit);
         // filter_rays (_solvers.py:340-356): squared distance between the receiver and the ray, only
         // for receivers ahead of the origin and before the hit
         for (int64_t ir = 0; ir < nrx; ++ir) {
@@ -211,7 +213,7 @@ int32_t drt_launch_paths(drt_mesh_t m, const float *ro, const float *rd, int64_t
     }
     const TileTieB tt = make_tie_b(T > 0 ? T : 1, batch_size);
     hipLaunchKernelGGL(launch_paths_kernel, dim3((unsigned)ceil_div(ntx * num_rays, 256)), dim3(256), 0,
-                       as_stream(stream), reinterpret_cast<const BvhNode *>(m->bvh_nodes), T, m->tri_verts,
+                       as_stream(stream), reinterpret_cast<const BvhNode *>(m->bvh_nodes), m->bvh_leaf_ids, T, m->tri_verts,
                        m->normals, m->has_mask ? m->mask : nullptr, ro, rd, ntx, num_rays, rx, nrx,
                        (int)order, epsilon, tt, max_dist, triangles_out, vertices_out, masks_out);
     DRT_LAUNCH_CHECK();

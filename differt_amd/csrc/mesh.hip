@@ -116,6 +116,7 @@ int32_t drt_mesh_destroy(drt_mesh_t m) {
     (void)hipFree(m->shape);
     (void)hipFree(m->mask);
     (void)hipFree(m->bvh_nodes);
+    (void)hipFree(m->bvh_leaf_ids);
     (void)hipFree(m->beam_blob);
     delete m;
     return DRT_OK;

@@ -16,6 +16,7 @@ struct drt_mesh {
     float *shape = nullptr;        // [T]      largest 1/sin(corner angle) per triangle (beam.hip error bounds)
     uint8_t *mask = nullptr;       // [T] or nullptr (all active)
     void *bvh_nodes = nullptr;     // LBVH (csrc/bvh.hip), built lazily by drt_mesh_build_bvh
+    uint32_t *bvh_leaf_ids = nullptr;  // [T] triangle ids in Morton order (leaf ranges of the nodes index it)
     // Primitive clusters of the beam-pruned tracer (csrc/beam.hip), built lazily by
     // drt_mesh_build_beam_clusters: primitives (triangles, or quads = triangle pairs) sorted along a Morton
     // curve, 64 per cluster.  One allocation (`beam_blob`), the others point into it.

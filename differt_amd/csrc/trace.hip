@@ -450,10 +450,12 @@ __global__ __launch_bounds__(256) void trace_occlusion_kernel(
 // O(T): the choice for very large meshes (configs[4], 200k triangles).
 template <int K, bool DENSE>
 __global__ __launch_bounds__(256) void trace_occlusion_bvh_kernel(
-    TraceArgs a, CandSrc cs, const BvhNode *__restrict__ nodes,
+    TraceArgs a, CandSrc cs, const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids,
     const unsigned long long *__restrict__ q_count, const long long *__restrict__ queue, int64_t q_cap,
     unsigned long long *__restrict__ v_count, long long *__restrict__ valid, int64_t v_cap,
     uint8_t *__restrict__ d_mask) {
+    DRT_BVH_LDS_STACK(lds_stack, 256);
+    int32_t *col = &lds_stack[0][threadIdx.x];
     int64_t count = (int64_t)*q_count;
     if (count > q_cap) count = q_cap;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) {
@@ -463,10 +465,13 @@ __global__ __launch_bounds__(256) void trace_occlusion_bvh_kernel(
         V3 p[KA<K>::n], n[KA<K>::n], full[K + 2];
         key_to_path<K>(a, cs, flat, it, ir, id, p, n, full);
         bool blocked = false;
-#pragma unroll 1
-        for (int s = 0; s <= K && !blocked; ++s)
-            blocked = bvh_any_hit(nodes, a.T, a.tri_verts, a.mask, full[s], full[s + 1] - full[s], a.eps,
-                                  a.thr);
+        // unrolled over the K + 1 segments: `full[s]` with a runtime s puts the path in scratch memory
+#pragma unroll
+        for (int s = 0; s <= K; ++s) {
+            if (!blocked)
+                blocked = bvh_any_hit<256>(nodes, leaf_ids, a.T, a.tri_verts, a.mask, full[s], full[s + 1] - full[s],
+                                           a.eps, a.thr, col);
+        }
         if (DENSE) {
             if (blocked) d_mask[flat] = 0;
         } else if (!blocked) {
@@ -691,6 +696,7 @@ struct Launch {
     CandSrc cs;
     bool quads;
     const BvhNode *bvh = nullptr;  // non-null: stage B walks the LBVH
+    const uint32_t *bvh_leaf_ids = nullptr;
 };
 
 static void filter_grid(const Launch &L, dim3 *grid, int64_t *tx_per_block) {
@@ -745,7 +751,7 @@ static void launch_occlusion(const Launch &L, const unsigned long long *qc, cons
     // persistent-style grid: the survivor count lives on the device
     if (L.bvh && L.a.T_occ > 0)
         hipLaunchKernelGGL((trace_occlusion_bvh_kernel<K, DENSE>), dim3(256 * 8), dim3(256), 0, L.s, L.a,
-                           L.cs, L.bvh, qc, q, qcap, vc, v, vcap, dm);
+                           L.cs, L.bvh, L.bvh_leaf_ids, qc, q, qcap, vc, v, vcap, dm);
     else
         hipLaunchKernelGGL((trace_occlusion_kernel<K, DENSE>), dim3(256 * 4), dim3(256), 0, L.s, L.a,
                            L.cs, qc, q, qcap, vc, v, vcap, dm);
@@ -848,6 +854,7 @@ int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *pr, const
         rc = drt_mesh_build_bvh(mesh, stream);
         if (rc != DRT_OK) return rc;
         L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
+        L.bvh_leaf_ids = mesh->bvh_leaf_ids;
     }
     const int64_t total = ntx * nrx * L.cs.count;
     if (total == 0) return DRT_OK;  // SV:566-573
@@ -898,6 +905,7 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
         rc = drt_mesh_build_bvh(mesh, stream);
         if (rc != DRT_OK) return rc;
         L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
+        L.bvh_leaf_ids = mesh->bvh_leaf_ids;
     }
     DRT_REQUIRE(!L.cs.packed, "packed keys address traced paths (drt_trace_paths_vjp), they are not a candidate source");
     L.cs.npairs = ntx * nrx;
@@ -996,6 +1004,7 @@ int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *p
         DRT_REQUIRE(mesh->bvh_nodes != nullptr,
                     "DRT_TRACE_USE_BVH in the async entry point needs drt_mesh_build_bvh() beforehand");
         L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
+        L.bvh_leaf_ids = mesh->bvh_leaf_ids;
     }
     DRT_REQUIRE(!L.cs.packed, "packed keys address traced paths (drt_trace_paths_vjp), they are not a candidate source");
     L.cs.npairs = ntx * nrx;

@@ -197,3 +197,23 @@ def test_bvh_visibility_equals_brute_force(G):
         a = mesh.triangles_visible_from_vertex(pts, num_rays=200_000)
         b = mesh.triangles_visible_from_vertex(pts, num_rays=200_000, accel="bvh")
         assert torch.equal(a, b) and int(a.sum()) > 50
+
+
+def test_overflow_path_of_the_lds_stack(tmp_path):
+    """The traversal stack is a 20-entry LDS column per lane; a walk that needs more tests the far subtree at once
+    through the node's leaf range.  A library built with a 2-entry column takes that path on almost every walk:
+    this whole file must pass against it unchanged (bit-identical to brute force and to the oracle)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    lib = tmp_path / "libdiffert_amd_stack2.so"
+    env = {**os.environ, "DIFFERT_AMD_LIB": str(lib), "DRT_EXTRA_FLAGS": "-DDRT_BVH_LDS_STACK_N=2"}
+    r = subprocess.run([sys.executable, "-m", "differt_amd.build"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0 and lib.exists(), r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_bvh_gpu.py", "-m", "gpu", "-q", "-x", "-k",
+                        "not overflow_path"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
