@@ -52,7 +52,15 @@ constexpr int kDenseStageDwords = 5 * 64 * 4;  // LDS triangle staging per wave:
 // one wait state, and LLVM's hazard recogniser does not look inside inline asm -- the `s_nop 0` covers it
 // whatever the scheduler places after the store (one issue cycle per 1-KiB wave store).
 __device__ __forceinline__ void store_nt_b128(char *base, uint32_t off, f32x4 v) {
+#if defined(DRT_LAB_AGPR_STORE)
+    // experiment: the same store sourced from accumulation registers -- separates "the store's
+    // data movement blocks the SIMD's VALU issue" from "VGPR read-port contention"
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "a"(v), "s"(base) : "memory");
+#elif defined(DRT_LAB_SETPRIO)
+    asm volatile("s_setprio 3\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0\n\ts_setprio 0" : : "v"(off), "v"(v), "s"(base) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
+#endif
 }
 __device__ __forceinline__ void store_nt_b128(char *base, uint32_t off, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
