@@ -45,6 +45,15 @@ def main() -> None:
              "`mt_dense_aligned_kernel [grid=524288x10]` are the timed launches of `bench.py` "
              "(65 536 rays x 10 000 triangles); `[grid=32768x10]` the literal 256-ray configs[1] launches.", "",
              "| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
+    # the timed launches of the driver-style run are the LAST `--steps` launches of the big grid (a time-based
+    # pre-warm and the counted warm-up precede them)
+    big = [k for k in groups if "mt_dense" in k and "524288" in k]
+    if big:
+        last20 = groups[big[0]][-20:]
+        lines += [f"Timed launches of the bench (last 20 of `{big[0]}`): avg {sum(last20) / len(last20) / 1e3:.2f} us, "
+                  f"min {min(last20) / 1e3:.2f}, max {max(last20) / 1e3:.2f}.", ""]
+        lines += ["| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
+        del lines[lines.index("| kernel | calls | avg us | min us | max us | total ms |"):lines.index("| kernel | calls | avg us | min us | max us | total ms |") + 2]
     for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"| `{k}` | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | "
                      f"{max(v) / 1e3:.2f} | {sum(v) / 1e6:.3f} |")
@@ -67,6 +76,14 @@ def main() -> None:
             "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE reads 1/2)",
             "mt_dense_kernel_bytes_per_launch": traffic,
         }
+        try:  # the record describes the kernel sources in the tree at collection time (differt_amd/_srchash.py)
+            sys.path.insert(0, str(d.resolve().parent.parent))
+            from differt_amd._srchash import source_hash
+
+            out["source_hash"] = source_hash("dense")
+            out["source_hash_of"] = 'differt_amd/_srchash.py GROUPS["dense"]'
+        except Exception:  # noqa: BLE001
+            pass
         (d.parent / "pmc_traffic.json").write_text(json.dumps(out, indent=1))
         lines += ["", "## HBM traffic of `mt_dense_aligned_kernel` (PMC, per launch of 65536 rays x 10000 triangles)",
                   "", f"FETCH_SIZE {per['FETCH_SIZE']:.1f} KiB, WRITE_SIZE {per['WRITE_SIZE']:.1f} KiB -> "
