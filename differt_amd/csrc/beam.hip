@@ -544,8 +544,16 @@ struct BeamClusters {
     int64_t nclusters;
 };
 
+#ifndef BEAM_EXPAND_WAVES
+#define BEAM_EXPAND_WAVES 0
+#endif
+#if BEAM_EXPAND_WAVES > 0
+#define BEAM_EXPAND_OCC __attribute__((amdgpu_waves_per_eu(BEAM_EXPAND_WAVES, BEAM_EXPAND_WAVES)))
+#else
+#define BEAM_EXPAND_OCC
+#endif
 template <int SCALE, int LEVEL>
-__global__ __launch_bounds__(128) void beam_expand_clustered_kernel(
+__global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_kernel(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split) {
