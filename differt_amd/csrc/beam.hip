@@ -412,7 +412,10 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
 
 constexpr int kBeamTile = 128;         // primitives per LDS tile of the plain expansion
 constexpr int kBeamWaveBuf = 192;      // records staged per wave before one flush (>= 128: a flush moves 64+)
-constexpr int kBeamWaveBufBig = 1024;  // the same for kernels that emit ~1e10 records (one atomic per ~960)
+#ifndef BEAM_WAVE_BUF_BIG
+#define BEAM_WAVE_BUF_BIG 512
+#endif
+constexpr int kBeamWaveBufBig = BEAM_WAVE_BUF_BIG;  // the same for kernels that emit ~1e10 records (one atomic per ~450; 1024 measured 2 % slower: LDS occupancy)
 
 // wave-private LDS staging buffer -> output list: ONE global atomic for `n` records (one atomic per ballot
 // meant 7e9 same-address atomics at configs[3]: the L2 atomic unit, not the arithmetic, set the pace)
@@ -538,9 +541,12 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
 // the work drops from one ~150-instruction test per primitive to one box test per 64 primitives plus full-lane
 // tests of the clusters its cones actually reach.
 // ---------------------------------------------------------------------------------------------
+#ifdef BEAM_LAB_COUNT
+__device__ unsigned long long beam_dbg[8];  // [0] box tests, [1] surviving pairs, [2] pairs with >= 1 child, [3] children
+#endif
 struct BeamClusters {
     const int32_t *order;
-    const float *verts, *planes, *uplanes, *sigma, *boxes;
+    const float *verts, *planes, *uplanes, *sigma, *boxes, *subboxes;
     int64_t nclusters;
 };
 
@@ -641,7 +647,27 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
 #else
         const float eps_max = beam_eps(u, bx[6], margin_len(far) * 1.0001f, hmin);
 #endif
-        unsigned long long todo = __ballot(have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max));
+        bool alive = have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max);
+        // second level for the survivors: the four sub-boxes of 16 consecutive primitives (one or two buildings of a
+        // city) -- a cluster's box is mostly streets, and half of the (prefix, cluster) pairs that passed it had no
+        // child at all (debug counters, profiles/r03/beam.md).  The same test with the same (cluster-wide) bound.
+        if (__any(alive)) {
+            const float *sb = C.subboxes + 24 * cl;
+            bool sub = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float slo[3] = {sb[6 * q], sb[6 * q + 1], sb[6 * q + 2]}, shi[3] = {sb[6 * q + 3], sb[6 * q + 4], sb[6 * q + 5]};
+                sub = sub || !box_pruned<SCALE, LEVEL>(ctx, slo, shi, eps_max);
+            }
+            alive = alive && sub;
+        }
+        unsigned long long todo = __ballot(alive);
+#ifdef BEAM_LAB_COUNT
+        if (lane == 0) {
+            atomicAdd(&beam_dbg[0], (unsigned long long)__popcll(__ballot(have)));
+            atomicAdd(&beam_dbg[1], (unsigned long long)__popcll(todo));
+        }
+#endif
         if (todo == 0) continue;
         // ---- transposed: lane = primitive of the cluster ----
         const int64_t pos = cl * 64 + lane;
@@ -652,6 +678,15 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
             todo &= todo - 1;
             const BeamCtx<SCALE, LEVEL> cx = lane_bcast<SCALE, LEVEL>(ctx, l);
             const bool keep = act && (p != __builtin_amdgcn_readlane(m, l)) && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg);
+#ifdef BEAM_LAB_COUNT
+            {
+                const unsigned long long kv = __ballot(keep);
+                if (lane == 0) {
+                    if (kv) atomicAdd(&beam_dbg[2], 1ull);
+                    atomicAdd(&beam_dbg[3], (unsigned long long)__popcll(kv));
+                }
+            }
+#endif
             beam_stage<kBeamWaveBufBig>(keep, ((gbase + (unsigned long long)l) << 32) | (uint32_t)p, wbuf[wave], wcount,
                                         lane, out, cap, count);
         }
@@ -890,7 +925,8 @@ template <int SCALE>
 __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint32_t *__restrict__ sorted_ids,
                                                           int32_t *__restrict__ order, float *__restrict__ verts,
                                                           float *__restrict__ planes, float *__restrict__ uplanes,
-                                                          float *__restrict__ sigma, float *__restrict__ boxes) {
+                                                          float *__restrict__ sigma, float *__restrict__ boxes,
+                                                          float *__restrict__ subboxes) {
     const int64_t cl = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t pos = cl * 64 + lane;
@@ -950,6 +986,21 @@ __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint
         ndistinct += __popcll(keepm);
     }
     if (__any(bad_plane)) sg = kInf;
+    {  // boxes of the four groups of 16 consecutive primitives
+        float slo[3] = {lo[0], lo[1], lo[2]}, shi[3] = {hi[0], hi[1], hi[2]};
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                slo[k] = fminf(slo[k], __shfl_xor(slo[k], off, 64));
+                shi[k] = fmaxf(shi[k], __shfl_xor(shi[k], off, 64));
+            }
+        if ((lane & 15) == 0) {
+            float *b = subboxes + 24 * cl + 6 * (lane >> 4);
+            b[0] = slo[0]; b[1] = slo[1]; b[2] = slo[2];
+            b[3] = shi[0]; b[4] = shi[1]; b[5] = shi[2];
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -1259,6 +1310,17 @@ static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, 
 
 }  // namespace
 
+#ifdef BEAM_LAB_COUNT
+extern "C" void drt_debug_beam_counts(unsigned long long *out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(drt::beam_dbg), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(drt::beam_dbg), z, sizeof(z));
+    }
+}
+#endif
+
 extern "C" {
 
 int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
@@ -1276,7 +1338,7 @@ int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
     };
     const size_t o_order = take((size_t)M.nprim * 4), o_verts = take((size_t)pp * 36 * sc),
                  o_planes = take((size_t)pp * 16 * sc), o_uplanes = take((size_t)pp * 16 * sc),
-                 o_sigma = take((size_t)pp * 4), o_boxes = take((size_t)ncl * 32);
+                 o_sigma = take((size_t)pp * 4), o_boxes = take((size_t)ncl * 32), o_subboxes = take((size_t)ncl * 96);
     char *blob = nullptr, *tmp = nullptr;
     DRT_HIP(hipMalloc(&blob, off));
     const size_t tmp_bytes = morton_scratch_bytes(M.nprim);
@@ -1293,10 +1355,11 @@ int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
         auto *uplanes = reinterpret_cast<float *>(blob + o_uplanes);
         auto *sigma = reinterpret_cast<float *>(blob + o_sigma);
         auto *boxes = reinterpret_cast<float *>(blob + o_boxes);
+        auto *subboxes = reinterpret_cast<float *>(blob + o_subboxes);
         if (sc == 2)
-            hipLaunchKernelGGL(prim_cluster_kernel<2>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes);
+            hipLaunchKernelGGL(prim_cluster_kernel<2>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes, subboxes);
         else
-            hipLaunchKernelGGL(prim_cluster_kernel<1>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes);
+            hipLaunchKernelGGL(prim_cluster_kernel<1>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes, subboxes);
         uint32_t mag_bits = 0;
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&mag_bits, bounds + 6, 4, hipMemcpyDeviceToHost, s);
@@ -1312,6 +1375,7 @@ int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
             mesh->beam_uplanes = uplanes;
             mesh->beam_sigma = sigma;
             mesh->beam_boxes = boxes;
+            mesh->beam_subboxes = subboxes;
             mesh->beam_clusters = ncl;
             mesh->beam_blob = blob;
         }
@@ -1408,6 +1472,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     C.uplanes = mesh->beam_uplanes;
     C.sigma = mesh->beam_sigma;
     C.boxes = mesh->beam_boxes;
+    C.subboxes = mesh->beam_subboxes;
     C.nclusters = mesh->beam_clusters;
 
     // receivers: Morton clusters (also yields the largest |coordinate| of the receivers); transmitters: bounds only

@@ -28,6 +28,7 @@ struct drt_mesh {
     float *beam_planes = nullptr;    // [Pp*scale,4]   (n, <n, v0>) per triangle
     float *beam_uplanes = nullptr;   // [Pp*scale,4]   per cluster: its DISTINCT planes first (count in beam_boxes[.,7])
     float *beam_boxes = nullptr;     // [clusters,8]   lo[3], hi[3], max sigma, number of distinct planes
+    float *beam_subboxes = nullptr;  // [clusters,4,6] lo[3], hi[3] of each group of 16 consecutive primitives
     int64_t beam_clusters = 0;
     float beam_max_abs = 0.0f;       // largest |coordinate| of the mesh vertices
 };

@@ -152,3 +152,38 @@ def test_stats_report_switched_off_prefixes(G):
     scene = G.Scene(torch.tensor([[20.0, 9.0, 12.0]], device="cuda"), torch.tensor([[18.0, 12.0, 1.5]], device="cuda"), mesh)
     tracer.trace_beam_pruned(scene, 2)
     assert tracer.last_beam_stats["grazing_prefixes"] == 0
+
+
+def test_capacities_are_errors_or_retries_never_wrong_results(G):
+    """max_paths too small: the Python layer grows it from the count the call reports; a workspace that is too
+    small, a rank outside the shard world or an order above 3: status codes (exceptions), nothing is computed."""
+    import ctypes as C
+
+    from differt_amd import _lib
+    from differt_amd._tensors import ptr, stream
+
+    V, Tr, c, h = S.manhattan(40, seed=9)
+    tx, rx = S.manhattan_tx_rx(c, h, 3, 10, seed=19)
+    mesh = G.Mesh(V, Tr)
+    scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(rx, device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    full = tracer.trace_beam_pruned(scene, 2)
+    assert full.objects.shape[0] > 3
+    small = tracer.trace_beam_pruned(scene, 2, max_paths=1)
+    assert torch.equal(small.keys, full.keys) and torch.equal(small.vertices.view(torch.int32), full.vertices.view(torch.int32))
+    with pytest.raises(ValueError):
+        tracer.trace_beam_pruned(scene, 4)
+    with pytest.raises(ValueError):
+        tracer.trace_beam_pruned(scene, 2, prefix_shard=(2, 2))
+    # raw call with a 1 KiB workspace
+    t, r = scene.transmitters.reshape(-1, 3).contiguous(), scene.receivers.reshape(-1, 3).contiguous()
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    keys = torch.empty(64, dtype=torch.int64, device="cuda")
+    verts = torch.empty((64, 4, 3), device="cuda")
+    objs = torch.empty((64, 4), dtype=torch.int32, device="cuda")
+    nv = C.c_int64(-1)
+    pr = _lib.TraceParams(1.2e-6, 1.2e-5, 1.2e-6, 0)
+    with pytest.raises(_lib.CapacityError):
+        _lib.call("drt_trace_paths_beam", mesh.handle().h, C.byref(pr), None, ptr(t), t.shape[0], ptr(r), r.shape[0], 2, 64,
+                  ptr(keys), ptr(verts), ptr(objs), C.byref(nv), ptr(ws), 1024, stream())
+    assert nv.value == 0
