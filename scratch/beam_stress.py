@@ -35,6 +35,21 @@ while time.time() - t0 < budget:
     tx[:, 2] = rng.uniform(1.5, 70, len(tx))
     if rng.random() < 0.3:
         rx[:, 2] = rng.uniform(1.0, 50, len(rx))
+    # round 3: adversarial perturbations -- end points in / next to wall planes, scenes far from the origin
+    if rng.random() < 0.3:
+        k = int(rng.integers(0, len(tx)))
+        ax = int(rng.integers(0, 3))
+        tx[k, ax] = V[int(rng.integers(0, len(V))), ax] + np.float32(rng.choice([0.0, 1e-6, -1e-5, 1e-4, -1e-3]))
+        st["tx_on_planes"] = st.get("tx_on_planes", 0) + 1
+    if rng.random() < 0.3:
+        for k in rng.choice(len(rx), size=min(len(rx), 3), replace=False):
+            ax = int(rng.integers(0, 3))
+            rx[k, ax] = V[int(rng.integers(0, len(V))), ax] + np.float32(rng.choice([0.0, 1e-6, -1e-4]))
+        st["rx_on_planes"] = st.get("rx_on_planes", 0) + 1
+    if rng.random() < 0.15:
+        off = np.array([3000.0, -2000.0, 50.0], np.float32)
+        V, tx, rx = (V + off).astype(np.float32), (tx + off).astype(np.float32), (rx + off).astype(np.float32)
+        st["far_from_origin"] = st.get("far_from_origin", 0) + 1
     assume_quads = bool(rng.random() < 0.4)
     mask = None
     if rng.random() < 0.3:
