@@ -249,18 +249,15 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
     }
 }
 
-// true: primitive (vertices vx, per-triangle planes pl = (n, d), shape factor sigma) cannot follow this prefix
+// true: primitive (vertices vx, per-triangle planes pl = (n, d), shape factor sigma) cannot follow this prefix.
+// The side test and the pyramids in turn, the prefix's own (last) mirror first; the wave leaves as soon as none of
+// its lanes is still a candidate (same tests, same result for every lane that matters: a lane that failed one
+// test is pruned whatever the others say) -- 44 % of the (prefix, cluster) pairs that pass the box tests have no
+// child at all (debug counters, profiles/r03/beam.md).
 template <int SCALE, int LEVEL>
 __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, const V3 (&vx)[3 * SCALE],
-                                            const float (&pl)[SCALE][4], float sigma) {
+                                            const float (&pl)[SCALE][4], float sigma, bool lane_on = true) {
     float dmin = kInf, dmax = -kInf, D2 = 0.0f;
-    float mf[LEVEL][SCALE][3];  // max over the vertices of <x - I, n_f> + g |x - I|_1
-#pragma unroll
-    for (int j = 0; j < LEVEL; ++j)
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t)
-#pragma unroll
-            for (int f = 0; f < 3; ++f) mf[j][t][f] = -kInf;
     bool nan = false;
 #pragma unroll
     for (int k = 0; k < 3 * SCALE; ++k) {
@@ -269,17 +266,9 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
         dmin = fminf(dmin, d);
         dmax = fmaxf(dmax, d);
         const V3 w = x - c.I;
-        const float wl = l1_len(w);  // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
-        const float chk = d + wl;    // NaN vertex, plane or apex (the maxima below ignore NaNs): never prune
+        const float chk = d + l1_len(w);  // NaN vertex, plane or apex (the maxima below ignore NaNs): never prune
         nan = nan || !(chk == chk);
         D2 = fmaxf(D2, fdot(w, w));
-#pragma unroll
-        for (int j = 0; j < LEVEL; ++j)
-#pragma unroll
-            for (int t = 0; t < SCALE; ++t)
-#pragma unroll
-                for (int f = 0; f < 3; ++f)
-                    mf[j][t][f] = fmaxf(mf[j][t][f], __builtin_fmaf(c.pyr[j][t].g[f], wl, fdot(w, c.pyr[j][t].n[f])));
     }
     float h = kInf;
 #pragma unroll
@@ -290,18 +279,30 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
     const float eps_c = beam_eps(c.u, sigma, __builtin_amdgcn_sqrtf(D2) * 1.000001f, h);
 #endif
     const float base = -(2.0f * eps_c + c.u);  // -inf for a candidate seen at grazing incidence: nothing separates
+    const int side_c = side_of_range(dmin, dmax, eps_c + 2.0f * c.u);
+    bool pruned = !nan && (c.side_prev * side_c == -1);
     // separated by a pyramid: for EACH of the mirror's triangles SOME face has all vertices outside, i.e. the
-    // smallest of its three maxima is below the threshold; (a NaN vertex: `nan` below keeps the primitive)
-    bool separated = false;
+    // smallest of its three maxima (over the vertices, of <x - I, n_f> + g |x - I|_1) is below the threshold
 #pragma unroll
-    for (int j = 0; j < LEVEL; ++j) {
+    for (int j = LEVEL - 1; j >= 0; --j) {
+        if (!__any(lane_on && !pruned)) return true;  // nobody left in this wave: the caller keeps no lane
         float worst = -kInf;  // max over the triangles of min over the faces
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) worst = fmaxf(worst, min3f(mf[j][t][0], mf[j][t][1], mf[j][t][2]));
-        separated = separated || (worst < base);
+        for (int t = 0; t < SCALE; ++t) {
+            float m0 = -kInf, m1 = -kInf, m2 = -kInf;
+#pragma unroll
+            for (int k = 0; k < 3 * SCALE; ++k) {
+                const V3 w = vx[k] - c.I;       // (recomputed per pyramid: 6 instructions, no array of differences to keep)
+                const float wl = l1_len(w);     // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
+                m0 = fmaxf(m0, __builtin_fmaf(c.pyr[j][t].g[0], wl, fdot(w, c.pyr[j][t].n[0])));
+                m1 = fmaxf(m1, __builtin_fmaf(c.pyr[j][t].g[1], wl, fdot(w, c.pyr[j][t].n[1])));
+                m2 = fmaxf(m2, __builtin_fmaf(c.pyr[j][t].g[2], wl, fdot(w, c.pyr[j][t].n[2])));
+            }
+            worst = fmaxf(worst, min3f(m0, m1, m2));
+        }
+        pruned = pruned || (!nan && worst < base);
     }
-    const int side_c = side_of_range(dmin, dmax, eps_c + 2.0f * c.u);
-    return !nan && (separated || (c.side_prev * side_c == -1));
+    return pruned;
 }
 
 // true: NO primitive inside the box [lo, hi] whose own bound is <= eps_max can follow this prefix (the box form
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             for (int t = 0; t < SCALE; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pl[t][q] = lds_pl[j][t][q];
-            const bool keep = have && (c != m) && !prim_pruned<SCALE, LEVEL>(ctx, vx, pl, lds_sg[j]);
+            const bool cand = have && (c != m);
+            const bool keep = cand && !prim_pruned<SCALE, LEVEL>(ctx, vx, pl, lds_sg[j], cand);
             beam_stage<kBeamWaveBuf>(keep, ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c, wbuf[wave], wcount,
                                      lane, out, cap, count);
         }
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
     // flight while this cluster is tested -- fetched whether or not the cluster will be hit (the mesh lives in L2)
     int32_t p_next = -1;
     V3 vx_next[3 * SCALE];
-    float4 pl_next[SCALE], uq_next[SCALE];
+    float pl_next[SCALE][4], uq_next[SCALE][4];  // (plain floats: float4 arrays captured by the lambda stayed in scratch)
     auto fetch = [&](int64_t c) {
         const int64_t cc = (c < cl_end) ? c : cl_end - 1;  // the last trip re-reads its own cluster
         const int64_t pos = cc * 64 + lane;
@@ -597,8 +599,10 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
         for (int k = 0; k < 3 * SCALE; ++k) vx_next[k] = ld3(C.verts + 9 * pos * SCALE + 3 * k);  // padded to whole clusters
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
-            pl_next[t] = reinterpret_cast<const float4 *>(C.planes)[pos * SCALE + t];
-            uq_next[t] = reinterpret_cast<const float4 *>(C.uplanes)[pos * SCALE + t];
+            const float4 a = reinterpret_cast<const float4 *>(C.planes)[pos * SCALE + t];
+            const float4 b = reinterpret_cast<const float4 *>(C.uplanes)[pos * SCALE + t];
+            pl_next[t][0] = a.x; pl_next[t][1] = a.y; pl_next[t][2] = a.z; pl_next[t][3] = a.w;
+            uq_next[t][0] = b.x; uq_next[t][1] = b.y; uq_next[t][2] = b.z; uq_next[t][3] = b.w;
         }
     };
     if (cl_begin < cl_end) fetch(cl_begin);
@@ -610,8 +614,10 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
         for (int k = 0; k < 3 * SCALE; ++k) vx[k] = vx_next[k];
 #pragma unroll
         for (int t = 0; t < SCALE; ++t) {
-            pl[t][0] = pl_next[t].x; pl[t][1] = pl_next[t].y; pl[t][2] = pl_next[t].z; pl[t][3] = pl_next[t].w;
-            lds_planes[wave][lane * SCALE + t] = uq_next[t];  // wave-private: ordered by the wave's own LDS queue
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pl[t][q] = pl_next[t][q];
+            // wave-private: ordered by the wave's own LDS queue
+            lds_planes[wave][lane * SCALE + t] = float4{uq_next[t][0], uq_next[t][1], uq_next[t][2], uq_next[t][3]};
         }
         fetch(cl + 1);
         // ---- lane = prefix: box of the cluster (wave-uniform scalar loads) ----
@@ -677,7 +683,8 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
             const BeamCtx<SCALE, LEVEL> cx = lane_bcast<SCALE, LEVEL>(ctx, l);
-            const bool keep = act && (p != __builtin_amdgcn_readlane(m, l)) && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg);
+            const bool cand = act && (p != __builtin_amdgcn_readlane(m, l));
+            const bool keep = cand && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg, cand);
 #ifdef BEAM_LAB_COUNT
             {
                 const unsigned long long kv = __ballot(keep);
