@@ -39,6 +39,8 @@ def test_single_gpu_line():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] == "hbm"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    assert "strong_headline" not in d  # N = 1: the line is the plain single-GPU bench
+    assert d["prewarm_ms"] > 0 and d["roofline"]["pmc_stale"] in (True, False)
     _check_strong(d["strong_scaling"], 1)
     Path(os.environ.get("DRT_BENCH_N1_JSON", "/tmp/drt_bench_n1.json")).write_text(json.dumps(d["strong_scaling"]))
 
@@ -67,6 +69,11 @@ def test_two_ranks_share_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "TEST HOOK" in d["data"]
     assert d["value"] > 0 and d["config"]["rays_per_gpu"] == 2048
     _check_strong(d["strong_scaling"], 2)
+    # N > 1: the fixed-total-work legs are surfaced at top level (the north-star scaling claim), `value` stays weak
+    heads = {h["leg"]: h for h in d["strong_headline"]}
+    assert set(heads) == {"beam_sharded", "candidate_sharded"}
+    for leg, h in heads.items():
+        assert h["n_gpus"] == 2 and h["scaling"] == "strong" and h["s_per_step"] == d["strong_scaling"][leg]["s_per_step"]
     ref = Path(os.environ.get("DRT_BENCH_N1_JSON", "/tmp/drt_bench_n1.json"))
     if ref.exists():  # same fixed work as the single-rank run: same valid paths, same first hits, same gradient
         one = json.loads(ref.read_text())
