@@ -174,6 +174,50 @@ __global__ __launch_bounds__(256) void refit_kernel(int64_t n, const uint32_t *_
     }
 }
 
+// binary -> 4-ary collapse, one thread per binary node (after the refit)
+struct WideEntry {
+    float lo[3], hi[3];
+    int32_t child;
+};
+__device__ __forceinline__ WideEntry wide_entry(const float *lo, const float *hi, int32_t child) {
+    return WideEntry{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}, child};
+}
+__global__ __launch_bounds__(256) void collapse_kernel(const BvhNode *__restrict__ nodes, int64_t n_internal,
+                                                       Bvh4Node *__restrict__ wide) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_internal) return;
+    const BvhNode nd = nodes[b];
+    const float inf3[3] = {kInf, kInf, kInf}, ninf3[3] = {-kInf, -kInf, -kInf};
+    const WideEntry none = wide_entry(inf3, ninf3, kBvhNoChild);
+    // each binary child contributes itself (a leaf) or its two children
+    WideEntry l0 = wide_entry(nd.llo, nd.lhi, nd.left), l1 = none, r0 = wide_entry(nd.rlo, nd.rhi, nd.right), r1 = none;
+    if (nd.left >= 0) {
+        const BvhNode g = nodes[nd.left];
+        l0 = wide_entry(g.llo, g.lhi, g.left);
+        l1 = wide_entry(g.rlo, g.rhi, g.right);
+    }
+    if (nd.right >= 0) {
+        const BvhNode g = nodes[nd.right];
+        r0 = wide_entry(g.llo, g.lhi, g.left);
+        r1 = wide_entry(g.rlo, g.rhi, g.right);
+    }
+    // slots: l0, then l1 if there is one, then r0, r1; empty slots last (inverted box, kBvhNoChild)
+    const bool two_l = nd.left >= 0;
+    const WideEntry e[4] = {l0, two_l ? l1 : r0, two_l ? r0 : r1, two_l ? r1 : none};
+    Bvh4Node w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            w.lo[k][c] = e[k].lo[c];
+            w.hi[k][c] = e[k].hi[c];
+        }
+        w.child[k] = e[k].child;
+        w.pad[k] = 0;
+    }
+    wide[b] = w;
+}
+
 template <bool FIRST>
 __global__ __launch_bounds__(256) void bvh_query_kernel(
     const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids, int64_t T,
@@ -301,7 +345,9 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
             return fail(DRT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
         }                                                                                \
     } while (0)
-    TRY_HIP(hipMalloc(&nodes, nn * sizeof(BvhNode)));
+    // binary nodes, then (128-B aligned) one 4-ary node per binary node
+    const size_t wide_off = (size_t)bvh_wide_offset(T);
+    TRY_HIP(hipMalloc(&nodes, wide_off * sizeof(BvhNode) + nn * sizeof(Bvh4Node)));
     TRY_HIP(hipMalloc(&tri_boxes, (size_t)T * sizeof(Box)));
     TRY_HIP(hipMalloc(&node_boxes, nn * sizeof(Box)));
     TRY_HIP(hipMalloc(&keys, (size_t)T * 8));
@@ -332,6 +378,8 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
                            keys_sorted, T, nodes, par_int, par_leaf);
         hipLaunchKernelGGL(refit_kernel, gt, dim3(256), 0, s, T, ids_sorted, tri_boxes, nodes, par_int,
                            par_leaf, node_boxes, flags);
+        hipLaunchKernelGGL(collapse_kernel, dim3((unsigned)ceil_div(T - 1, 256)), dim3(256), 0, s, nodes, T - 1,
+                           reinterpret_cast<Bvh4Node *>(nodes + wide_off));
         TRY_HIP(hipGetLastError());
     }
     TRY_HIP(hipStreamSynchronize(s));
