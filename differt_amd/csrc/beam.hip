@@ -673,6 +673,15 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
             atomicAdd(&beam_dbg[0], (unsigned long long)__popcll(__ballot(have)));
             atomicAdd(&beam_dbg[1], (unsigned long long)__popcll(todo));
         }
+        {
+            const unsigned long long einf = __ballot(alive && !(eps_max < kInf)), ebig = __ballot(alive && eps_max > 1.0f && eps_max < kInf),
+                                     emid = __ballot(alive && eps_max > 0.1f && eps_max <= 1.0f);
+            if (lane == 0) {
+                atomicAdd(&beam_dbg[4], (unsigned long long)__popcll(einf));
+                atomicAdd(&beam_dbg[5], (unsigned long long)__popcll(ebig));
+                atomicAdd(&beam_dbg[6], (unsigned long long)__popcll(emid));
+            }
+        }
 #endif
         if (todo == 0) continue;
         // ---- transposed: lane = primitive of the cluster ----
