@@ -12,9 +12,9 @@ tx, rx = S.manhattan_tx_rx(c, h, 16, 64)
 mesh = G.Mesh(V, Tr)
 scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
 tr = G.ExhaustivePathTracer()
-for cm, kp in ((0.25, 8.0), (0.125, 16.0), (0.5, 4.0)):
+for kp in (4.0, 16.0, 64.0, 256.0):  # error unit u = kappa * ulp(M); rows / levels / time as a function of it
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        p = tr.trace_beam_pruned(scene, order, cos_min=cm, kappa=kp)
+        p = tr.trace_beam_pruned(scene, order, kappa=kp)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"boxes": boxes, "order": order, "cos_min": cm, "kappa": kp, "s": dt, "valid": int(p.objects.shape[0]), **tr.last_beam_stats}), flush=True)
+    print(json.dumps({"boxes": boxes, "order": order, "kappa": kp, "s": dt, "valid": int(p.objects.shape[0]), **tr.last_beam_stats}), flush=True)
