@@ -90,7 +90,15 @@ struct BeamMesh {
     const uint8_t *mask;   // [T] or null
     int64_t nprim;
     int32_t scale;  // triangles per primitive (2 with assume_quads)
+    float inv_2m;   // 1 / (2 M), M = largest coordinate magnitude of mesh, transmitters and receivers
 };
+// The error unit u = kappa ulp(M) assumes operands within 2 M (differences of scene points, images one reflection
+// away).  Images of images can reach (2k+1) M, and float32 rounding grows with the operand: a prefix whose apex lies
+// beyond 2 M scales its unit by |apex|_inf / (2 M).
+__device__ __forceinline__ float mag_scale(const BeamMesh &M, V3 I) {
+    const float m = fmaxf(__builtin_fabsf(I.x), fmaxf(__builtin_fabsf(I.y), __builtin_fabsf(I.z)));
+    return fmaxf(1.0f, m * M.inv_2m);  // NaN apex: 1 (its tests are off anyway)
+}
 
 __device__ __forceinline__ bool prim_active(const BeamMesh &M, int64_t p) {
     if (!M.mask) return true;
@@ -207,8 +215,9 @@ struct BeamCtx {
 template <int SCALE, int LEVEL>
 __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e, float u, bool have,
                                           BeamCtx<SCALE, LEVEL> &c) {
-    c.u = u;
     c.I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    u = u * mag_scale(M, c.I);
+    c.u = u;
     c.pm = V3{0, 0, 0};
     c.nm = V3{0, 0, 1};
     c.side_prev = have ? entry_side(e) : 0;
@@ -356,7 +365,7 @@ __device__ __forceinline__ BeamCtx<SCALE, LEVEL> lane_bcast(const BeamCtx<SCALE,
     o.I = lane_bcast(c.I, l);
     o.pm = lane_bcast(c.pm, l);
     o.nm = lane_bcast(c.nm, l);
-    o.u = c.u;
+    o.u = lane_bcast(c.u, l);  // per prefix since the magnitude rescaling
     o.side_prev = __builtin_amdgcn_readlane(c.side_prev, l);
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j)
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
         e.apex[0] = I.x;
         e.apex[1] = I.y;
         e.apex[2] = I.z;
-        e.esum = prim_eps_global(M, a, t, u);
+        e.esum = prim_eps_global(M, a, t, u * mag_scale(M, I));
     }
     const unsigned long long vote = __ballot(keep);
     if (vote) {
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
 #ifdef BEAM_LAB_NO_HMIN
         const float eps_max = 0.0f;
 #else
-        const float eps_max = beam_eps(u, bx[6], margin_len(far) * 1.0001f, hmin);
+        const float eps_max = beam_eps(ctx.u, bx[6], margin_len(far) * 1.0001f, hmin);  // ctx.u: the prefix's own unit
 #endif
         bool alive = have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max);
         // second level for the survivors: the four sub-boxes of 16 consecutive primitives (one or two buildings of a
@@ -723,9 +732,10 @@ __device__ __forceinline__ BeamEntry beam_child(const BeamMesh &M, const BeamEnt
     o.apex[0] = I2.x;
     o.apex[1] = I2.y;
     o.apex[2] = I2.z;
-    o.esum = e.esum + prim_eps_global(M, c, I, u);
+    const float us = u * fmaxf(mag_scale(M, I), mag_scale(M, I2));
+    o.esum = e.esum + prim_eps_global(M, c, I, us);
     // the previous reflection point lies within S_parent of the parent's last mirror
-    o.tx_side = pack_tx_side(entry_tx(e), side_of_prim(M, e.id[LEVEL - 1], pc, nc, e.esum + 2.0f * u));
+    o.tx_side = pack_tx_side(entry_tx(e), side_of_prim(M, e.id[LEVEL - 1], pc, nc, e.esum + 2.0f * us));
     return o;
 }
 
@@ -1143,6 +1153,7 @@ static BeamMesh beam_mesh(drt_mesh_t m) {
     M.mask = m->has_mask ? m->mask : nullptr;
     M.scale = m->assume_quads ? 2 : 1;
     M.nprim = m->num_triangles / M.scale;
+    M.inv_2m = 0.0f;  // set by the driver once the scene magnitude is known (0: no rescaling)
     return M;
 }
 
@@ -1430,7 +1441,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     drt_beam_stats *st = bp ? bp->stats : nullptr;
     if (st) memset(st, 0, sizeof(*st));
     hipStream_t s = as_stream(stream);
-    const BeamMesh M = beam_mesh(mesh);
+    BeamMesh M = beam_mesh(mesh);
     drt_trace_params tp = *pr;
     tp.stats = nullptr;
 
@@ -1508,6 +1519,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     int ex = 0;
     (void)std::frexp(mag, &ex);                  // mag = f * 2^ex, f in [0.5, 1)
     const float u = kappa * std::ldexp(1.0f, ex - 1 - 23);  // kappa * ulp(M)
+    M.inv_2m = 0.5f / mag;
     if (st) {
         st->unit_m = u;
         st->magnitude = mag;

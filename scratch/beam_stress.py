@@ -14,7 +14,8 @@ sys.path.insert(0, ".")
 import differt_amd.geometry as G  # noqa: E402
 import synthetic_scenes as S  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+budget = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 60.0
+KAPPA = float(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--kappa=")), "64"))  # error unit of the bounds
 rng = np.random.default_rng(77)
 st = {"cases": 0, "exhaustive_candidates": 0, "rows_traced": 0, "valid_paths": 0, "missed": 0, "extra": 0,
       "vertex_mismatch": 0, "mapping_row_mismatch": 0, "mapping_checks": 0}
@@ -63,7 +64,7 @@ while time.time() - t0 < budget:
     scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
     tracer = G.ExhaustivePathTracer()
     ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
-    bp = tracer.trace_beam_pruned(scene, order)
+    bp = tracer.trace_beam_pruned(scene, order, kappa=KAPPA)
     rows = tracer.last_beam_stats["rows"]
     a = set(ex.keys.cpu().tolist()) if ex.keys is not None else set()
     # exhaustive keys are (pair, candidate rank); compare through objects
@@ -79,9 +80,10 @@ while time.time() - t0 < budget:
     st["valid_paths"] += len(ea)
     if st["cases"] % 4 == 0:
         for kw in ({"expansion": "plain"}, {"emit": "clustered"}, {"emit": "plain"}):
-            other = tracer.trace_beam_pruned(scene, order, **kw)
+            other = tracer.trace_beam_pruned(scene, order, kappa=KAPPA, **kw)
             st["mapping_checks"] += 1
             if tracer.last_beam_stats["rows"] != rows or not torch.equal(other.keys, bp.keys):
                 st["mapping_row_mismatch"] += 1
 st["seconds"] = time.time() - t0
+st["kappa"] = KAPPA
 print(json.dumps(st))
