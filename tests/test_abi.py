@@ -81,3 +81,20 @@ def test_product_never_imports_the_oracle():
         if "import oracle" in text or "from oracle" in text or "differt_oracle" in text:
             offenders.append(str(p))
     assert not offenders, offenders
+
+
+def test_workspace_size_queries_work_without_a_gpu():
+    """Size queries are host arithmetic: callable on a CPU box, monotone in the capacities, never zero."""
+    L = _lib.load()
+    bp = _lib.BeamParams()
+    a = L.drt_trace_beam_workspace_size(16, 64, 10000, 2, C.byref(bp), 1 << 16)
+    b = L.drt_trace_beam_workspace_size(16, 64, 10000, 3, C.byref(bp), 1 << 16)
+    assert 0 < a < b  # order 3 adds the level-2 prefix list
+    bp.max_rows = 1 << 20
+    bp.max_records = 1 << 20
+    bp.max_entries = 1 << 20
+    c = L.drt_trace_beam_workspace_size(16, 64, 10000, 3, C.byref(bp), 1 << 16)
+    assert 0 < c < b
+    assert L.drt_trace_beam_workspace_size(1, 1, 12, 0, None, 4) == L.drt_trace_compact_workspace_size(1, 4)
+    assert L.drt_trace_vjp_workspace_size(0, 2) > 0
+    assert L.drt_trace_vjp_workspace_size(1000, 3) > L.drt_trace_vjp_workspace_size(1000, 1)

@@ -187,3 +187,28 @@ def test_capacities_are_errors_or_retries_never_wrong_results(G):
         _lib.call("drt_trace_paths_beam", mesh.handle().h, C.byref(pr), None, ptr(t), t.shape[0], ptr(r), r.shape[0], 2, 64,
                   ptr(keys), ptr(verts), ptr(objs), C.byref(nv), ptr(ws), 1024, stream())
     assert nv.value == 0
+
+
+@pytest.mark.parametrize("assume_quads", [False, True])
+def test_degenerate_meshes(G, assume_quads):
+    """Zero-area and duplicated triangles, a vertex at infinity, coincident transmitter / receiver, a transmitter ON a
+    vertex, tiny meshes (2 triangles): the pruned search still returns exactly what the exhaustive tracer returns."""
+    base = [(20.0, 10.0, 30.0, 0.0, 0.0), (14.0, 14.0, 22.0, 30.0, 6.0), (10.0, 18.0, 16.0, -8.0, 26.0)]
+    V, Tr = boxes_mesh(base, ground=60.0)
+    nv = len(V)
+    # a degenerate (zero-area) pair, an exact duplicate of an existing wall pair, a needle pair
+    extra_v = np.array([[5, 5, 5], [5, 5, 5], [6, 6, 6], [7, 7, 7], [40, -20, 0], [40, -20, 30], [40.00001, -20, 30], [40.00001, -20, 0]],
+                       np.float32)
+    extra_t = np.array([[nv, nv + 1, nv + 2], [nv, nv + 2, nv + 3], [0, 1, 2], [0, 2, 3], [nv + 4, nv + 5, nv + 6], [nv + 4, nv + 6, nv + 7]],
+                       np.int32)
+    V2, Tr2 = np.concatenate((V, extra_v)), np.concatenate((Tr, extra_t))
+    tx = [[-20.0, -12.0, 14.0], [float(V[0, 0]), float(V[0, 1]), float(V[0, 2])], [18.0, 15.0, 40.0]]
+    rx = [[15.0, 8.0, 1.5], [-20.0, -12.0, 14.0], [30.0, -15.0, 12.0], [18.0, 15.0, 40.0]]
+    assert check(G, V2, Tr2, tx, rx, assume_quads=assume_quads, min_paths=3) > 0
+    # two triangles only (one quad), and a mesh with an infinite vertex (its triangles never reflect, never prune)
+    Vq = np.array([[-10, -10, 0], [10, -10, 0], [10, 10, 0], [-10, 10, 0]], np.float32)
+    Tq = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    check(G, Vq, Tq, [[1.0, 2.0, 5.0]], [[-3.0, 1.0, 4.0], [2.0, 2.0, 9.0]], orders=(1, 2), assume_quads=assume_quads, min_paths=1)
+    V3 = V2.copy()
+    V3[nv + 3] = [np.inf, 0.0, 0.0]
+    check(G, V3, Tr2, tx[:1], rx[:2], orders=(1, 2), assume_quads=assume_quads)
