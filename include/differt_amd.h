@@ -517,7 +517,9 @@ typedef struct drt_beam_stats {
 /* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on) */
 
 typedef struct drt_beam_params {
-    float kappa;            /* error unit u = kappa * ulp(M); <= 0: default 64 */
+    float kappa;            /* error unit u = kappa * ulp(M); <= 0: default 64 = the worst-case rounding count of
+                               DESIGN.md section 9 (measured errors are 5-50x smaller: oracle/studies/beam_error_model.py;
+                               configs[3]: 1.26 s at 64, 0.87 s at 16, same paths) */
     int32_t flags;          /* DRT_BEAM_* */
     int64_t max_entries;    /* level-2 prefix list (order 3), 32 B each; <= 0: 2^26 */
     int64_t max_records;    /* records of one expansion slice, 8 B each; <= 0: 2^27 */
