@@ -128,7 +128,7 @@ class Scene:
         self,
         order: int | None = None,
         *,
-        solver: AbstractPathTracer | Literal["exhaustive", "hybrid"] = "exhaustive",
+        solver: AbstractPathTracer | Literal["exhaustive", "hybrid", "beam"] = "exhaustive",
         path_candidates=None,
         chunk_size: int | None = None,
         compact: bool = False,
@@ -138,10 +138,18 @@ class Scene:
 
         Result batch shape: ``[*tx_batch, *rx_batch, num_candidates]`` (:762-764).  ``compact=True``
         (MI355X extension) returns only the valid paths, flattened, without building the dense
-        arrays or the candidate table.
+        arrays or the candidate table.  ``solver="beam"`` (MI355X extension, orders 0..3): the valid paths of the
+        exhaustive solver -- same objects, order and vertex bits -- through the geometrically pruned search
+        (``drt_trace_paths_beam``), always compact; ``solver_kwargs`` go to ``ExhaustivePathTracer`` except
+        ``kappa`` / ``max_paths``, which go to the search.
         """
         if (order is None) == (path_candidates is None):  # _scene.py:692-695
             raise ValueError("You must specify one of 'order' or `path_candidates`, not both.")
+        if isinstance(solver, str) and solver == "beam":
+            if path_candidates is not None or chunk_size is not None:
+                raise ValueError("solver='beam' enumerates the candidates itself: pass 'order' only.")
+            beam_kwargs = {k: solver_kwargs.pop(k) for k in ("kappa", "max_paths") if k in solver_kwargs}
+            return ExhaustivePathTracer(**solver_kwargs).trace_beam_pruned(self, order, **beam_kwargs)
         if isinstance(solver, str):
             if solver not in ("exhaustive", "hybrid"):
                 raise ValueError(f"Unknown solver: {solver}")  # :702

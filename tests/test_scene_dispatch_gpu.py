@@ -228,3 +228,20 @@ def test_mesh_mask_matches_sub_mesh_without_mask(G, order, method):
     assert torch.equal(got.vertices, exp.vertices)
     if method != "sbr" and order <= 2:
         assert got.objects.shape[0] > 0
+
+
+def test_trace_paths_beam_solver_equals_compact_exhaustive(G, two_buildings, goldens):
+    """``Scene.trace_paths(order, solver="beam")``: the exhaustive solver's valid paths (reference scene goldens,
+    differt/tests/geometry/test_scene.py:116-160) through the pruned search, same objects / vertex bits as ``compact=True``."""
+    ex = goldens["advanced_path_tracing_example"]
+    scene = G.Scene(np.asarray([ex["tx"]], np.float32), np.asarray([ex["rx"]], np.float32),
+                    G.Mesh(two_buildings["vertices"], two_buildings["triangles"]))
+    for order in (0, 1, 2, 3):
+        a = scene.trace_paths(order, compact=True)
+        b = scene.trace_paths(order, solver="beam", kappa=64.0)
+        assert b.objects.cpu().numpy().tolist() == ex["orders"][str(order)]["objects"]
+        assert torch.equal(a.objects, b.objects) and torch.equal(a.vertices.view(torch.int32), b.vertices.view(torch.int32))
+    with pytest.raises(ValueError):
+        scene.trace_paths(2, solver="beam", chunk_size=10)
+    with pytest.raises(ValueError):
+        scene.trace_paths(4, solver="beam")
