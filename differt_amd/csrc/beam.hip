@@ -765,15 +765,36 @@ __device__ __forceinline__ BeamEntry emit_entry(const BeamMesh &M, const BeamEnt
 // turn, earliest mirror first (unfolded farthest from the apex = the narrowest cone); with WAVE_EXIT the wave leaves
 // the receiver as soon as none of its 64 lanes is still inside (same tests, same result: a lane that fails one
 // pyramid is dropped whatever the others say).
-template <int SCALE, int ORDER, bool WAVE_EXIT>
-__device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, V3 r, bool lane_on) {
-    const float d = fdot(r - c.pm, c.nm);
-    // side_prev in {-1, 0, +1}; 0 or a NaN distance never rejects (the receiver is exact: margin 2u)
-    bool alive = lane_on && !((float)c.side_prev * d < -2.0f * c.u);
+// first half of the receiver test: the narrowest pyramid (index 0: the earliest mirror, unfolded farthest from the
+// apex) -- the test that rejects most receivers, alone so that the plain emit kernel's common trip is short
+template <int SCALE, int ORDER>
+__device__ __forceinline__ bool receiver_first(const BeamCtx<SCALE, ORDER> &c, V3 r, bool lane_on) {
     const V3 w = r - c.I;
     const float wl = l1_len(w);
+    bool inside_any = false;
 #pragma unroll
-    for (int j = 0; j < ORDER; ++j) {
+    for (int t = 0; t < SCALE; ++t) {
+        const Pyr &P = c.pyr[0][t];
+        const float lowest = min3f(__builtin_fmaf(P.g[0], wl, fdot(w, P.n[0])), __builtin_fmaf(P.g[1], wl, fdot(w, P.n[1])),
+                                   __builtin_fmaf(P.g[2], wl, fdot(w, P.n[2])));
+        inside_any = inside_any | !(lowest < -c.u);
+    }
+    return lane_on & inside_any;  // (& not &&: no branch around a handful of instructions)
+}
+
+// second half: the side of the last mirror, then the remaining pyramids; with WAVE_EXIT the wave leaves as soon as
+// none of its 64 lanes is still inside (same tests, same result: a lane that fails one test is dropped whatever
+// the others say)
+template <int SCALE, int ORDER, bool WAVE_EXIT>
+__device__ __forceinline__ bool receiver_rest(const BeamCtx<SCALE, ORDER> &c, V3 r, bool alive) {
+    if (WAVE_EXIT && !__any(alive)) return false;
+    const V3 w = r - c.I;  // (again: the rare half recomputes five instructions instead of keeping them live)
+    const float wl = l1_len(w);
+    const float d = fdot(r - c.pm, c.nm);
+    // side_prev in {-1, 0, +1}; 0 or a NaN distance never rejects (the receiver is exact: margin 2u)
+    alive = alive & !((float)c.side_prev * d < -2.0f * c.u);
+#pragma unroll
+    for (int j = 1; j < ORDER; ++j) {
         if (WAVE_EXIT && !__any(alive)) return false;
         bool inside_any = false;
 #pragma unroll
@@ -781,18 +802,25 @@ __device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, 
             const Pyr &P = c.pyr[j][t];
             const float lowest = min3f(__builtin_fmaf(P.g[0], wl, fdot(w, P.n[0])), __builtin_fmaf(P.g[1], wl, fdot(w, P.n[1])),
                                        __builtin_fmaf(P.g[2], wl, fdot(w, P.n[2])));
-            inside_any = inside_any || !(lowest < -c.u);
+            inside_any = inside_any | !(lowest < -c.u);
         }
-        alive = alive && inside_any;
+        alive = alive & inside_any;
     }
     return alive;
+}
+
+template <int SCALE, int ORDER, bool WAVE_EXIT>
+__device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, V3 r, bool lane_on) {
+    const bool alive = receiver_first<SCALE, ORDER>(c, r, lane_on);
+    return receiver_rest<SCALE, ORDER, WAVE_EXIT>(c, r, alive);
 }
 
 // lane = level-ORDER prefix, loop over the receivers (wave-uniform scalar loads, the next one in flight)
 template <int SCALE, int ORDER>
 __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in,
                                                         const unsigned long long *__restrict__ rec, int64_t n_in,
-                                                        const float *__restrict__ rx, int64_t nrx, float u,
+                                                        const float *__restrict__ rx_sorted,
+                                                        const int32_t *__restrict__ rx_index, int64_t nrx, float u,
                                                         long long *__restrict__ rows, int64_t cap,
                                                         unsigned long long *__restrict__ count,
                                                         unsigned long long *__restrict__ grazing) {
@@ -815,16 +843,61 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     }
     if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);  // every test of this prefix is off (informational)
     const long long pair0 = (long long)entry_tx(e) * (long long)nrx;
-    const float *prx = rx;
-    V3 r_next = ld3(prx);
     const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
-    for (int ir = 0; ir < nrx32; ++ir) {
-        const V3 r = r_next;
-        prx += (ir + 1 < nrx32) ? 3 : 0;
-        r_next = ld3(prx);
-        const bool keep = receiver_inside<SCALE, ORDER, true>(ctx, r, have);
-        beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((pair0 + (long long)ir) * npow + tail), wbuf[wave], wcount,
-                                 lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+    // G receivers per trip, read from the Morton-sorted copy (padded to a multiple of 64 with copies of the last
+    // receiver: wave-uniform 16-byte scalar loads, the next trip's in flight): the first-pyramid tests of all G,
+    // ONE wave vote, and only the trips where some lane is still inside some receiver go on.  Same per-receiver
+    // arithmetic as receiver_inside -> the same rows.
+#ifndef BEAM_EMIT_GROUP
+#define BEAM_EMIT_GROUP 4
+#endif
+    constexpr int G = BEAM_EMIT_GROUP;  // 4 or 8 (divides the padding of 64)
+    static_assert(G == 4 || G == 8, "trip size");
+    struct Trip {
+        float4 v[3 * G / 4];  // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3 | ...
+    };
+    auto load_trip = [&](int t) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(rx_sorted) + (3 * G / 4) * (int64_t)t;
+        Trip o;
+#pragma unroll
+        for (int k = 0; k < 3 * G / 4; ++k) o.v[k] = p4[k];
+        return o;
+    };
+    const int ntrips = (nrx32 + G - 1) / G;
+#ifdef BEAM_LAB_EMIT_TRIPS  // experiment (NOT a valid build): only the first trips of the receiver loop
+    const int lab_end = (ntrips < BEAM_LAB_EMIT_TRIPS) ? ntrips : BEAM_LAB_EMIT_TRIPS;
+#else
+    const int lab_end = ntrips;
+#endif
+    Trip nxt = load_trip(0);
+    for (int t = 0; t < lab_end; ++t) {
+        const Trip cur = nxt;
+        nxt = load_trip((t + 1 < ntrips) ? t + 1 : t);
+        V3 r[G];
+#pragma unroll
+        for (int q4 = 0; q4 < G / 4; ++q4) {
+            const float4 a4 = cur.v[3 * q4], b4 = cur.v[3 * q4 + 1], c4 = cur.v[3 * q4 + 2];
+            r[4 * q4 + 0] = V3{a4.x, a4.y, a4.z};
+            r[4 * q4 + 1] = V3{a4.w, b4.x, b4.y};
+            r[4 * q4 + 2] = V3{b4.z, b4.w, c4.x};
+            r[4 * q4 + 3] = V3{c4.y, c4.z, c4.w};
+        }
+        bool a[G];
+        bool any_lane = false;
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            a[q] = receiver_first<SCALE, ORDER>(ctx, r[q], have & (G * t + q < nrx32));
+            any_lane = any_lane | a[q];
+        }
+        if (!__any(any_lane)) continue;
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            if (!__any(a[q])) continue;
+            const bool keep = receiver_rest<SCALE, ORDER, true>(ctx, r[q], a[q]);
+            const long long id = (long long)rx_index[G * t + q];
+            beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((pair0 + id) * npow + tail), wbuf[wave], wcount, lane,
+                                     reinterpret_cast<unsigned long long *>(rows), cap, count);
+        }
     }
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
 }
@@ -1059,10 +1132,9 @@ __global__ __launch_bounds__(64) void rx_cluster_kernel(const float *__restrict_
     const int64_t src = (pos < nrx) ? pos : nrx - 1;
     const int64_t i = (int64_t)sorted_ids[src];
     const V3 r = ld3(rx + 3 * i);
-    if (pos < nrx) {
-        st3(rx_sorted + 3 * pos, r);
-        rx_index[pos] = (int32_t)i;
-    }
+    // the tail of the last cluster holds copies of the last receiver (the plain emit kernel reads whole trips)
+    st3(rx_sorted + 3 * pos, r);
+    rx_index[pos] = (int32_t)i;
     float lo[3] = {r.x, r.y, r.z}, hi[3] = {r.x, r.y, r.z};
     bool nan = !(r.x == r.x) || !(r.y == r.y) || !(r.z == r.z);
 #pragma unroll
@@ -1323,7 +1395,7 @@ static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, 
                            s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing);
     else
         hipLaunchKernelGGL((beam_emit_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 256)), dim3(256), 0, s, M, in,
-                           rec, n_in, rx, nrx, u, rows, cap, count, grazing);
+                           rec, n_in, rx_sorted, rx_index, nrx, u, rows, cap, count, grazing);
 }
 
 #define BEAM_DISPATCH2(SC, K, CALL) \
@@ -1475,6 +1547,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     const BeamSizes z = beam_sizes(bp, ntx, M.nprim);
     const BeamLayout L = beam_layout(z, ntx, nrx, M.nprim, order, max_paths);
     if (!ws || ws_bytes < L.total) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", L.total);
+    DRT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15u) == 0, "workspace must be 16-byte aligned");
     char *base = reinterpret_cast<char *>(ws);
     auto *counters = reinterpret_cast<unsigned long long *>(base + L.counters);  // [0] list count, [1] grazing prefixes
     auto *rx_sorted = reinterpret_cast<float *>(base + L.rx_sorted);
