@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
 // tests of the clusters its cones actually reach.
 // ---------------------------------------------------------------------------------------------
 #ifdef BEAM_LAB_COUNT
-__device__ unsigned long long beam_dbg[8];  // [0] box tests, [1] surviving pairs, [2] pairs with >= 1 child, [3] children
+__device__ unsigned long long beam_dbg[8];  // [0] box tests, [1] surviving pairs, [2] pairs with >= 1 child, [3] children, [4..6] pairs by bound, [7] sub-boxes passing
 #endif
 struct BeamClusters {
     const int32_t *order;
@@ -672,7 +672,14 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float slo[3] = {sb[6 * q], sb[6 * q + 1], sb[6 * q + 2]}, shi[3] = {sb[6 * q + 3], sb[6 * q + 4], sb[6 * q + 5]};
+#ifdef BEAM_LAB_COUNT
+                const bool sq = !box_pruned<SCALE, LEVEL>(ctx, slo, shi, eps_max);
+                sub = sub || sq;
+                const unsigned long long sv = __ballot(alive && sq);
+                if (lane == 0) atomicAdd(&beam_dbg[7], (unsigned long long)__popcll(sv));
+#else
                 sub = sub || !box_pruned<SCALE, LEVEL>(ctx, slo, shi, eps_max);
+#endif
             }
             alive = alive && sub;
         }
@@ -815,12 +822,13 @@ __device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, 
     return receiver_rest<SCALE, ORDER, WAVE_EXIT>(c, r, alive);
 }
 
-// lane = level-ORDER prefix, loop over the receivers (wave-uniform scalar loads, the next one in flight)
+// lane = level-ORDER prefix, loop over the receivers
 template <int SCALE, int ORDER>
 __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in,
                                                         const unsigned long long *__restrict__ rec, int64_t n_in,
                                                         const float *__restrict__ rx_sorted,
-                                                        const int32_t *__restrict__ rx_index, int64_t nrx, float u,
+                                                        const int32_t *__restrict__ rx_index,
+                                                        const float *__restrict__ rx_boxes, int64_t nrx, float u,
                                                         long long *__restrict__ rows, int64_t cap,
                                                         unsigned long long *__restrict__ count,
                                                         unsigned long long *__restrict__ grazing) {
@@ -834,6 +842,9 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     if (have) e = emit_entry<ORDER>(M, in, rec, g, u);
     BeamCtx<SCALE, ORDER> ctx;
     build_ctx<SCALE, ORDER>(M, e, u, have, ctx);
+    if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);  // every test of this prefix is off (informational)
+    const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
+    const int nclusters = (nrx32 + 63) / 64;
     long long tail = 0;  // sum_j id_j n^(k-1-j)
     long long npow = 1;
 #pragma unroll
@@ -841,62 +852,50 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
         tail = tail * (long long)M.nprim + (long long)(have ? e.id[j] : 0);
         npow *= (long long)M.nprim;
     }
-    if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);  // every test of this prefix is off (informational)
     const long long pair0 = (long long)entry_tx(e) * (long long)nrx;
-    const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
-    // G receivers per trip, read from the Morton-sorted copy (padded to a multiple of 64 with copies of the last
-    // receiver: wave-uniform 16-byte scalar loads, the next trip's in flight): the first-pyramid tests of all G,
+    // The receivers are read from the Morton-sorted copy (clusters of 64 with a bounding box each, padded to whole
+    // clusters with copies of the last receiver; wave-uniform scalar loads).  Per cluster: ONE box test per lane
+    // (box_pruned with eps = 0: receivers are exact points) and a wave vote -- at configs[3] only 18 % of the
+    // prefixes, 36 % of the waves, reach the box of all 64 receivers with every pyramid.  Inside a cluster, four
+    // receivers per trip (three 16-byte loads, the next trip's in flight): the first-pyramid tests of all four,
     // ONE wave vote, and only the trips where some lane is still inside some receiver go on.  Same per-receiver
     // arithmetic as receiver_inside -> the same rows.
-#ifndef BEAM_EMIT_GROUP
-#define BEAM_EMIT_GROUP 4
-#endif
-    constexpr int G = BEAM_EMIT_GROUP;  // 4 or 8 (divides the padding of 64)
-    static_assert(G == 4 || G == 8, "trip size");
+    constexpr int G = 4;
     struct Trip {
-        float4 v[3 * G / 4];  // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3 | ...
+        float4 v[3];  // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
     };
     auto load_trip = [&](int t) {
-        const float4 *p4 = reinterpret_cast<const float4 *>(rx_sorted) + (3 * G / 4) * (int64_t)t;
-        Trip o;
-#pragma unroll
-        for (int k = 0; k < 3 * G / 4; ++k) o.v[k] = p4[k];
-        return o;
+        const float4 *p4 = reinterpret_cast<const float4 *>(rx_sorted) + 3 * (int64_t)t;
+        return Trip{{p4[0], p4[1], p4[2]}};
     };
     const int ntrips = (nrx32 + G - 1) / G;
-#ifdef BEAM_LAB_EMIT_TRIPS  // experiment (NOT a valid build): only the first trips of the receiver loop
-    const int lab_end = (ntrips < BEAM_LAB_EMIT_TRIPS) ? ntrips : BEAM_LAB_EMIT_TRIPS;
-#else
-    const int lab_end = ntrips;
-#endif
-    Trip nxt = load_trip(0);
-    for (int t = 0; t < lab_end; ++t) {
-        const Trip cur = nxt;
-        nxt = load_trip((t + 1 < ntrips) ? t + 1 : t);
-        V3 r[G];
+    for (int cl = 0; cl < nclusters; ++cl) {
+        const float *bx = rx_boxes + 6 * cl;
+        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        if (!__any(have && !box_pruned<SCALE, ORDER>(ctx, lo, hi, 0.0f))) continue;
+        const int t_end = ((cl + 1) * (64 / G) < ntrips) ? (cl + 1) * (64 / G) : ntrips;
+        Trip nxt = load_trip(cl * (64 / G));
+        for (int t = cl * (64 / G); t < t_end; ++t) {
+            const Trip cur = nxt;
+            nxt = load_trip((t + 1 < t_end) ? t + 1 : t);
+            const V3 r[G] = {V3{cur.v[0].x, cur.v[0].y, cur.v[0].z}, V3{cur.v[0].w, cur.v[1].x, cur.v[1].y},
+                             V3{cur.v[1].z, cur.v[1].w, cur.v[2].x}, V3{cur.v[2].y, cur.v[2].z, cur.v[2].w}};
+            bool a[G];
+            bool any_lane = false;
 #pragma unroll
-        for (int q4 = 0; q4 < G / 4; ++q4) {
-            const float4 a4 = cur.v[3 * q4], b4 = cur.v[3 * q4 + 1], c4 = cur.v[3 * q4 + 2];
-            r[4 * q4 + 0] = V3{a4.x, a4.y, a4.z};
-            r[4 * q4 + 1] = V3{a4.w, b4.x, b4.y};
-            r[4 * q4 + 2] = V3{b4.z, b4.w, c4.x};
-            r[4 * q4 + 3] = V3{c4.y, c4.z, c4.w};
-        }
-        bool a[G];
-        bool any_lane = false;
+            for (int q = 0; q < G; ++q) {
+                a[q] = receiver_first<SCALE, ORDER>(ctx, r[q], have & (G * t + q < nrx32));
+                any_lane = any_lane | a[q];
+            }
+            if (!__any(any_lane)) continue;
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-            a[q] = receiver_first<SCALE, ORDER>(ctx, r[q], have & (G * t + q < nrx32));
-            any_lane = any_lane | a[q];
-        }
-        if (!__any(any_lane)) continue;
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-            if (!__any(a[q])) continue;
-            const bool keep = receiver_rest<SCALE, ORDER, true>(ctx, r[q], a[q]);
-            const long long id = (long long)rx_index[G * t + q];
-            beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((pair0 + id) * npow + tail), wbuf[wave], wcount, lane,
-                                     reinterpret_cast<unsigned long long *>(rows), cap, count);
+            for (int q = 0; q < G; ++q) {
+                if (!__any(a[q])) continue;
+                const bool keep = receiver_rest<SCALE, ORDER, true>(ctx, r[q], a[q]);
+                const long long id = (long long)rx_index[G * t + q];
+                beam_stage<kBeamWaveBuf>(keep, (unsigned long long)((pair0 + id) * npow + tail), wbuf[wave], wcount, lane,
+                                         reinterpret_cast<unsigned long long *>(rows), cap, count);
+            }
         }
     }
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
@@ -1395,7 +1394,7 @@ static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, 
                            s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing);
     else
         hipLaunchKernelGGL((beam_emit_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 256)), dim3(256), 0, s, M, in,
-                           rec, n_in, rx_sorted, rx_index, nrx, u, rows, cap, count, grazing);
+                           rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing);
 }
 
 #define BEAM_DISPATCH2(SC, K, CALL) \

@@ -24,4 +24,5 @@ for order in (2, 3):
     b = list(buf)
     print(json.dumps({"order": order, "box_tests": b[0], "pairs": b[1], "pairs_with_children": b[2], "children": b[3],
                       "pair_frac": b[1] / max(b[0], 1), "fruitful_frac": b[2] / max(b[1], 1),
-                      "children_per_pair": b[3] / max(b[1], 1), "pairs_eps_inf": b[4], "pairs_eps_gt_1m": b[5], "pairs_eps_0p1_1m": b[6], **tr.last_beam_stats}))
+                      "children_per_pair": b[3] / max(b[1], 1), "pairs_eps_inf": b[4], "pairs_eps_gt_1m": b[5], "pairs_eps_0p1_1m": b[6], "subboxes_passing": b[7],
+                      "subboxes_per_pair": b[7] / max(b[1], 1), **tr.last_beam_stats}))
