@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
 // per-triangle padded boxes + scene bounds (atomic min/max on ordered uints)
 __global__ __launch_bounds__(256) void tri_boxes_kernel(const float *__restrict__ tv, int64_t T,
                                                         Box *__restrict__ boxes,
-                                                        uint32_t *__restrict__ scene /*[6]*/) {
+                                                        uint32_t *__restrict__ scene /*[6] + [6]: non-finite flag*/) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
     const V3 a = ld3(tv + 9 * t), b = ld3(tv + 9 * t + 3), c = ld3(tv + 9 * t + 6);
@@ -54,11 +54,14 @@ __global__ __launch_bounds__(256) void tri_boxes_kernel(const float *__restrict_
     bx.lo[1] = fminf(a.y, fminf(b.y, c.y)); bx.hi[1] = fmaxf(a.y, fmaxf(b.y, c.y));
     bx.lo[2] = fminf(a.z, fminf(b.z, c.z)); bx.hi[2] = fmaxf(a.z, fmaxf(b.z, c.z));
     boxes[t] = bx;
+    bool all_finite = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (is_finite(bx.lo[k])) atomicMin(scene + k, float_to_ordered(bx.lo[k]));
         if (is_finite(bx.hi[k])) atomicMax(scene + 3 + k, float_to_ordered(bx.hi[k]));
+        all_finite = all_finite && is_finite(bx.lo[k]) && is_finite(bx.hi[k]);
     }
+    if (!all_finite) atomicOr(scene + 6, 1u);
 }
 
 __global__ __launch_bounds__(256) void pad_and_morton_kernel(Box *__restrict__ boxes, int64_t T,
@@ -182,8 +185,52 @@ struct WideEntry {
 __device__ __forceinline__ WideEntry wide_entry(const float *lo, const float *hi, int32_t child) {
     return WideEntry{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}, child};
 }
+// the 16-bit grid of the wide nodes: the scene bounds widened by twice the boxes' padding (every finite padded box
+// lies inside), 65535 cells per axis; ok = 0 (binary walk) when some triangle box is not finite or the bounds are
+__global__ void wide_grid_kernel(const uint32_t *__restrict__ scene, Bvh4Grid *__restrict__ grid) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float slo[3], shi[3], ext = 0.0f, mag = 0.0f;
+    bool ok = scene[6] == 0u;
+    for (int k = 0; k < 3; ++k) {
+        slo[k] = ordered_to_float(scene[k]);
+        shi[k] = ordered_to_float(scene[3 + k]);
+        ok = ok && is_finite(slo[k]) && is_finite(shi[k]) && slo[k] <= shi[k];
+        ext = fmaxf(ext, shi[k] - slo[k]);
+        mag = fmaxf(mag, fmaxf(fabsf(slo[k]), fabsf(shi[k])));
+    }
+    const float pad = fmaxf(mag, ext) * 0x1p-14f + 1e-30f;  // pad_and_morton_kernel's
+    Bvh4Grid g{};
+    for (int k = 0; k < 3; ++k) {
+        const float lo = slo[k] - 2.0f * pad, hi = shi[k] + 2.0f * pad;
+        float cell = (hi - lo) * (1.0f / 65535.0f);
+        // the last grid line must not fall short of hi (one or two steps of the float above, if at all)
+        for (int it = 0; it < 64 && ok && !(bvh_q_decode(65535u, cell, lo) >= hi); ++it)
+            cell = __uint_as_float(__float_as_uint(cell) + 1u);
+        ok = ok && is_finite(lo) && is_finite(hi) && is_finite(cell) && cell > 0.0f && bvh_q_decode(65535u, cell, lo) >= hi;
+        g.lo[k] = lo;
+        g.cell[k] = cell;
+    }
+    g.ok = ok ? 1u : 0u;
+    *grid = g;
+}
+
+// largest grid line <= v / smallest grid line >= v, by the decode expression itself (v finite and inside the grid
+// whenever the grid is in use; anything else lands on an end line and the wide walk is off)
+__device__ __forceinline__ uint16_t quant_down(float v, float cell, float lo) {
+    const float x = (v - lo) / cell;
+    uint32_t q = (x >= 1.0f) ? ((x < 65535.0f) ? (uint32_t)x : 65535u) : 0u;  // NaN -> 0
+    while (q > 0u && bvh_q_decode(q, cell, lo) > v) --q;
+    return (uint16_t)q;
+}
+__device__ __forceinline__ uint16_t quant_up(float v, float cell, float lo) {
+    const float x = (v - lo) / cell;
+    uint32_t q = (x <= 65534.0f) ? ((x > 0.0f) ? (uint32_t)x + 1u : 0u) : 65535u;  // NaN -> 65535
+    while (q < 65535u && bvh_q_decode(q, cell, lo) < v) ++q;
+    return (uint16_t)q;
+}
+
 __global__ __launch_bounds__(256) void collapse_kernel(const BvhNode *__restrict__ nodes, int64_t n_internal,
-                                                       Bvh4Node *__restrict__ wide) {
+                                                       const Bvh4Grid *__restrict__ grid, Bvh4Node *__restrict__ wide) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= n_internal) return;
     const BvhNode nd = nodes[b];
@@ -201,19 +248,19 @@ __global__ __launch_bounds__(256) void collapse_kernel(const BvhNode *__restrict
         r0 = wide_entry(g.llo, g.lhi, g.left);
         r1 = wide_entry(g.rlo, g.rhi, g.right);
     }
-    // slots: l0, then l1 if there is one, then r0, r1; empty slots last (inverted box, kBvhNoChild)
+    // slots: l0, then l1 if there is one, then r0, r1; empty slots last (kBvhNoChild)
     const bool two_l = nd.left >= 0;
     const WideEntry e[4] = {l0, two_l ? l1 : r0, two_l ? r0 : r1, two_l ? r1 : none};
+    const float glo[3] = {grid->lo[0], grid->lo[1], grid->lo[2]}, cell[3] = {grid->cell[0], grid->cell[1], grid->cell[2]};
     Bvh4Node w;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            w.lo[k][c] = e[k].lo[c];
-            w.hi[k][c] = e[k].hi[c];
+            w.qlo[k][c] = quant_down(e[k].lo[c], cell[c], glo[c]);
+            w.qhi[k][c] = quant_up(e[k].hi[c], cell[c], glo[c]);
         }
         w.child[k] = e[k].child;
-        w.pad[k] = 0;
     }
     wide[b] = w;
 }
@@ -345,24 +392,24 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
             return fail(DRT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
         }                                                                                \
     } while (0)
-    // binary nodes, then (128-B aligned) one 4-ary node per binary node
+    // binary nodes, then (128-B aligned) the grid header and one 4-ary node per binary node
     const size_t wide_off = (size_t)bvh_wide_offset(T);
-    TRY_HIP(hipMalloc(&nodes, wide_off * sizeof(BvhNode) + nn * sizeof(Bvh4Node)));
+    TRY_HIP(hipMalloc(&nodes, wide_off * sizeof(BvhNode) + bvh_wide_bytes(T)));
     TRY_HIP(hipMalloc(&tri_boxes, (size_t)T * sizeof(Box)));
     TRY_HIP(hipMalloc(&node_boxes, nn * sizeof(Box)));
     TRY_HIP(hipMalloc(&keys, (size_t)T * 8));
     TRY_HIP(hipMalloc(&keys_sorted, (size_t)T * 8));
     TRY_HIP(hipMalloc(&ids, (size_t)T * 4));
     TRY_HIP(hipMalloc(&ids_sorted, (size_t)T * 4));
-    TRY_HIP(hipMalloc(&scene, 24));
+    TRY_HIP(hipMalloc(&scene, 32));
     TRY_HIP(hipMalloc(&flags, nn * 4));
     TRY_HIP(hipMalloc(&par_int, nn * 4));
     TRY_HIP(hipMalloc(&par_leaf, (size_t)T * 4));
     // scene bounds as ordered uints: min slots start at +max, max slots at 0
     TRY_HIP(hipMemsetAsync(scene, 0xff, 12, s));
-    TRY_HIP(hipMemsetAsync(scene + 3, 0, 12, s));
+    TRY_HIP(hipMemsetAsync(scene + 3, 0, 20, s));  // max slots and the non-finite flag
     TRY_HIP(hipMemsetAsync(flags, 0, nn * 4, s));
-    TRY_HIP(hipMemsetAsync(nodes, 0, nn * sizeof(BvhNode), s));
+    TRY_HIP(hipMemsetAsync(nodes, 0, wide_off * sizeof(BvhNode) + sizeof(Bvh4Grid), s));  // (grid.ok = 0 until built)
     const dim3 gt((unsigned)ceil_div(T, 256));
     hipLaunchKernelGGL(tri_boxes_kernel, gt, dim3(256), 0, s, m->tri_verts, T, tri_boxes, scene);
     hipLaunchKernelGGL(pad_and_morton_kernel, gt, dim3(256), 0, s, tri_boxes, T, scene, keys, ids);
@@ -378,8 +425,10 @@ int32_t drt_mesh_build_bvh(drt_mesh_t m, void *stream) {
                            keys_sorted, T, nodes, par_int, par_leaf);
         hipLaunchKernelGGL(refit_kernel, gt, dim3(256), 0, s, T, ids_sorted, tri_boxes, nodes, par_int,
                            par_leaf, node_boxes, flags);
-        hipLaunchKernelGGL(collapse_kernel, dim3((unsigned)ceil_div(T - 1, 256)), dim3(256), 0, s, nodes, T - 1,
-                           reinterpret_cast<Bvh4Node *>(nodes + wide_off));
+        Bvh4Grid *grid = reinterpret_cast<Bvh4Grid *>(nodes + wide_off);
+        hipLaunchKernelGGL(wide_grid_kernel, dim3(1), dim3(64), 0, s, scene, grid);
+        hipLaunchKernelGGL(collapse_kernel, dim3((unsigned)ceil_div(T - 1, 256)), dim3(256), 0, s, nodes, T - 1, grid,
+                           reinterpret_cast<Bvh4Node *>(grid + 1));
         TRY_HIP(hipGetLastError());
     }
     TRY_HIP(hipStreamSynchronize(s));

@@ -25,22 +25,41 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
 // with incoherent rays on a 200k-triangle mesh the walk is a chain of L2 / MALL latencies, not arithmetic.
 // Wide node i describes binary node i (every binary node gets one; only those reachable from the root by
 // two-level steps are ever visited).  They live in the same allocation, behind the binary nodes (which stay:
-// leaf ranges, refit).  child: >= 0 binary / wide node index, < 0 leaf (triangle id = ~child); an empty slot has an
-// inverted box (never hit) and child = kBvhNoChild.
+// leaf ranges, refit, and the walk of a mesh whose boxes are not all finite).  child: >= 0 binary / wide node
+// index, < 0 leaf (triangle id = ~child); an empty slot has child = kBvhNoChild.
 struct __attribute__((aligned(16))) Bvh4Node {
-    float lo[4][3];
-    float hi[4][3];
+    uint16_t qlo[4][3];  // child boxes on a 16-bit grid over the padded scene bounds (Bvh4Grid), rounded OUTWARD:
+    uint16_t qhi[4][3];  // decode(qlo) <= lo and decode(qhi) >= hi, checked with the decode expression itself at build
     int32_t child[4];
-    uint32_t pad[4];
 };
-static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 B");
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node must be 64 B");  // four 16-byte loads per lane and node: with incoherent
+                                                                   // rays the walk is bound by L1 look-ups per lane
+// header of the wide region: the grid, and whether the wide walk may be used at all (every triangle box finite)
+struct __attribute__((aligned(16))) Bvh4Grid {
+    float lo[3];
+    float cell[3];
+    uint32_t ok;
+    uint32_t pad[9];
+};
+static_assert(sizeof(Bvh4Grid) == 64, "Bvh4Grid must be 64 B");
 constexpr int32_t kBvhNoChild = 0x7fffffff;
 __host__ __device__ inline int64_t bvh_wide_offset(int64_t T) {  // in BvhNode units, 128-B aligned
     const int64_t nn = T > 1 ? T - 1 : 1;
     return (nn + 1) & ~(int64_t)1;
 }
+__host__ __device__ inline size_t bvh_wide_bytes(int64_t T) {  // header + one wide node per binary node
+    const int64_t nn = T > 1 ? T - 1 : 1;
+    return sizeof(Bvh4Grid) + (size_t)nn * sizeof(Bvh4Node);
+}
+__device__ __forceinline__ const Bvh4Grid *bvh_grid(const BvhNode *nodes, int64_t T) {
+    return reinterpret_cast<const Bvh4Grid *>(nodes + bvh_wide_offset(T));
+}
 __device__ __forceinline__ const Bvh4Node *bvh_wide(const BvhNode *nodes, int64_t T) {
-    return reinterpret_cast<const Bvh4Node *>(nodes + bvh_wide_offset(T));
+    return reinterpret_cast<const Bvh4Node *>(bvh_grid(nodes, T) + 1);
+}
+// THE decode expression (build-time check and walk use this one function)
+__device__ __forceinline__ float bvh_q_decode(uint32_t q, float cell, float lo) {
+    return __builtin_fmaf((float)q, cell, lo);
 }
 
 // ---- traversal ---------------------------------------------------------------------------------
@@ -90,6 +109,8 @@ template <int BLOCK, bool ORDERED, class Leaf>
 __device__ __forceinline__ void bvh_walk4(const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids,
                                           int64_t T, const RayPrep &ray, const float &limit, int32_t *col, Leaf &&leaf) {
     const Bvh4Node *__restrict__ wide = bvh_wide(nodes, T);
+    const Bvh4Grid *__restrict__ grid = bvh_grid(nodes, T);  // wave-uniform: scalar loads
+    const float glo[3] = {grid->lo[0], grid->lo[1], grid->lo[2]}, cell[3] = {grid->cell[0], grid->cell[1], grid->cell[2]};
     int sp = 0;
     int32_t node = (T == 1) ? ~0 : 0;  // T == 1: the single triangle is tested directly
     // a child that cannot be pushed (column full) is dealt with here and now: its whole subtree through the
@@ -111,8 +132,12 @@ __device__ __forceinline__ void bvh_walk4(const BvhNode *__restrict__ nodes, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float a0, a1;
-                slab(ray, nd.lo[i], nd.hi[i], a0, a1);
-                // (an empty slot's inverted infinite box passes the slab test with t in (-inf, +inf): test the id)
+                const float lo[3] = {bvh_q_decode(nd.qlo[i][0], cell[0], glo[0]), bvh_q_decode(nd.qlo[i][1], cell[1], glo[1]),
+                                     bvh_q_decode(nd.qlo[i][2], cell[2], glo[2])};
+                const float hi[3] = {bvh_q_decode(nd.qhi[i][0], cell[0], glo[0]), bvh_q_decode(nd.qhi[i][1], cell[1], glo[1]),
+                                     bvh_q_decode(nd.qhi[i][2], cell[2], glo[2])};
+                slab(ray, lo, hi, a0, a1);
+                // (an empty slot has no box: test the id)
                 const bool hit = (a0 <= a1) && (a1 >= 0.0f) && (a0 <= limit) && (nd.child[i] != kBvhNoChild);
                 t0[i] = hit ? a0 : kInf;
                 ch[i] = hit ? nd.child[i] : kBvhNoChild;
@@ -211,11 +236,16 @@ __device__ __forceinline__ void bvh_walk2(const BvhNode *__restrict__ nodes, con
 // Which tree a walk uses (measured, 1e6 incoherent rays, profiles/r03/bvh.md): any-hit walks are faster on the 4-ary
 // tree at every size (200k triangles: 1.84e9 vs 1.65e9 rays/s); ordered (first-hit) walks pay for sorting four
 // children and win only on big meshes (200k: 1.46e9 vs 1.41e9; 10k: 4.2e9 vs 4.5e9) -- a wave-uniform switch on T.
-constexpr int64_t kBvhWideOrderedMinT = 65536;
+#ifndef DRT_BVH_WIDE_ORDERED_MIN_T
+#define DRT_BVH_WIDE_ORDERED_MIN_T 65536
+#endif
+constexpr int64_t kBvhWideOrderedMinT = DRT_BVH_WIDE_ORDERED_MIN_T;
 template <int BLOCK, bool ORDERED, class Leaf>
 __device__ __forceinline__ void bvh_walk(const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids,
                                          int64_t T, const RayPrep &ray, const float &limit, int32_t *col, Leaf &&leaf) {
-    if (!ORDERED || T >= kBvhWideOrderedMinT) bvh_walk4<BLOCK, ORDERED>(nodes, leaf_ids, T, ray, limit, col, leaf);
+    // (a mesh with a non-finite triangle box has no grid: binary walk on the float boxes)
+    const bool wide_ok = __builtin_amdgcn_readfirstlane((int)bvh_grid(nodes, T)->ok) != 0;
+    if (wide_ok && (!ORDERED || T >= kBvhWideOrderedMinT)) bvh_walk4<BLOCK, ORDERED>(nodes, leaf_ids, T, ray, limit, col, leaf);
     else bvh_walk2<BLOCK, ORDERED>(nodes, leaf_ids, T, ray, limit, col, leaf);
 }
 

@@ -130,6 +130,49 @@ def test_tiny_meshes(G):
     assert not _np(e.ray_intersect_any_triangle(o, d, accel="bvh")).any()
 
 
+@pytest.mark.parametrize(
+    "case", ["far_from_origin", "flat", "huge_extent", "non_finite", "tiny", "big_far"], ids=str
+)
+def test_quantised_wide_nodes_stay_conservative(G, rng, case):
+    """The 4-ary nodes hold their child boxes on a 16-bit grid over the scene (csrc/bvh.hpp, Bvh4Node), rounded
+    outward with the decode expression itself: results stay bit-identical to the brute-force operators where the
+    grid is coarser than the coordinates' float spacing is fine (far from the origin), degenerate (flat scene),
+    stretched by one remote triangle, or unusable (a non-finite vertex: binary walk)."""
+    T, R = 6000, 30000
+    tv = rng.uniform(-30, 30, (T, 3, 3)).astype(np.float32)
+    tv[:, 1:] = tv[:, :1] + rng.normal(0, 1.0, (T, 2, 3)).astype(np.float32)
+    shift = np.zeros(3, np.float32)
+    if case == "far_from_origin":  # ulp(1e6) = 0.0625 > the grid cell (60 / 65535)
+        shift = np.array([1.0e6, -2.0e6, 5.0e5], np.float32)
+    elif case == "big_far":  # ordered walks on the wide tree need >= 65536 triangles
+        T = 70000
+        tv = rng.uniform(-300, 300, (T, 3, 3)).astype(np.float32)
+        tv[:, 1:] = tv[:, :1] + rng.normal(0, 2.0, (T, 2, 3)).astype(np.float32)
+        shift = np.array([3.0e5, 3.0e5, -3.0e5], np.float32)
+    elif case == "flat":
+        tv[..., 2] = 0.0
+    elif case == "huge_extent":
+        tv[0] = np.array([[1e30, 0, 0], [1e30, 1e28, 0], [1e30, 0, 1e28]], np.float32)
+    elif case == "non_finite":
+        tv[0, 1, 0] = np.inf
+        tv[1, 2, 2] = np.nan
+        tv[2, 0, 1] = -np.inf
+    elif case == "tiny":
+        tv *= 1e-20
+    tv = tv + shift
+    span = 40.0 if case != "big_far" else 350.0
+    scale = 1e-20 if case == "tiny" else 1.0
+    o = (rng.uniform(-span, span, (R, 3)) * scale).astype(np.float32) + shift
+    tgt = tv[rng.integers(0, T, R), rng.integers(0, 3, R)]  # aim at vertices: grazing box faces
+    tgt = np.where(np.isfinite(tgt), tgt, 0.0).astype(np.float32)
+    d = (tgt - o) * rng.uniform(0.5, 2.0, (R, 1)).astype(np.float32)
+    d[: R // 4] = rng.normal(size=(R // 4, 3)).astype(np.float32) * np.float32(scale * 10)
+    mesh = G.Mesh(tv.reshape(-1, 3), np.arange(3 * T, dtype=np.int32).reshape(T, 3))
+    hits, _ = _check(G, mesh, o, d)
+    if case in ("far_from_origin", "big_far", "flat"):
+        assert hits > R // 100
+
+
 def test_bvh_first_hit_gradients(G):
     """The BVH path keeps the custom VJP (test_mesh.py:2028-2072)."""
     mesh0 = G.Mesh.box(2.0, 2.0, 2.0)
