@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void bvh_visibility_kernel(
     const RayPrep ray = prep_ray(ld3(view + 3 * b), lattice_direction(i, num_rays, frusta + 6 * b));
     float best_t = kInf;
     int64_t best_j = -1;
-    bvh_walk<256, true>(nodes, leaf_ids, T, ray, best_t, col, [&](int64_t j) {
+    bvh_walk<256, true, true>(nodes, leaf_ids, T, ray, best_t, col, [&](int64_t j) {  // lattice rays: coherent
         float t;
         const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) && (!mask || mask[j]);
         if (h && is_finite(t) && (t < best_t || (t == best_t && j < best_j))) {

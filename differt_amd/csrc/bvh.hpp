@@ -233,20 +233,25 @@ __device__ __forceinline__ void bvh_walk2(const BvhNode *__restrict__ nodes, con
     }
 }
 
-// Which tree a walk uses (measured, 1e6 incoherent rays, profiles/r03/bvh.md): any-hit walks are faster on the 4-ary
-// tree at every size (200k triangles: 1.84e9 vs 1.65e9 rays/s); ordered (first-hit) walks pay for sorting four
-// children and win only on big meshes (200k: 1.46e9 vs 1.41e9; 10k: 4.2e9 vs 4.5e9) -- a wave-uniform switch on T.
+// Which tree a walk uses (measured, 1e6 rays, profiles/r03/bvh.md).  Incoherent rays -- every lane of a load another
+// line -- are bound by L1 look-ups per lane: the 64-B wide node serves four children with the four 16-byte loads the
+// binary node spends on two, and wins at every size, ordered or not (10k triangles: first hit 5.3e9 vs 4.5e9, any hit
+// 6.9e9 vs 5.5e9 rays/s).  COHERENT rays (the lattices of launch_paths and of the visibility estimate) share their
+// lines; there the ordered wide walk pays for decoding and sorting four children and loses below ~65k triangles
+// (launch_paths order 3, 10k triangles: 1.23e9 vs 1.14e9 rays/s) -- a wave-uniform switch on T for those callers.
 #ifndef DRT_BVH_WIDE_ORDERED_MIN_T
 #define DRT_BVH_WIDE_ORDERED_MIN_T 65536
 #endif
 constexpr int64_t kBvhWideOrderedMinT = DRT_BVH_WIDE_ORDERED_MIN_T;
-template <int BLOCK, bool ORDERED, class Leaf>
+template <int BLOCK, bool ORDERED, bool COHERENT = false, class Leaf>
 __device__ __forceinline__ void bvh_walk(const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids,
                                          int64_t T, const RayPrep &ray, const float &limit, int32_t *col, Leaf &&leaf) {
     // (a mesh with a non-finite triangle box has no grid: binary walk on the float boxes)
     const bool wide_ok = __builtin_amdgcn_readfirstlane((int)bvh_grid(nodes, T)->ok) != 0;
-    if (wide_ok && (!ORDERED || T >= kBvhWideOrderedMinT)) bvh_walk4<BLOCK, ORDERED>(nodes, leaf_ids, T, ray, limit, col, leaf);
-    else bvh_walk2<BLOCK, ORDERED>(nodes, leaf_ids, T, ray, limit, col, leaf);
+    if (wide_ok && (!(ORDERED && COHERENT) || T >= kBvhWideOrderedMinT))
+        bvh_walk4<BLOCK, ORDERED>(nodes, leaf_ids, T, ray, limit, col, leaf);
+    else
+        bvh_walk2<BLOCK, ORDERED>(nodes, leaf_ids, T, ray, limit, col, leaf);
 }
 
 // packed first-hit key, see ray_ops.hip: smallest t, then the LATEST batch_size-tile, then the lowest
@@ -275,7 +280,7 @@ inline TileTieB make_tie_b(int64_t T, int64_t batch_size) {
 
 // closest hit through the BVH as a packed key (~0 = miss); boxes entered at t <= best t are still
 // visited so that ties resolve exactly like the brute-force kernels
-template <int BLOCK>
+template <int BLOCK, bool COHERENT = false>
 __device__ __forceinline__ uint64_t bvh_first_hit(const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ leaf_ids,
                                                   int64_t T, const float *__restrict__ tv,
                                                   const uint8_t *__restrict__ mask, V3 o, V3 d,
@@ -283,7 +288,7 @@ __device__ __forceinline__ uint64_t bvh_first_hit(const BvhNode *__restrict__ no
     const RayPrep ray = prep_ray(o, d);
     uint64_t best = ~0ull;
     float best_t = kInf;
-    bvh_walk<BLOCK, true>(nodes, leaf_ids, T, ray, best_t, col, [&](int64_t j) {
+    bvh_walk<BLOCK, true, COHERENT>(nodes, leaf_ids, T, ray, best_t, col, [&](int64_t j) {
         float t;
         const bool h = moller_trumbore(ray.o, ray.d, load_tri(tv + 9 * j), eps, t) && (!mask || mask[j]);
         if (h && is_finite(t)) {

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void launch_paths_kernel(
     for (int b = 0; b <= order; ++b) {
         int32_t tri = -1;
         float t_hit = kInf;
-        if (T > 0) decode_first_hit(bvh_first_hit<256>(nodes, leaf_ids, T, tv, mask, o, d, eps, tt, col), tt, tri, t_hit);
+        if (T > 0) decode_first_hit(bvh_first_hit<256, true>(nodes, leaf_ids, T, tv, mask, o, d, eps, tt, col), tt, tri, t_hit);
         // filter_rays (_solvers.py:340-356): squared distance between the receiver and the ray, only
         // for receivers ahead of the origin and before the hit
         for (int64_t ir = 0; ir < nrx; ++ir) {
