@@ -494,7 +494,7 @@ int32_t drt_trace_paths_vjp_ex(drt_mesh_t mesh, const drt_trace_params *params, 
  *   vertices [max_paths,order+2,3] f32, objects [max_paths,order+2] i32 (triangle ids, even for quads)
  *   *num_valid_host: number of valid paths; the call synchronises the stream (list sizes are read back once
  *   per level / slice).  DRT_E_CAPACITY: a capacity of drt_beam_params / max_paths / the workspace is too small
- *   (*num_valid_host then holds the count that did not fit).
+ *   (*num_valid_host then holds the count that did not fit).  workspace: device memory, 16-byte aligned.
  * Gradients: drt_trace_paths_vjp with a drt_candidates of {table NULL, num_nodes = n, order,
  * reserved = DRT_CAND_PACKED_KEYS} and these keys.
  * Everything -- Morton clustering of primitives (cached in the mesh handle, like the LBVH) and receivers,
@@ -512,14 +512,14 @@ typedef struct drt_beam_stats {
 } drt_beam_stats;
 
 #define DRT_BEAM_EXPAND_PLAIN 1   /* expansion: every (prefix, primitive) pair tested, no cluster culling */
-#define DRT_BEAM_EMIT_PLAIN 2     /* receiver stage: every (prefix, receiver) pair tested */
+#define DRT_BEAM_EMIT_PLAIN 2     /* receiver stage: lane = prefix walks the receivers (after a vote on their clusters' boxes) */
 #define DRT_BEAM_EMIT_CLUSTERED 4 /* receiver stage: Morton clusters of 64 even below 128 receivers */
 /* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on) */
 
 typedef struct drt_beam_params {
     float kappa;            /* error unit u = kappa * ulp(M); <= 0: default 64 = the worst-case rounding count of
                                DESIGN.md section 9 (measured errors are 5-50x smaller: oracle/studies/beam_error_model.py;
-                               configs[3]: 1.26 s at 64, 0.87 s at 16, same paths) */
+                               configs[3]: 1.10 s at 64, 0.78 s at 16, same paths) */
     int32_t flags;          /* DRT_BEAM_* */
     int64_t max_entries;    /* level-2 prefix list (order 3), 32 B each; <= 0: 2^26 */
     int64_t max_records;    /* records of one expansion slice, 8 B each; <= 0: 2^27 */

@@ -187,6 +187,12 @@ def test_capacities_are_errors_or_retries_never_wrong_results(G):
         _lib.call("drt_trace_paths_beam", mesh.handle().h, C.byref(pr), None, ptr(t), t.shape[0], ptr(r), r.shape[0], 2, 64,
                   ptr(keys), ptr(verts), ptr(objs), C.byref(nv), ptr(ws), 1024, stream())
     assert nv.value == 0
+    # a workspace that is large enough but not 16-byte aligned (the receiver stage reads it with 16-byte loads)
+    need = _lib.load().drt_trace_beam_workspace_size(t.shape[0], r.shape[0], Tr.shape[0], 2, None, 64)
+    big = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError, match="aligned"):
+        _lib.call("drt_trace_paths_beam", mesh.handle().h, C.byref(pr), None, ptr(t), t.shape[0], ptr(r), r.shape[0], 2, 64,
+                  ptr(keys), ptr(verts), ptr(objs), C.byref(nv), big.data_ptr() + 4, need, stream())
 
 
 @pytest.mark.parametrize("assume_quads", [False, True])
