@@ -131,6 +131,28 @@ def test_slivers_and_quads(G, rng):
     assert check(G, V, Tr, tx, rx, assume_quads=True, min_paths=5) > 0
 
 
+@pytest.mark.parametrize("nrx", [1, 2, 3, 5, 63, 64, 65, 127, 128, 130])
+def test_receiver_counts_around_trip_and_cluster_boundaries(G, nrx):
+    """The receiver stage reads the receivers in trips of four from a copy padded to whole clusters of 64 (plain
+    mapping, below 128 receivers) or per cluster (from 128 on): every count around those boundaries, both mappings
+    forced, against the exhaustive tracer; a NaN receiver in the set changes nothing for the others."""
+    V, Tr, c, h = S.manhattan(30, seed=5)
+    tx, rx = S.manhattan_tx_rx(c, h, 2, nrx, seed=23)
+    mesh = G.Mesh(V, Tr)
+    tracer = G.ExhaustivePathTracer()
+    for poison in (False, True):
+        r = np.array(rx, np.float32)
+        if poison:
+            r[nrx // 2] = np.nan
+        scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(r, device="cuda"), mesh)
+        for order in (1, 2):
+            ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+            for emit in ("plain", "clustered"):
+                bp = tracer.trace_beam_pruned(scene, order, emit=emit, max_paths=1 << 18)
+                assert torch.equal(bp.objects, ex.objects), (order, emit, poison)
+                assert torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+
+
 def test_small_error_unit_still_complete_here(G):
     """Slack of the bounds on ordinary geometry: with an error unit 16x smaller than the default the random
     cities of the stress driver still lose nothing (evidence for the constants, not part of the guarantee)."""
