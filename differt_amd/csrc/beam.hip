@@ -756,16 +756,142 @@ __global__ __launch_bounds__(256) void beam_finish_kernel(BeamMesh M, const Beam
     out[i] = beam_child<LEVEL>(M, src[r >> 32], (int32_t)(uint32_t)r, u);
 }
 
-template <int ORDER>
-__device__ __forceinline__ BeamEntry emit_entry(const BeamMesh &M, const BeamEntry *__restrict__ in,
-                                                const unsigned long long *__restrict__ rec, int64_t g, float u) {
-    if constexpr (ORDER >= 2) {
-        if (rec) {  // (level ORDER-1 prefix, last primitive) record: build the level-ORDER prefix here
-            const unsigned long long r = rec[g];
-            return beam_child<ORDER - 1>(M, in[r >> 32], (int32_t)(uint32_t)r, u);
+// ---- the same set-up from geometry loaded ONCE -----------------------------------------------------------------
+// beam_child + build_ctx read a mirror's vertices up to three times (plane, error bound, pyramid) in as many
+// dependent phases; the receiver stage, whose set-up is a third of its time, loads every mirror once -- the new
+// mirror's data together with the source prefix, the others as soon as that prefix is there -- and feeds the SAME
+// expressions (checked against the loading forms by the mapping tests: identical rows).
+template <int SCALE>
+struct PrimGeom {
+    V3 v[SCALE][3];
+    V3 n[SCALE];
+    float sg[SCALE];
+};
+template <int SCALE>
+__device__ __forceinline__ PrimGeom<SCALE> load_prim(const BeamMesh &M, int64_t p) {
+    PrimGeom<SCALE> g;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        const int64_t f = p * SCALE + t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g.v[t][k] = ld3(M.tv + 9 * f + 3 * k);
+        g.n[t] = ld3(M.normals + 3 * f);
+        g.sg[t] = M.shape[f];
+    }
+    return g;
+}
+template <int SCALE>  // prim_eps_global
+__device__ __forceinline__ float prim_eps_from(const PrimGeom<SCALE> &g, V3 I, float u) {
+    float D = 0.0f, h = kInf, sg = 0.0f;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        h = fminf(h, plane_dist(I, g.n[t], plane_offset(g.n[t], g.v[t][0])));
+        sg = fmaxf(sg, g.sg[t]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D = fmaxf(D, margin_len(g.v[t][k] - I));
+    }
+    return beam_eps(u, sg, D, h);
+}
+template <int SCALE>  // side_of_prim
+__device__ __forceinline__ int side_from(const PrimGeom<SCALE> &g, V3 pt, V3 n, float E) {
+    float dmin = kInf, dmax = -kInf;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = fdot(g.v[t][k] - pt, n);
+            dmin = fminf(dmin, d);
+            dmax = fmaxf(dmax, d);
+        }
+    if (!(dmin == dmin) || !(dmax == dmax)) return 0;
+    return side_of_range(dmin, dmax, E);
+}
+template <int SCALE, int LEVEL>  // beam_child; gc = the new mirror, glast = the parent's last mirror
+__device__ __forceinline__ BeamEntry beam_child_from(const BeamMesh &M, const BeamEntry &e, int32_t c,
+                                                     const PrimGeom<SCALE> &gc, const PrimGeom<SCALE> &glast, float u) {
+    const V3 pc = gc.v[0][0], nc = gc.n[0];
+    const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    const V3 I2 = image_of_vertex(I, pc, nc);
+    BeamEntry o = e;
+    o.id[LEVEL] = c;
+    o.apex[0] = I2.x;
+    o.apex[1] = I2.y;
+    o.apex[2] = I2.z;
+    const float us = u * fmaxf(mag_scale(M, I), mag_scale(M, I2));
+    o.esum = e.esum + prim_eps_from<SCALE>(gc, I, us);
+    o.tx_side = pack_tx_side(entry_tx(e), side_from<SCALE>(glast, pc, nc, e.esum + 2.0f * us));
+    return o;
+}
+template <int SCALE, int LEVEL>  // build_ctx
+__device__ __forceinline__ void build_ctx_from(const BeamMesh &M, const BeamEntry &e, const PrimGeom<SCALE> (&geo)[LEVEL],
+                                               float u, bool have, BeamCtx<SCALE, LEVEL> &c) {
+    c.I = V3{e.apex[0], e.apex[1], e.apex[2]};
+    u = u * mag_scale(M, c.I);
+    c.u = u;
+    c.pm = V3{0, 0, 0};
+    c.nm = V3{0, 0, 1};
+    c.side_prev = have ? entry_side(e) : 0;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j)
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            c.pyr[j][t].n[0] = c.pyr[j][t].n[1] = c.pyr[j][t].n[2] = V3{0, 0, 0};
+            c.pyr[j][t].g[0] = c.pyr[j][t].g[1] = c.pyr[j][t].g[2] = 0.0f;
+        }
+    if (!have) return;
+    c.pm = geo[LEVEL - 1].v[0][0];
+    c.nm = geo[LEVEL - 1].n[0];
+    float lat = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) {
+        float sg = geo[j].sg[0];
+        if (SCALE == 2) sg = fmaxf(sg, geo[j].sg[SCALE - 1]);
+        lat += u * sg;
+    }
+    const float delta = 2.0f * lat;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) {
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t) {
+            V3 v[3] = {geo[j].v[t][0], geo[j].v[t][1], geo[j].v[t][2]};
+#pragma unroll
+            for (int r = j + 1; r < LEVEL; ++r) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], geo[r].v[0][0], geo[r].n[0]);
+            }
+            c.pyr[j][t] = make_pyr(c.I, v[0], v[1], v[2], delta);
         }
     }
-    return in[g];
+}
+
+// prefix g of the receiver stage (a level-ORDER entry, or a (level ORDER-1 prefix, last primitive) record whose
+// child is built here) and its context, every mirror loaded once
+template <int SCALE, int ORDER>
+__device__ __forceinline__ void emit_setup(const BeamMesh &M, const BeamEntry *__restrict__ in,
+                                           const unsigned long long *__restrict__ rec, int64_t g, bool have, float u,
+                                           BeamEntry &e, BeamCtx<SCALE, ORDER> &ctx) {
+    PrimGeom<SCALE> geo[ORDER] = {};
+    if (have) {
+        bool from_record = false;
+        if constexpr (ORDER >= 2) {
+            if (rec) {
+                from_record = true;
+                const unsigned long long r = rec[g];
+                const int32_t c = (int32_t)(uint32_t)r;
+                geo[ORDER - 1] = load_prim<SCALE>(M, c);  // (does not wait for the source prefix)
+                const BeamEntry par = in[r >> 32];
+#pragma unroll
+                for (int j = 0; j < ORDER - 1; ++j) geo[j] = load_prim<SCALE>(M, par.id[j]);
+                e = beam_child_from<SCALE, ORDER - 1>(M, par, c, geo[ORDER - 1], geo[ORDER - 2], u);
+            }
+        }
+        if (!from_record) {
+            e = in[g];
+#pragma unroll
+            for (int j = 0; j < ORDER; ++j) geo[j] = load_prim<SCALE>(M, e.id[j]);
+        }
+    }
+    build_ctx_from<SCALE, ORDER>(M, e, geo, u, have, ctx);
 }
 
 // receiver r vs prefix: on the wrong side of the last mirror, or outside one of the pyramids?  The pyramids in
@@ -839,9 +965,8 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
-    if (have) e = emit_entry<ORDER>(M, in, rec, g, u);
     BeamCtx<SCALE, ORDER> ctx;
-    build_ctx<SCALE, ORDER>(M, e, u, have, ctx);
+    emit_setup<SCALE, ORDER>(M, in, rec, g, have, u, e, ctx);
     if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);  // every test of this prefix is off (informational)
     const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
     const int nclusters = (nrx32 + 63) / 64;
@@ -919,9 +1044,8 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
     const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
-    if (have) e = emit_entry<ORDER>(M, in, rec, g, u);
     BeamCtx<SCALE, ORDER> ctx;
-    build_ctx<SCALE, ORDER>(M, e, u, have, ctx);
+    emit_setup<SCALE, ORDER>(M, in, rec, g, have, u, e, ctx);
     long long tail = 0, npow = 1;
 #pragma unroll
     for (int j = 0; j < ORDER; ++j) {
