@@ -561,6 +561,94 @@ struct BeamClusters {
     int64_t nclusters;
 };
 
+// The LAST expansion may drop a child before its record is written: a child none of whose receivers can lie inside
+// its narrowest pyramid (the first mirror, unfolded through every later one) yields no row in the receiver stage.
+// box = bounds of all receivers (finite ones; `on` = 0 when some receiver is not finite, or at earlier levels).
+struct RxAll {
+    float lo[3], hi[3];
+    int32_t on;
+};
+// what that test needs from the PARENT prefix besides its context: per face of its narrowest pyramid the distance
+// rho of the apex from the edge line (pyr_face's expression; a reflection does not change it), and the sum of its
+// mirrors' shape factors
+template <int SCALE, int LEVEL>
+__device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamEntry &e, V3 I, bool have,
+                                                  float (&rho)[SCALE][3], float &sig_sum) {
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) rho[t][0] = rho[t][1] = rho[t][2] = 0.0f;
+    sig_sum = kInf;
+    if (!have) return;
+    sig_sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j) {
+        float sg = M.shape[(int64_t)e.id[j] * SCALE];
+        if (SCALE == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * SCALE + 1]);
+        sig_sum += sg;
+    }
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        const float *tri = M.tv + 9 * ((int64_t)e.id[0] * SCALE + t);
+        V3 v[3] = {ld3(tri), ld3(tri + 3), ld3(tri + 6)};
+#pragma unroll
+        for (int r = 1; r < LEVEL; ++r) {
+            V3 pt, n;
+            prim_plane(M, e.id[r], pt, n);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const V3 a = v[f], b = v[(f + 1) % 3];
+            const V3 N = cross(a - I, b - I);
+            const float len = __builtin_amdgcn_sqrtf(fdot(N, N));
+            const V3 ed = b - a;
+            const float el = __builtin_amdgcn_sqrtf(fdot(ed, ed));
+            rho[t][f] = (el > 0.0f) ? 0.9999f * len * __builtin_amdgcn_rcpf(el) : 0.0f;
+        }
+    }
+}
+// true: NO point of the receivers' box can lie inside the narrowest pyramid of the child (parent prefix + new mirror
+// with plane <nc, x> = dc and shape factor sig_c) -- the receiver stage would reject every receiver for that pyramid
+// alone.  The child's pyramid is the parent's, reflected in the new plane: apex I3, face normals reflected, the same
+// rho; its slopes use the CHILD's lateral tolerance.  Margins strictly wider than the receiver stage's own (which
+// builds the pyramid from reflected vertices): rho 0.1 % smaller, tolerance 2e-5 larger, 2e-4 of extra slope for the
+// rounding of the two routes to the normal, 10 % on the threshold -- whatever this test drops, that stage drops too.
+template <int SCALE>
+__device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const BeamMesh &M, float u0, V3 I2,
+                                                       const V3 (&n0)[SCALE][3], const float (&rho)[SCALE][3],
+                                                       float sig_parent, V3 nc, float dc, float sig_c) {
+    const float s2 = 2.0f * __builtin_fmaf(nc.x, I2.x, __builtin_fmaf(nc.y, I2.y, __builtin_fmaf(nc.z, I2.z, -dc)));
+    const V3 I3 = V3{I2.x - nc.x * s2, I2.y - nc.y * s2, I2.z - nc.z * s2};
+    const float uc = u0 * mag_scale(M, I3);
+    const float delta = 2.0f * uc * (sig_parent + sig_c) * 1.00002f;  // +inf for a degenerate mirror: every face off
+    const V3 ce = V3{0.5f * (rx.lo[0] + rx.hi[0]), 0.5f * (rx.lo[1] + rx.hi[1]), 0.5f * (rx.lo[2] + rx.hi[2])};
+    const V3 he = V3{(rx.hi[0] - rx.lo[0]) * 0.50001f, (rx.hi[1] - rx.lo[1]) * 0.50001f, (rx.hi[2] - rx.lo[2]) * 0.50001f};
+    if (!(he.x >= 0.0f) || !(he.y >= 0.0f) || !(he.z >= 0.0f)) return false;
+    const V3 w = ce - I3;
+    const float wl = l1_len(w) + ((he.x + he.y) + he.z);
+    const float thr = -1.1f * uc;
+    bool all_t = true;
+#pragma unroll
+    for (int t = 0; t < SCALE; ++t) {
+        float v[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const V3 n = n0[t][f];
+            const float k2 = 2.0f * fdot(n, nc);
+            const V3 nr = V3{n.x - nc.x * k2, n.y - nc.y * k2, n.z - nc.z * k2};
+            const float r = rho[t][f] * 0.999f;
+            const float g = 1.0101f * delta * __builtin_amdgcn_rcpf(r - delta) + 2.1e-4f;
+            const bool on = r > 1.06f * delta;  // otherwise the child's face may be off: it never separates
+            const float smax = fdot(w, nr) + ((__builtin_fabsf(nr.x) * he.x + __builtin_fabsf(nr.y) * he.y) +
+                                              __builtin_fabsf(nr.z) * he.z);
+            const float val = __builtin_fmaf(g, wl, smax);
+            v[f] = on ? val : 0.0f;  // (a parent face that is off has n = 0: val = g wl >= 0; NaNs compare false)
+        }
+        all_t = all_t && (min3f(v[0], v[1], v[2]) < thr);
+    }
+    return all_t;
+}
+
 #ifndef BEAM_EXPAND_WAVES
 #define BEAM_EXPAND_WAVES 0
 #endif
@@ -569,11 +657,11 @@ struct BeamClusters {
 #else
 #define BEAM_EXPAND_OCC
 #endif
-template <int SCALE, int LEVEL>
-__global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_kernel(
-    BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
+template <int SCALE, int LEVEL, bool FILTER>
+__device__ __forceinline__ void expand_clustered_body(
+    const BeamMesh &M, const BeamClusters &C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
-    int64_t clusters_per_split) {
+    int64_t clusters_per_split, const RxAll &rxall) {
     // 8 KiB per wave: a flush every ~960 records (with 192 the flush atomics -- all on ONE address -- were half
     // of the kernel's time at configs[3])
     __shared__ unsigned long long wbuf[2][kBeamWaveBufBig];
@@ -591,10 +679,47 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
     const int32_t m = have ? e.id[LEVEL - 1] : -1;
     BeamCtx<SCALE, LEVEL> ctx;
     build_ctx<SCALE, LEVEL>(M, e, u, have, ctx);
+    // last expansion: children are tested against the receivers' box before their records are written -- not in
+    // the transposed loop (one test per pass would cost as much as the pass), but on FULL waves of kept children:
+    // kept lanes park (record, plane of the new mirror, its shape factor) in a wave-private LDS queue, and whenever
+    // 64 wait, lane = parked child gathers its parent's apex / narrowest pyramid from the parent's lane
+    // (ds_bpermute) and decides.  At configs[3] three quarters of the 7.1e9 children go no further.
+    __shared__ unsigned long long raw_rec[2][128];
+    __shared__ float raw_f[2][5][128];
+    constexpr bool filter_on = FILTER;
+    float rho0[SCALE][3];
+    float sig_sum = kInf;
+    if (filter_on) first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rho0, sig_sum);
+    int rawcount = 0;
     const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
     const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
     const unsigned long long gbase = (unsigned long long)((int64_t)blockIdx.x * 128 + wave * 64);
     int wcount = 0;
+    // the last n parked children (n <= 64): lane = child
+    auto filter_parked = [&](int n) {
+        const int j = rawcount - n + lane;
+        const bool mine = lane < n;
+        const unsigned long long rec = mine ? raw_rec[wave][j] : 0ull;
+        const V3 nc = mine ? V3{raw_f[wave][0][j], raw_f[wave][1][j], raw_f[wave][2][j]} : V3{0, 0, 1};
+        const float dc = mine ? raw_f[wave][3][j] : 0.0f;
+        const float sgc = mine ? raw_f[wave][4][j] : 1.0f;
+        const int l = (int)((rec >> 32) - gbase) & 63;  // the parent's lane
+        const V3 I2 = V3{__shfl(ctx.I.x, l, 64), __shfl(ctx.I.y, l, 64), __shfl(ctx.I.z, l, 64)};
+        const float sp = __shfl(sig_sum, l, 64);
+        V3 n0[SCALE][3];
+        float rh[SCALE][3];
+#pragma unroll
+        for (int t = 0; t < SCALE; ++t)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                n0[t][f] = V3{__shfl(ctx.pyr[0][t].n[f].x, l, 64), __shfl(ctx.pyr[0][t].n[f].y, l, 64),
+                              __shfl(ctx.pyr[0][t].n[f].z, l, 64)};
+                rh[t][f] = __shfl(rho0[t][f], l, 64);
+            }
+        const bool pass = mine && !child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, sp, nc, dc, sgc);
+        rawcount -= n;
+        beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
+    };
     // software pipeline: the next cluster's primitive id and vertices (sorted copy, no indirection) are in
     // flight while this cluster is tested -- fetched whether or not the cluster will be hit (the mesh lives in L2)
     int32_t p_next = -1;
@@ -719,11 +844,53 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
                 }
             }
 #endif
-            beam_stage<kBeamWaveBufBig>(keep, ((gbase + (unsigned long long)l) << 32) | (uint32_t)p, wbuf[wave], wcount,
-                                        lane, out, cap, count);
+            const unsigned long long record = ((gbase + (unsigned long long)l) << 32) | (uint32_t)p;
+            if constexpr (filter_on) {
+                const unsigned long long vote = __ballot(keep);
+                if (vote) {
+                    if (keep) {
+                        const int j = rawcount + __popcll(vote & ((1ull << lane) - 1ull));
+                        raw_rec[wave][j] = record;
+                        raw_f[wave][0][j] = pl[0][0];
+                        raw_f[wave][1][j] = pl[0][1];
+                        raw_f[wave][2][j] = pl[0][2];
+                        raw_f[wave][3][j] = pl[0][3];
+                        raw_f[wave][4][j] = sg;
+                    }
+                    rawcount += __popcll(vote);
+                    if (rawcount >= 64) filter_parked(64);
+                }
+            } else {
+                beam_stage<kBeamWaveBufBig>(keep, record, wbuf[wave], wcount, lane, out, cap, count);
+            }
         }
     }
+    if (filter_on && rawcount > 0) filter_parked(rawcount);
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+}
+template <int SCALE, int LEVEL>
+__global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_kernel(
+    BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
+    unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
+    int64_t clusters_per_split) {
+    expand_clustered_body<SCALE, LEVEL, false>(M, C, in, n_in, u, out, cap, count, clusters_per_split, RxAll{});
+}
+// the LAST expansion, with the receiver-box child filter.  One triangle per primitive: 130 VGPRs without the
+// occupancy attribute, 128 and no scratch with it (4 waves per SIMD: 0.69 against 0.76 s at configs[3]); quads keep
+// the compiler's own choice (the attribute would spill there).
+template <int LEVEL>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void beam_expand_clustered_last_kernel_s1(
+    BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
+    unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
+    int64_t clusters_per_split, RxAll rxall) {
+    expand_clustered_body<1, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
+}
+template <int LEVEL>
+__global__ __launch_bounds__(128) void beam_expand_clustered_last_kernel_s2(
+    BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
+    unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
+    int64_t clusters_per_split, RxAll rxall) {
+    expand_clustered_body<2, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
 }
 
 // (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the parent's
@@ -1098,10 +1265,12 @@ __global__ __launch_bounds__(256) void point_bounds_kernel(const float *__restri
     if (i >= n) return;
     V3 s{0, 0, 0};
     float mag = 0.0f;
+    bool fin = true;
     for (int k = 0; k < group; ++k) {
         const V3 p = ld3(pts + 3 * (i * group + k));
         s = s + p;
         mag = fmaxf(mag, fmaxf(__builtin_fabsf(p.x), fmaxf(__builtin_fabsf(p.y), __builtin_fabsf(p.z))));
+        fin = fin && is_finite(p.x) && is_finite(p.y) && is_finite(p.z);
     }
     const float inv = 1.0f / (float)group;
     const float c[3] = {s.x * inv, s.y * inv, s.z * inv};
@@ -1113,6 +1282,7 @@ __global__ __launch_bounds__(256) void point_bounds_kernel(const float *__restri
         }
     }
     if (mag == mag) atomicMax(bounds + 6, __float_as_uint(mag));  // NaN coordinates: ignored here, never pruned later
+    if (!fin) atomicOr(bounds + 7, 1u);                           // some point is not finite
 }
 
 __global__ __launch_bounds__(256) void morton_kernel(const float *__restrict__ pts, int64_t n, int32_t group,
@@ -1484,7 +1654,8 @@ static int32_t read_count(const unsigned long long *dev, int64_t *host, hipStrea
 
 template <int SCALE, int LEVEL>
 static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool clustered, const BeamEntry *in, int64_t n_in,
-                          float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s) {
+                          float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s,
+                          const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0}) {
     if (clustered) {
         const int64_t bx = ceil_div(n_in, 128);
         int64_t by = ceil_div(2048, bx);  // few prefixes: split the cluster range so that the launch fills the chip
@@ -1493,8 +1664,17 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
         if (by < 1) by = 1;
         const int64_t cps = ceil_div(C.nclusters, by);
         by = ceil_div(C.nclusters, cps);
-        hipLaunchKernelGGL((beam_expand_clustered_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128), 0, s,
-                           M, C, in, n_in, u, out, cap, count, cps);
+        if (rxall.on) {
+            if constexpr (SCALE == 1)
+                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s1<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
+                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
+            else
+                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s2<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
+                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
+        } else {
+            hipLaunchKernelGGL((beam_expand_clustered_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128), 0,
+                               s, M, C, in, n_in, u, out, cap, count, cps);
+        }
     } else {
         const int64_t bx = ceil_div(n_in, 256), tiles = ceil_div(M.nprim, kBeamTile);
         int64_t by = ceil_div(2048, bx);
@@ -1704,14 +1884,34 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     if (rc != DRT_OK) return rc;
     hipLaunchKernelGGL(rx_cluster_kernel, dim3((unsigned)ceil_div(nrx, 64)), dim3(64), 0, s, rx, nrx, rx_ids, rx_sorted,
                        rx_index, rx_boxes);
-    hipLaunchKernelGGL(point_bounds_kernel, dim3((unsigned)ceil_div(ntx, 256)), dim3(256), 0, s, tx, ntx, 1, rx_bounds);
+    // (the transmitters' bounds in slots 8.. of the same scratch: the receivers' own box is needed below)
+    uint32_t *tx_bounds = rx_bounds + 8;
+    DRT_HIP(fill_bytes_async(tx_bounds, 0xff, 12, s));
+    DRT_HIP(fill_bytes_async(tx_bounds + 3, 0, 20, s));
+    hipLaunchKernelGGL(point_bounds_kernel, dim3((unsigned)ceil_div(ntx, 256)), dim3(256), 0, s, tx, ntx, 1, tx_bounds);
     DRT_LAUNCH_CHECK();
-    uint32_t mag_bits = 0;
-    DRT_HIP(hipMemcpyAsync(&mag_bits, rx_bounds + 6, 4, hipMemcpyDeviceToHost, s));
+    uint32_t hb[16] = {0};
+    DRT_HIP(hipMemcpyAsync(hb, rx_bounds, sizeof(hb), hipMemcpyDeviceToHost, s));
     DRT_HIP(hipStreamSynchronize(s));
-    float mag;
-    memcpy(&mag, &mag_bits, 4);
+    auto bits_to_float = [](uint32_t b) {
+        float f;
+        memcpy(&f, &b, 4);
+        return f;
+    };
+    auto ordered_to_float_host = [&](uint32_t v) { return bits_to_float((v & 0x80000000u) ? (v & 0x7fffffffu) : ~v); };
+    float mag = std::max(bits_to_float(hb[6]), bits_to_float(hb[14]));
     mag = std::max(std::max(mag, mesh->beam_max_abs), 1e-30f);
+    // box of all receivers for the last expansion's child filter: off unless every receiver is finite
+    RxAll rxall{{0, 0, 0}, {0, 0, 0}, 0};
+    if (hb[7] == 0u && !(flags & DRT_BEAM_EXPAND_PLAIN)) {
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) {
+            rxall.lo[k] = ordered_to_float_host(hb[k]);
+            rxall.hi[k] = ordered_to_float_host(hb[3 + k]);
+            ok = ok && std::isfinite(rxall.lo[k]) && std::isfinite(rxall.hi[k]) && rxall.lo[k] <= rxall.hi[k];
+        }
+        rxall.on = ok ? 1 : 0;
+    }
     int ex = 0;
     (void)std::frexp(mag, &ex);                  // mag = f * 2^ex, f in [0.5, 1)
     const float u = kappa * std::ldexp(1.0f, ex - 1 - 23);  // kappa * ulp(M)
@@ -1775,6 +1975,13 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         rc2 = drt_trace_paths_compact(mesh, &tp, tx, ntx, rx, nrx, &c, z.max_survivors, max_paths - nvalid,
                                       reinterpret_cast<int64_t *>(slice_keys), vertices ? vertices + nvalid * k2 * 3 : nullptr,
                                       objects ? objects + nvalid * k2 : nullptr, &nv, base + L.trace_ws, L.trace_ws_bytes, stream);
+        if (rc2 == DRT_E_CAPACITY && nv > z.max_survivors) {
+            // the survivor queue of the trace overflowed (it reports the survivor count, which a count of valid
+            // paths can never exceed): the slice is too large, like one whose rows do not fit
+            *fits = false;
+            *rows_out = nv;
+            return DRT_OK;
+        }
         if (rc2 == DRT_E_CAPACITY && nv > max_paths - nvalid) {
             *num_valid_host = nvalid + nv;
             return fail(DRT_E_CAPACITY, "more than %lld valid paths: raise max_paths", (long long)max_paths);
@@ -1806,11 +2013,11 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             const int64_t i1 = std::min(i0 + step, ncur);
             DRT_HIP(fill_bytes_async(counters, 0, 8, s));
             if (order == 2) {
-#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s)
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall)
                 BEAM_DISPATCH2(M.scale, 1, CALL);
 #undef CALL
             } else {
-#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s)
+#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall)
                 BEAM_DISPATCH2(M.scale, 1, CALL);
 #undef CALL
             }
@@ -1826,7 +2033,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             if (!fits) {
                 if (step == 1) {
                     *num_valid_host = std::max(c, r);
-                    return fail(DRT_E_CAPACITY, "one prefix overflows max_records / max_rows (%lld records, %lld rows)",
+                    return fail(DRT_E_CAPACITY, "one prefix overflows max_records / max_rows / max_survivors (%lld records, %lld rows or survivors)",
                                 (long long)c, (long long)r);
                 }
                 step = std::max<int64_t>(step / 4, 1);
@@ -1837,7 +2044,9 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             ++nslices;
             ++done;
             const double per = (double)(i1 - i0);
-            const double fan = std::max({(double)c / per / (double)z.max_records, (double)r / per / (double)z.max_rows, 1e-18});
+            // (rows also against the survivor queue of the trace: survivors <= rows, so half of it never overflows)
+            const double row_budget = (double)std::min(z.max_rows, z.max_survivors);
+            const double fan = std::max({(double)c / per / (double)z.max_records, (double)r / per / row_budget, 1e-18});
             double next = 0.5 / fan;
             if (done > 1) next = std::min(next, 4.0 * (double)step);
             step_hint = (int64_t)std::max(1.0, std::min(next, 4e18));
@@ -1854,7 +2063,8 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         if (rc != DRT_OK) return rc;
         if (!fits) {
             *num_valid_host = r;
-            return fail(DRT_E_CAPACITY, "%lld candidate rows: raise max_rows (%lld)", (long long)r, (long long)z.max_rows);
+            return fail(DRT_E_CAPACITY, "%lld candidate rows or survivors: raise max_rows (%lld) / max_survivors (%lld)",
+                        (long long)r, (long long)z.max_rows, (long long)z.max_survivors);
         }
         total_rows = r;
         nslices = 1;

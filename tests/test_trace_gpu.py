@@ -719,8 +719,12 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
     for mapping in ("plain",):  # default "auto" = clustered; "plain" tests every (prefix, primitive) pair
         other = tracer.trace_beam_pruned(scene, 3, expansion=mapping)
         _assert_same_paths(ex, other)
-        # box culling is the same test on a box with a bound of the candidates' own error: identical survivors at every level
-        assert st_bvh["levels"] == tracer.last_beam_stats["levels"] and st_bvh["rows"] == tracer.last_beam_stats["rows"]
+        # box culling is the same test on a box with a bound of the candidates' own error: identical survivors at every
+        # level but the last, where only the clustered mapping drops the children that cannot reach the receivers'
+        # box -- children the receiver stage rejects anyway: identical ROWS
+        pl = tracer.last_beam_stats
+        assert st_bvh["levels"][:-1] == pl["levels"][:-1] and st_bvh["levels"][-1] <= pl["levels"][-1]
+        assert st_bvh["rows"] == pl["rows"]
     n = Tr.shape[0]
     evaluated, total = tracer.last_beam_stats["rows"], 64 * n * (n - 1) ** 2
     assert ex.objects.shape[0] > 0 and evaluated < total / 20, (evaluated, total)
