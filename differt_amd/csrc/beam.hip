@@ -567,12 +567,13 @@ struct BeamClusters {
 struct RxAll {
     float lo[3], hi[3];
     int32_t on;
+    float ulp_m;  // ulp of the largest coordinate magnitude M (the error unit without its kappa)
 };
 // what that test needs from the PARENT prefix besides its context: per face of its narrowest pyramid the distance
 // rho of the apex from the edge line (pyr_face's expression; a reflection does not change it), and the sum of its
 // mirrors' shape factors
 template <int SCALE, int LEVEL>
-__device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamEntry &e, V3 I, bool have,
+__device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamEntry &e, V3 I, bool have, float ulp_m,
                                                   float (&rho)[SCALE][3], float &sig_sum) {
 #pragma unroll
     for (int t = 0; t < SCALE; ++t) rho[t][0] = rho[t][1] = rho[t][2] = 0.0f;
@@ -596,14 +597,28 @@ __device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamE
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
         }
+        // pyr_face switches a face off when its orientation is undefined: s = <third vertex - I, N> exactly 0 (or NaN),
+        // non-finite lengths.  The child's pyramid is built from vertices reflected once more: a pyramid that is flat
+        // up to rounding HERE (apex in the plane of the unfolded mirror: axis-aligned walls, a transmitter placed in a
+        // wall plane) can be exactly flat THERE -- all faces off, every receiver kept (found by the stress driver:
+        // tests/golden/beam_cases/filter_case99516.npz).  s is the triple product of the three apex-to-vertex vectors,
+        // the same for every face up to sign; moving one of the four points by d changes it by at most d times the sum
+        // of the three |N_f|, and a reflection moves each point by a few ulp(M'), M' <= 3 M.  Below
+        // 64 ulp(M) sum |N_f| (or the rounding of the product itself, far from the scene) the pyramid counts as flat:
+        // rho = 0 for its faces, never "on" in child_misses_receivers.
+        const V3 w0 = v[0] - I, w1 = v[1] - I, w2 = v[2] - I;
+        const V3 N0 = cross(w0, w1), N1 = cross(w1, w2), N2 = cross(w2, w0);
+        const float len[3] = {__builtin_amdgcn_sqrtf(fdot(N0, N0)), __builtin_amdgcn_sqrtf(fdot(N1, N1)),
+                              __builtin_amdgcn_sqrtf(fdot(N2, N2))};
+        const float sv = fdot(w2, N0);
+        const float D = __builtin_amdgcn_sqrtf(fmaxf(fdot(w0, w0), fmaxf(fdot(w1, w1), fdot(w2, w2))));
+        const float tol = 64.0f * fmaxf(ulp_m, 1.2e-7f * D) * ((len[0] + len[1]) + len[2]);
+        const bool defined = is_finite(len[0]) && is_finite(len[1]) && is_finite(len[2]) && __builtin_fabsf(sv) > tol;
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            const V3 a = v[f], b = v[(f + 1) % 3];
-            const V3 N = cross(a - I, b - I);
-            const float len = __builtin_amdgcn_sqrtf(fdot(N, N));
-            const V3 ed = b - a;
+            const V3 ed = v[(f + 1) % 3] - v[f];
             const float el = __builtin_amdgcn_sqrtf(fdot(ed, ed));
-            rho[t][f] = (el > 0.0f) ? 0.9999f * len * __builtin_amdgcn_rcpf(el) : 0.0f;
+            rho[t][f] = (el > 0.0f && defined) ? 0.9999f * len[f] * __builtin_amdgcn_rcpf(el) : 0.0f;  // pyr_face's rho
         }
     }
 }
@@ -689,7 +704,7 @@ __device__ __forceinline__ void expand_clustered_body(
     constexpr bool filter_on = FILTER;
     float rho0[SCALE][3];
     float sig_sum = kInf;
-    if (filter_on) first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rho0, sig_sum);
+    if (filter_on) first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum);
     int rawcount = 0;
     const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
     const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
@@ -1655,7 +1670,7 @@ static int32_t read_count(const unsigned long long *dev, int64_t *host, hipStrea
 template <int SCALE, int LEVEL>
 static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool clustered, const BeamEntry *in, int64_t n_in,
                           float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s,
-                          const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0}) {
+                          const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f}) {
     if (clustered) {
         const int64_t bx = ceil_div(n_in, 128);
         int64_t by = ceil_div(2048, bx);  // few prefixes: split the cluster range so that the launch fills the chip
@@ -1902,7 +1917,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     float mag = std::max(bits_to_float(hb[6]), bits_to_float(hb[14]));
     mag = std::max(std::max(mag, mesh->beam_max_abs), 1e-30f);
     // box of all receivers for the last expansion's child filter: off unless every receiver is finite
-    RxAll rxall{{0, 0, 0}, {0, 0, 0}, 0};
+    RxAll rxall{{0, 0, 0}, {0, 0, 0}, 0, 0.0f};
     if (hb[7] == 0u && !(flags & DRT_BEAM_EXPAND_PLAIN)) {
         bool ok = true;
         for (int k = 0; k < 3; ++k) {
@@ -1916,6 +1931,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     (void)std::frexp(mag, &ex);                  // mag = f * 2^ex, f in [0.5, 1)
     const float u = kappa * std::ldexp(1.0f, ex - 1 - 23);  // kappa * ulp(M)
     M.inv_2m = 0.5f / mag;
+    rxall.ulp_m = std::ldexp(1.0f, ex - 1 - 23);
     if (st) {
         st->unit_m = u;
         st->magnitude = mag;

@@ -84,6 +84,15 @@ while time.time() - t0 < budget:
             st["mapping_checks"] += 1
             if tracer.last_beam_stats["rows"] != rows or not torch.equal(other.keys, bp.keys):
                 st["mapping_row_mismatch"] += 1
+                # keep the scene: a mismatch must be reproducible
+                import os
+                os.makedirs("gpurun_out/stress_mismatch", exist_ok=True)
+                tag = f"gpurun_out/stress_mismatch/case{st['cases']}_{'_'.join(f'{k}-{v}' for k, v in kw.items())}"
+                np.savez(tag + ".npz", V=V, Tr=Tr, tx=tx, rx=rx, mask=np.zeros(0, bool) if mask is None else mask,
+                         order=order, assume_quads=assume_quads, rows_auto=rows, rows_other=tracer.last_beam_stats["rows"])
+                st.setdefault("mismatches", []).append({"case": st["cases"], **kw, "rows_auto": rows,
+                                                         "rows_other": tracer.last_beam_stats["rows"], "order": order,
+                                                         "n": n, "nrx": len(rx), "assume_quads": assume_quads})
 st["seconds"] = time.time() - t0
 st["kappa"] = KAPPA
 print(json.dumps(st))

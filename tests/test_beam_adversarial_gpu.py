@@ -9,6 +9,8 @@ behaviour being matched: full enumeration + validation, geometry/_solvers.py:803
 
 from __future__ import annotations
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -151,6 +153,31 @@ def test_receiver_counts_around_trip_and_cluster_boundaries(G, nrx):
                 bp = tracer.trace_beam_pruned(scene, order, emit=emit, max_paths=1 << 18)
                 assert torch.equal(bp.objects, ex.objects), (order, emit, poison)
                 assert torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+
+
+def test_child_filter_keeps_what_the_receiver_stage_keeps(G):
+    """The last expansion of the clustered mapping drops children that cannot reach the receivers' box, judged on the
+    PARENT's narrowest pyramid reflected once more; the receiver stage builds that pyramid from reflected vertices.
+    Captured by the stress driver (case 99516 of `scratch/beam_stress.py`, a scene 3.6 km from the origin with a
+    transmitter in a wall plane): the apex lies in the plane of the unfolded first mirror, the parent's pyramid is flat
+    up to rounding, the child's EXACTLY flat -- all faces off, every receiver kept.  Same rows from both mappings,
+    same paths as the exhaustive tracer."""
+    d = np.load(Path(__file__).parent / "golden" / "beam_cases" / "filter_case99516.npz")
+    mesh = G.Mesh(d["V"], d["Tr"], assume_quads=bool(d["assume_quads"]))
+    scene = G.Scene(torch.as_tensor(d["tx"], device="cuda"), torch.as_tensor(d["rx"], device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    order = int(d["order"])
+    ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    auto = tracer.trace_beam_pruned(scene, order)
+    st_auto = dict(tracer.last_beam_stats)
+    plain = tracer.trace_beam_pruned(scene, order, expansion="plain")
+    st_plain = dict(tracer.last_beam_stats)
+    assert st_auto["rows"] == st_plain["rows"] == int(d["rows_other"])
+    assert st_auto["levels"][-1] < st_plain["levels"][-1]  # the filter does drop children here
+    for r in (auto, plain):
+        assert torch.equal(r.objects, ex.objects)
+        assert torch.equal(r.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+    assert ex.objects.shape[0] == 8
 
 
 def test_small_error_unit_still_complete_here(G):
