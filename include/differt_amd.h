@@ -519,7 +519,7 @@ typedef struct drt_beam_stats {
 typedef struct drt_beam_params {
     float kappa;            /* error unit u = kappa * ulp(M); <= 0: default 64 = the worst-case rounding count of
                                DESIGN.md section 9 (measured errors are 5-50x smaller: oracle/studies/beam_error_model.py;
-                               configs[3]: 1.08 s at 64, 0.77 s at 16, same paths) */
+                               configs[3]: 0.83 s at 64, 0.63 s at 16, same paths) */
     int32_t flags;          /* DRT_BEAM_* */
     int64_t max_entries;    /* level-2 prefix list (order 3), 32 B each; <= 0: 2^26 */
     int64_t max_records;    /* records of one expansion slice, 8 B each; <= 0: 2^27 */
