@@ -65,7 +65,7 @@ DRT_TRACE_USE_BVH = 1
 DRT_TRACE_SKIP_OCCLUSION = 2
 DRT_TRACE_DETERMINISTIC_GRAD = 4
 DRT_TRACE_OVERFLOW_SURVIVORS, DRT_TRACE_OVERFLOW_PATHS = 1, 2
-ABI_VERSION = 5  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
+ABI_VERSION = 6  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
 
 
 class BeamStats(C.Structure):
@@ -162,6 +162,11 @@ _SIGNATURES = {
         _i32,
         [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     ),
+    "drt_image_method_strided": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "drt_image_method_vjp_strided": (
+        _i32,
+        [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    ),
     "drt_consecutive_vertices_same_side": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "drt_mesh_build_bvh": (_i32, [_vp, _vp]),
     "drt_mesh_has_bvh": (_i32, [_vp]),
@@ -203,6 +208,11 @@ _SIGNATURES = {
         _i32,
         [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _vp, _vp, _vp,
          _vp, _sz, _vp],
+    ),
+    "drt_trace_paths_dense_ex": (
+        _i32,
+        [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _vp, _vp, _vp, _vp,
+         _vp, _vp, _sz, _vp],
     ),
     "drt_trace_compact_workspace_size": (_sz, [_i64, _i64]),
     "drt_comm_unique_id": (_i32, [_vp]),

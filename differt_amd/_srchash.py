@@ -18,7 +18,11 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 # record kind -> the sources whose change invalidates it
 GROUPS = {
     "dense": ("ray_ops.hip", "geom.hpp", "common.hpp"),
-    "trace_filter": ("trace.hip", "trace_common.hpp", "image_chain.hpp", "geom.hpp", "common.hpp"),
+    "trace_filter": ("trace.hip", "trace_stages.hpp", "trace_common.hpp", "image_chain.hpp", "geom.hpp", "common.hpp"),
+    "trace_dense": ("trace_dense.hip", "stores.hpp", "trace_stages.hpp", "trace_common.hpp", "image_chain.hpp", "geom.hpp",
+                    "common.hpp"),
+    "image_method": ("image_method.hip", "stores.hpp", "image_chain.hpp", "geom.hpp", "common.hpp"),
+    "beam": ("beam.hip", "mesh.hpp", "geom.hpp", "common.hpp"),
 }
 
 

@@ -28,12 +28,22 @@ def _bcast(batch, *arrs_and_tails):
     return out
 
 
+def _rows(x: torch.Tensor, dense: int):
+    """``(tensor whose pointer to pass, stride in floats)`` of a ``[B, ...]`` input: a row shared by the whole batch
+    (an expanded view, stride 0) is read in place by the kernel instead of being materialised ``B`` times."""
+    if x.shape[0] > 1 and x.stride(0) == 0 and x[0].is_contiguous():
+        return x[0], 0
+    return x.contiguous(), dense
+
+
 class _ImageMethodFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, mv, mn):
         B, k = mv.shape[0], mv.shape[1]
         out = torch.empty((B, k, 3), dtype=torch.float32, device=mv.device)
-        _lib.call("drt_image_method", ptr(a), ptr(b), ptr(mv), ptr(mn), B, k, ptr(out), stream())
+        (pa, sa), (pb, sb), (pmv, smv), (pmn, smn) = _rows(a, 3), _rows(b, 3), _rows(mv, 3 * k), _rows(mn, 3 * k)
+        _lib.call("drt_image_method_strided", ptr(pa), sa, ptr(pb), sb, ptr(pmv), smv, ptr(pmn), smn, B, k, ptr(out),
+                  stream())
         ctx.save_for_backward(a, b, mv, mn)
         return out
 
@@ -42,11 +52,21 @@ class _ImageMethodFn(torch.autograd.Function):
         a, b, mv, mn = ctx.saved_tensors
         B, k = mv.shape[0], mv.shape[1]
         g = g.contiguous()
-        ga, gb = torch.empty_like(a), torch.empty_like(b)
-        gmv, gmn = torch.empty_like(mv), torch.empty_like(mn)
-        _lib.call("drt_image_method_vjp", ptr(a), ptr(b), ptr(mv), ptr(mn), ptr(g), B, k,
+        dev = g.device
+        # per-element gradients; autograd sums those of rows that were broadcast (expand's backward)
+        ga, gb = (torch.empty((B, 3), dtype=torch.float32, device=dev) for _ in range(2))
+        gmv, gmn = (torch.empty((B, k, 3), dtype=torch.float32, device=dev) for _ in range(2))
+        (pa, sa), (pb, sb), (pmv, smv), (pmn, smn) = _rows(a, 3), _rows(b, 3), _rows(mv, 3 * k), _rows(mn, 3 * k)
+        _lib.call("drt_image_method_vjp_strided", ptr(pa), sa, ptr(pb), sb, ptr(pmv), smv, ptr(pmn), smn, ptr(g), B, k,
                   ptr(ga), ptr(gb), ptr(gmv), ptr(gmn), stream())
         return ga, gb, gmv, gmn
+
+
+def _flat_rows(x: torch.Tensor, batch, B: int, tail) -> torch.Tensor:
+    """``x`` broadcast to ``[*batch, *tail]`` as a ``[B, *tail]`` tensor: a stride-0 view when ``x`` is one row."""
+    if x.numel() == int(np.prod(tail, dtype=np.int64)):
+        return x.reshape(1, *tail).expand(B, *tail)
+    return x.expand(*batch, *tail).reshape(B, *tail)
 
 
 def image_method(from_vertex, to_vertex, mirror_vertices, mirror_normals):
@@ -54,7 +74,7 @@ def image_method(from_vertex, to_vertex, mirror_vertices, mirror_normals):
 
     Reference: ``image_method`` _solver_image_method.py:206-363 (forward scan of images :191-195,
     reverse scan of ray/plane intersections :196-201, inf propagation :165-181, ``k == 0`` -> empty
-    :349-358)."""
+    :349-358; broadcasting ``(3),(3),(n,3),(n,3)->(n,3)`` :360-363)."""
     dev = device()
     a, b = as_f32(from_vertex, dev), as_f32(to_vertex, dev)
     mv, mn = as_f32(mirror_vertices, dev), as_f32(mirror_normals, dev)
@@ -63,9 +83,8 @@ def image_method(from_vertex, to_vertex, mirror_vertices, mirror_normals):
     B = int(np.prod(batch, dtype=np.int64))
     if k == 0 or B == 0:
         return torch.empty((*batch, k, 3), dtype=torch.float32, device=dev)
-    a, b = _bcast(batch, (a, (3,)), (b, (3,)))
-    mv, mn = _bcast(batch, (mv, (k, 3)), (mn, (k, 3)))
-    out = _ImageMethodFn.apply(a.reshape(B, 3), b.reshape(B, 3), mv.reshape(B, k, 3), mn.reshape(B, k, 3))
+    out = _ImageMethodFn.apply(_flat_rows(a, batch, B, (3,)), _flat_rows(b, batch, B, (3,)),
+                               _flat_rows(mv, batch, B, (k, 3)), _flat_rows(mn, batch, B, (k, 3)))
     return out.reshape(*batch, k, 3)
 
 

@@ -95,30 +95,33 @@ def _rank_candidates(order: int, rank_lo: int, count: int, num_nodes: int,
 
 
 class _TraceDenseFn(torch.autograd.Function):
-    """vertices/objects/mask for every (tx, rx, candidate); vertices differentiable in
+    """vertices/objects/mask/interaction types for every (tx, rx, candidate) through ``drt_trace_paths_dense_ex``
+    (every element is written by the kernel: outputs are allocated uninitialised); vertices differentiable in
     (tx, rx, mesh vertices) through ``drt_trace_paths_vjp``."""
 
     @staticmethod
-    def forward(ctx, tx, rx, mesh_vertices, mesh, table, params):
+    def forward(ctx, tx, rx, mesh_vertices, mesh, table, types, params):
         dev = tx.device
         ntx, nrx, (Cn, k) = tx.shape[0], rx.shape[0], table.shape
-        verts = torch.zeros((ntx, nrx, Cn, k + 2, 3), dtype=torch.float32, device=dev)
-        objs = torch.zeros((ntx, nrx, Cn, k + 2), dtype=torch.int32, device=dev)
-        mask = torch.zeros((ntx, nrx, Cn), dtype=torch.uint8, device=dev)
+        verts = torch.empty((ntx, nrx, Cn, k + 2, 3), dtype=torch.float32, device=dev)
+        objs = torch.empty((ntx, nrx, Cn, k + 2), dtype=torch.int32, device=dev)
+        mask = torch.empty((ntx, nrx, Cn), dtype=torch.uint8, device=dev)
+        tout = torch.empty((ntx, nrx, Cn, k), dtype=torch.int32, device=dev)
         if ntx * nrx * Cn:
             lib = _lib.load()
             nbytes = lib.drt_trace_dense_workspace_size(ntx, nrx, Cn)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             cands = _table_candidates(table)
-            _lib.call("drt_trace_paths_dense", mesh.handle().h, C.byref(params), ptr(tx), ntx, ptr(rx),
-                      nrx, C.byref(cands), ptr(verts), ptr(objs), ptr(mask), ptr(ws), nbytes, stream())
+            _lib.call("drt_trace_paths_dense_ex", mesh.handle().h, C.byref(params), ptr(tx), ntx, ptr(rx),
+                      nrx, C.byref(cands), ptr(types), ptr(verts), ptr(objs), ptr(mask), ptr(tout), ptr(ws), nbytes,
+                      stream())
         ctx.mesh, ctx.table, ctx.params = mesh, table, params
         ctx.save_for_backward(tx, rx)
-        ctx.mark_non_differentiable(objs, mask)
-        return verts, objs, mask
+        ctx.mark_non_differentiable(objs, mask, tout)
+        return verts, objs, mask, tout
 
     @staticmethod
-    def backward(ctx, gv, _go, _gm):
+    def backward(ctx, gv, _go, _gm, _gt):
         tx, rx = ctx.saved_tensors
         mesh, table = ctx.mesh, ctx.table
         n = gv.numel() // (3 * (table.shape[1] + 2))
@@ -128,7 +131,7 @@ class _TraceDenseFn(torch.autograd.Function):
             keys = torch.arange(n, dtype=torch.int64, device=tx.device)
             _paths_vjp(mesh, ctx.params, tx, rx, _table_candidates(table), keys, gv.contiguous(), n, table.shape[1],
                        gtx, grx, gmv)
-        return gtx, grx, gmv, None, None, None
+        return gtx, grx, gmv, None, None, None, None
 
 
 class _TraceCompactFn(torch.autograd.Function):
@@ -281,27 +284,35 @@ class _TraceSmoothFn(torch.autograd.Function):
 
 def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, interaction_types=None, *,
                            epsilon, hit_tol, min_len, smoothing_factor, confidence_threshold,
-                           batch_size, accel=None, deterministic_grad: bool = False) -> TracedPaths:
+                           batch_size, accel=None, deterministic_grad: bool = False, stats=None) -> TracedPaths:
     """Reference ``_trace_path_candidates`` (_solvers.py:499-770), dense layout
     ``[num_tx, num_rx, num_candidates, ...]``; ``smoothing_factor`` switches to the float-mask mode
     (:599-713), whose blocked term uses the pure operator with ``batch_size`` tiles (:665-674)."""
     table = as_i32(path_candidates).contiguous()
     tx = tx_vertices.contiguous()
     rx = rx_vertices.contiguous()
+    if interaction_types is not None:
+        types = as_i32(interaction_types)
+        if tuple(types.shape) != tuple(table.shape):  # the reference broadcasts [C, order] over (tx, rx), SV:751-757
+            types = types.expand(table.shape)
+        types = types.contiguous()
+    else:
+        types = None  # all specular reflections (0), SV:758-762
     if smoothing_factor is not None:
         verts, objs, mask = _TraceSmoothFn.apply(
             tx, rx, mesh.vertices, mesh, table, _params(epsilon, hit_tol, min_len, None),
             float(smoothing_factor), 0 if batch_size is None else int(batch_size))
-    else:
-        verts, objs, mask = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table,
-                                                _params(epsilon, hit_tol, min_len, accel,
-                                                        deterministic_grad=deterministic_grad))
-    if interaction_types is None:  # _solvers.py:751-762
-        it = torch.zeros(objs.shape[:-1] + (table.shape[1],), dtype=torch.int32, device=objs.device)
-    else:
-        it = as_i32(interaction_types).expand(*objs.shape[:-1], table.shape[1])
-    return TracedPaths(verts, objs, mask if smoothing_factor is not None else mask.bool(), it,
-                       confidence_threshold)
+        if types is None:
+            it = torch.zeros(objs.shape[:-1] + (table.shape[1],), dtype=torch.int32, device=objs.device)
+        else:
+            it = types.expand(*objs.shape[:-1], table.shape[1])
+        return TracedPaths(verts, objs, mask, it, confidence_threshold)
+    params = _params(epsilon, hit_tol, min_len, accel, deterministic_grad=deterministic_grad)
+    if stats is not None:  # drt_trace_stats of the dense call: HIP-event kernel times, one stream synchronisation
+        params.stats = C.pointer(stats)
+    verts, objs, mask, it = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table, types, params)
+    # the kernel writes 0 / 1 bytes: reinterpret, do not copy
+    return TracedPaths(verts, objs, mask.view(torch.bool), it, confidence_threshold)
 
 
 class AbstractPathTracer:
@@ -418,9 +429,32 @@ class ExhaustivePathTracer(AbstractPathTracer):
             return SizedIterator(iter([self.generate_path_candidates(scene, order, *args, **kwargs)]), size=1)
         if isinstance(order, Sequence):
             raise NotImplementedError("ExhaustivePathTracer does not support multiple orders yet.")
+        quads = scene.mesh.assume_quads
+        if type(self) is ExhaustivePathTracer and order >= 1:
+            # complete graph (optionally over the active primitives only): every chunk is a rank interval unranked
+            # on the GPU straight into the chunk's table -- no host enumeration, no host->device copy
+            # (reference: Rust iterator + transfer, _solvers.py:870-934); same rows, same order (graph.rs:400-470)
+            n, node_map = self._num_nodes_and_map(scene)
+            total = n * (n - 1) ** (order - 1) if n > 0 else 0
+            if total > 0:
+                eff = int(eff)
+                nchunks = -(-total // eff)
+
+                def gen_gpu() -> Iterator:
+                    dev = device()
+                    for i in range(nchunks):
+                        lo, hi = i * eff, min((i + 1) * eff, total)
+                        if pad_chunks and hi - lo < eff:  # _solvers.py:912-918
+                            c = torch.full((eff, order), -1, dtype=torch.int32, device=dev)
+                        else:
+                            c = torch.empty((hi - lo, order), dtype=torch.int32, device=dev)
+                        _lib.call("drt_candidates_fill", n, order, lo, hi, ptr(node_map), 2 if quads else 1, ptr(c),
+                                  stream())
+                        yield c, torch.zeros_like(c)
+
+                return SizedIterator(gen_gpu(), size=nchunks)
         graph, from_, to = self._graph(scene)
         it = graph.all_paths_array_chunks(from_, to, order + 2, include_from_and_to=False, chunk_size=eff)
-        quads = scene.mesh.assume_quads
 
         def gen() -> Iterator:
             for chunk in it:
@@ -439,13 +473,17 @@ class ExhaustivePathTracer(AbstractPathTracer):
     # ---- tracing ----
     def trace_path_candidates(self, scene, path_candidates, interaction_types=None) -> TracedPaths:
         """_solvers.py:936-957."""
-        return _trace_path_candidates(
+        st = _lib.TraceStats() if (self.collect_stats and self.smoothing_factor is None) else None
+        out = _trace_path_candidates(
             scene.mesh, scene.transmitters.reshape(-1, 3), scene.receivers.reshape(-1, 3),
             path_candidates, interaction_types, epsilon=self.epsilon, hit_tol=self.hit_tol,
             min_len=self.min_len, smoothing_factor=self.smoothing_factor,
             confidence_threshold=self.confidence_threshold, batch_size=self.batch_size,
-            accel=self.accel, deterministic_grad=self.deterministic_grad,
+            accel=self.accel, deterministic_grad=self.deterministic_grad, stats=st,
         )
+        if st is not None:
+            self.last_stats = {f: getattr(st, f) for f, _ in _lib.TraceStats._fields_ if f != "reserved"}
+        return out
 
     def num_path_candidates(self, scene, order: int) -> int:
         """``n * (n-1)**(order-1)`` over the (active) primitives; 1 for order 0."""

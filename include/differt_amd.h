@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRT_ABI_VERSION 5
+#define DRT_ABI_VERSION 6
 
 enum {
     DRT_OK = 0,
@@ -158,6 +158,21 @@ int32_t drt_image_method_vjp(const float *from_vertices, const float *to_vertice
                              const float *paths_cotangent, int64_t batch, int32_t num_mirrors,
                              float *grad_from, float *grad_to, float *grad_mirror_vertices,
                              float *grad_mirror_normals, void *stream);
+/* The same operators with BROADCAST inputs (reference signature `(3),(3),(n,3),(n,3)->(n,3)` over `*#batch`,
+ * _solver_image_method.py:360-363; its benchmark passes from / to of shape [3] against [10000, 8, 3] mirrors,
+ * tests/benchmarks/fixtures.py:19-40): every *_stride is the number of floats between consecutive batch elements,
+ * either 0 (one row shared by the whole batch, read in place) or the dense row size (3, resp. 3 * num_mirrors).
+ * Outputs and the cotangent are dense; the VJP writes PER-ELEMENT gradients (the caller sums those of shared rows). */
+int32_t drt_image_method_strided(const float *from_vertices, int64_t from_stride, const float *to_vertices,
+                                 int64_t to_stride, const float *mirror_vertices, int64_t mirror_vertices_stride,
+                                 const float *mirror_normals, int64_t mirror_normals_stride, int64_t batch,
+                                 int32_t num_mirrors, float *paths_out, void *stream);
+int32_t drt_image_method_vjp_strided(const float *from_vertices, int64_t from_stride, const float *to_vertices,
+                                     int64_t to_stride, const float *mirror_vertices,
+                                     int64_t mirror_vertices_stride, const float *mirror_normals,
+                                     int64_t mirror_normals_stride, const float *paths_cotangent, int64_t batch,
+                                     int32_t num_mirrors, float *grad_from, float *grad_to,
+                                     float *grad_mirror_vertices, float *grad_mirror_normals, void *stream);
 int32_t drt_consecutive_vertices_same_side(const float *vertices, const float *mirror_vertices,
                                            const float *mirror_normals, int64_t batch,
                                            int32_t num_mirrors, uint8_t *out, void *stream);
@@ -337,7 +352,7 @@ int32_t drt_digraph_iter_next_chunk(drt_digraph_iter_t it, uint64_t max_rows, ui
  * invalid) or a rank interval of the complete graph, unranked on the GPU (no table in HBM).
  * ------------------------------------------------------------------------------------------- */
 /* Per-stage counters and HIP-event timers of one drt_trace_paths_compact call (SURVEY.md section 5,
- * "metrics" / "tracing" rows).  Filled when drt_trace_params.stats is non-NULL; costs two extra
+ * "metrics" / "tracing" rows; the dense entry points fill `valid` with -1: the mask holds it).  Filled when drt_trace_params.stats is non-NULL; costs two extra
  * stream synchronisations, so leave it NULL on the hot path. */
 typedef struct drt_trace_stats {
     int64_t candidates;     /* (tx, rx, candidate) rows evaluated by the filter stage */
@@ -354,7 +369,7 @@ typedef struct drt_trace_params {
     float hit_tol;          /* occlusion tolerance; default 100*eps (_utils.py:1418-1420) */
     float min_len;          /* squared-length threshold; default 10*eps (_solvers.py:514-516) */
     int32_t flags;          /* DRT_TRACE_* bits */
-    drt_trace_stats *stats; /* host pointer or NULL (drt_trace_paths_compact only) */
+    drt_trace_stats *stats; /* host pointer or NULL (drt_trace_paths_compact, drt_trace_paths_dense[_ex]) */
 } drt_trace_params;
 #define DRT_TRACE_USE_BVH 1 /* occlusion stage walks the mesh LBVH instead of testing every triangle */
 #define DRT_TRACE_SKIP_OCCLUSION 2 /* return the candidates that pass the GEOMETRIC checks; the caller tests
@@ -417,6 +432,20 @@ int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *params, c
                               int64_t num_tx, const float *rx, int64_t num_rx,
                               const drt_candidates *cands, float *vertices, int32_t *objects,
                               uint8_t *mask, void *workspace, size_t workspace_bytes, void *stream);
+/* The same call with the fourth field of the reference's TracedPaths (_solvers.py:751-762):
+ *   interaction_types_out [Ntx,Nrx,C,order] i32 = interaction_types_in [C,order] broadcast over (tx, rx), or zeros
+ *   (specular reflection) when interaction_types_in is NULL; interaction_types_out may be NULL (not written).
+ * Every element of every output is written (callers need not clear them).  The operator is HBM-write bound
+ * (81 B per (tx, rx, candidate) at order 2): rows are staged per wave and stored as whole 128-byte lines with
+ * 16-byte nontemporal stores whenever num_candidates * (row bytes) is a multiple of 16 for the array (always for
+ * the vertices at orders 2 and 6; num_candidates % 4 == 0 covers vertices, objects and types at every order,
+ * % 16 the mask as well); other shapes take a 4-byte coalesced path.  Same results either way. */
+int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
+                                 int64_t num_tx, const float *rx, int64_t num_rx,
+                                 const drt_candidates *cands, const int32_t *interaction_types_in,
+                                 float *vertices, int32_t *objects, uint8_t *mask,
+                                 int32_t *interaction_types_out, void *workspace, size_t workspace_bytes,
+                                 void *stream);
 
 /* Compacted output: only valid paths, in the order of TracedPaths.masked_vertices
  * (geometry/_paths.py:274-297: row-major over [tx, rx, candidate]).
