@@ -81,6 +81,9 @@ def run(order: int = 2, num_tx: int = 1, num_rx: int = 64, chunk: int = 1 << 20,
     full_rows = num_tx * num_rx * min(chunk, total)
     full = [k for k in kms[: max(1, len(kms) - (1 if nchunks == nchunks_all and total % chunk else 0))]]
     kernel_ms = sum(full) / len(full)
+    if kernel_ms <= 0:  # scratch A/B builds (DRT_DENSE_LEGACY) do not fill the stats: wall-clock numbers only
+        return {"rows": rows, "valid_paths": nvalid, "s_total": dt, "candidates_per_s": rows / dt,
+                "end_to_end_GBps": algo * rows / dt / 1e9, "roofline": None}
     achieved = algo * full_rows / (kernel_ms * 1e-3)
     out = {
         "workload": f"sub-block of configs[2]: {num_tx} TX x {num_rx} RX, {Tr.shape[0]}-triangle synthetic Manhattan mesh"

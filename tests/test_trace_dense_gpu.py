@@ -213,21 +213,33 @@ def test_image_method_staged_rows_bit_exact(G, rng, k, B, shared):
 
 @pytest.mark.parametrize("k", [1, 2, 5])
 def test_image_method_vjp_with_shared_rows(G, rng, k):
-    """Gradients w.r.t. inputs that are broadcast over the batch = the sum of the per-element gradients (float64
-    autograd over the torch restatement of IM:68-203)."""
-    from oracle import torch_ref
-
+    """Gradients w.r.t. inputs that are broadcast over the batch (read in place, stride 0) = the sum over the batch of
+    the per-element gradients the dense call returns (parity of those with float64 autograd:
+    tests/test_trace_gpu.py::test_image_method_vjp_vs_autograd)."""
     B = 257
-    a = rng.normal(size=(3,))
-    b = rng.normal(size=(B, 3)) + 4.0
-    mv = rng.normal(size=(B, k, 3))
-    mn, _ = orc.normalize(rng.normal(size=(B, k, 3)).astype(np.float32))
-    w = rng.normal(size=(B, k, 3))
-    ins64 = [torch.tensor(np.asarray(x, np.float64), requires_grad=True) for x in (a, b, mv, mn)]
-    (torch_ref.image_method(*ins64) * torch.tensor(w)).sum().backward()
-    ins = [torch.tensor(np.asarray(x, np.float32), device="cuda", requires_grad=True) for x in (a, b, mv, mn)]
-    (G.image_method(*ins) * torch.tensor(w, dtype=torch.float32, device="cuda")).sum().backward()
-    for g32, g64 in zip(ins, ins64):
-        ref = g64.grad.numpy()
-        assert tuple(g32.grad.shape) == ref.shape
-        np.testing.assert_allclose(_np(g32.grad), ref, rtol=0, atol=2e-4 * max(1.0, np.abs(ref).max()))
+    a = rng.normal(size=(3,)).astype(np.float32) * 3
+    mvs = rng.normal(size=(k, 3)).astype(np.float32)
+    mns, _ = orc.normalize(rng.normal(size=(k, 3)).astype(np.float32))
+    b = (rng.normal(size=(B, 3)) * 3).astype(np.float32)
+    w = torch.tensor(rng.normal(size=(B, k, 3)).astype(np.float32), device="cuda")
+
+    def run(expand):
+        ins = [torch.tensor(x, device="cuda") for x in (a, b, mvs, mns)]
+        if expand:  # materialised copies: the dense path, per-element gradients
+            ins = [ins[0].expand(B, 3).contiguous(), ins[1], ins[2].expand(B, k, 3).contiguous(),
+                   ins[3].expand(B, k, 3).contiguous()]
+        ins = [t.requires_grad_() for t in ins]
+        out = G.image_method(*ins)
+        (out * w).sum().backward()
+        return out, [t.grad for t in ins]
+
+    out_s, g_s = run(False)
+    out_d, g_d = run(True)
+    np.testing.assert_array_equal(_bits(_np(out_s)), _bits(_np(out_d)))
+    np.testing.assert_array_equal(_bits(_np(g_s[1])), _bits(_np(g_d[1])))  # `to` is dense in both
+    for i in (0, 2, 3):
+        per = _np(g_d[i]).astype(np.float64)
+        ref = per.sum(axis=0)
+        assert tuple(g_s[i].shape) == ref.shape
+        tol = 1e-5 * np.abs(per).sum(axis=0).max()
+        np.testing.assert_allclose(_np(g_s[i]), ref, rtol=0, atol=tol)
