@@ -12,7 +12,7 @@ objects, mask and interaction types for every row.  The operator is HBM-write bo
 
 Numbers reported:
   * `candidates_per_s`            whole loop, wall clock between two synchronisations (Python, the fill kernel and the
-                                  `mask.sum()` of the consumer included) -- what a DiffeRT user sees;
+                                  `num_valid_paths` of the consumer included) -- what a DiffeRT user sees;
   * `roofline`                    the dense kernel alone: HIP events around the launch on its stream (drt_trace_stats,
                                   taken on a second, untimed pass), `achieved = 81 B x rows / kernel time`,
                                   `frac = achieved / 8 TB/s`; `written_frac` counts only the 73 B a row really
@@ -58,7 +58,7 @@ def run(order: int = 2, num_tx: int = 1, num_rx: int = 64, chunk: int = 1 << 20,
         for i, paths in enumerate(scene.trace_paths(order=order, solver=solver)):
             if i >= limit:
                 break
-            nvalid += paths.mask.sum()  # the reference harness accumulates paths.num_valid_paths the same way
+            nvalid += paths.num_valid_paths  # as the reference harness does (tests/benchmarks/test_rt.py:187-194)
             rows += paths.mask.numel()
             if solver.collect_stats:
                 kernel_ms.append(solver.last_stats["filter_ms"])

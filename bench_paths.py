@@ -101,6 +101,14 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         # search (no exhaustive count to compare with: 91 paths, re-validated by the oracle in tests/test_full_size_gpu.py)
         out["beam_pruned_order3"] = beam_leg(G, mesh, tx, rx, 3, None, reps=1)
         out["visibility_pruned"] = pruned_leg(G, mesh, tx, rx, order, nvalid)
+    if rank == 0 and world == 1 and num_ranks is None and order == 2:
+        # the drop-in itself: Scene.trace_paths(order, chunk_size=...) in the reference's dense layout (bench_dense.py)
+        try:
+            import bench_dense
+
+            out["reference_api"] = bench_dense.legs()
+        except Exception as exc:  # noqa: BLE001
+            out["reference_api"] = {"error": repr(exc)}
     if cpu_sample and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_sample_rate(V, Tr, tx, rx, order, n)
     return out
@@ -140,7 +148,7 @@ def paths_roofline(order: int, stage: dict | None) -> dict | None:
         except Exception:  # noqa: BLE001
             per_cand = None
     out = {
-        "kernel": f"drt::trace_filter_kernel<{order}, false, false>",
+        "kernel": f"drt::trace_filter_kernel<{order}, false>",
         "bound": "valu",
         "kernel_ms": stage["filter_ms"],
         "candidates_per_launch": stage["candidates"],

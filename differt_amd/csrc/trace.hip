@@ -55,12 +55,11 @@ namespace drt {
 #else
 #define DRT_FILTER_ATTR __attribute__((amdgpu_waves_per_eu(DRT_FILTER_WAVES, DRT_FILTER_WAVES)))
 #endif
-template <int K, bool QUADS, bool DENSE>
+template <int K, bool QUADS>
 __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
     TraceArgs a, const float *__restrict__ txp, const float *__restrict__ rxp, CandSrc cs,
     unsigned long long *__restrict__ q_count,
-    long long *__restrict__ queue, int64_t q_cap, int64_t tx_per_block,
-    float *__restrict__ d_vertices, int32_t *__restrict__ d_objects, uint8_t *__restrict__ d_mask) {
+    long long *__restrict__ queue, int64_t q_cap, int64_t tx_per_block) {
     const int lane = threadIdx.x & 63;
     const int64_t it0 = (int64_t)blockIdx.y * tx_per_block;
     const int64_t it1 = (it0 + tx_per_block < a.ntx) ? it0 + tx_per_block : a.ntx;
@@ -142,21 +141,14 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                 // (scratch/filter_debug.py) -- not rare enough to run all remaining checks for: the other
                 // mirrors' inside tests come next, still as wave masks, and the wave leaves as soon as the mask
                 // is empty (the checks are independent, so their order cannot change the result)
-                if (!DENSE) {
 #pragma unroll
-                    for (int j = K - 2; j >= 0; --j)
-                        if (alive_mask != 0) alive_mask = inside_one_wave<K, QUADS>(m, full, j, a.eps, alive_mask);
-                }
-                if (DENSE || alive_mask != 0) {
+                for (int j = K - 2; j >= 0; --j)
+                    if (alive_mask != 0) alive_mask = inside_one_wave<K, QUADS>(m, full, j, a.eps, alive_mask);
+                if (alive_mask != 0) {
                     DRT_DBG(4);
                     alive = (alive_mask >> lane) & 1ull;
                     fin = path_finite<K>(full);
                     alive = alive && fin;
-                    if (DENSE) {
-#pragma unroll
-                        for (int j = K - 2; j >= 0; --j)
-                            alive = alive && inside_one<K, QUADS>(m, full, j, a.eps);
-                    }
 #pragma unroll
                     for (int j = 0; j < K; ++j)  // IM:443-454
                         alive = alive && same_sign(dot(full[j] - m.p[j], m.n[j]),
@@ -168,20 +160,8 @@ __global__ __launch_bounds__(256) DRT_FILTER_ATTR void trace_filter_kernel(
                     }
                 }
                 const int64_t flat = (it * a.nrx + (int64_t)ir) * cs.count + row;
-                if (DENSE && in_range) {
-                    float *v = d_vertices + flat * 3 * (K + 2);
-#pragma unroll
-                    for (int j = 0; j < K + 2; ++j)
-                        st3(v + 3 * j, (fin && cand_ok) ? full[j] : V3{0, 0, 0});  // SV:696-699
-                    int32_t *ob = d_objects + flat * (K + 2);
-                    ob[0] = (int32_t)it;
-#pragma unroll
-                    for (int j = 0; j < K; ++j) ob[1 + j] = id[j];
-                    ob[K + 1] = (int32_t)ir;
-                    d_mask[flat] = (uint8_t)alive;  // stage B clears it when the path is blocked
-                }
                 // wave-level compaction of the survivors: one ballot + one atomic per wave
-                const unsigned long long vote = (DENSE || alive_mask != 0) ? __ballot(alive) : 0ull;
+                const unsigned long long vote = (alive_mask != 0) ? __ballot(alive) : 0ull;
                 if (vote) {
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(q_count, (unsigned long long)__popcll(vote));
@@ -580,11 +560,10 @@ static void filter_grid(const Launch &L, dim3 *grid, int64_t *tx_per_block) {
     *grid = dim3((unsigned)bx, (unsigned)by);
 }
 
-template <int K, bool QUADS, bool DENSE>
-static void launch_filter(const Launch &L, unsigned long long *qc, long long *q, int64_t qcap,
-                          float *dv, int32_t *dob, uint8_t *dm) {
+template <int K, bool QUADS>
+static void launch_filter(const Launch &L, unsigned long long *qc, long long *q, int64_t qcap) {
     if (L.cs.ragged) {
-        if constexpr (!DENSE && K >= 3) {
+        if constexpr (K >= 3) {
             if (L.cs.prefix_kernel) {
                 // rows per transmitter = F_tx * N^(K-2) <= num_first_max * mid_pw: size the grid for the largest
                 int64_t bx = ceil_div(L.cs.max_prefixes, 256);
@@ -594,7 +573,7 @@ static void launch_filter(const Launch &L, unsigned long long *qc, long long *q,
                 return;
             }
         }
-        if constexpr (!DENSE && K >= 1) {  // K == 1 only occurs with a per-pair TABLE (beam-pruned rows)
+        if constexpr (K >= 1) {  // K == 1 only occurs with a per-pair TABLE (beam-pruned rows)
             int64_t bx = ceil_div(L.cs.count, 256);
             if (bx > 256 * 32) bx = 256 * 32;
             hipLaunchKernelGGL((trace_filter_ragged_kernel<K, QUADS>), dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0,
@@ -605,8 +584,8 @@ static void launch_filter(const Launch &L, unsigned long long *qc, long long *q,
     dim3 grid;
     int64_t tpb;
     filter_grid(L, &grid, &tpb);
-    hipLaunchKernelGGL((trace_filter_kernel<K, QUADS, DENSE>), grid, dim3(256), 0, L.s, L.a, L.a.tx,
-                       L.a.rx, L.cs, qc, q, qcap, tpb, dv, dob, dm);
+    hipLaunchKernelGGL((trace_filter_kernel<K, QUADS>), grid, dim3(256), 0, L.s, L.a, L.a.tx,
+                       L.a.rx, L.cs, qc, q, qcap, tpb);
 }
 
 static size_t sort_temp_bytes(int64_t n) {
@@ -651,52 +630,6 @@ int32_t drt_candidates_fill(int64_t num_nodes, int32_t order, int64_t rank_lo, i
     const dim3 grid((unsigned)ceil_div(cs.count, 256));
 #define CALL(K) hipLaunchKernelGGL(candidates_fill_kernel<K>, grid, dim3(256), 0, as_stream(stream), cs, out)
     DRT_ORDER_SWITCH(order, CALL)
-#undef CALL
-    DRT_LAUNCH_CHECK();
-    return DRT_OK;
-}
-
-// round-3 form of the dense tracer (direct per-lane stores), kept for ONE A/B measurement against trace_dense.hip
-// (scratch: selected by the environment variable DRT_DENSE_LEGACY; not declared in the header)
-int32_t drt_trace_paths_dense_legacy(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx,
-                              int64_t ntx, const float *rx, int64_t nrx, const drt_candidates *cands,
-                              float *vertices, int32_t *objects, uint8_t *mask, void *ws,
-                              size_t ws_bytes, void *stream) {
-    DRT_REQUIRE(mesh && pr && cands, "null argument");
-    DRT_REQUIRE(ntx >= 0 && nrx >= 0, "negative size");
-    DRT_REQUIRE(nrx < (1ll << 31), "too many receivers for one launch");
-    Launch L;
-    L.s = as_stream(stream);
-    L.quads = mesh->assume_quads != 0;
-    int32_t rc = make_cand_src(cands, L.quads ? 2 : 1, &L.cs);
-    if (rc != DRT_OK) return rc;
-    DRT_REQUIRE(!L.cs.ragged, "ragged pair spaces have no dense layout: use drt_trace_paths_compact");
-    DRT_REQUIRE(!L.cs.packed, "packed keys address traced paths (drt_trace_paths_vjp), they are not a candidate source");
-    L.a = make_args(mesh, pr, tx, ntx, rx, nrx);
-    if ((pr->flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0) {
-        rc = drt_mesh_build_bvh(mesh, stream);
-        if (rc != DRT_OK) return rc;
-        L.bvh = reinterpret_cast<const BvhNode *>(mesh->bvh_nodes);
-        L.bvh_leaf_ids = mesh->bvh_leaf_ids;
-    }
-    const int64_t total = ntx * nrx * L.cs.count;
-    if (total == 0) return DRT_OK;  // SV:566-573
-    DRT_REQUIRE(tx && rx && vertices && objects && mask, "null pointer");
-    const size_t need = drt_trace_dense_workspace_size(ntx, nrx, L.cs.count);
-    if (!ws || ws_bytes < need) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", need);
-    auto *qc = reinterpret_cast<unsigned long long *>(ws);
-    auto *q = reinterpret_cast<long long *>(reinterpret_cast<char *>(ws) + 64);
-    DRT_HIP(hipMemsetAsync(qc, 0, 64, L.s));
-    const int k = cands->order;
-#define CALL(K)                                                                            \
-    do {                                                                                   \
-        if (L.quads)                                                                       \
-            launch_filter<K, true, true>(L, qc, q, total, vertices, objects, mask);        \
-        else                                                                               \
-            launch_filter<K, false, true>(L, qc, q, total, vertices, objects, mask);       \
-        launch_occlusion<K, true>(L, qc, q, total, nullptr, nullptr, 0, mask);             \
-    } while (0)
-    DRT_ORDER_SWITCH(k, CALL)
 #undef CALL
     DRT_LAUNCH_CHECK();
     return DRT_OK;
@@ -754,9 +687,9 @@ int32_t drt_trace_paths_compact(drt_mesh_t mesh, const drt_trace_params *pr, con
 #define CALL(K)                                                                                   \
     do {                                                                                          \
         if (L.quads)                                                                              \
-            launch_filter<K, true, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+            launch_filter<K, true>(L, counters, q1, max_survivors); \
         else                                                                                      \
-            launch_filter<K, false, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+            launch_filter<K, false>(L, counters, q1, max_survivors); \
         timer.mark(1);                                                                            \
         launch_occlusion<K, false>(L, counters, q1, max_survivors, counters + 1, q2, max_paths,  \
                                    nullptr);                                                      \
@@ -852,9 +785,9 @@ int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *p
 #define CALL(K)                                                                                   \
     do {                                                                                          \
         if (L.quads)                                                                              \
-            launch_filter<K, true, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+            launch_filter<K, true>(L, counters, q1, max_survivors); \
         else                                                                                      \
-            launch_filter<K, false, false>(L, counters, q1, max_survivors, nullptr, nullptr, nullptr); \
+            launch_filter<K, false>(L, counters, q1, max_survivors); \
         launch_occlusion<K, false>(L, counters, q1, max_survivors, counters + 1, q2, max_paths,  \
                                    nullptr);                                                      \
     } while (0)

@@ -10,14 +10,15 @@
 //     contiguous segment of every output array (3072 B of vertices, 1024 B of objects, 512 B of types, 64 B of mask
 //     at K = 2);
 //   * each wave stages its rows in a wave-private LDS region and flushes them with 16-B nontemporal stores whose
-//     chunks start on 128-B lines of the output (stores.hpp) -- the direct form (one lane = one row, K+2 `st3` at a
-//     12(K+2)-byte lane stride) touched 24+ lines per store instruction;
+//     chunks start on 128-B lines of the output (stores.hpp).  Measured against the direct form of round 3 (one lane
+//     = one row, K+2 `st3` at a 12(K+2)-byte lane stride, 24+ lines per store instruction) on the same box,
+//     profiles/r04/dense.md: 5.74 TB/s of stores against 5.25 TB/s -- the L2 already merged most of the direct
+//     form's partial lines, the staged form is worth 9 % and writes the interaction types too;
 //   * the mask row comes straight from the wave ballot that also drives the survivor queue (four lanes store 16 B);
 //   * no block barrier anywhere: waves run free, 8 blocks per CU at K = 2 (18 KiB of LDS per block).
 // The arithmetic (image chain with the reference's where-guards, inside / same-side / length / finite / active
 // checks) is the compact tracer's, bit for bit; candidates that pass go to the same stage B (occlusion), which
 // clears their mask byte when blocked.
-#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -225,17 +226,11 @@ size_t drt_trace_dense_workspace_size(int64_t ntx, int64_t nrx, int64_t C) {
     return 64 + (size_t)ntx * (size_t)nrx * (size_t)C * 8;
 }
 
-int32_t drt_trace_paths_dense_legacy(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx, int64_t ntx,
-                                     const float *rx, int64_t nrx, const drt_candidates *cands, float *vertices,
-                                     int32_t *objects, uint8_t *mask, void *ws, size_t ws_bytes, void *stream);
-
 int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx, int64_t ntx,
                                  const float *rx, int64_t nrx, const drt_candidates *cands,
                                  const int32_t *types_in, float *vertices, int32_t *objects, uint8_t *mask,
                                  int32_t *types_out, void *ws, size_t ws_bytes, void *stream) {
     DRT_REQUIRE(mesh && pr && cands, "null argument");
-    if (std::getenv("DRT_DENSE_LEGACY"))  // scratch A/B switch, see trace.hip (interaction types are NOT written)
-        return drt_trace_paths_dense_legacy(mesh, pr, tx, ntx, rx, nrx, cands, vertices, objects, mask, ws, ws_bytes, stream);
     DRT_REQUIRE(ntx >= 0 && nrx >= 0, "negative size");
     DRT_REQUIRE(nrx < (1ll << 31), "too many receivers for one launch");
     Launch L;

@@ -87,8 +87,8 @@ class TracedPaths:
 
     @property
     def num_valid_paths(self) -> torch.Tensor:
-        """geometry/_paths.py:264-272."""
-        return self._bool_mask().sum()
+        """geometry/_paths.py:264-272 (one reduction kernel over the 1-byte mask; `.sum()` would first widen it to int64)."""
+        return torch.count_nonzero(self._bool_mask())
 
     @property
     def masked_vertices(self) -> torch.Tensor:
