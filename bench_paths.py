@@ -100,6 +100,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         # BASELINE configs[3]: the same scene at order 3 -- 1.02e15 candidates, reachable only through the pruned
         # search (no exhaustive count to compare with: 91 paths, re-validated by the oracle in tests/test_full_size_gpu.py)
         out["beam_pruned_order3"] = beam_leg(G, mesh, tx, rx, 3, None, reps=1)
+        out["beam_pruned_order3"]["same_valid_paths_as_exhaustive"] = exhaustive_record("configs[3]")
         out["visibility_pruned"] = pruned_leg(G, mesh, tx, rx, order, nvalid)
     if rank == 0 and world == 1 and num_ranks is None and order == 2:
         # the drop-in itself: Scene.trace_paths(order, chunk_size=...) in the reference's dense layout (bench_dense.py)
@@ -203,6 +204,29 @@ def beam_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps: int 
                             "incidence geometry (no smallest-cosine parameter)"}
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}
+
+
+def exhaustive_record(config: str) -> dict | None:
+    """Order 3 has no exhaustive count for the whole 16 x 64 problem (1.02e15 candidates); what exists is the committed
+    record of scratch/exhaustive_pairs.py: the WHOLE 9.998e11-candidate space of single pairs through the exhaustive
+    tracer == the pruned search's rows of those pairs (objects and vertex bits, kappa = 64 and 1), plus the 1-pair
+    slice of it in the -m gpu suite (tests/test_full_size_gpu.py)."""
+    import json
+    from pathlib import Path
+
+    recs = sorted((Path(__file__).resolve().parent / "profiles").glob("r*/stress/exhaustive_pairs.json"))
+    if not recs:
+        return None
+    try:
+        data = json.loads(recs[-1].read_text())
+        for r in data["records"]:
+            if r["config"] == config:
+                return {"checked_pairs": r["checked_pairs"], "all_equal": r["all_equal"],
+                        "candidates_evaluated": r["candidates_evaluated"], "kappas": r["kappas"],
+                        "record": f"profiles/{recs[-1].parent.parent.name}/stress/exhaustive_pairs.json"}
+    except Exception:  # noqa: BLE001
+        return None
+    return None
 
 
 def pruned_leg(G, mesh, tx, rx, order: int, expected_valid: int) -> dict:

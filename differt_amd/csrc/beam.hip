@@ -1610,14 +1610,44 @@ struct BeamSizes {
     int64_t max_entries, max_records, max_rows, max_survivors;
 };
 
-static BeamSizes beam_sizes(const drt_beam_params *bp, int64_t ntx, int64_t nprim) {
+// Default list capacities, sized from the scene (results never depend on them: a slice that overflows is retried
+// smaller, drt_trace_paths_beam; round 3 took 2^26 / 2^27 / 2^26 / 2^22 whatever the scene = 5.5 GiB of workspace
+// for a 12-triangle box).  Two ingredients:
+//   * hard bounds: a level-2 list has at most ntx * n^2 prefixes, an expansion slice at most (its prefixes) * n
+//     records, a slice's rows at most records * nrx, the survivors at most the rows;
+//   * a fan-out estimate for scenes in between: the level-2 list of a city mesh holds F = 2-8 % of the n children of a
+//     level-1 prefix (configs[2]: 480 of 10 000; configs[4]: 2 600 of 200 000) -- est = ntx * n * max(256, n / 8),
+//     capacities 4x that, between 2^18 and the round-3 values.
+// configs[2] / [3] / [4] resolve to exactly the round-3 capacities.
+static int64_t sat_mul(int64_t a, int64_t b) {
+    if (a <= 0 || b <= 0) return 0;
+    return (a > (int64_t)(1ll << 62) / b) ? (int64_t)(1ll << 62) : a * b;
+}
+static int64_t pow2_at_least(int64_t v) {
+    int64_t p = 1;
+    while (p < v && p < (int64_t)(1ll << 62)) p <<= 1;
+    return p;
+}
+static int64_t clamp64(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static BeamSizes beam_sizes(const drt_beam_params *bp, int64_t ntx, int64_t nrx, int64_t nprim, int32_t order) {
+    const int64_t n1 = sat_mul(ntx > 0 ? ntx : 1, nprim > 0 ? nprim : 1);          // level-1 prefixes at most
+    const int64_t n2 = sat_mul(n1, nprim > 0 ? nprim : 1);                          // level-2 prefixes at most
+    const int64_t fan = std::min<int64_t>(nprim > 0 ? nprim : 1, std::max<int64_t>(256, nprim / 8));
+    const int64_t est = sat_mul(n1, fan);                                           // expected level-2 size
+    const int64_t rx1 = nrx > 0 ? nrx : 1;
     BeamSizes z;
-    z.max_entries = (bp && bp->max_entries > 0) ? bp->max_entries : (int64_t)1 << 26;
-    z.max_records = (bp && bp->max_records > 0) ? bp->max_records : (int64_t)1 << 27;
-    z.max_rows = (bp && bp->max_rows > 0) ? bp->max_rows : (int64_t)1 << 26;
-    z.max_survivors = (bp && bp->max_survivors > 0) ? bp->max_survivors : (int64_t)1 << 22;
-    (void)ntx;
-    (void)nprim;
+    const int64_t d_entries = std::min(clamp64(pow2_at_least(sat_mul(est, 2)), (int64_t)1 << 16, (int64_t)1 << 26), std::max<int64_t>(n2, 64));
+    z.max_entries = (bp && bp->max_entries > 0) ? bp->max_entries : d_entries;
+    // records of one slice: order 2 expands level-1 prefixes (<= n2 in all); order 3 expands slices of the level-2
+    // list, each prefix into at most nprim records
+    const int64_t rec_bound = (order >= 3) ? sat_mul(z.max_entries, nprim > 0 ? nprim : 1) : n2;
+    const int64_t d_records = std::min(clamp64(pow2_at_least(sat_mul(est, 4)), (int64_t)1 << 18, (int64_t)1 << 27), std::max<int64_t>(rec_bound, 64));
+    z.max_records = (bp && bp->max_records > 0) ? bp->max_records : d_records;
+    const int64_t row_bound = sat_mul(order >= 2 ? z.max_records : n1, rx1);
+    const int64_t d_rows = std::min(clamp64(z.max_records / 2, (int64_t)1 << 18, (int64_t)1 << 26), std::max<int64_t>(row_bound, 64));
+    z.max_rows = (bp && bp->max_rows > 0) ? bp->max_rows : d_rows;
+    z.max_survivors = (bp && bp->max_survivors > 0) ? bp->max_survivors : std::min<int64_t>((int64_t)1 << 22, z.max_rows);
     return z;
 }
 
@@ -1811,7 +1841,7 @@ size_t drt_trace_beam_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num
     if (order < 0) order = 0;
     if (order > 3) order = 3;
     if (order == 0) return drt_trace_compact_workspace_size(num_tx * num_rx, max_paths);  // line of sight: plain trace
-    return beam_layout(beam_sizes(bp, num_tx, num_primitives), num_tx, num_rx, num_primitives, order, max_paths).total;
+    return beam_layout(beam_sizes(bp, num_tx, num_rx, num_primitives, order), num_tx, num_rx, num_primitives, order, max_paths).total;
 }
 
 int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const drt_beam_params *bp, const float *tx,
@@ -1846,6 +1876,8 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         const int32_t rc0 = drt_trace_paths_compact(mesh, &tp, tx, ntx, rx, nrx, &c, ntx * nrx, max_paths, keys, vertices,
                                                     objects, num_valid_host, ws, ws_bytes, stream);
         if (st) st->valid = *num_valid_host;
+        if (rc0 == DRT_E_CAPACITY && *num_valid_host > max_paths)  // same wording as the pruned orders: callers regrow on it
+            return fail(DRT_E_CAPACITY, "more than %lld valid paths: raise max_paths", (long long)max_paths);
         return rc0;
     }
     if (M.nprim == 0 || ntx == 0 || nrx == 0) return DRT_OK;
@@ -1862,7 +1894,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     int key_bits = 1;
     while (key_bits < 64 && ((unsigned __int128)1 << key_bits) < total) ++key_bits;
 
-    const BeamSizes z = beam_sizes(bp, ntx, M.nprim);
+    const BeamSizes z = beam_sizes(bp, ntx, nrx, M.nprim, order);
     const BeamLayout L = beam_layout(z, ntx, nrx, M.nprim, order, max_paths);
     if (!ws || ws_bytes < L.total) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", L.total);
     DRT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15u) == 0, "workspace must be 16-byte aligned");

@@ -550,10 +550,13 @@ typedef struct drt_beam_params {
                                DESIGN.md section 9 (measured errors are 5-50x smaller: oracle/studies/beam_error_model.py;
                                configs[3]: 0.83 s at 64, 0.63 s at 16, same paths) */
     int32_t flags;          /* DRT_BEAM_* */
-    int64_t max_entries;    /* level-2 prefix list (order 3), 32 B each; <= 0: 2^26 */
-    int64_t max_records;    /* records of one expansion slice, 8 B each; <= 0: 2^27 */
-    int64_t max_rows;       /* candidate rows of one slice, 8 + 8 + 4 order B each; <= 0: 2^26 */
-    int64_t max_survivors;  /* survivor queue of the fused trace; <= 0: 2^22 */
+    /* list capacities; <= 0: sized from the scene (hard bounds num_tx * n^2 etc. and a fan-out estimate; at most
+     * 2^26 / 2^27 / 2^26 / 2^22, which is what 10k+ triangle cities resolve to; a 12-triangle box at order 3 needs
+     * < 1 MB).  Results never depend on them: the call slices its lists to fit. */
+    int64_t max_entries;    /* level-2 prefix list (order 3), 32 B each */
+    int64_t max_records;    /* records of one expansion slice, 8 B each */
+    int64_t max_rows;       /* candidate rows of one slice, 8 + 8 + 4 order B each */
+    int64_t max_survivors;  /* survivor queue of the fused trace */
     int64_t probe_prefixes; /* size of the first slice of the last expansion; <= 0: 4096 */
     int64_t shard_rank;     /* multi-GPU split: keep the level-1 prefixes (tx, m) with */
     int64_t shard_world;    /*   (tx * n + m) % shard_world == shard_rank; <= 1: everything */

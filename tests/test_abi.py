@@ -96,5 +96,17 @@ def test_workspace_size_queries_work_without_a_gpu():
     c = L.drt_trace_beam_workspace_size(16, 64, 10000, 3, C.byref(bp), 1 << 16)
     assert 0 < c < b
     assert L.drt_trace_beam_workspace_size(1, 1, 12, 0, None, 4) == L.drt_trace_compact_workspace_size(1, 4)
+    # default capacities follow the scene: BASELINE configs[0]'s 12-triangle box at order 3 stays
+    # under 64 MB (round 3: 5.5 GiB whatever the scene); the 10k-triangle configs keep the round-3 capacities
+    box = L.drt_trace_beam_workspace_size(1, 1, 12, 3, None, 1 << 16)
+    assert 0 < box < 64 << 20
+    assert L.drt_trace_beam_workspace_size(1, 1, 12, 3, None, 64) < 1 << 20
+    full = _lib.BeamParams()
+    full.max_entries, full.max_records, full.max_rows, full.max_survivors = 1 << 26, 1 << 27, 1 << 26, 1 << 22
+    for (ntx, nrx, n, order) in ((16, 64, 10000, 2), (16, 64, 10000, 3), (1, 1024, 200000, 2)):
+        assert (L.drt_trace_beam_workspace_size(ntx, nrx, n, order, None, 1 << 16)
+                == L.drt_trace_beam_workspace_size(ntx, nrx, n, order, C.byref(full), 1 << 16))
+    mid = L.drt_trace_beam_workspace_size(4, 16, 1000, 3, None, 1 << 16)
+    assert box < mid < b
     assert L.drt_trace_vjp_workspace_size(0, 2) > 0
     assert L.drt_trace_vjp_workspace_size(1000, 3) > L.drt_trace_vjp_workspace_size(1000, 1)

@@ -256,6 +256,38 @@ def test_cfg4_full_coverage_beam_pruned(G, manhattan):
     assert torch.equal(merged, bp.keys)
 
 
+def _exhaustive_pairs_module():
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("exhaustive_pairs",
+                                                  Path(__file__).resolve().parents[1] / "scratch" / "exhaustive_pairs.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_cfg4_beam_equals_exhaustive_on_a_whole_pair_space(G, manhattan):
+    """configs[3] completeness AT ITS OWN SIZE: every one of the 9.998e11 order-3 candidates of
+    one (tx, rx) pair -- the pair with the most paths -- through the exhaustive tracer (reference enumeration
+    _solvers.py:803-848), against the rows of the full 16 x 64 pruned search that belong to the pair, at kappa = 64
+    and kappa = 1: same objects, same vertex bits.  ~12 s; scratch/exhaustive_pairs.py runs more pairs (record:
+    profiles/r04/stress/exhaustive_pairs.json)."""
+    V, Tr, tx, rx = manhattan
+    rec = _exhaustive_pairs_module().check_config("configs[3]", V, Tr, tx, rx, 3, 1, (64.0, 1.0), 64, 1 << 24)
+    assert rec["all_equal"] and rec["checked_pairs"] == 1
+    assert rec["pairs"][0]["candidates"] == 10000 * 9999 ** 2 and rec["pairs"][0]["exhaustive_valid_paths"] >= 1
+
+
+def test_cfg5_beam_equals_exhaustive_on_whole_pair_spaces(G):
+    """configs[4] (200 000 triangles, order 2): all 4.0e10 candidates of 3 pairs (most paths / grazing-heavy / no
+    path) against the pruned search, kappa = 64 and 1."""
+    V, Tr, tx, rx = S.cfg5_scene()
+    rec = _exhaustive_pairs_module().check_config("configs[4]", V, Tr, tx, rx, 2, 3, (64.0, 1.0), 4, 1 << 24)
+    assert rec["all_equal"] and rec["checked_pairs"] == 3
+    assert sum(p["exhaustive_valid_paths"] for p in rec["pairs"]) >= 1
+
+
 def test_cfg5_full_coverage_beam_pruned(G):
     """configs[4] at FULL size (1 TX x 1024 RX, 200 000 triangles, order 2, 4.1e13 candidates) through the pruned
     search with the clustered expansion / receiver stage: every path re-validated by the oracle against the whole

@@ -298,6 +298,52 @@ def test_config1_box(G):
     assert int(q.num_valid_paths) == 6
 
 
+def test_config1_box_beam_raw_call_with_the_queried_workspace(G):
+    """configs[0] at orders 0..3 through drt_trace_paths_beam called directly with drt_trace_beam_workspace_size's
+    answer for the scene (default capacities: < 64 MB for the box) == the exhaustive tracer."""
+    import ctypes as C
+
+    from differt_amd import _lib
+    from differt_amd._tensors import ptr, stream
+    from differt_amd.geometry._solvers import _params
+
+    scene = G.Scene([0.1, -0.2, 0.05], [-0.3, 0.25, -0.1], G.Mesh.box(with_top=True))
+    tx = scene.transmitters.reshape(-1, 3).contiguous()
+    rx = scene.receivers.reshape(-1, 3).contiguous()
+    L = _lib.load()
+    for order in (0, 1, 2, 3):
+        ex = G.ExhaustivePathTracer().trace_rank_range(scene, order)
+        mp = 256
+        nbytes = L.drt_trace_beam_workspace_size(1, 1, 12, order, None, mp)
+        assert nbytes < 64 << 20
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        keys = torch.empty(mp, dtype=torch.int64, device="cuda")
+        verts = torch.empty((mp, order + 2, 3), dtype=torch.float32, device="cuda")
+        objs = torch.empty((mp, order + 2), dtype=torch.int32, device="cuda")
+        nv = C.c_int64(0)
+        params = _params(None, None, None)
+        _lib.call("drt_trace_paths_beam", scene.mesh.handle().h, C.byref(params), None, ptr(tx), 1, ptr(rx), 1, order, mp,
+                  ptr(keys), ptr(verts), ptr(objs), C.byref(nv), ptr(ws), nbytes, stream())
+        n = int(nv.value)
+        assert n == ex.objects.shape[0] and (order == 0 or n > 0)
+        np.testing.assert_array_equal(_np(objs[:n]), _np(ex.objects))
+        np.testing.assert_array_equal(_bits(_np(verts[:n])), _bits(_np(ex.vertices)))
+
+
+def test_beam_order0_output_overflow_regrows(G, rng):
+    """line-of-sight pairs beyond max_paths -- the order-0 branch forwards to the compact tracer, whose
+    overflow must come back as the regrowable "raise max_paths" condition, not as a hard CapacityError."""
+    tx = rng.uniform(-1, 1, (40, 3)).astype(np.float32) + np.array([0, 0, 50], np.float32)
+    rx = rng.uniform(-1, 1, (50, 3)).astype(np.float32) + np.array([0, 0, 60], np.float32)
+    scene = G.Scene(tx, rx, G.Mesh.box(with_top=True))
+    ex = G.ExhaustivePathTracer().trace_rank_range(scene, 0)
+    assert ex.objects.shape[0] == 2000
+    bp = G.ExhaustivePathTracer().trace_beam_pruned(scene, 0, max_paths=64)
+    assert torch.equal(bp.objects, ex.objects) and torch.equal(bp.vertices, ex.vertices)
+    cp = scene.trace_paths(0, solver="beam", max_paths=100)
+    assert cp.objects.shape[0] == 2000
+
+
 # ------------------------------------------------------------------ gradients ----
 @pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("compact", [False, True])
