@@ -15,10 +15,11 @@ which = [a for a in sys.argv[1:] if a.startswith("cfg")] or ["cfg3", "cfg4"]
 EXPANSION = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--expansion=")), "auto")
 EMIT = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--emit=")), "auto")
 KAPPA = float(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--kappa=")), "64"))
+QUADS = "--quads" in sys.argv[1:]  # assume_quads=True, as the reference harness (tests/benchmarks/test_rt.py:151-196)
 
 
 def run(name, V, Tr, tx, rx, order, verify=None):
-    mesh = G.Mesh(V, Tr)
+    mesh = G.Mesh(V, Tr, assume_quads=QUADS)
     tracer = G.ExhaustivePathTracer(accel="bvh")  # occlusion stage on the LBVH (bit-identical, O(log T))
 
     def step():
@@ -38,7 +39,7 @@ def run(name, V, Tr, tx, rx, order, verify=None):
     n = mesh.num_primitives
     out = {"config": name, "order": order, "triangles": int(Tr.shape[0]), "num_tx": len(tx), "num_rx": len(rx),
            "exhaustive_candidates": len(tx) * len(rx) * n * (n - 1) ** (order - 1), "s_per_step": dt,
-           "valid_paths": int(p.objects.shape[0]), "expansion": EXPANSION, "emit": EMIT, "kappa": KAPPA, **tracer.last_beam_stats,
+           "valid_paths": int(p.objects.shape[0]), "expansion": EXPANSION, "emit": EMIT, "kappa": KAPPA, "assume_quads": QUADS, **tracer.last_beam_stats,
            "grad_finite": bool(torch.isfinite(g).all()) if g is not None else None}
     if verify is not None:
         ex = verify(mesh)
