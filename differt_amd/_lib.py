@@ -79,6 +79,8 @@ class BeamStats(C.Structure):
         ("grazing_prefixes", C.c_int64),
         ("unit_m", C.c_float),
         ("magnitude", C.c_float),
+        ("pair_mode", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -99,7 +101,7 @@ class BeamParams(C.Structure):
     ]
 
 
-DRT_BEAM_EXPAND_PLAIN, DRT_BEAM_EMIT_PLAIN, DRT_BEAM_EMIT_CLUSTERED = 1, 2, 4
+DRT_BEAM_EXPAND_PLAIN, DRT_BEAM_EMIT_PLAIN, DRT_BEAM_EMIT_CLUSTERED, DRT_BEAM_NO_PAIRS = 1, 2, 4, 8
 DRT_CAND_PACKED_KEYS = 4
 
 

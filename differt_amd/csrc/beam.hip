@@ -89,8 +89,10 @@ struct BeamMesh {
     const float *shape;    // [T]
     const uint8_t *mask;   // [T] or null
     int64_t nprim;
-    int32_t scale;  // triangles per primitive (2 with assume_quads)
+    int32_t scale;  // triangles per primitive (2 with assume_quads, or for the coplanar pairs of a triangle mesh)
     float inv_2m;   // 1 / (2 M), M = largest coordinate magnitude of mesh, transmitters and receivers
+    int32_t self_loops;  // coplanar-pair mode of a TRIANGLE mesh: a pair may follow itself (its two triangles are
+                         // different candidates of the triangle-level space; assume_quads has no such candidate)
 };
 // The error unit u = kappa ulp(M) assumes operands within 2 M (differences of scene points, images one reflection
 // away).  Images of images can reach (2k+1) M, and float32 rounding grows with the operand: a prefix whose apex lies
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             for (int t = 0; t < SCALE; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pl[t][q] = lds_pl[j][t][q];
-            const bool cand = have && (c != m);
+            const bool cand = have && (c != m || M.self_loops);
             const bool keep = cand && !prim_pruned<SCALE, LEVEL>(ctx, vx, pl, lds_sg[j], cand);
             beam_stage<kBeamWaveBuf>(keep, ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c, wbuf[wave], wcount,
                                      lane, out, cap, count);
@@ -848,7 +850,7 @@ __device__ __forceinline__ void expand_clustered_body(
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
             const BeamCtx<SCALE, LEVEL> cx = lane_bcast<SCALE, LEVEL>(ctx, l);
-            const bool cand = act && (p != __builtin_amdgcn_readlane(m, l));
+            const bool cand = act && (p != __builtin_amdgcn_readlane(m, l) || M.self_loops);
             const bool keep = cand && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg, cand);
 #ifdef BEAM_LAB_COUNT
             {
@@ -1491,7 +1493,7 @@ __global__ __launch_bounds__(256) void rows_decode_kernel(const unsigned long lo
 // offsets[p] = first sorted row of pair p (lower bound of p * n^ORDER), p = 0 .. npairs
 __global__ __launch_bounds__(256) void pair_offsets_kernel(const unsigned long long *__restrict__ rows, int64_t n,
                                                            unsigned long long npow, int64_t npairs,
-                                                           long long *__restrict__ offsets) {
+                                                           long long *__restrict__ offsets, int64_t mult) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p > npairs) return;
     const unsigned long long target = (unsigned long long)p * npow;
@@ -1500,7 +1502,60 @@ __global__ __launch_bounds__(256) void pair_offsets_kernel(const unsigned long l
         const int64_t mid = (lo + hi) >> 1;
         if (rows[mid] < target) lo = mid + 1; else hi = mid;
     }
-    offsets[p] = lo;
+    offsets[p] = lo * mult;  // (mult: table rows per sorted row, 2^ORDER in coplanar-pair mode)
+}
+
+// ---- coplanar-pair mode (a triangle mesh searched over its n/2 pairs) ------------------------------------------
+// flag[0] stays 1 when every pair of triangles (2i, 2i+1) has EQUAL unit normals, the same first vertex (float
+// equality: +0 == -0 -- the cross product of axis-aligned edges yields zeros of either sign -- and a NaN equals
+// nothing) and the same mask value: both triangles then are THE SAME MIRROR for the reference (plane point and normal
+// feed image_of_vertex / the ray-plane step, _solvers.py:552-562; the sign of a zero component changes no value there,
+// only the sign of a zero result), every image and reflection point of a candidate has the same value whichever of
+// the two it names, and only the inside test tells them apart.  The exact trace of a triangle row uses that
+// triangle's own normal, zeros' signs included.
+__global__ __launch_bounds__(256) void pairable_kernel(const float *__restrict__ tv, const float *__restrict__ normals,
+                                                       const uint8_t *__restrict__ mask, int64_t npairs,
+                                                       uint32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const float *a = normals + 6 * i, *b = a + 3;
+    const float *va = tv + 18 * i, *vb = va + 9;
+    bool ok = a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && va[0] == vb[0] && va[1] == vb[1] && va[2] == vb[2];
+    if (mask) ok = ok && ((mask[2 * i] != 0) == (mask[2 * i + 1] != 0));
+    if (!ok) atomicAnd(flag, 0u);
+}
+
+// sorted packed PAIR rows ((tx nrx + rx) nq^K + sum q_j nq^(K-1-j)) -> the 2^K triangle rows of each, in place of
+// rows_decode: table rows [i 2^K + c] = triangle ids 2 q_j + bit_j(c) (a repeated pair row, or a combination that
+// names the same triangle twice in a row -- not a candidate of the reference's graph, graph.rs:400-470 -- becomes a
+// padding row of -1) and tri_keys[i 2^K + c] = the triangle-level packed key, what drt_trace_paths_beam returns.
+template <int ORDER>
+__global__ __launch_bounds__(256) void rows_expand_pairs_kernel(const unsigned long long *__restrict__ rows, int64_t n,
+                                                                unsigned long long nq, int32_t *__restrict__ table,
+                                                                unsigned long long *__restrict__ tri_keys) {
+    constexpr int COMBOS = 1 << ORDER;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n * COMBOS) return;
+    const int64_t i = g >> ORDER;
+    const int c = (int)(g & (COMBOS - 1));
+    const unsigned long long key = rows[i];
+    bool bad = i > 0 && rows[i - 1] == key;
+    unsigned long long rest = key;
+    int32_t id[ORDER];
+#pragma unroll
+    for (int j = ORDER - 1; j >= 0; --j) {
+        const unsigned long long q = rest / nq;
+        id[j] = (int32_t)(rest - q * nq) * 2 + ((c >> (ORDER - 1 - j)) & 1);
+        rest = q;
+    }
+#pragma unroll
+    for (int j = 1; j < ORDER; ++j) bad = bad || (id[j] == id[j - 1]);
+    unsigned long long tk = rest;  // the pair index
+#pragma unroll
+    for (int j = 0; j < ORDER; ++j) tk = tk * (2ull * nq) + (unsigned long long)id[j];
+#pragma unroll
+    for (int j = 0; j < ORDER; ++j) table[g * ORDER + j] = bad ? -1 : id[j];
+    tri_keys[g] = tk;
 }
 
 // keys of the slice's trace are rows of its table: back to packed rows
@@ -1534,6 +1589,15 @@ static BeamMesh beam_mesh(drt_mesh_t m) {
     M.scale = m->assume_quads ? 2 : 1;
     M.nprim = m->num_triangles / M.scale;
     M.inv_2m = 0.0f;  // set by the driver once the scene magnitude is known (0: no rescaling)
+    M.self_loops = 0;
+    return M;
+}
+// the same mesh searched over its coplanar triangle pairs (drt_mesh::beam_pairs == 1)
+static BeamMesh beam_mesh_pairs(drt_mesh_t m) {
+    BeamMesh M = beam_mesh(m);
+    M.scale = 2;
+    M.nprim = m->num_triangles / 2;
+    M.self_loops = 1;
     return M;
 }
 
@@ -1770,12 +1834,48 @@ extern "C" void drt_debug_beam_counts(unsigned long long *out, int reset) {
 
 extern "C" {
 
-int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
+// Clusters for the search's primitives: quads of an assume_quads mesh, triangles, or -- `allow_pairs` and the mesh
+// qualifies (pairable_kernel) -- the coplanar pairs of a triangle mesh.  Cached in the handle per primitive kind; a
+// call that asks for the other kind of the same mesh rebuilds (only A/B runs and tests do that).
+static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stream) {
     DRT_REQUIRE(mesh, "mesh is null");
-    if (mesh->beam_blob) return DRT_OK;
-    const BeamMesh M = beam_mesh(mesh);
-    if (M.nprim == 0) return DRT_OK;
     hipStream_t s = as_stream(stream);
+    if (!mesh->assume_quads && mesh->beam_pairs < 0) {
+        mesh->beam_pairs = 0;
+        const int64_t T = mesh->num_triangles;
+        if (T >= 2 && T % 2 == 0) {
+            uint32_t *flag = nullptr, h = 0;
+            DRT_HIP(hipMalloc(&flag, 4));
+            hipError_t e = fill_bytes_async(flag, 0, 4, s);
+            if (e == hipSuccess) {
+                const uint32_t one = 1;
+                e = hipMemcpyAsync(flag, &one, 4, hipMemcpyHostToDevice, s);
+            }
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(pairable_kernel, dim3((unsigned)ceil_div(T / 2, 256)), dim3(256), 0, s, mesh->tri_verts,
+                                   mesh->normals, mesh->has_mask ? mesh->mask : nullptr, T / 2, flag);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            (void)hipFree(flag);
+            if (e != hipSuccess) {
+                mesh->beam_pairs = -1;
+                return fail(DRT_E_HIP, "coplanar-pair check failed: %s", hipGetErrorString(e));
+            }
+            mesh->beam_pairs = h ? 1 : 0;
+        }
+    }
+    const bool pairs = !mesh->assume_quads && allow_pairs && mesh->beam_pairs == 1;
+    const BeamMesh M = pairs ? beam_mesh_pairs(mesh) : beam_mesh(mesh);
+    if (mesh->beam_blob && mesh->beam_scale == M.scale) return DRT_OK;
+    if (mesh->beam_blob) {  // built for the other primitive kind
+        DRT_HIP(hipStreamSynchronize(s));
+        (void)hipFree(mesh->beam_blob);
+        mesh->beam_blob = nullptr;
+        mesh->beam_scale = 0;
+    }
+    if (M.nprim == 0) return DRT_OK;
     const int64_t ncl = ceil_div(M.nprim, 64), pp = ncl * 64, sc = M.scale;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1825,12 +1925,15 @@ int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) {
             mesh->beam_subboxes = subboxes;
             mesh->beam_clusters = ncl;
             mesh->beam_blob = blob;
+            mesh->beam_scale = (int32_t)sc;
         }
     }
     (void)hipFree(tmp);
     if (rc != DRT_OK) (void)hipFree(blob);
     return rc;
 }
+
+int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) { return build_beam_clusters(mesh, true, stream); }
 
 size_t drt_trace_beam_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_primitives, int32_t order,
                                      const drt_beam_params *bp, int64_t max_paths) {
@@ -1861,7 +1964,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     drt_beam_stats *st = bp ? bp->stats : nullptr;
     if (st) memset(st, 0, sizeof(*st));
     hipStream_t s = as_stream(stream);
-    BeamMesh M = beam_mesh(mesh);
+    BeamMesh M = beam_mesh(mesh);  // the caller's view: triangles, or quads with assume_quads (sizes, keys, early outs)
     drt_trace_params tp = *pr;
     tp.stats = nullptr;
 
@@ -1894,8 +1997,9 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     int key_bits = 1;
     while (key_bits < 64 && ((unsigned __int128)1 << key_bits) < total) ++key_bits;
 
-    const BeamSizes z = beam_sizes(bp, ntx, nrx, M.nprim, order);
-    const BeamLayout L = beam_layout(z, ntx, nrx, M.nprim, order, max_paths);
+    const int64_t nprim_caller = M.nprim;  // the workspace query was made with this count
+    const BeamSizes z = beam_sizes(bp, ntx, nrx, nprim_caller, order);
+    const BeamLayout L = beam_layout(z, ntx, nrx, nprim_caller, order, max_paths);
     if (!ws || ws_bytes < L.total) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", L.total);
     DRT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15u) == 0, "workspace must be 16-byte aligned");
     char *base = reinterpret_cast<char *>(ws);
@@ -1913,8 +2017,27 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     char *sort_tmp = base + L.sort_tmp;
     auto *slice_keys = reinterpret_cast<long long *>(base + L.slice_keys);
 
-    int32_t rc = drt_mesh_build_beam_clusters(mesh, stream);
+    int32_t rc = build_beam_clusters(mesh, !(flags & DRT_BEAM_NO_PAIRS), stream);
     if (rc != DRT_OK) return rc;
+    // Coplanar-pair mode: a triangle mesh whose triangles (2i, 2i+1) are the same mirror is searched over its n/2
+    // pairs with the quad kernels (pyramid of a pair = union of its triangles' pyramids: what keeps a triangle
+    // sequence keeps its pair sequence; a pair may follow itself), a quarter of the level-2 prefixes of a box city;
+    // every surviving pair row is then split into its 2^order triangle rows, which the exact trace decides.
+    const bool pairs = !mesh->assume_quads && mesh->beam_scale == 2;
+    int key_bits_rows = key_bits;  // bits of the keys the row sort sees
+    int64_t rows_cap = z.max_rows;
+    if (pairs) {
+        M = beam_mesh_pairs(mesh);
+        npow = 1;
+        unsigned __int128 tq = (unsigned __int128)ntx * (unsigned __int128)nrx;
+        for (int j = 0; j < order; ++j) {
+            npow *= (unsigned long long)M.nprim;
+            tq *= (unsigned __int128)M.nprim;
+        }
+        key_bits_rows = 1;
+        while (key_bits_rows < 64 && ((unsigned __int128)1 << key_bits_rows) < tq) ++key_bits_rows;
+        rows_cap = std::max<int64_t>(z.max_rows >> order, 1);  // the split needs 2^order table rows per pair row
+    }
     BeamClusters C;
     C.order = mesh->beam_order;
     C.verts = mesh->beam_verts;
@@ -1990,32 +2113,46 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         *rows_out = 0;
         if (nsrc == 0) return DRT_OK;
         DRT_HIP(fill_bytes_async(counters, 0, 8, s));
-#define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, src, rec, nsrc, rx, rx_sorted, rx_index, rx_boxes, nrx, u, rows, z.max_rows, counters, counters + 1, s)
+#define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, src, rec, nsrc, rx, rx_sorted, rx_index, rx_boxes, nrx, u, rows, rows_cap, counters, counters + 1, s)
         BEAM_DISPATCH2(M.scale, order, CALL);
 #undef CALL
         DRT_LAUNCH_CHECK();
         int64_t r = 0;
         int32_t rc2 = read_count(counters, &r, s);
         if (rc2 != DRT_OK) return rc2;
-        *rows_out = r;
-        if (r > z.max_rows) {
+        *rows_out = r;  // in the unit of rows_cap: pair rows in coplanar-pair mode
+        if (r > rows_cap) {
             *fits = false;
             return DRT_OK;
         }
         if (r == 0) return DRT_OK;
         size_t tb = sort_keys64_temp_bytes(r);
         DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted, (size_t)r,
-                                         0, key_bits, s));
-        const dim3 gr((unsigned)ceil_div(r, 256));
-        if (order == 1) hipLaunchKernelGGL(rows_decode_kernel<1>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
-        else if (order == 2) hipLaunchKernelGGL(rows_decode_kernel<2>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
-        else hipLaunchKernelGGL(rows_decode_kernel<3>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
+                                         0, key_bits_rows, s));
+        int64_t table_rows = r;
+        const unsigned long long *row_keys = rows_sorted;  // table row -> packed key the caller gets
+        if (pairs) {
+            // every sorted pair row -> its 2^order triangle rows (table) and their triangle-level keys (into `rows`,
+            // whose unsorted content is no longer needed); pairs stay grouped, the order inside a pair is fixed later
+            table_rows = r << order;
+            const dim3 ge((unsigned)ceil_div(table_rows, 256));
+            auto *tri_keys = reinterpret_cast<unsigned long long *>(rows);
+            if (order == 1) hipLaunchKernelGGL(rows_expand_pairs_kernel<1>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, table, tri_keys);
+            else if (order == 2) hipLaunchKernelGGL(rows_expand_pairs_kernel<2>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, table, tri_keys);
+            else hipLaunchKernelGGL(rows_expand_pairs_kernel<3>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, table, tri_keys);
+            row_keys = tri_keys;
+        } else {
+            const dim3 gr((unsigned)ceil_div(r, 256));
+            if (order == 1) hipLaunchKernelGGL(rows_decode_kernel<1>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
+            else if (order == 2) hipLaunchKernelGGL(rows_decode_kernel<2>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
+            else hipLaunchKernelGGL(rows_decode_kernel<3>, gr, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.scale, table);
+        }
         hipLaunchKernelGGL(pair_offsets_kernel, dim3((unsigned)ceil_div(ntx * nrx + 1, 256)), dim3(256), 0, s, rows_sorted, r,
-                           npow, ntx * nrx, pair_offsets);
+                           npow, ntx * nrx, pair_offsets, pairs ? ((int64_t)1 << order) : (int64_t)1);
         DRT_LAUNCH_CHECK();
         drt_candidates c{};
         c.table = table;
-        c.num_candidates = r;
+        c.num_candidates = table_rows;
         c.order = order;
         c.pair_offsets = reinterpret_cast<const int64_t *>(pair_offsets);
         int64_t nv = 0;
@@ -2040,7 +2177,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         }
         if (nv > 0) {
             hipLaunchKernelGGL(keys_to_rows_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, s, slice_keys, nv,
-                               rows_sorted, reinterpret_cast<long long *>(keys) + nvalid);
+                               row_keys, reinterpret_cast<long long *>(keys) + nvalid);
             DRT_LAUNCH_CHECK();
             nvalid += nv;
             ++slices_with_paths;
@@ -2088,12 +2225,14 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
                 continue;
             }
             *records_total += c;
-            total_rows += r;
+            total_rows += pairs ? (r << order) : r;  // rows handed to the tracer
             ++nslices;
             ++done;
             const double per = (double)(i1 - i0);
             // (rows also against the survivor queue of the trace: survivors <= rows, so half of it never overflows)
-            const double row_budget = (double)std::min(z.max_rows, z.max_survivors);
+            // (pair mode: most of a pair row's 2^order triangle rows fail the first inside test -- the survivors are
+            // bounded like the pair rows, and an overflow of that queue only makes the slice retry smaller)
+            const double row_budget = (double)std::min(rows_cap, z.max_survivors);
             const double fan = std::max({(double)c / per / (double)z.max_records, (double)r / per / row_budget, 1e-18});
             double next = 0.5 / fan;
             if (done > 1) next = std::min(next, 4.0 * (double)step);
@@ -2111,10 +2250,11 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         if (rc != DRT_OK) return rc;
         if (!fits) {
             *num_valid_host = r;
-            return fail(DRT_E_CAPACITY, "%lld candidate rows or survivors: raise max_rows (%lld) / max_survivors (%lld)",
-                        (long long)r, (long long)z.max_rows, (long long)z.max_survivors);
+            return fail(DRT_E_CAPACITY, "%lld candidate rows or survivors: raise max_rows (%lld%s) / max_survivors (%lld)",
+                        (long long)r, (long long)z.max_rows, pairs ? ", 2^order table rows per pair row" : "",
+                        (long long)z.max_survivors);
         }
-        total_rows = r;
+        total_rows = pairs ? (r << order) : r;
         nslices = 1;
     } else if (order == 2) {
         int64_t last = 0;
@@ -2168,7 +2308,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     }
 
     // ---- slices interleave in key order: one final sort of (key, position) and a gather ----
-    if (slices_with_paths > 1 && nvalid > 1) {
+    if ((slices_with_paths > 1 || pairs) && nvalid > 1) {  // (pair mode: a slice's rows are grouped by pair, not sorted by triangle key)
         const int64_t k2 = order + 2;
         auto *mk = reinterpret_cast<unsigned long long *>(base + L.merge_keys);
         auto *perm = reinterpret_cast<uint32_t *>(base + L.merge_perm);
@@ -2194,6 +2334,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         if (rc != DRT_OK) return rc;
         st->grazing_prefixes = gz;
         st->rows = total_rows;
+        st->pair_mode = pairs ? 1 : 0;
         st->slices = nslices;
         st->valid = nvalid;
     }

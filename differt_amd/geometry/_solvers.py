@@ -527,7 +527,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
     def trace_beam_pruned(self, scene, order: int, *, kappa: float = 64.0, expansion: str = "auto", emit: str = "auto",
                           max_entries: int | None = None, max_records: int | None = None, max_rows: int | None = None,
                           max_survivors: int | None = None, max_paths: int = 1 << 16, probe_prefixes: int | None = None,
-                          prefix_shard: tuple[int, int] | None = None) -> TracedPaths:
+                          prefix_shard: tuple[int, int] | None = None, pairs: bool = True) -> TracedPaths:
         """The valid paths of the exhaustive tracer -- same objects, same ``masked_vertices`` order, identical
         vertex bits, same autograd -- without visiting ``n (n-1)**(order-1)`` candidates per pair: ONE call of
         ``drt_trace_paths_beam`` (csrc/beam.hip; reference context: the exhaustive enumeration
@@ -548,7 +548,10 @@ class ExhaustivePathTracer(AbstractPathTracer):
         ``prefix_shard=(rank, world)`` keeps the level-1 prefixes (transmitter ``t``, first mirror ``m``) with
         ``(t * n + m) % world == rank``: the multi-GPU split of
         ``differt_amd.distributed.trace_beam_pruned_sharded`` -- every valid path has exactly one level-1
-        prefix, so the shards' results partition the full result; rank 0 owns the line-of-sight paths."""
+        prefix, so the shards' results partition the full result; rank 0 owns the line-of-sight paths.
+        ``pairs=False`` (``DRT_BEAM_NO_PAIRS``) searches a triangle mesh triangle by triangle even when its triangles
+        ``(2i, 2i+1)`` are coplanar pairs (same mirror bit for bit: the walls of a box city), which the search otherwise
+        runs over -- the same result either way (tested), a quarter of the level-2 prefixes."""
         if self.smoothing_factor is not None:
             raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
         if not 0 <= order <= 3:
@@ -561,7 +564,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
         beam.kappa = float(kappa)
         beam.flags = ((_lib.DRT_BEAM_EXPAND_PLAIN if expansion == "plain" else 0)
                       | (_lib.DRT_BEAM_EMIT_PLAIN if emit == "plain" else 0)
-                      | (_lib.DRT_BEAM_EMIT_CLUSTERED if emit == "clustered" else 0))
+                      | (_lib.DRT_BEAM_EMIT_CLUSTERED if emit == "clustered" else 0)
+                      | (0 if pairs else _lib.DRT_BEAM_NO_PAIRS))
         beam.max_entries, beam.max_records = int(max_entries or 0), int(max_records or 0)
         beam.max_rows, beam.max_survivors = int(max_rows or 0), int(max_survivors or 0)
         beam.probe_prefixes = int(probe_prefixes or 0)
@@ -581,7 +585,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
                                                beam, int(max_paths), self._beam_workspace)
         self.last_beam_stats = {"unit_m": st.unit_m, "magnitude": st.magnitude, "levels": [int(x) for x in st.levels[:max(order, 1)]],
                                 "rows": int(st.rows), "chunks": int(st.slices), "valid": int(st.valid),
-                                "grazing_prefixes": int(st.grazing_prefixes)}
+                                "grazing_prefixes": int(st.grazing_prefixes), "pair_mode": bool(st.pair_mode)}
         nv = objs.shape[0]
         return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=objs.device),
                            torch.zeros((nv, order), dtype=torch.int32, device=objs.device), self.confidence_threshold, keys)

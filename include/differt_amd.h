@@ -538,12 +538,20 @@ typedef struct drt_beam_stats {
                                  (they were kept, never dropped) -- informational */
     float unit_m;             /* u = kappa * ulp(largest coordinate magnitude), metres */
     float magnitude;          /* that magnitude */
+    int32_t pair_mode;        /* 1: a triangle mesh searched over its coplanar pairs (levels[] count pair prefixes) */
+    int32_t reserved;
 } drt_beam_stats;
 
 #define DRT_BEAM_EXPAND_PLAIN 1   /* expansion: every (prefix, primitive) pair tested, no cluster culling */
 #define DRT_BEAM_EMIT_PLAIN 2     /* receiver stage: lane = prefix walks the receivers (after a vote on their clusters' boxes) */
 #define DRT_BEAM_EMIT_CLUSTERED 4 /* receiver stage: Morton clusters of 64 even below 128 receivers */
-/* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on) */
+#define DRT_BEAM_NO_PAIRS 8        /* triangle meshes: search triangle by triangle even when (2i, 2i+1) are coplanar pairs */
+/* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on).
+ * COPLANAR PAIRS (round 4): on a triangle mesh (assume_quads == 0) whose triangles 2i and 2i+1 have equal (==)
+ * unit normals, first vertices and mask values -- the two halves of a wall of a box city -- both triangles are the
+ * same mirror for the reference's arithmetic, so the prefix search runs over the n/2 PAIRS (a quarter of the level-2
+ * prefixes) and every surviving pair row is split into its 2^order triangle rows for the exact trace.  Same paths,
+ * same keys / order / vertex bits; levels[] and grazing_prefixes of drt_beam_stats then count pair prefixes. */
 
 typedef struct drt_beam_params {
     float kappa;            /* error unit u = kappa * ulp(M); <= 0: default 64 = the worst-case rounding count of

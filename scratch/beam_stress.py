@@ -55,7 +55,7 @@ while time.time() - t0 < budget:
     mask = None
     if rng.random() < 0.3:
         mask = rng.random(Tr.shape[0]) > 0.15
-        if assume_quads:
+        if assume_quads or rng.random() < 0.5:  # pairwise masks keep a triangle mesh searchable over its coplanar pairs
             mask[1::2] = mask[0::2]
     mesh = G.Mesh(V, Tr, mask=mask, assume_quads=assume_quads)
     n = mesh.num_primitives
@@ -66,6 +66,8 @@ while time.time() - t0 < budget:
     ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
     bp = tracer.trace_beam_pruned(scene, order, kappa=KAPPA)
     rows = tracer.last_beam_stats["rows"]
+    pair_mode = tracer.last_beam_stats["pair_mode"]
+    st["pair_mode_cases"] = st.get("pair_mode_cases", 0) + int(pair_mode)
     a = set(ex.keys.cpu().tolist()) if ex.keys is not None else set()
     # exhaustive keys are (pair, candidate rank); compare through objects
     ea = [tuple(o) for o in ex.objects.cpu().tolist()]
@@ -79,10 +81,13 @@ while time.time() - t0 < budget:
     st["rows_traced"] += rows
     st["valid_paths"] += len(ea)
     if st["cases"] % 4 == 0:
-        for kw in ({"expansion": "plain"}, {"emit": "clustered"}, {"emit": "plain"}):
+        for kw in ({"expansion": "plain"}, {"emit": "clustered"}, {"emit": "plain"}, {"pairs": False}):
+            if "pairs" in kw and not pair_mode:
+                continue
             other = tracer.trace_beam_pruned(scene, order, kappa=KAPPA, **kw)
             st["mapping_checks"] += 1
-            if tracer.last_beam_stats["rows"] != rows or not torch.equal(other.keys, bp.keys):
+            # (the triangle-by-triangle search of a pairable mesh has its own rows: only the paths must agree)
+            if ("pairs" not in kw and tracer.last_beam_stats["rows"] != rows) or not torch.equal(other.keys, bp.keys):
                 st["mapping_row_mismatch"] += 1
                 # keep the scene: a mismatch must be reproducible
                 import os

@@ -53,11 +53,15 @@ def check(G, V, Tr, tx, rx, orders=(1, 2, 3), assume_quads=False, kappas=(64.0,)
         ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
         for kappa in kappas:
             for expansion in ("auto", "plain"):
-                bp = tracer.trace_beam_pruned(scene, order, kappa=kappa, expansion=expansion, max_paths=1 << 18)
-                assert bp.objects.shape == ex.objects.shape, (order, kappa, expansion, tuple(ex.objects.shape),
-                                                              tuple(bp.objects.shape), tracer.last_beam_stats)
-                assert torch.equal(bp.objects, ex.objects)
-                assert torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+                # triangle meshes of boxes are searched over their coplanar pairs by default: both forms
+                for pairs in ((True, False) if not assume_quads else (True,)):
+                    bp = tracer.trace_beam_pruned(scene, order, kappa=kappa, expansion=expansion, max_paths=1 << 18,
+                                                  pairs=pairs)
+                    assert bp.objects.shape == ex.objects.shape, (order, kappa, expansion, pairs, tuple(ex.objects.shape),
+                                                                  tuple(bp.objects.shape), tracer.last_beam_stats)
+                    assert torch.equal(bp.objects, ex.objects)
+                    assert torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+                    assert not tracer.last_beam_stats["pair_mode"] or pairs
         total += ex.objects.shape[0]
     assert total >= min_paths, total
     return total
@@ -168,15 +172,20 @@ def test_child_filter_keeps_what_the_receiver_stage_keeps(G):
     tracer = G.ExhaustivePathTracer()
     order = int(d["order"])
     ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
-    auto = tracer.trace_beam_pruned(scene, order)
-    st_auto = dict(tracer.last_beam_stats)
-    plain = tracer.trace_beam_pruned(scene, order, expansion="plain")
-    st_plain = dict(tracer.last_beam_stats)
-    assert st_auto["rows"] == st_plain["rows"] == int(d["rows_other"])
-    assert st_auto["levels"][-1] < st_plain["levels"][-1]  # the filter does drop children here
-    for r in (auto, plain):
-        assert torch.equal(r.objects, ex.objects)
-        assert torch.equal(r.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+    pairable = not bool(d["assume_quads"])  # a triangle mesh of boxes: also searched over its coplanar pairs
+    for pairs in ((False, True) if pairable else (False,)):
+        auto = tracer.trace_beam_pruned(scene, order, pairs=pairs)
+        st_auto = dict(tracer.last_beam_stats)
+        plain = tracer.trace_beam_pruned(scene, order, expansion="plain", pairs=pairs)
+        st_plain = dict(tracer.last_beam_stats)
+        assert st_auto["rows"] == st_plain["rows"]
+        if not pairs:
+            assert st_auto["rows"] == int(d["rows_other"])
+        assert st_auto["levels"][-1] < st_plain["levels"][-1]  # the filter does drop children here
+        for r in (auto, plain):
+            assert torch.equal(r.objects, ex.objects)
+            assert torch.equal(r.keys, auto.keys)
+            assert torch.equal(r.vertices.view(torch.int32), ex.vertices.view(torch.int32))
     assert ex.objects.shape[0] == 8
 
 
@@ -267,3 +276,47 @@ def test_degenerate_meshes(G, assume_quads):
     V3 = V2.copy()
     V3[nv + 3] = [np.inf, 0.0, 0.0]
     check(G, V3, Tr2, tx[:1], rx[:2], orders=(1, 2), assume_quads=assume_quads)
+
+
+def test_coplanar_pair_mode_engages_and_equals_the_triangle_search(G, rng):
+    """A triangle mesh whose triangles (2i, 2i+1) are the same mirror (equal unit normal and first vertex: the walls
+    and roofs of box cities) is searched over its n/2 pairs: half the level-1 prefixes, the same keys / objects /
+    vertex bits / gradients as the triangle-by-triangle search and as the exhaustive tracer, masks included; a mesh
+    with ONE perturbed wall, or a mask that splits a pair, falls back to the triangle search."""
+    V, Tr, c, h = S.manhattan(14, seed=5)
+    tx, rx = S.manhattan_tx_rx(c, h, 3, 24, seed=6)
+    tx[:, 2] = rng.uniform(2, 40, len(tx))
+    tracer = G.ExhaustivePathTracer()
+
+    def run(V, Tr, mask, order, pairs):
+        txg = torch.tensor(tx, device="cuda", requires_grad=True)
+        scene = G.Scene(txg, torch.tensor(rx, device="cuda"), G.Mesh(V, Tr, mask=mask))
+        p = tracer.trace_beam_pruned(scene, order, pairs=pairs)
+        st = dict(tracer.last_beam_stats)
+        if p.objects.shape[0]:
+            torch.sqrt((torch.diff(p.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+        return p, st, txg.grad, scene
+
+    pair_mask = np.ones(Tr.shape[0], bool)
+    pair_mask[[20, 21, 46, 47]] = False
+    split_mask = np.ones(Tr.shape[0], bool)
+    split_mask[21] = False
+    for order in (1, 2, 3):
+        for mask in (None, pair_mask):
+            a, sa, ga, scene = run(V, Tr, mask, order, True)
+            b, sb, gb, _ = run(V, Tr, mask, order, False)
+            assert sa["pair_mode"] and not sb["pair_mode"] and 2 * sa["levels"][0] == sb["levels"][0]
+            ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+            for r in (a, b):
+                assert torch.equal(r.objects, ex.objects) and torch.equal(r.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+            assert torch.equal(a.keys, b.keys) and bool((a.keys[1:] > a.keys[:-1]).all())
+            if ga is not None:
+                torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-6)
+        assert order == 1 or a.objects.shape[0] > 0
+    V2 = V.copy()
+    V2[Tr[7, 2], 0] += np.float32(0.25)  # one wall no longer planar: the whole mesh is searched by triangles
+    for Vx, mk in ((V2, None), (V, split_mask)):
+        a, sa, _, scene = run(Vx, Tr, mk, 2, True)
+        assert not sa["pair_mode"]
+        ex = tracer.trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
+        assert torch.equal(a.objects, ex.objects)
