@@ -90,6 +90,7 @@ struct BeamMesh {
     const uint8_t *mask;   // [T] or null
     int64_t nprim;
     int32_t scale;  // triangles per primitive (2 with assume_quads, or for the coplanar pairs of a triangle mesh)
+    int32_t kind;   // primitive shape the kernels are instantiated for: 1, 2 or 4 (struct Shape)
     float inv_2m;   // 1 / (2 M), M = largest coordinate magnitude of mesh, transmitters and receivers
     int32_t self_loops;  // coplanar-pair mode of a TRIANGLE mesh: a pair may follow itself (its two triangles are
                          // different candidates of the triangle-level space; assume_quads has no such candidate)
@@ -169,14 +170,49 @@ __device__ __forceinline__ float prim_eps_global(const BeamMesh &M, int64_t p, V
 // LATERAL distance delta (the along-ray error of a reflection point, which incidence amplifies, does not move
 // the line apex -> point): a line through the apex that passes within delta of the face's edge makes an angle
 // of at most delta / (rho - delta) with the face plane, rho = distance of the apex from the EDGE LINE.
-struct Pyr {
-    V3 n[3];
-    float g[3];  // a face whose test is off (apex within the arithmetic's resolution of the edge line, degenerate
-                 // face, unbounded tolerance) has n = 0 and g = 0: its value <x - I, n> + g |x - I| is 0, never below a
-                 // negative threshold -- no guard compare anywhere
+// ---- primitive shapes ------------------------------------------------------------------------------------------
+// The kernels are templated on the SHAPE of a primitive (template parameter SCALE, for history):
+//   1  one triangle                       3 vertices, one 3-face pyramid, one plane
+//   2  two arbitrary triangles            6 vertices, two 3-face pyramids (a point is "inside" when inside either),
+//      (assume_quads as the reference      two planes
+//      defines it, _solvers.py:526-627)
+//   4  a CONVEX PLANAR FAN QUAD           4 vertices, ONE 4-face pyramid, one plane -- both triangles lie in one plane
+//      (v0 v1 v2) + (v0 v2 v3)            with equal unit normals and first vertices, share the diagonal v0-v2 and form
+//                                         a convex quadrilateral (quad_shape_kernel checks every primitive; the walls and
+//                                         roofs of box meshes).  The cone over the quad IS the union of the two
+//                                         triangles' cones, and whenever the two 3-face tests separate a candidate an
+//                                         OUTER face does (the two diagonal half-spaces are complementary): same pruning
+//                                         power for 16 instead of 36 vertex-face products per pyramid.
+// In the mesh arrays shapes 2 and 4 both occupy two consecutive triangles.
+template <int S> struct Shape {
+    static_assert(S == 1 || S == 2 || S == 4, "primitive shape");
+    static constexpr int NV = (S == 1) ? 3 : (S == 2 ? 6 : 4);   // vertices of a primitive
+    static constexpr int NP = (S == 2) ? 2 : 1;                  // pyramids per mirror = planes per primitive
+    static constexpr int NF = (S == 4) ? 4 : 3;                  // faces of a pyramid
+    static constexpr int TPP = (S == 1) ? 1 : 2;                 // triangles per primitive in the mesh arrays
 };
-// three-way minimum / maximum that IGNORE NaN operands (v_min3_f32 / v_max3_f32): a NaN never separates
+// vertex k of a primitive from its triangles' vertex arrays tv[TPP][3][3] (shape 4: v3 = third vertex of the 2nd triangle)
+template <int S>
+__device__ __forceinline__ V3 shape_vertex(const float *__restrict__ tv, int k) {
+    if (S == 4) return (k < 3) ? ld3(tv + 3 * k) : ld3(tv + 9 + 6);
+    return ld3(tv + 3 * k);  // shapes 1 and 2: the 3 or 6 vertices in storage order
+}
+
+template <int NF>
+struct PyrN {
+    V3 n[NF];
+    float g[NF];  // a face whose test is off (apex within the arithmetic's resolution of the edge line, degenerate
+                  // face, unbounded tolerance) has n = 0 and g = 0: its value <x - I, n> + g |x - I| is 0, never below a
+                  // negative threshold -- no guard compare anywhere
+};
+// minimum that IGNORES NaN operands (v_min3_f32 / v_max3_f32): a NaN never separates
 __device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+template <int NF>
+__device__ __forceinline__ float min_faces(const float (&v)[NF]) {
+    float m = min3f(v[0], v[1], v[2]);
+    if (NF == 4) m = __builtin_fminf(m, v[3]);
+    return m;
+}
 __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, float delta, V3 &n_out, float &g_out) {
     // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded forms (~12 instructions each, five per face,
     // three faces per pyramid, up to three pyramids per prefix): these are margins, and the 2e-6 |x - I|_1 in the
@@ -194,11 +230,12 @@ __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, float delta
     n_out = on ? N * sc : V3{0, 0, 0};  // (0 * inf = NaN for a huge N: the select, not the product, zeroes it)
     g_out = on ? g : 0.0f;
 }
-__device__ __forceinline__ Pyr make_pyr(V3 I, V3 v0, V3 v1, V3 v2, float delta) {
-    Pyr P;
-    pyr_face(I, v0, v1, v2, delta, P.n[0], P.g[0]);
-    pyr_face(I, v1, v2, v0, delta, P.n[1], P.g[1]);
-    pyr_face(I, v2, v0, v1, delta, P.n[2], P.g[2]);
+// pyramid over the polygon v[0..NF): face f spans the edge v[f] -> v[f+1]; the vertex after that edge fixes "inside"
+template <int NF>
+__device__ __forceinline__ PyrN<NF> make_pyr(V3 I, const V3 (&v)[NF], float delta) {
+    PyrN<NF> P;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) pyr_face(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], delta, P.n[f], P.g[f]);
     return P;
 }
 
@@ -211,25 +248,33 @@ struct BeamCtx {
     V3 I, pm, nm;
     float u;    // kappa * ulp(M)
     int side_prev;
-    Pyr pyr[LEVEL][SCALE];
+    PyrN<Shape<SCALE>::NF> pyr[LEVEL][Shape<SCALE>::NP];
 };
+
+template <int SCALE, int LEVEL>
+__device__ __forceinline__ void ctx_clear(BeamCtx<SCALE, LEVEL> &c) {
+#pragma unroll
+    for (int j = 0; j < LEVEL; ++j)
+#pragma unroll
+        for (int t = 0; t < Shape<SCALE>::NP; ++t)
+#pragma unroll
+            for (int f = 0; f < Shape<SCALE>::NF; ++f) {
+                c.pyr[j][t].n[f] = V3{0, 0, 0};
+                c.pyr[j][t].g[f] = 0.0f;
+            }
+}
 
 template <int SCALE, int LEVEL>
 __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e, float u, bool have,
                                           BeamCtx<SCALE, LEVEL> &c) {
+    using Sh = Shape<SCALE>;
     c.I = V3{e.apex[0], e.apex[1], e.apex[2]};
     u = u * mag_scale(M, c.I);
     c.u = u;
     c.pm = V3{0, 0, 0};
     c.nm = V3{0, 0, 1};
     c.side_prev = have ? entry_side(e) : 0;
-#pragma unroll
-    for (int j = 0; j < LEVEL; ++j)
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            c.pyr[j][t].n[0] = c.pyr[j][t].n[1] = c.pyr[j][t].n[2] = V3{0, 0, 0};
-            c.pyr[j][t].g[0] = c.pyr[j][t].g[1] = c.pyr[j][t].g[2] = 0.0f;
-        }
+    ctx_clear<SCALE, LEVEL>(c);
     if (!have) return;
     prim_plane(M, e.id[LEVEL - 1], c.pm, c.nm);
     // lateral tolerance of the prefix: u sigma per mirror (Moller-Trumbore's edge tests + the lateral rounding of
@@ -237,25 +282,27 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
     float lat = 0.0f;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
-        float sg = M.shape[(int64_t)e.id[j] * SCALE];
-        if (SCALE == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * SCALE + 1]);
+        float sg = M.shape[(int64_t)e.id[j] * Sh::TPP];
+        if (Sh::TPP == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * Sh::TPP + 1]);
         lat += u * sg;
     }
     const float delta = 2.0f * lat;  // +inf for a degenerate mirror: every face off
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
+        const float *tv = M.tv + 9 * ((int64_t)e.id[j] * Sh::TPP);
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            const float *tri = M.tv + 9 * ((int64_t)e.id[j] * SCALE + t);
-            V3 v[3] = {ld3(tri), ld3(tri + 3), ld3(tri + 6)};
+        for (int t = 0; t < Sh::NP; ++t) {
+            V3 v[Sh::NF];
+#pragma unroll
+            for (int k = 0; k < Sh::NF; ++k) v[k] = shape_vertex<SCALE>(tv, t * Sh::NF + k);
 #pragma unroll
             for (int r = j + 1; r < LEVEL; ++r) {
                 V3 pt, n;
                 prim_plane(M, e.id[r], pt, n);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
+                for (int k = 0; k < Sh::NF; ++k) v[k] = image_of_vertex(v[k], pt, n);
             }
-            c.pyr[j][t] = make_pyr(c.I, v[0], v[1], v[2], delta);
+            c.pyr[j][t] = make_pyr<Sh::NF>(c.I, v, delta);
         }
     }
 }
@@ -266,12 +313,13 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
 // test is pruned whatever the others say) -- 44 % of the (prefix, cluster) pairs that pass the box tests have no
 // child at all (debug counters, profiles/r03/beam.md).
 template <int SCALE, int LEVEL>
-__device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, const V3 (&vx)[3 * SCALE],
-                                            const float (&pl)[SCALE][4], float sigma, bool lane_on = true) {
+__device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, const V3 (&vx)[Shape<SCALE>::NV],
+                                            const float (&pl)[Shape<SCALE>::NP][4], float sigma, bool lane_on = true) {
+    using Sh = Shape<SCALE>;
     float dmin = kInf, dmax = -kInf, D2 = 0.0f;
     bool nan = false;
 #pragma unroll
-    for (int k = 0; k < 3 * SCALE; ++k) {
+    for (int k = 0; k < Sh::NV; ++k) {
         const V3 x = vx[k];
         const float d = fdot(x - c.pm, c.nm);
         dmin = fminf(dmin, d);
@@ -283,7 +331,7 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
     }
     float h = kInf;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) h = fminf(h, plane_dist(c.I, V3{pl[t][0], pl[t][1], pl[t][2]}, pl[t][3]));
+    for (int t = 0; t < Sh::NP; ++t) h = fminf(h, plane_dist(c.I, V3{pl[t][0], pl[t][1], pl[t][2]}, pl[t][3]));
 #ifdef BEAM_LAB_NO_PRIM_EPS
     const float eps_c = 0.0f * (sigma + D2 + h);
 #else
@@ -292,24 +340,26 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
     const float base = -(2.0f * eps_c + c.u);  // -inf for a candidate seen at grazing incidence: nothing separates
     const int side_c = side_of_range(dmin, dmax, eps_c + 2.0f * c.u);
     bool pruned = !nan && (c.side_prev * side_c == -1);
-    // separated by a pyramid: for EACH of the mirror's triangles SOME face has all vertices outside, i.e. the
-    // smallest of its three maxima (over the vertices, of <x - I, n_f> + g |x - I|_1) is below the threshold
+    // separated by a pyramid: for EACH of the mirror's pyramids SOME face has all vertices outside, i.e. the
+    // smallest of its face maxima (over the vertices, of <x - I, n_f> + g |x - I|_1) is below the threshold
 #pragma unroll
     for (int j = LEVEL - 1; j >= 0; --j) {
         if (!__any(lane_on && !pruned)) return true;  // nobody left in this wave: the caller keeps no lane
-        float worst = -kInf;  // max over the triangles of min over the faces
+        float worst = -kInf;  // max over the pyramids of min over the faces
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            float m0 = -kInf, m1 = -kInf, m2 = -kInf;
+        for (int t = 0; t < Sh::NP; ++t) {
+            float m[Sh::NF];
 #pragma unroll
-            for (int k = 0; k < 3 * SCALE; ++k) {
+            for (int f = 0; f < Sh::NF; ++f) m[f] = -kInf;
+#pragma unroll
+            for (int k = 0; k < Sh::NV; ++k) {
                 const V3 w = vx[k] - c.I;       // (recomputed per pyramid: 6 instructions, no array of differences to keep)
                 const float wl = l1_len(w);     // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
-                m0 = fmaxf(m0, __builtin_fmaf(c.pyr[j][t].g[0], wl, fdot(w, c.pyr[j][t].n[0])));
-                m1 = fmaxf(m1, __builtin_fmaf(c.pyr[j][t].g[1], wl, fdot(w, c.pyr[j][t].n[1])));
-                m2 = fmaxf(m2, __builtin_fmaf(c.pyr[j][t].g[2], wl, fdot(w, c.pyr[j][t].n[2])));
+#pragma unroll
+                for (int f = 0; f < Sh::NF; ++f)
+                    m[f] = fmaxf(m[f], __builtin_fmaf(c.pyr[j][t].g[f], wl, fdot(w, c.pyr[j][t].n[f])));
             }
-            worst = fmaxf(worst, min3f(m0, m1, m2));
+            worst = fmaxf(worst, min_faces<Sh::NF>(m));
         }
         pruned = pruned || (!nan && worst < base);
     }
@@ -339,17 +389,17 @@ __device__ __forceinline__ bool box_pruned(const BeamCtx<SCALE, LEVEL> &c, const
     for (int j = 0; j < LEVEL; ++j) {
         bool all_t = true;
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            const Pyr &P = c.pyr[j][t];
-            float v[3];
+        for (int t = 0; t < Shape<SCALE>::NP; ++t) {
+            const PyrN<Shape<SCALE>::NF> &P = c.pyr[j][t];
+            float v[Shape<SCALE>::NF];
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
+            for (int f = 0; f < Shape<SCALE>::NF; ++f) {
                 const V3 n = P.n[f];
                 const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * e.x + __builtin_fabsf(n.y) * e.y) +
                                                 __builtin_fabsf(n.z) * e.z);
                 v[f] = __builtin_fmaf(P.g[f], wl, smax);
             }
-            all_t = all_t && (min3f(v[0], v[1], v[2]) < base);
+            all_t = all_t && (min_faces<Shape<SCALE>::NF>(v) < base);
         }
         separated = separated || all_t;
     }
@@ -372,9 +422,9 @@ __device__ __forceinline__ BeamCtx<SCALE, LEVEL> lane_bcast(const BeamCtx<SCALE,
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j)
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
+        for (int t = 0; t < Shape<SCALE>::NP; ++t) {
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
+            for (int f = 0; f < Shape<SCALE>::NF; ++f) {
                 o.pyr[j][t].g[f] = lane_bcast(c.pyr[j][t].g[f], l);
                 o.pyr[j][t].n[f] = lane_bcast(c.pyr[j][t].n[f], l);
             }
@@ -467,8 +517,9 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
                                                           float u, unsigned long long *__restrict__ out, int64_t cap,
                                                           unsigned long long *__restrict__ count,
                                                           int64_t prims_per_split) {
-    __shared__ float lds_v[kBeamTile][3 * SCALE][3];
-    __shared__ float lds_pl[kBeamTile][SCALE][4];
+    using Sh = Shape<SCALE>;
+    __shared__ float lds_v[kBeamTile][Sh::NV][3];
+    __shared__ float lds_pl[kBeamTile][Sh::NP][4];
     __shared__ float lds_sg[kBeamTile];
     __shared__ uint8_t lds_act[kBeamTile];
     __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
@@ -488,28 +539,28 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
     const int64_t prim_end = (prim_begin + prims_per_split < M.nprim) ? prim_begin + prims_per_split : M.nprim;
     for (int64_t base = prim_begin; base < prim_end; base += kBeamTile) {
         __syncthreads();
-        for (int i = threadIdx.x; i < kBeamTile * 3 * SCALE; i += 256) {
-            const int64_t p = base + i / (3 * SCALE);
-            const int vtx = i % (3 * SCALE);
+        for (int i = threadIdx.x; i < kBeamTile * Sh::NV; i += 256) {
+            const int64_t p = base + i / Sh::NV;
+            const int vtx = i % Sh::NV;
             V3 v{0, 0, 0};
-            if (p < prim_end) v = ld3(M.tv + 9 * p * SCALE + 3 * vtx);
-            lds_v[i / (3 * SCALE)][vtx][0] = v.x;
-            lds_v[i / (3 * SCALE)][vtx][1] = v.y;
-            lds_v[i / (3 * SCALE)][vtx][2] = v.z;
+            if (p < prim_end) v = shape_vertex<SCALE>(M.tv + 9 * p * Sh::TPP, vtx);
+            lds_v[i / Sh::NV][vtx][0] = v.x;
+            lds_v[i / Sh::NV][vtx][1] = v.y;
+            lds_v[i / Sh::NV][vtx][2] = v.z;
         }
-        for (int i = threadIdx.x; i < kBeamTile * SCALE; i += 256) {
-            const int64_t p = base + i / SCALE;
-            const int t = i % SCALE;
+        for (int i = threadIdx.x; i < kBeamTile * Sh::NP; i += 256) {
+            const int64_t p = base + i / Sh::NP;
+            const int t = i % Sh::NP;
             V3 n{0, 0, 1};
             float d = 0.0f;
             if (p < prim_end) {
-                n = ld3(M.normals + 3 * (p * SCALE + t));
-                d = plane_offset(n, ld3(M.tv + 9 * (p * SCALE + t)));
+                n = ld3(M.normals + 3 * (p * Sh::TPP + t));
+                d = plane_offset(n, ld3(M.tv + 9 * (p * Sh::TPP + t)));
             }
-            lds_pl[i / SCALE][t][0] = n.x;
-            lds_pl[i / SCALE][t][1] = n.y;
-            lds_pl[i / SCALE][t][2] = n.z;
-            lds_pl[i / SCALE][t][3] = d;
+            lds_pl[i / Sh::NP][t][0] = n.x;
+            lds_pl[i / Sh::NP][t][1] = n.y;
+            lds_pl[i / Sh::NP][t][2] = n.z;
+            lds_pl[i / Sh::NP][t][3] = d;
         }
         if (threadIdx.x < kBeamTile) {
             const int64_t p = base + threadIdx.x;
@@ -517,8 +568,8 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             lds_act[threadIdx.x] = (uint8_t)(ok && prim_active(M, p));
             float sg = 1.0f;
             if (ok) {
-                sg = M.shape[p * SCALE];
-                if (SCALE == 2) sg = fmaxf(sg, M.shape[p * SCALE + 1]);
+                sg = M.shape[p * Sh::TPP];
+                if (Sh::TPP == 2) sg = fmaxf(sg, M.shape[p * Sh::TPP + 1]);
             }
             lds_sg[threadIdx.x] = sg;
         }
@@ -527,12 +578,12 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
         for (int j = 0; j < nt; ++j) {
             if (!lds_act[j]) continue;  // wave-uniform
             const int32_t c = (int32_t)(base + j);
-            V3 vx[3 * SCALE];
-            float pl[SCALE][4];
+            V3 vx[Sh::NV];
+            float pl[Sh::NP][4];
 #pragma unroll
-            for (int k = 0; k < 3 * SCALE; ++k) vx[k] = V3{lds_v[j][k][0], lds_v[j][k][1], lds_v[j][k][2]};
+            for (int k = 0; k < Sh::NV; ++k) vx[k] = V3{lds_v[j][k][0], lds_v[j][k][1], lds_v[j][k][2]};
 #pragma unroll
-            for (int t = 0; t < SCALE; ++t)
+            for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pl[t][q] = lds_pl[j][t][q];
             const bool cand = have && (c != m || M.self_loops);
@@ -576,49 +627,65 @@ struct RxAll {
 // mirrors' shape factors
 template <int SCALE, int LEVEL>
 __device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamEntry &e, V3 I, bool have, float ulp_m,
-                                                  float (&rho)[SCALE][3], float &sig_sum) {
+                                                  float (&rho)[Shape<SCALE>::NP][Shape<SCALE>::NF], float &sig_sum) {
+    using Sh = Shape<SCALE>;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) rho[t][0] = rho[t][1] = rho[t][2] = 0.0f;
+    for (int t = 0; t < Sh::NP; ++t)
+#pragma unroll
+        for (int f = 0; f < Sh::NF; ++f) rho[t][f] = 0.0f;
     sig_sum = kInf;
     if (!have) return;
     sig_sum = 0.0f;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
-        float sg = M.shape[(int64_t)e.id[j] * SCALE];
-        if (SCALE == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * SCALE + 1]);
+        float sg = M.shape[(int64_t)e.id[j] * Sh::TPP];
+        if (Sh::TPP == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * Sh::TPP + 1]);
         sig_sum += sg;
     }
+    const float *tv = M.tv + 9 * ((int64_t)e.id[0] * Sh::TPP);
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        const float *tri = M.tv + 9 * ((int64_t)e.id[0] * SCALE + t);
-        V3 v[3] = {ld3(tri), ld3(tri + 3), ld3(tri + 6)};
+    for (int t = 0; t < Sh::NP; ++t) {
+        V3 v[Sh::NF];
+#pragma unroll
+        for (int k = 0; k < Sh::NF; ++k) v[k] = shape_vertex<SCALE>(tv, t * Sh::NF + k);
 #pragma unroll
         for (int r = 1; r < LEVEL; ++r) {
             V3 pt, n;
             prim_plane(M, e.id[r], pt, n);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], pt, n);
+            for (int k = 0; k < Sh::NF; ++k) v[k] = image_of_vertex(v[k], pt, n);
         }
-        // pyr_face switches a face off when its orientation is undefined: s = <third vertex - I, N> exactly 0 (or NaN),
+        // pyr_face switches a face off when its orientation is undefined: s = <next vertex - I, N> exactly 0 (or NaN),
         // non-finite lengths.  The child's pyramid is built from vertices reflected once more: a pyramid that is flat
         // up to rounding HERE (apex in the plane of the unfolded mirror: axis-aligned walls, a transmitter placed in a
         // wall plane) can be exactly flat THERE -- all faces off, every receiver kept (found by the stress driver:
-        // tests/golden/beam_cases/filter_case99516.npz).  s is the triple product of the three apex-to-vertex vectors,
-        // the same for every face up to sign; moving one of the four points by d changes it by at most d times the sum
-        // of the three |N_f|, and a reflection moves each point by a few ulp(M'), M' <= 3 M.  Below
+        // tests/golden/beam_cases/filter_case99516.npz).  s is a triple product of three apex-to-vertex vectors (for
+        // a planar polygon every face's s vanishes together); moving one of the points by d changes it by at most d times
+        // the sum of the |N_f|, and a reflection moves each point by a few ulp(M'), M' <= 3 M.  Below
         // 64 ulp(M) sum |N_f| (or the rounding of the product itself, far from the scene) the pyramid counts as flat:
         // rho = 0 for its faces, never "on" in child_misses_receivers.
-        const V3 w0 = v[0] - I, w1 = v[1] - I, w2 = v[2] - I;
-        const V3 N0 = cross(w0, w1), N1 = cross(w1, w2), N2 = cross(w2, w0);
-        const float len[3] = {__builtin_amdgcn_sqrtf(fdot(N0, N0)), __builtin_amdgcn_sqrtf(fdot(N1, N1)),
-                              __builtin_amdgcn_sqrtf(fdot(N2, N2))};
-        const float sv = fdot(w2, N0);
-        const float D = __builtin_amdgcn_sqrtf(fmaxf(fdot(w0, w0), fmaxf(fdot(w1, w1), fdot(w2, w2))));
-        const float tol = 64.0f * fmaxf(ulp_m, 1.2e-7f * D) * ((len[0] + len[1]) + len[2]);
-        const bool defined = is_finite(len[0]) && is_finite(len[1]) && is_finite(len[2]) && __builtin_fabsf(sv) > tol;
+        V3 w[Sh::NF];
 #pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            const V3 ed = v[(f + 1) % 3] - v[f];
+        for (int k = 0; k < Sh::NF; ++k) w[k] = v[k] - I;
+        float len[Sh::NF], lensum = 0.0f, D2 = 0.0f;
+        bool fin = true;
+        V3 N0{0, 0, 0};
+#pragma unroll
+        for (int f = 0; f < Sh::NF; ++f) {
+            const V3 N = cross(w[f], w[(f + 1) % Sh::NF]);
+            if (f == 0) N0 = N;
+            len[f] = __builtin_amdgcn_sqrtf(fdot(N, N));
+            lensum = (f == 0) ? len[0] : lensum + len[f];
+            fin = fin && is_finite(len[f]);
+            D2 = fmaxf(D2, fdot(w[f], w[f]));
+        }
+        const float sv = fdot(w[2], N0);
+        const float D = __builtin_amdgcn_sqrtf(D2);
+        const float tol = 64.0f * fmaxf(ulp_m, 1.2e-7f * D) * lensum;
+        const bool defined = fin && __builtin_fabsf(sv) > tol;
+#pragma unroll
+        for (int f = 0; f < Sh::NF; ++f) {
+            const V3 ed = v[(f + 1) % Sh::NF] - v[f];
             const float el = __builtin_amdgcn_sqrtf(fdot(ed, ed));
             rho[t][f] = (el > 0.0f && defined) ? 0.9999f * len[f] * __builtin_amdgcn_rcpf(el) : 0.0f;  // pyr_face's rho
         }
@@ -632,8 +699,10 @@ __device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamE
 // rounding of the two routes to the normal, 10 % on the threshold -- whatever this test drops, that stage drops too.
 template <int SCALE>
 __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const BeamMesh &M, float u0, V3 I2,
-                                                       const V3 (&n0)[SCALE][3], const float (&rho)[SCALE][3],
+                                                       const V3 (&n0)[Shape<SCALE>::NP][Shape<SCALE>::NF],
+                                                       const float (&rho)[Shape<SCALE>::NP][Shape<SCALE>::NF],
                                                        float sig_parent, V3 nc, float dc, float sig_c) {
+    using Sh = Shape<SCALE>;
     const float s2 = 2.0f * __builtin_fmaf(nc.x, I2.x, __builtin_fmaf(nc.y, I2.y, __builtin_fmaf(nc.z, I2.z, -dc)));
     const V3 I3 = V3{I2.x - nc.x * s2, I2.y - nc.y * s2, I2.z - nc.z * s2};
     const float uc = u0 * mag_scale(M, I3);
@@ -646,10 +715,10 @@ __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const Be
     const float thr = -1.1f * uc;
     bool all_t = true;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        float v[3];
+    for (int t = 0; t < Sh::NP; ++t) {
+        float v[Sh::NF];
 #pragma unroll
-        for (int f = 0; f < 3; ++f) {
+        for (int f = 0; f < Sh::NF; ++f) {
             const V3 n = n0[t][f];
             const float k2 = 2.0f * fdot(n, nc);
             const V3 nr = V3{n.x - nc.x * k2, n.y - nc.y * k2, n.z - nc.z * k2};
@@ -661,7 +730,7 @@ __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const Be
             const float val = __builtin_fmaf(g, wl, smax);
             v[f] = on ? val : 0.0f;  // (a parent face that is off has n = 0: val = g wl >= 0; NaNs compare false)
         }
-        all_t = all_t && (min3f(v[0], v[1], v[2]) < thr);
+        all_t = all_t && (min_faces<Sh::NF>(v) < thr);
     }
     return all_t;
 }
@@ -673,6 +742,14 @@ __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const Be
 #define BEAM_EXPAND_OCC __attribute__((amdgpu_waves_per_eu(BEAM_EXPAND_WAVES, BEAM_EXPAND_WAVES)))
 #else
 #define BEAM_EXPAND_OCC
+#endif
+#ifndef BEAM_Q4_WAVES
+#define BEAM_Q4_WAVES 0
+#endif
+#if BEAM_Q4_WAVES > 0
+#define BEAM_Q4_OCC __attribute__((amdgpu_waves_per_eu(BEAM_Q4_WAVES, BEAM_Q4_WAVES)))
+#else
+#define BEAM_Q4_OCC
 #endif
 template <int SCALE, int LEVEL, bool FILTER>
 __device__ __forceinline__ void expand_clustered_body(
@@ -686,7 +763,8 @@ __device__ __forceinline__ void expand_clustered_body(
     // cluster ahead), the 64 prefixes of the wave then read them back as LDS broadcasts.  As 64 scalar loads per
     // (wave, cluster) this loop was half of the kernel's time (profiles/r03/beam.md): 157 KiB of planes per wave
     // do not live in the 16-KiB scalar cache
-    __shared__ __attribute__((aligned(16))) float4 lds_planes[2][64 * SCALE];
+    using Sh = Shape<SCALE>;
+    __shared__ __attribute__((aligned(16))) float4 lds_planes[2][64 * Sh::NP];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
@@ -704,7 +782,7 @@ __device__ __forceinline__ void expand_clustered_body(
     __shared__ unsigned long long raw_rec[2][128];
     __shared__ float raw_f[2][5][128];
     constexpr bool filter_on = FILTER;
-    float rho0[SCALE][3];
+    float rho0[Sh::NP][Sh::NF];
     float sig_sum = kInf;
     if (filter_on) first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum);
     int rawcount = 0;
@@ -723,12 +801,12 @@ __device__ __forceinline__ void expand_clustered_body(
         const int l = (int)((rec >> 32) - gbase) & 63;  // the parent's lane
         const V3 I2 = V3{__shfl(ctx.I.x, l, 64), __shfl(ctx.I.y, l, 64), __shfl(ctx.I.z, l, 64)};
         const float sp = __shfl(sig_sum, l, 64);
-        V3 n0[SCALE][3];
-        float rh[SCALE][3];
+        V3 n0[Sh::NP][Sh::NF];
+        float rh[Sh::NP][Sh::NF];
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t)
+        for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
+            for (int f = 0; f < Sh::NF; ++f) {
                 n0[t][f] = V3{__shfl(ctx.pyr[0][t].n[f].x, l, 64), __shfl(ctx.pyr[0][t].n[f].y, l, 64),
                               __shfl(ctx.pyr[0][t].n[f].z, l, 64)};
                 rh[t][f] = __shfl(rho0[t][f], l, 64);
@@ -740,18 +818,18 @@ __device__ __forceinline__ void expand_clustered_body(
     // software pipeline: the next cluster's primitive id and vertices (sorted copy, no indirection) are in
     // flight while this cluster is tested -- fetched whether or not the cluster will be hit (the mesh lives in L2)
     int32_t p_next = -1;
-    V3 vx_next[3 * SCALE];
-    float pl_next[SCALE][4], uq_next[SCALE][4];  // (plain floats: float4 arrays captured by the lambda stayed in scratch)
+    V3 vx_next[Sh::NV];
+    float pl_next[Sh::NP][4], uq_next[Sh::NP][4];  // (plain floats: float4 arrays captured by the lambda stayed in scratch)
     auto fetch = [&](int64_t c) {
         const int64_t cc = (c < cl_end) ? c : cl_end - 1;  // the last trip re-reads its own cluster
         const int64_t pos = cc * 64 + lane;
         p_next = (pos < M.nprim) ? C.order[pos] : -1;
 #pragma unroll
-        for (int k = 0; k < 3 * SCALE; ++k) vx_next[k] = ld3(C.verts + 9 * pos * SCALE + 3 * k);  // padded to whole clusters
+        for (int k = 0; k < Sh::NV; ++k) vx_next[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));  // padded to whole clusters
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            const float4 a = reinterpret_cast<const float4 *>(C.planes)[pos * SCALE + t];
-            const float4 b = reinterpret_cast<const float4 *>(C.uplanes)[pos * SCALE + t];
+        for (int t = 0; t < Sh::NP; ++t) {
+            const float4 a = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP + t];
+            const float4 b = reinterpret_cast<const float4 *>(C.uplanes)[pos * Sh::NP + t];
             pl_next[t][0] = a.x; pl_next[t][1] = a.y; pl_next[t][2] = a.z; pl_next[t][3] = a.w;
             uq_next[t][0] = b.x; uq_next[t][1] = b.y; uq_next[t][2] = b.z; uq_next[t][3] = b.w;
         }
@@ -759,16 +837,16 @@ __device__ __forceinline__ void expand_clustered_body(
     if (cl_begin < cl_end) fetch(cl_begin);
     for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
         const int32_t p = p_next;
-        V3 vx[3 * SCALE];
-        float pl[SCALE][4];
+        V3 vx[Sh::NV];
+        float pl[Sh::NP][4];
 #pragma unroll
-        for (int k = 0; k < 3 * SCALE; ++k) vx[k] = vx_next[k];
+        for (int k = 0; k < Sh::NV; ++k) vx[k] = vx_next[k];
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
+        for (int t = 0; t < Sh::NP; ++t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) pl[t][q] = pl_next[t][q];
             // wave-private: ordered by the wave's own LDS queue
-            lds_planes[wave][lane * SCALE + t] = float4{uq_next[t][0], uq_next[t][1], uq_next[t][2], uq_next[t][3]};
+            lds_planes[wave][lane * Sh::NP + t] = float4{uq_next[t][0], uq_next[t][1], uq_next[t][2], uq_next[t][3]};
         }
         fetch(cl + 1);
         // ---- lane = prefix: box of the cluster (wave-uniform scalar loads) ----
@@ -909,6 +987,14 @@ __global__ __launch_bounds__(128) void beam_expand_clustered_last_kernel_s2(
     int64_t clusters_per_split, RxAll rxall) {
     expand_clustered_body<2, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
 }
+// convex planar fan quads (shape 4): one 4-face pyramid and four vertices per primitive
+template <int LEVEL>
+__global__ __launch_bounds__(128) BEAM_Q4_OCC void beam_expand_clustered_last_kernel_q4(
+    BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
+    unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
+    int64_t clusters_per_split, RxAll rxall) {
+    expand_clustered_body<4, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
+}
 
 // (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the parent's
 // last mirror w.r.t. the new mirror's plane, error sum extended by the new mirror's own bound
@@ -947,53 +1033,49 @@ __global__ __launch_bounds__(256) void beam_finish_kernel(BeamMesh M, const Beam
 // expressions (checked against the loading forms by the mapping tests: identical rows).
 template <int SCALE>
 struct PrimGeom {
-    V3 v[SCALE][3];
-    V3 n[SCALE];
-    float sg[SCALE];
+    V3 v[Shape<SCALE>::NV];
+    V3 n[Shape<SCALE>::NP];
+    float sg;  // largest shape factor of the primitive's triangles
 };
 template <int SCALE>
 __device__ __forceinline__ PrimGeom<SCALE> load_prim(const BeamMesh &M, int64_t p) {
+    using Sh = Shape<SCALE>;
     PrimGeom<SCALE> g;
+    const int64_t f0 = p * Sh::TPP;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        const int64_t f = p * SCALE + t;
+    for (int k = 0; k < Sh::NV; ++k) g.v[k] = shape_vertex<SCALE>(M.tv + 9 * f0, k);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) g.v[t][k] = ld3(M.tv + 9 * f + 3 * k);
-        g.n[t] = ld3(M.normals + 3 * f);
-        g.sg[t] = M.shape[f];
-    }
+    for (int t = 0; t < Sh::NP; ++t) g.n[t] = ld3(M.normals + 3 * (f0 + t));
+    g.sg = M.shape[f0];
+    if (Sh::TPP == 2) g.sg = fmaxf(g.sg, M.shape[f0 + 1]);
     return g;
 }
-template <int SCALE>  // prim_eps_global
+template <int SCALE>  // prim_eps_global (plane t of shapes 1 / 2 passes through vertex 3 t; shape 4: one plane, through v0)
 __device__ __forceinline__ float prim_eps_from(const PrimGeom<SCALE> &g, V3 I, float u) {
-    float D = 0.0f, h = kInf, sg = 0.0f;
+    using Sh = Shape<SCALE>;
+    float D = 0.0f, h = kInf;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        h = fminf(h, plane_dist(I, g.n[t], plane_offset(g.n[t], g.v[t][0])));
-        sg = fmaxf(sg, g.sg[t]);
+    for (int t = 0; t < Sh::NP; ++t) h = fminf(h, plane_dist(I, g.n[t], plane_offset(g.n[t], g.v[3 * t])));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) D = fmaxf(D, margin_len(g.v[t][k] - I));
-    }
-    return beam_eps(u, sg, D, h);
+    for (int k = 0; k < Sh::NV; ++k) D = fmaxf(D, margin_len(g.v[k] - I));
+    return beam_eps(u, g.sg, D, h);
 }
 template <int SCALE>  // side_of_prim
 __device__ __forceinline__ int side_from(const PrimGeom<SCALE> &g, V3 pt, V3 n, float E) {
     float dmin = kInf, dmax = -kInf;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float d = fdot(g.v[t][k] - pt, n);
-            dmin = fminf(dmin, d);
-            dmax = fmaxf(dmax, d);
-        }
+    for (int k = 0; k < Shape<SCALE>::NV; ++k) {
+        const float d = fdot(g.v[k] - pt, n);
+        dmin = fminf(dmin, d);
+        dmax = fmaxf(dmax, d);
+    }
     if (!(dmin == dmin) || !(dmax == dmax)) return 0;
     return side_of_range(dmin, dmax, E);
 }
 template <int SCALE, int LEVEL>  // beam_child; gc = the new mirror, glast = the parent's last mirror
 __device__ __forceinline__ BeamEntry beam_child_from(const BeamMesh &M, const BeamEntry &e, int32_t c,
                                                      const PrimGeom<SCALE> &gc, const PrimGeom<SCALE> &glast, float u) {
-    const V3 pc = gc.v[0][0], nc = gc.n[0];
+    const V3 pc = gc.v[0], nc = gc.n[0];
     const V3 I = V3{e.apex[0], e.apex[1], e.apex[2]};
     const V3 I2 = image_of_vertex(I, pc, nc);
     BeamEntry o = e;
@@ -1009,41 +1091,34 @@ __device__ __forceinline__ BeamEntry beam_child_from(const BeamMesh &M, const Be
 template <int SCALE, int LEVEL>  // build_ctx
 __device__ __forceinline__ void build_ctx_from(const BeamMesh &M, const BeamEntry &e, const PrimGeom<SCALE> (&geo)[LEVEL],
                                                float u, bool have, BeamCtx<SCALE, LEVEL> &c) {
+    using Sh = Shape<SCALE>;
     c.I = V3{e.apex[0], e.apex[1], e.apex[2]};
     u = u * mag_scale(M, c.I);
     c.u = u;
     c.pm = V3{0, 0, 0};
     c.nm = V3{0, 0, 1};
     c.side_prev = have ? entry_side(e) : 0;
-#pragma unroll
-    for (int j = 0; j < LEVEL; ++j)
-#pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            c.pyr[j][t].n[0] = c.pyr[j][t].n[1] = c.pyr[j][t].n[2] = V3{0, 0, 0};
-            c.pyr[j][t].g[0] = c.pyr[j][t].g[1] = c.pyr[j][t].g[2] = 0.0f;
-        }
+    ctx_clear<SCALE, LEVEL>(c);
     if (!have) return;
-    c.pm = geo[LEVEL - 1].v[0][0];
+    c.pm = geo[LEVEL - 1].v[0];
     c.nm = geo[LEVEL - 1].n[0];
     float lat = 0.0f;
 #pragma unroll
-    for (int j = 0; j < LEVEL; ++j) {
-        float sg = geo[j].sg[0];
-        if (SCALE == 2) sg = fmaxf(sg, geo[j].sg[SCALE - 1]);
-        lat += u * sg;
-    }
+    for (int j = 0; j < LEVEL; ++j) lat += u * geo[j].sg;
     const float delta = 2.0f * lat;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            V3 v[3] = {geo[j].v[t][0], geo[j].v[t][1], geo[j].v[t][2]};
+        for (int t = 0; t < Sh::NP; ++t) {
+            V3 v[Sh::NF];
+#pragma unroll
+            for (int k = 0; k < Sh::NF; ++k) v[k] = geo[j].v[t * Sh::NF + k];
 #pragma unroll
             for (int r = j + 1; r < LEVEL; ++r) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) v[k] = image_of_vertex(v[k], geo[r].v[0][0], geo[r].n[0]);
+                for (int k = 0; k < Sh::NF; ++k) v[k] = image_of_vertex(v[k], geo[r].v[0], geo[r].n[0]);
             }
-            c.pyr[j][t] = make_pyr(c.I, v[0], v[1], v[2], delta);
+            c.pyr[j][t] = make_pyr<Sh::NF>(c.I, v, delta);
         }
     }
 }
@@ -1090,11 +1165,12 @@ __device__ __forceinline__ bool receiver_first(const BeamCtx<SCALE, ORDER> &c, V
     const float wl = l1_len(w);
     bool inside_any = false;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        const Pyr &P = c.pyr[0][t];
-        const float lowest = min3f(__builtin_fmaf(P.g[0], wl, fdot(w, P.n[0])), __builtin_fmaf(P.g[1], wl, fdot(w, P.n[1])),
-                                   __builtin_fmaf(P.g[2], wl, fdot(w, P.n[2])));
-        inside_any = inside_any | !(lowest < -c.u);
+    for (int t = 0; t < Shape<SCALE>::NP; ++t) {
+        const PyrN<Shape<SCALE>::NF> &P = c.pyr[0][t];
+        float fv[Shape<SCALE>::NF];
+#pragma unroll
+        for (int f = 0; f < Shape<SCALE>::NF; ++f) fv[f] = __builtin_fmaf(P.g[f], wl, fdot(w, P.n[f]));
+        inside_any = inside_any | !(min_faces<Shape<SCALE>::NF>(fv) < -c.u);
     }
     return lane_on & inside_any;  // (& not &&: no branch around a handful of instructions)
 }
@@ -1115,11 +1191,12 @@ __device__ __forceinline__ bool receiver_rest(const BeamCtx<SCALE, ORDER> &c, V3
         if (WAVE_EXIT && !__any(alive)) return false;
         bool inside_any = false;
 #pragma unroll
-        for (int t = 0; t < SCALE; ++t) {
-            const Pyr &P = c.pyr[j][t];
-            const float lowest = min3f(__builtin_fmaf(P.g[0], wl, fdot(w, P.n[0])), __builtin_fmaf(P.g[1], wl, fdot(w, P.n[1])),
-                                       __builtin_fmaf(P.g[2], wl, fdot(w, P.n[2])));
-            inside_any = inside_any | !(lowest < -c.u);
+        for (int t = 0; t < Shape<SCALE>::NP; ++t) {
+            const PyrN<Shape<SCALE>::NF> &P = c.pyr[j][t];
+            float fv[Shape<SCALE>::NF];
+#pragma unroll
+            for (int f = 0; f < Shape<SCALE>::NF; ++f) fv[f] = __builtin_fmaf(P.g[f], wl, fdot(w, P.n[f]));
+            inside_any = inside_any | !(min_faces<Shape<SCALE>::NF>(fv) < -c.u);
         }
         alive = alive & inside_any;
     }
@@ -1342,26 +1419,29 @@ __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint
     const int64_t src = (pos < M.nprim) ? pos : M.nprim - 1;
     const int64_t p = (int64_t)sorted_ids[src];
     if (pos < M.nprim) order[pos] = (int32_t)p;
+    using Sh = Shape<SCALE>;
     float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
     float sg = 0.0f;
-    float myq[SCALE][4];
+    float myq[Sh::NP][4];
+    const int64_t f0 = p * Sh::TPP;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
-        const int64_t f = p * SCALE + t;
+    for (int t = 0; t < Sh::TPP; ++t) sg = fmaxf(sg, M.shape[f0 + t]);
+#pragma unroll
+    for (int t = 0; t < Sh::NP; ++t) {
+        const int64_t f = f0 + t;
         const V3 n = ld3(M.normals + 3 * f);
         const V3 v0 = ld3(M.tv + 9 * f);
-        float *q = planes + 4 * (pos * SCALE + t);
+        float *q = planes + 4 * (pos * Sh::NP + t);
         myq[t][0] = n.x; myq[t][1] = n.y; myq[t][2] = n.z; myq[t][3] = plane_offset(n, v0);
         q[0] = myq[t][0]; q[1] = myq[t][1]; q[2] = myq[t][2]; q[3] = myq[t][3];
-        sg = fmaxf(sg, M.shape[f]);
+    }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const V3 v = ld3(M.tv + 9 * f + 3 * k);
-            st3(verts + 9 * pos * SCALE + 9 * t + 3 * k, v);
-            lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
-            lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
-            lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
-        }
+    for (int k = 0; k < Sh::NV; ++k) {
+        const V3 v = shape_vertex<SCALE>(M.tv + 9 * f0, k);
+        st3(verts + 3 * (pos * Sh::NV + k), v);
+        lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+        lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+        lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
     }
     sigma[pos] = sg;
     // DISTINCT planes of the cluster, compacted to the front of `uplanes` (the two triangles of a box face, the
@@ -1371,13 +1451,13 @@ __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint
     int ndistinct = 0;
     bool bad_plane = false;
 #pragma unroll
-    for (int t = 0; t < SCALE; ++t) {
+    for (int t = 0; t < Sh::NP; ++t) {
         const float qx = myq[t][0], qy = myq[t][1], qz = myq[t][2], qw = myq[t][3];
         bad_plane = bad_plane || !is_finite(qx) || !is_finite(qy) || !is_finite(qz) || !is_finite(qw);
         bool dup = false;
         for (int l = 0; l < 64; ++l) {
 #pragma unroll
-            for (int t2 = 0; t2 < SCALE; ++t2) {
+            for (int t2 = 0; t2 < Sh::NP; ++t2) {
                 const float ox = __shfl(myq[t2][0], l, 64), oy = __shfl(myq[t2][1], l, 64);
                 const float oz = __shfl(myq[t2][2], l, 64), ow = __shfl(myq[t2][3], l, 64);
                 // list order: (triangle t of every lane) before (triangle t + 1 of every lane)
@@ -1389,7 +1469,7 @@ __global__ __launch_bounds__(64) void prim_cluster_kernel(BeamMesh M, const uint
         }
         const unsigned long long keepm = __ballot(!dup);
         if (!dup) {
-            float *o = uplanes + 4 * (cl * 64 * SCALE + ndistinct + __popcll(keepm & ((1ull << lane) - 1ull)));
+            float *o = uplanes + 4 * (cl * 64 * Sh::NP + ndistinct + __popcll(keepm & ((1ull << lane) - 1ull)));
             o[0] = qx; o[1] = qy; o[2] = qz; o[3] = qw;
         }
         ndistinct += __popcll(keepm);
@@ -1506,23 +1586,41 @@ __global__ __launch_bounds__(256) void pair_offsets_kernel(const unsigned long l
 }
 
 // ---- coplanar-pair mode (a triangle mesh searched over its n/2 pairs) ------------------------------------------
-// flag[0] stays 1 when every pair of triangles (2i, 2i+1) has EQUAL unit normals, the same first vertex (float
-// equality: +0 == -0 -- the cross product of axis-aligned edges yields zeros of either sign -- and a NaN equals
-// nothing) and the same mask value: both triangles then are THE SAME MIRROR for the reference (plane point and normal
-// feed image_of_vertex / the ray-plane step, _solvers.py:552-562; the sign of a zero component changes no value there,
-// only the sign of a zero result), every image and reflection point of a candidate has the same value whichever of
-// the two it names, and only the inside test tells them apart.  The exact trace of a triangle row uses that
-// triangle's own normal, zeros' signs included.
-__global__ __launch_bounds__(256) void pairable_kernel(const float *__restrict__ tv, const float *__restrict__ normals,
-                                                       const uint8_t *__restrict__ mask, int64_t npairs,
-                                                       uint32_t *__restrict__ flag) {
+// What the triangle pairs (2i, 2i+1) of a mesh are, for ALL pairs at once:
+// flag[0] stays 1 when every pair has EQUAL unit normals, the same first vertex (float equality: +0 == -0 -- the cross
+// product of axis-aligned edges yields zeros of either sign -- and a NaN equals nothing) and the same mask value: both
+// triangles then are THE SAME MIRROR for the reference (plane point and normal feed image_of_vertex / the ray-plane
+// step, _solvers.py:552-562; the sign of a zero component changes no value there, only the sign of a zero result),
+// every image and reflection point of a candidate has the same value whichever of the two it names, and only the
+// inside test tells them apart.  The exact trace of a triangle row uses that triangle's own normal, zeros' signs
+// included.  A triangle mesh with flag[0] is searched over its pairs.
+// flag[1] stays 1 when every pair moreover is a CONVEX PLANAR FAN QUAD (struct Shape, shape 4): second triangle =
+// (v0, v2, v3) of the first one's (v0, v1, v2), every corner of v0 v1 v2 v3 turns the way the normal says by at least
+// sin = 1e-3 (a clear margin: a corner that is flat or reflex within rounding falls back to the two-triangle form).
+__global__ __launch_bounds__(256) void pair_shape_kernel(const float *__restrict__ tv, const float *__restrict__ normals,
+                                                         const uint8_t *__restrict__ mask, int64_t npairs,
+                                                         uint32_t *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npairs) return;
     const float *a = normals + 6 * i, *b = a + 3;
     const float *va = tv + 18 * i, *vb = va + 9;
-    bool ok = a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && va[0] == vb[0] && va[1] == vb[1] && va[2] == vb[2];
-    if (mask) ok = ok && ((mask[2 * i] != 0) == (mask[2 * i + 1] != 0));
-    if (!ok) atomicAnd(flag, 0u);
+    const bool same_plane = a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && va[0] == vb[0] && va[1] == vb[1] && va[2] == vb[2];
+    bool pair_ok = same_plane;
+    if (mask) pair_ok = pair_ok && ((mask[2 * i] != 0) == (mask[2 * i + 1] != 0));
+    if (!pair_ok) atomicAnd(flag, 0u);
+    bool quad = same_plane && va[6] == vb[3] && va[7] == vb[4] && va[8] == vb[5];  // shared diagonal v0 - v2
+    if (quad) {
+        const V3 n = ld3(a);
+        const V3 q[4] = {ld3(va), ld3(va + 3), ld3(va + 6), ld3(vb + 6)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const V3 e0 = q[(k + 1) % 4] - q[k], e1 = q[(k + 2) % 4] - q[(k + 1) % 4];
+            const float turn = fdot(cross(e0, e1), n);
+            const float scale = __builtin_sqrtf(fdot(e0, e0) * fdot(e1, e1));
+            quad = quad && (turn > 1e-3f * scale) && is_finite(scale);
+        }
+    }
+    if (!quad) atomicAnd(flag + 1, 0u);
 }
 
 // sorted packed PAIR rows ((tx nrx + rx) nq^K + sum q_j nq^(K-1-j)) -> the 2^K triangle rows of each, in place of
@@ -1587,6 +1685,7 @@ static BeamMesh beam_mesh(drt_mesh_t m) {
     M.shape = m->shape;
     M.mask = m->has_mask ? m->mask : nullptr;
     M.scale = m->assume_quads ? 2 : 1;
+    M.kind = m->assume_quads ? ((m->beam_quad4 == 1) ? 4 : 2) : 1;
     M.nprim = m->num_triangles / M.scale;
     M.inv_2m = 0.0f;  // set by the driver once the scene magnitude is known (0: no rescaling)
     M.self_loops = 0;
@@ -1596,6 +1695,7 @@ static BeamMesh beam_mesh(drt_mesh_t m) {
 static BeamMesh beam_mesh_pairs(drt_mesh_t m) {
     BeamMesh M = beam_mesh(m);
     M.scale = 2;
+    M.kind = (m->beam_quad4 == 1) ? 4 : 2;
     M.nprim = m->num_triangles / 2;
     M.self_loops = 1;
     return M;
@@ -1777,8 +1877,11 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
             if constexpr (SCALE == 1)
                 hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s1<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
                                    0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
-            else
+            else if constexpr (SCALE == 2)
                 hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s2<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
+                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
+            else
+                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_q4<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
                                    0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
         } else {
             hipLaunchKernelGGL((beam_expand_clustered_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128), 0,
@@ -1810,9 +1913,11 @@ static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, 
                            rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing);
 }
 
-#define BEAM_DISPATCH2(SC, K, CALL) \
+#define BEAM_DISPATCH2(SC, K, CALL) /* SC = primitive shape (BeamMesh::kind) */ \
     do {                            \
-        if ((SC) == 2) {            \
+        if ((SC) == 4) {            \
+            if ((K) == 1) CALL(4, 1); else if ((K) == 2) CALL(4, 2); else CALL(4, 3); \
+        } else if ((SC) == 2) {     \
             if ((K) == 1) CALL(2, 1); else if ((K) == 2) CALL(2, 2); else CALL(2, 3); \
         } else {                    \
             if ((K) == 1) CALL(1, 1); else if ((K) == 2) CALL(1, 2); else CALL(1, 3); \
@@ -1840,35 +1945,35 @@ extern "C" {
 static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stream) {
     DRT_REQUIRE(mesh, "mesh is null");
     hipStream_t s = as_stream(stream);
-    if (!mesh->assume_quads && mesh->beam_pairs < 0) {
+    if (mesh->beam_pairs < 0) {  // examine the triangle pairs once per mesh
         mesh->beam_pairs = 0;
+        mesh->beam_quad4 = 0;
         const int64_t T = mesh->num_triangles;
         if (T >= 2 && T % 2 == 0) {
-            uint32_t *flag = nullptr, h = 0;
-            DRT_HIP(hipMalloc(&flag, 4));
-            hipError_t e = fill_bytes_async(flag, 0, 4, s);
+            uint32_t *flag = nullptr, h[2] = {0, 0};
+            DRT_HIP(hipMalloc(&flag, 8));
+            const uint32_t ones[2] = {1, 1};
+            hipError_t e = hipMemcpyAsync(flag, ones, 8, hipMemcpyHostToDevice, s);
             if (e == hipSuccess) {
-                const uint32_t one = 1;
-                e = hipMemcpyAsync(flag, &one, 4, hipMemcpyHostToDevice, s);
-            }
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(pairable_kernel, dim3((unsigned)ceil_div(T / 2, 256)), dim3(256), 0, s, mesh->tri_verts,
+                hipLaunchKernelGGL(pair_shape_kernel, dim3((unsigned)ceil_div(T / 2, 256)), dim3(256), 0, s, mesh->tri_verts,
                                    mesh->normals, mesh->has_mask ? mesh->mask : nullptr, T / 2, flag);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             (void)hipFree(flag);
             if (e != hipSuccess) {
                 mesh->beam_pairs = -1;
-                return fail(DRT_E_HIP, "coplanar-pair check failed: %s", hipGetErrorString(e));
+                return fail(DRT_E_HIP, "triangle-pair shape check failed: %s", hipGetErrorString(e));
             }
-            mesh->beam_pairs = h ? 1 : 0;
+            mesh->beam_pairs = h[0] ? 1 : 0;
+            mesh->beam_quad4 = h[1] ? 1 : 0;
         }
     }
     const bool pairs = !mesh->assume_quads && allow_pairs && mesh->beam_pairs == 1;
     const BeamMesh M = pairs ? beam_mesh_pairs(mesh) : beam_mesh(mesh);
-    if (mesh->beam_blob && mesh->beam_scale == M.scale) return DRT_OK;
+    const int32_t want = M.kind + (pairs ? 16 : 0);  // what the cached clusters were built for
+    if (mesh->beam_blob && mesh->beam_scale == want) return DRT_OK;
     if (mesh->beam_blob) {  // built for the other primitive kind
         DRT_HIP(hipStreamSynchronize(s));
         (void)hipFree(mesh->beam_blob);
@@ -1877,14 +1982,15 @@ static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stre
     }
     if (M.nprim == 0) return DRT_OK;
     const int64_t ncl = ceil_div(M.nprim, 64), pp = ncl * 64, sc = M.scale;
+    const int64_t nv = (M.kind == 1) ? 3 : (M.kind == 2 ? 6 : 4), np = (M.kind == 2) ? 2 : 1;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
         off += align_up(bytes, 256);
         return at;
     };
-    const size_t o_order = take((size_t)M.nprim * 4), o_verts = take((size_t)pp * 36 * sc),
-                 o_planes = take((size_t)pp * 16 * sc), o_uplanes = take((size_t)pp * 16 * sc),
+    const size_t o_order = take((size_t)M.nprim * 4), o_verts = take((size_t)pp * 12 * nv),
+                 o_planes = take((size_t)pp * 16 * np), o_uplanes = take((size_t)pp * 16 * np),
                  o_sigma = take((size_t)pp * 4), o_boxes = take((size_t)ncl * 32), o_subboxes = take((size_t)ncl * 96);
     char *blob = nullptr, *tmp = nullptr;
     DRT_HIP(hipMalloc(&blob, off));
@@ -1903,7 +2009,9 @@ static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stre
         auto *sigma = reinterpret_cast<float *>(blob + o_sigma);
         auto *boxes = reinterpret_cast<float *>(blob + o_boxes);
         auto *subboxes = reinterpret_cast<float *>(blob + o_subboxes);
-        if (sc == 2)
+        if (M.kind == 4)
+            hipLaunchKernelGGL(prim_cluster_kernel<4>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes, subboxes);
+        else if (M.kind == 2)
             hipLaunchKernelGGL(prim_cluster_kernel<2>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes, subboxes);
         else
             hipLaunchKernelGGL(prim_cluster_kernel<1>, dim3((unsigned)ncl), dim3(64), 0, s, M, ids, order, verts, planes, uplanes, sigma, boxes, subboxes);
@@ -1925,7 +2033,7 @@ static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stre
             mesh->beam_subboxes = subboxes;
             mesh->beam_clusters = ncl;
             mesh->beam_blob = blob;
-            mesh->beam_scale = (int32_t)sc;
+            mesh->beam_scale = want;
         }
     }
     (void)hipFree(tmp);
@@ -2023,11 +2131,11 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     // pairs with the quad kernels (pyramid of a pair = union of its triangles' pyramids: what keeps a triangle
     // sequence keeps its pair sequence; a pair may follow itself), a quarter of the level-2 prefixes of a box city;
     // every surviving pair row is then split into its 2^order triangle rows, which the exact trace decides.
-    const bool pairs = !mesh->assume_quads && mesh->beam_scale == 2;
+    const bool pairs = !mesh->assume_quads && mesh->beam_scale >= 16;
     int key_bits_rows = key_bits;  // bits of the keys the row sort sees
     int64_t rows_cap = z.max_rows;
+    M = pairs ? beam_mesh_pairs(mesh) : beam_mesh(mesh);  // (the shape of the pairs is known only now)
     if (pairs) {
-        M = beam_mesh_pairs(mesh);
         npow = 1;
         unsigned __int128 tq = (unsigned __int128)ntx * (unsigned __int128)nrx;
         for (int j = 0; j < order; ++j) {
@@ -2114,7 +2222,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         if (nsrc == 0) return DRT_OK;
         DRT_HIP(fill_bytes_async(counters, 0, 8, s));
 #define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, src, rec, nsrc, rx, rx_sorted, rx_index, rx_boxes, nrx, u, rows, rows_cap, counters, counters + 1, s)
-        BEAM_DISPATCH2(M.scale, order, CALL);
+        BEAM_DISPATCH2(M.kind, order, CALL);
 #undef CALL
         DRT_LAUNCH_CHECK();
         int64_t r = 0;
@@ -2199,11 +2307,11 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             DRT_HIP(fill_bytes_async(counters, 0, 8, s));
             if (order == 2) {
 #define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall)
-                BEAM_DISPATCH2(M.scale, 1, CALL);
+                BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
             } else {
 #define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall)
-                BEAM_DISPATCH2(M.scale, 1, CALL);
+                BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
             }
             DRT_LAUNCH_CHECK();
@@ -2271,7 +2379,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             const int64_t i1 = std::min(i0 + step, ncur);
             DRT_HIP(fill_bytes_async(counters, 0, 8, s));
 #define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, entries1 + i0, i1 - i0, u, records, cap2, counters, s)
-            BEAM_DISPATCH2(M.scale, 1, CALL);
+            BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
             DRT_LAUNCH_CHECK();
             int64_t c2 = 0;

@@ -31,7 +31,9 @@ struct drt_mesh {
     float *beam_subboxes = nullptr;  // [clusters,4,6] lo[3], hi[3] of each group of 16 consecutive primitives
     int64_t beam_clusters = 0;
     float beam_max_abs = 0.0f;       // largest |coordinate| of the mesh vertices
-    int32_t beam_scale = 0;          // triangles per primitive the clusters were built for (1 or 2)
+    int32_t beam_scale = 0;          // what the clusters were built for: primitive shape (1, 2, 4: beam.hip struct Shape)
+                                     // + 16 when a triangle mesh is searched over its coplanar pairs
+    int32_t beam_quad4 = -1;         // every pair (2i, 2i+1) is a convex planar fan quad (shape 4): -1 / 0 / 1
     int32_t beam_pairs = -1;         // triangle mesh whose triangles (2i, 2i+1) share their mirror plane
                                      // (same unit normal, same first vertex, same mask): -1 not examined, 0 no, 1 yes
                                      // -- the pruned search then runs over the n/2 coplanar PAIRS (beam.hip)
