@@ -103,6 +103,37 @@ __device__ __forceinline__ float mag_scale(const BeamMesh &M, V3 I) {
     return fmaxf(1.0f, m * M.inv_2m);  // NaN apex: 1 (its tests are off anyway)
 }
 
+// The LAST expansion may drop a child before its record is written: a child none of whose receivers can lie inside
+// its narrowest pyramid (the first mirror, unfolded through every later one) yields no row in the receiver stage.
+// box = bounds of all receivers (finite ones; `on` = 0 when some receiver is not finite, or at earlier levels).
+struct RxAll {
+    float lo[3], hi[3];
+    int32_t on;
+    float ulp_m;  // ulp of the largest coordinate magnitude M (the error unit without its kappa)
+};
+// Scene-dependent scalars of a call, for the entry point that may not read anything back
+// (drt_trace_paths_beam_async): computed on the device by beam_dyn_kernel -- the same expressions the synchronous
+// entry point evaluates on the host -- and list sizes that live in device counters.  A kernel given a BeamDev with
+// non-null members takes u / inv_2m / the receivers' box from `dyn` and the smaller of `*n` and its size argument.
+struct BeamDyn {
+    float u, inv_2m;
+    RxAll rxall;
+};
+struct BeamDev {
+    const BeamDyn *dyn;
+    const unsigned long long *n;
+};
+__device__ __forceinline__ void beam_dev_apply(const BeamDev &dv, BeamMesh &M, float &u, int64_t &n) {
+    if (dv.dyn) {
+        u = dv.dyn->u;
+        M.inv_2m = dv.dyn->inv_2m;
+    }
+    if (dv.n) {
+        const int64_t nd = (int64_t)*dv.n;
+        n = nd < n ? nd : n;
+    }
+}
+
 __device__ __forceinline__ bool prim_active(const BeamMesh &M, int64_t p) {
     if (!M.mask) return true;
     const int64_t f = p * M.scale;
@@ -210,7 +241,7 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return __bui
 template <int NF>
 __device__ __forceinline__ float min_faces(const float (&v)[NF]) {
     float m = min3f(v[0], v[1], v[2]);
-    if (NF == 4) m = __builtin_fminf(m, v[3]);
+    if constexpr (NF == 4) m = __builtin_fminf(m, v[3]);
     return m;
 }
 __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, float delta, V3 &n_out, float &g_out) {
@@ -439,7 +470,11 @@ __device__ __forceinline__ BeamCtx<SCALE, LEVEL> lane_bcast(const BeamCtx<SCALE,
 __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float *__restrict__ tx, int64_t ntx,
                                                         float u, int64_t shard_rank, int64_t shard_world,
                                                         BeamEntry *__restrict__ out, int64_t cap,
-                                                        unsigned long long *__restrict__ count) {
+                                                        unsigned long long *__restrict__ count, BeamDev dv) {
+    {
+        int64_t unused = 0;
+        beam_dev_apply(dv, M, u, unused);
+    }
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in = g < ntx * M.nprim;
@@ -516,8 +551,10 @@ template <int SCALE, int LEVEL>
 __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const BeamEntry *__restrict__ in, int64_t n_in,
                                                           float u, unsigned long long *__restrict__ out, int64_t cap,
                                                           unsigned long long *__restrict__ count,
-                                                          int64_t prims_per_split) {
+                                                          int64_t prims_per_split, BeamDev dv) {
     using Sh = Shape<SCALE>;
+    beam_dev_apply(dv, M, u, n_in);
+    if ((int64_t)blockIdx.x * 256 >= n_in) return;  // a grid sized for the list's CAPACITY (async entry point)
     __shared__ float lds_v[kBeamTile][Sh::NV][3];
     __shared__ float lds_pl[kBeamTile][Sh::NP][4];
     __shared__ float lds_sg[kBeamTile];
@@ -614,14 +651,6 @@ struct BeamClusters {
     int64_t nclusters;
 };
 
-// The LAST expansion may drop a child before its record is written: a child none of whose receivers can lie inside
-// its narrowest pyramid (the first mirror, unfolded through every later one) yields no row in the receiver stage.
-// box = bounds of all receivers (finite ones; `on` = 0 when some receiver is not finite, or at earlier levels).
-struct RxAll {
-    float lo[3], hi[3];
-    int32_t on;
-    float ulp_m;  // ulp of the largest coordinate magnitude M (the error unit without its kappa)
-};
 // what that test needs from the PARENT prefix besides its context: per face of its narrowest pyramid the distance
 // rho of the apex from the edge line (pyr_face's expression; a reflection does not change it), and the sum of its
 // mirrors' shape factors
@@ -744,7 +773,7 @@ __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const Be
 #define BEAM_EXPAND_OCC
 #endif
 #ifndef BEAM_Q4_WAVES
-#define BEAM_Q4_WAVES 0
+#define BEAM_Q4_WAVES 4  // 128 VGPRs, no scratch: 335 against 351 ms per two steps of configs[3] (profiles/r04/beam.md)
 #endif
 #if BEAM_Q4_WAVES > 0
 #define BEAM_Q4_OCC __attribute__((amdgpu_waves_per_eu(BEAM_Q4_WAVES, BEAM_Q4_WAVES)))
@@ -767,6 +796,7 @@ __device__ __forceinline__ void expand_clustered_body(
     __shared__ __attribute__((aligned(16))) float4 lds_planes[2][64 * Sh::NP];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if ((int64_t)blockIdx.x * 128 >= n_in) return;  // a grid sized for the list's CAPACITY (async entry point)
     const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
@@ -811,7 +841,8 @@ __device__ __forceinline__ void expand_clustered_body(
                               __shfl(ctx.pyr[0][t].n[f].z, l, 64)};
                 rh[t][f] = __shfl(rho0[t][f], l, 64);
             }
-        const bool pass = mine && !child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, sp, nc, dc, sgc);
+        // (rxall.on == 0 -- a non-finite receiver, known only on the device in the async entry point: every child passes)
+        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, sp, nc, dc, sgc));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
     };
@@ -967,7 +998,8 @@ template <int SCALE, int LEVEL>
 __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_kernel(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
-    int64_t clusters_per_split) {
+    int64_t clusters_per_split, BeamDev dv) {
+    beam_dev_apply(dv, M, u, n_in);
     expand_clustered_body<SCALE, LEVEL, false>(M, C, in, n_in, u, out, cap, count, clusters_per_split, RxAll{});
 }
 // the LAST expansion, with the receiver-box child filter.  One triangle per primitive: 130 VGPRs without the
@@ -977,14 +1009,18 @@ template <int LEVEL>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void beam_expand_clustered_last_kernel_s1(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
-    int64_t clusters_per_split, RxAll rxall) {
+    int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
+    beam_dev_apply(dv, M, u, n_in);
+    if (dv.dyn) rxall = dv.dyn->rxall;
     expand_clustered_body<1, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
 }
 template <int LEVEL>
 __global__ __launch_bounds__(128) void beam_expand_clustered_last_kernel_s2(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
-    int64_t clusters_per_split, RxAll rxall) {
+    int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
+    beam_dev_apply(dv, M, u, n_in);
+    if (dv.dyn) rxall = dv.dyn->rxall;
     expand_clustered_body<2, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
 }
 // convex planar fan quads (shape 4): one 4-face pyramid and four vertices per primitive
@@ -992,7 +1028,9 @@ template <int LEVEL>
 __global__ __launch_bounds__(128) BEAM_Q4_OCC void beam_expand_clustered_last_kernel_q4(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
-    int64_t clusters_per_split, RxAll rxall) {
+    int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
+    beam_dev_apply(dv, M, u, n_in);
+    if (dv.dyn) rxall = dv.dyn->rxall;
     expand_clustered_body<4, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
 }
 
@@ -1019,7 +1057,8 @@ __device__ __forceinline__ BeamEntry beam_child(const BeamMesh &M, const BeamEnt
 template <int LEVEL>
 __global__ __launch_bounds__(256) void beam_finish_kernel(BeamMesh M, const BeamEntry *__restrict__ src,
                                                           const unsigned long long *__restrict__ rec, int64_t n,
-                                                          float u, BeamEntry *__restrict__ out) {
+                                                          float u, BeamEntry *__restrict__ out, BeamDev dv) {
+    beam_dev_apply(dv, M, u, n);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long r = rec[i];
@@ -1218,7 +1257,9 @@ __global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEn
                                                         const float *__restrict__ rx_boxes, int64_t nrx, float u,
                                                         long long *__restrict__ rows, int64_t cap,
                                                         unsigned long long *__restrict__ count,
-                                                        unsigned long long *__restrict__ grazing) {
+                                                        unsigned long long *__restrict__ grazing, BeamDev dv) {
+    beam_dev_apply(dv, M, u, n_in);
+    if ((int64_t)blockIdx.x * 256 >= n_in) return;
     __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int wcount = 0;
@@ -1297,7 +1338,9 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
     BeamMesh M, const BeamEntry *__restrict__ in, const unsigned long long *__restrict__ rec, int64_t n_in,
     const float *__restrict__ rx_sorted, const int32_t *__restrict__ rx_index, const float *__restrict__ boxes,
     int64_t nrx, float u, long long *__restrict__ rows, int64_t cap, unsigned long long *__restrict__ count,
-    unsigned long long *__restrict__ grazing) {
+    unsigned long long *__restrict__ grazing, BeamDev dv) {
+    beam_dev_apply(dv, M, u, n_in);
+    if ((int64_t)blockIdx.x * 128 >= n_in) return;
     __shared__ unsigned long long wbuf[2][kBeamWaveBuf];
     int wcount = 0;
     const int lane = threadIdx.x & 63;
@@ -1549,6 +1592,8 @@ __global__ __launch_bounds__(64) void rx_cluster_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------
 // rows -> per-pair candidate table of the compact tracer
 // ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kRowSentinel = 1ull << 62;  // row keys are < 2^62 (checked by the entry points)
+
 // sorted packed rows -> table i32[rows, ORDER] (triangle ids; a repeated row becomes a padding row of -1)
 template <int ORDER>
 __global__ __launch_bounds__(256) void rows_decode_kernel(const unsigned long long *__restrict__ rows, int64_t n,
@@ -1557,7 +1602,8 @@ __global__ __launch_bounds__(256) void rows_decode_kernel(const unsigned long lo
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long key = rows[i];
-    const bool dup = i > 0 && rows[i - 1] == key;
+    // (keys at or above kRowSentinel pad a fixed-capacity list: drt_trace_paths_beam_async)
+    const bool dup = (i > 0 && rows[i - 1] == key) || key >= kRowSentinel;
     unsigned long long rest = key;
     int32_t id[ORDER];
 #pragma unroll
@@ -1637,7 +1683,7 @@ __global__ __launch_bounds__(256) void rows_expand_pairs_kernel(const unsigned l
     const int64_t i = g >> ORDER;
     const int c = (int)(g & (COMBOS - 1));
     const unsigned long long key = rows[i];
-    bool bad = i > 0 && rows[i - 1] == key;
+    bool bad = (i > 0 && rows[i - 1] == key) || key >= kRowSentinel;
     unsigned long long rest = key;
     int32_t id[ORDER];
 #pragma unroll
@@ -1653,7 +1699,7 @@ __global__ __launch_bounds__(256) void rows_expand_pairs_kernel(const unsigned l
     for (int j = 0; j < ORDER; ++j) tk = tk * (2ull * nq) + (unsigned long long)id[j];
 #pragma unroll
     for (int j = 0; j < ORDER; ++j) table[g * ORDER + j] = bad ? -1 : id[j];
-    tri_keys[g] = tk;
+    tri_keys[g] = (key >= kRowSentinel) ? ~0ull : tk;
 }
 
 // keys of the slice's trace are rows of its table: back to packed rows
@@ -1662,6 +1708,70 @@ __global__ __launch_bounds__(256) void keys_to_rows_kernel(const long long *__re
                                                            long long *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (long long)rows[keys[i]];
+}
+
+// ---- fixed-capacity, no-readback plumbing of drt_trace_paths_beam_async ------------------------------------------
+// scene scalars on the device: what drt_trace_paths_beam computes on the host from the same bounds
+__global__ void beam_dyn_kernel(const uint32_t *__restrict__ rx_bounds, const uint32_t *__restrict__ tx_bounds,
+                                float mesh_max_abs, float kappa, int32_t filter_allowed, BeamDyn *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float mag = fmaxf(__uint_as_float(rx_bounds[6]), __uint_as_float(tx_bounds[6]));
+    mag = fmaxf(fmaxf(mag, mesh_max_abs), 1e-30f);
+    BeamDyn d;
+    d.rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f};
+    if (rx_bounds[7] == 0u && filter_allowed) {
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) {
+            d.rxall.lo[k] = ordered_to_float(rx_bounds[k]);
+            d.rxall.hi[k] = ordered_to_float(rx_bounds[3 + k]);
+            ok = ok && is_finite(d.rxall.lo[k]) && is_finite(d.rxall.hi[k]) && d.rxall.lo[k] <= d.rxall.hi[k];
+        }
+        d.rxall.on = ok ? 1 : 0;
+    }
+    int ex = 0;
+    (void)__builtin_frexpf(mag, &ex);  // mag = f * 2^ex, f in [0.5, 1)
+    const float ulp = __builtin_ldexpf(1.0f, ex - 1 - 23);
+    d.u = kappa * ulp;
+    d.inv_2m = 0.5f / mag;
+    d.rxall.ulp_m = ulp;
+    *out = d;
+}
+
+// rows[min(*count, cap) .. cap) = sentinel: the static-size sort moves them behind every real row
+__global__ __launch_bounds__(256) void rows_pad_kernel(unsigned long long *__restrict__ rows,
+                                                       const unsigned long long *__restrict__ count, int64_t cap) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = ((int64_t)*count < cap) ? (int64_t)*count : cap;
+    if (i >= n && i < cap) rows[i] = kRowSentinel;
+}
+
+// table rows of the padded trace -> packed keys; padding stays -1
+__global__ __launch_bounds__(256) void keys_to_rows_padded_kernel(const long long *__restrict__ keys, int64_t n,
+                                                                  const unsigned long long *__restrict__ rows,
+                                                                  long long *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long k = keys[i];
+    out[i] = (k < 0) ? -1ll : (long long)rows[k];
+}
+
+// counts_dev[2] |= the pruned search's own overflow bits, counts_dev[3] = candidate rows traced
+__global__ void beam_counts_kernel(const unsigned long long *__restrict__ c, int64_t cap_entries, int64_t cap_records,
+                                   int64_t cap_rows, int32_t row_shift, long long *__restrict__ counts) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long st = counts[2];
+    if ((int64_t)c[3] > cap_entries) st |= DRT_BEAM_OVERFLOW_ENTRIES;
+    if ((int64_t)c[4] > cap_records) st |= DRT_BEAM_OVERFLOW_RECORDS;
+    if ((int64_t)c[5] > cap_rows) st |= DRT_BEAM_OVERFLOW_ROWS;
+    counts[2] = st;
+    const long long r = ((int64_t)c[5] < cap_rows) ? (long long)c[5] : (long long)cap_rows;
+    counts[3] = r << row_shift;
+}
+
+// (a copy KERNEL: memcpy / memset nodes of a captured graph are not trusted on this runtime, see fill_bytes_async)
+__global__ __launch_bounds__(256) void copy_u32_kernel(const uint32_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
 }
 
 __global__ __launch_bounds__(256) void iota_kernel(uint32_t *__restrict__ p, int64_t n) {
@@ -1861,10 +1971,14 @@ static int32_t read_count(const unsigned long long *dev, int64_t *host, hipStrea
     return DRT_OK;
 }
 
+// `dv`: device-side scalars / list size (async entry point; then n_in is the list's CAPACITY and sizes the grid);
+// `last`: the last expansion (receiver-box child filter; with dv.dyn the receivers' box comes from the device and a box
+// that is off lets every child pass)
 template <int SCALE, int LEVEL>
 static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool clustered, const BeamEntry *in, int64_t n_in,
                           float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s,
-                          const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f}) {
+                          const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f}, BeamDev dv = BeamDev{nullptr, nullptr},
+                          bool last = false) {
     if (clustered) {
         const int64_t bx = ceil_div(n_in, 128);
         int64_t by = ceil_div(2048, bx);  // few prefixes: split the cluster range so that the launch fills the chip
@@ -1873,19 +1987,19 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
         if (by < 1) by = 1;
         const int64_t cps = ceil_div(C.nclusters, by);
         by = ceil_div(C.nclusters, cps);
-        if (rxall.on) {
+        if (rxall.on || (last && dv.dyn)) {
             if constexpr (SCALE == 1)
                 hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s1<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
-                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
+                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall, dv);
             else if constexpr (SCALE == 2)
                 hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s2<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
-                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
+                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall, dv);
             else
                 hipLaunchKernelGGL((beam_expand_clustered_last_kernel_q4<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
-                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall);
+                                   0, s, M, C, in, n_in, u, out, cap, count, cps, rxall, dv);
         } else {
             hipLaunchKernelGGL((beam_expand_clustered_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128), 0,
-                               s, M, C, in, n_in, u, out, cap, count, cps);
+                               s, M, C, in, n_in, u, out, cap, count, cps, dv);
         }
     } else {
         const int64_t bx = ceil_div(n_in, 256), tiles = ceil_div(M.nprim, kBeamTile);
@@ -1896,7 +2010,7 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
         const int64_t pps = ceil_div(tiles, by) * kBeamTile;  // whole tiles per split
         by = ceil_div(M.nprim, pps);
         hipLaunchKernelGGL((beam_expand_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(256), 0, s, M, in,
-                           n_in, u, out, cap, count, pps);
+                           n_in, u, out, cap, count, pps, dv);
     }
 }
 
@@ -1904,13 +2018,14 @@ template <int SCALE, int ORDER>
 static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, const unsigned long long *rec,
                         int64_t n_in, const float *rx, const float *rx_sorted, const int32_t *rx_index,
                         const float *rx_boxes, int64_t nrx, float u, long long *rows, int64_t cap,
-                        unsigned long long *count, unsigned long long *grazing, hipStream_t s) {
+                        unsigned long long *count, unsigned long long *grazing, hipStream_t s,
+                        BeamDev dv = BeamDev{nullptr, nullptr}) {
     if (clustered)
         hipLaunchKernelGGL((beam_emit_clustered_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 128)), dim3(128), 0,
-                           s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing);
+                           s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing, dv);
     else
         hipLaunchKernelGGL((beam_emit_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 256)), dim3(256), 0, s, M, in,
-                           rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing);
+                           rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing, dv);
 }
 
 #define BEAM_DISPATCH2(SC, K, CALL) /* SC = primitive shape (BeamMesh::kind) */ \
@@ -2205,7 +2320,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     DRT_HIP(fill_bytes_async(counters, 0, 256, s));
     // ---- level 1 ----
     hipLaunchKernelGGL(beam_seed_kernel, dim3((unsigned)ceil_div(ntx * M.nprim, 256)), dim3(256), 0, s, M, tx, ntx, u,
-                       shard_rank, shard_world, entries1, ntx * M.nprim, counters);
+                       shard_rank, shard_world, entries1, ntx * M.nprim, counters, BeamDev{nullptr, nullptr});
     DRT_LAUNCH_CHECK();
     int64_t ncur = 0;
     rc = read_count(counters, &ncur, s);
@@ -2396,7 +2511,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             }
             if (c2 > 0) {
                 hipLaunchKernelGGL(beam_finish_kernel<1>, dim3((unsigned)ceil_div(c2, 256)), dim3(256), 0, s, M, entries1 + i0,
-                                   records, c2, u, entries2);
+                                   records, c2, u, entries2, BeamDev{nullptr, nullptr});
                 DRT_LAUNCH_CHECK();
                 rc = last_expansion(entries2, c2, &level3);
                 if (rc != DRT_OK) return rc;
@@ -2446,6 +2561,215 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         st->slices = nslices;
         st->valid = nvalid;
     }
+    return DRT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same search with STATIC shapes: nothing is read back, nothing is allocated, the launch sequence does not depend
+// on device data -- what an XLA FFI handler / a HIP graph needs (reference boundary: wp.jax_callable(func,
+// output_dims=...), geometry/_mesh.py:266-276, 3082-3092).  ONE pass with the caller's capacities instead of slices
+// sized from read-back counts: every list is sized by drt_beam_params (or the scene-sized defaults), every kernel of a
+// later stage is launched over the CAPACITY of its input list and takes the list's length from the device counter, the
+// scene scalars (error unit, receivers' box) are computed by beam_dyn_kernel, rows beyond the count are sentinels.  An
+// overflowing list is reported in counts_dev[2]; the rows written are then valid paths, but not all of them.
+int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, const drt_beam_params *bp,
+                                   const float *tx, int64_t ntx, const float *rx, int64_t nrx, int32_t order,
+                                   int64_t max_paths, int64_t *keys, float *vertices, int32_t *objects,
+                                   int64_t *counts_dev, void *ws, size_t ws_bytes, void *stream) {
+    DRT_REQUIRE(mesh && pr && counts_dev, "null argument");
+    DRT_REQUIRE(ntx >= 0 && nrx >= 0 && max_paths >= 0, "negative size");
+    DRT_REQUIRE(order >= 0 && order <= 3, "beam pruning covers orders 0..3");
+    DRT_REQUIRE(ntx < (1ll << 30) && nrx < (1ll << 31), "too many transmitters / receivers");
+    DRT_REQUIRE(max_paths == 0 || (keys && vertices && objects), "null output");
+    const float kappa = (bp && bp->kappa > 0.0f) ? bp->kappa : 64.0f;
+    const int32_t flags = bp ? bp->flags : 0;
+    const int64_t shard_world = (bp && bp->shard_world > 1) ? bp->shard_world : 1;
+    const int64_t shard_rank = bp ? bp->shard_rank : 0;
+    DRT_REQUIRE(shard_rank >= 0 && shard_rank < shard_world, "shard_rank must be in [0, shard_world)");
+    hipStream_t s = as_stream(stream);
+    BeamMesh M = beam_mesh(mesh);
+    drt_trace_params tp = *pr;
+    tp.stats = nullptr;
+    const int64_t k2 = order + 2;
+
+    if (order == 0) {  // line of sight: the plain static-shape trace (rank 0 of a sharded call owns it)
+        drt_candidates c{};
+        c.num_candidates = (shard_rank == 0) ? 1 : 0;
+        c.num_nodes = M.nprim > 0 ? M.nprim : 1;
+        c.order = 0;
+        return drt_trace_paths_compact_async(mesh, &tp, tx, ntx, rx, nrx, &c, ntx * nrx, max_paths, keys, vertices, objects,
+                                             counts_dev, ws, ws_bytes, stream);
+    }
+    DRT_REQUIRE((tx || ntx == 0) && (rx || nrx == 0), "null pointer");
+    unsigned __int128 total = (unsigned __int128)ntx * (unsigned __int128)nrx;
+    for (int j = 0; j < order; ++j) total *= (unsigned __int128)M.nprim;
+    if (total >= ((unsigned __int128)1 << 62))
+        return fail(DRT_E_OVERFLOW, "tx * rx * primitives^order does not fit a 62-bit row key");
+    const int64_t nprim_caller = M.nprim;
+    const BeamSizes z = beam_sizes(bp, ntx, nrx, nprim_caller, order);
+    const BeamLayout L = beam_layout(z, ntx, nrx, nprim_caller, order, max_paths);
+    if (!ws || ws_bytes < L.total) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", L.total);
+    DRT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15u) == 0, "workspace must be 16-byte aligned");
+    DRT_REQUIRE(M.nprim == 0 || mesh->beam_blob,
+                "the primitive clusters must exist before a no-allocation call: drt_mesh_build_beam_clusters(mesh) once");
+    const bool pairs = !mesh->assume_quads && mesh->beam_scale >= 16;
+    DRT_REQUIRE(M.nprim == 0 || !((flags & DRT_BEAM_NO_PAIRS) && pairs),
+                "DRT_BEAM_NO_PAIRS, but the cached clusters are those of the coplanar pairs (rebuilding would allocate)");
+    if ((tp.flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0)
+        DRT_REQUIRE(drt_mesh_has_bvh(mesh), "DRT_TRACE_USE_BVH: build the LBVH before a no-allocation call (drt_mesh_build_bvh)");
+    char *base = reinterpret_cast<char *>(ws);
+    auto *counters = reinterpret_cast<unsigned long long *>(base + L.counters);  // [1] grazing, [2] level 1, [3] level 2, [4] records, [5] rows
+    auto *dyn = reinterpret_cast<BeamDyn *>(base + L.counters + 128);
+    auto *rx_sorted = reinterpret_cast<float *>(base + L.rx_sorted);
+    auto *rx_index = reinterpret_cast<int32_t *>(base + L.rx_index);
+    auto *rx_boxes = reinterpret_cast<float *>(base + L.rx_boxes);
+    auto *entries1 = reinterpret_cast<BeamEntry *>(base + L.entries1);
+    auto *entries2 = reinterpret_cast<BeamEntry *>(base + L.entries2);
+    auto *records = reinterpret_cast<unsigned long long *>(base + L.records);
+    auto *rows = reinterpret_cast<long long *>(base + L.rows);
+    auto *rows_sorted = reinterpret_cast<unsigned long long *>(base + L.rows_sorted);
+    auto *table = reinterpret_cast<int32_t *>(base + L.table);
+    auto *pair_offsets = reinterpret_cast<long long *>(base + L.pair_offsets);
+    char *sort_tmp = base + L.sort_tmp;
+    auto *slice_keys = reinterpret_cast<long long *>(base + L.slice_keys);
+
+    if (M.nprim == 0 || ntx == 0 || nrx == 0) {  // nothing to reflect on: all padding
+        drt_candidates c{};
+        c.table = table;
+        c.num_candidates = 0;
+        c.order = order;
+        c.pair_offsets = reinterpret_cast<const int64_t *>(pair_offsets);
+        DRT_HIP(fill_bytes_async(pair_offsets, 0, (size_t)(ntx * nrx + 1) * 8, s));
+        return drt_trace_paths_compact_async(mesh, &tp, tx, ntx, rx, nrx, &c, z.max_survivors, max_paths, keys, vertices,
+                                             objects, counts_dev, base + L.trace_ws, L.trace_ws_bytes, stream);
+    }
+    M = pairs ? beam_mesh_pairs(mesh) : beam_mesh(mesh);
+    unsigned long long npow = 1;
+    for (int j = 0; j < order; ++j) npow *= (unsigned long long)M.nprim;
+    const int64_t rows_cap = pairs ? std::max<int64_t>(z.max_rows >> order, 1) : z.max_rows;
+    const int64_t table_rows = pairs ? (rows_cap << order) : rows_cap;
+    DRT_REQUIRE(ntx * M.nprim < (1ll << 32) && z.max_entries < (1ll << 32), "record format holds 32-bit prefix indices");
+    BeamClusters C;
+    C.order = mesh->beam_order;
+    C.verts = mesh->beam_verts;
+    C.planes = mesh->beam_planes;
+    C.uplanes = mesh->beam_uplanes;
+    C.sigma = mesh->beam_sigma;
+    C.boxes = mesh->beam_boxes;
+    C.subboxes = mesh->beam_subboxes;
+    C.nclusters = mesh->beam_clusters;
+
+    uint32_t *rx_ids = nullptr, *rx_bounds = nullptr;
+    int32_t rc = morton_order(rx, nrx, 1, base + L.morton, &rx_ids, &rx_bounds, s);
+    if (rc != DRT_OK) return rc;
+    hipLaunchKernelGGL(rx_cluster_kernel, dim3((unsigned)ceil_div(nrx, 64)), dim3(64), 0, s, rx, nrx, rx_ids, rx_sorted,
+                       rx_index, rx_boxes);
+    uint32_t *tx_bounds = rx_bounds + 8;
+    DRT_HIP(fill_bytes_async(tx_bounds, 0xff, 12, s));
+    DRT_HIP(fill_bytes_async(tx_bounds + 3, 0, 20, s));
+    hipLaunchKernelGGL(point_bounds_kernel, dim3((unsigned)ceil_div(ntx, 256)), dim3(256), 0, s, tx, ntx, 1, tx_bounds);
+    const bool expand_clustered = !(flags & DRT_BEAM_EXPAND_PLAIN);
+    const bool emit_clustered = (flags & DRT_BEAM_EMIT_CLUSTERED) || (!(flags & DRT_BEAM_EMIT_PLAIN) && nrx >= 128);
+    hipLaunchKernelGGL(beam_dyn_kernel, dim3(1), dim3(64), 0, s, rx_bounds, tx_bounds, mesh->beam_max_abs, kappa,
+                       expand_clustered ? 1 : 0, dyn);
+    DRT_HIP(fill_bytes_async(counters, 0, 128, s));
+    DRT_LAUNCH_CHECK();
+    const float u0 = 0.0f;  // (every kernel takes the unit from `dyn`)
+    const RxAll rx_off{{0, 0, 0}, {0, 0, 0}, 0, 0.0f};
+    const int64_t cap1 = ntx * M.nprim;
+    const int64_t cap2 = std::min(z.max_entries, z.max_records);
+    unsigned long long *c1 = counters + 2, *c2 = counters + 3, *c3 = counters + 4, *c4 = counters + 5;
+    hipLaunchKernelGGL(beam_seed_kernel, dim3((unsigned)ceil_div(cap1, 256)), dim3(256), 0, s, M, tx, ntx, u0, shard_rank,
+                       shard_world, entries1, cap1, c1, BeamDev{dyn, nullptr});
+    const BeamEntry *last_src = entries1;  // the list the receiver stage reads (with the records of the last expansion)
+    const unsigned long long *last_rec = nullptr;
+    int64_t emit_cap = cap1;
+    const unsigned long long *emit_count = c1;
+    if (order == 2) {
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, entries1, cap1, u0, records, z.max_records, c3, s, rx_off, BeamDev{dyn, c1}, true)
+        BEAM_DISPATCH2(M.kind, 1, CALL);
+#undef CALL
+        last_rec = records;
+        emit_cap = z.max_records;
+        emit_count = c3;
+    } else if (order == 3) {
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, entries1, cap1, u0, records, cap2, c2, s, rx_off, BeamDev{dyn, c1}, false)
+        BEAM_DISPATCH2(M.kind, 1, CALL);
+#undef CALL
+        hipLaunchKernelGGL(beam_finish_kernel<1>, dim3((unsigned)ceil_div(cap2, 256)), dim3(256), 0, s, M, entries1, records,
+                           cap2, u0, entries2, BeamDev{dyn, c2});
+#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, entries2, cap2, u0, records, z.max_records, c3, s, rx_off, BeamDev{dyn, c2}, true)
+        BEAM_DISPATCH2(M.kind, 1, CALL);
+#undef CALL
+        last_src = entries2;
+        last_rec = records;
+        emit_cap = z.max_records;
+        emit_count = c3;
+    }
+#define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, last_src, last_rec, emit_cap, rx, rx_sorted, rx_index, rx_boxes, nrx, u0, rows, rows_cap, c4, counters + 1, s, BeamDev{dyn, emit_count})
+    BEAM_DISPATCH2(M.kind, order, CALL);
+#undef CALL
+    hipLaunchKernelGGL(rows_pad_kernel, dim3((unsigned)ceil_div(rows_cap, 256)), dim3(256), 0, s,
+                       reinterpret_cast<unsigned long long *>(rows), c4, rows_cap);
+    DRT_LAUNCH_CHECK();
+    size_t tb = sort_keys64_temp_bytes(rows_cap);
+    DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted, (size_t)rows_cap,
+                                     0, 63, s));
+    const unsigned long long *row_keys = rows_sorted;
+    if (pairs) {
+        const dim3 ge((unsigned)ceil_div(table_rows, 256));
+        auto *tri_keys = reinterpret_cast<unsigned long long *>(rows);
+        if (order == 1) hipLaunchKernelGGL(rows_expand_pairs_kernel<1>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, table, tri_keys);
+        else if (order == 2) hipLaunchKernelGGL(rows_expand_pairs_kernel<2>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, table, tri_keys);
+        else hipLaunchKernelGGL(rows_expand_pairs_kernel<3>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, table, tri_keys);
+        row_keys = tri_keys;
+    } else {
+        const dim3 gr((unsigned)ceil_div(rows_cap, 256));
+        if (order == 1) hipLaunchKernelGGL(rows_decode_kernel<1>, gr, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, M.scale, table);
+        else if (order == 2) hipLaunchKernelGGL(rows_decode_kernel<2>, gr, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, M.scale, table);
+        else hipLaunchKernelGGL(rows_decode_kernel<3>, gr, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, M.scale, table);
+    }
+    hipLaunchKernelGGL(pair_offsets_kernel, dim3((unsigned)ceil_div(ntx * nrx + 1, 256)), dim3(256), 0, s, rows_sorted, rows_cap,
+                       npow, ntx * nrx, pair_offsets, pairs ? ((int64_t)1 << order) : (int64_t)1);
+    DRT_LAUNCH_CHECK();
+    drt_candidates c{};
+    c.table = table;
+    c.num_candidates = table_rows;
+    c.order = order;
+    c.pair_offsets = reinterpret_cast<const int64_t *>(pair_offsets);
+    rc = drt_trace_paths_compact_async(mesh, &tp, tx, ntx, rx, nrx, &c, z.max_survivors, max_paths,
+                                       reinterpret_cast<int64_t *>(slice_keys), vertices, objects, counts_dev,
+                                       base + L.trace_ws, L.trace_ws_bytes, stream);
+    if (rc != DRT_OK) return rc;
+    if (max_paths > 0) {
+        hipLaunchKernelGGL(keys_to_rows_padded_kernel, dim3((unsigned)ceil_div(max_paths, 256)), dim3(256), 0, s, slice_keys,
+                           max_paths, row_keys, reinterpret_cast<long long *>(keys));
+        if (pairs && max_paths > 1) {  // rows of a pair are grouped, not sorted by triangle key: one static-size sort
+            auto *mk = reinterpret_cast<unsigned long long *>(base + L.merge_keys);
+            auto *perm = reinterpret_cast<uint32_t *>(base + L.merge_perm);
+            auto *iota = reinterpret_cast<uint32_t *>(base + L.merge_iota);
+            auto *tmp_rows = reinterpret_cast<uint32_t *>(base + L.merge_rows);
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)ceil_div(max_paths, 256)), dim3(256), 0, s, iota, max_paths);
+            size_t tb2 = sort_pairs64_temp_bytes(max_paths);
+            DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb2, reinterpret_cast<unsigned long long *>(keys), mk, iota, perm,
+                                              (size_t)max_paths, 0, 64, s));  // padding keys (-1) sort last
+            auto copy = [&](const void *src, void *dst, int64_t words) {
+                hipLaunchKernelGGL(copy_u32_kernel, dim3((unsigned)ceil_div(words, 256)), dim3(256), 0, s,
+                                   reinterpret_cast<const uint32_t *>(src), words, reinterpret_cast<uint32_t *>(dst));
+            };
+            copy(mk, keys, max_paths * 2);
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(max_paths * k2 * 3, 256)), dim3(256), 0, s,
+                               reinterpret_cast<const uint32_t *>(vertices), perm, max_paths, (int32_t)(k2 * 3), tmp_rows);
+            copy(tmp_rows, vertices, max_paths * k2 * 3);
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(max_paths * k2, 256)), dim3(256), 0, s,
+                               reinterpret_cast<const uint32_t *>(objects), perm, max_paths, (int32_t)k2, tmp_rows);
+            copy(tmp_rows, objects, max_paths * k2);
+        }
+    }
+    hipLaunchKernelGGL(beam_counts_kernel, dim3(1), dim3(64), 0, s, counters, cap2, z.max_records, rows_cap,
+                       pairs ? order : 0, reinterpret_cast<long long *>(counts_dev));
+    DRT_LAUNCH_CHECK();
     return DRT_OK;
 }
 

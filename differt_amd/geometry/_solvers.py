@@ -315,6 +315,11 @@ def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, inte
     return TracedPaths(verts, objs, mask.view(torch.bool), it, confidence_threshold)
 
 
+def Scene_like(scene, tx, rx):
+    """``scene`` with other end points (same mesh object)."""
+    return type(scene)(tx, rx, scene.mesh)
+
+
 class AbstractPathTracer:
     """Solver interface of the reference (_solvers.py:53-247): any object with these methods can be
     passed as ``Scene.trace_paths(solver=...)``."""
@@ -589,6 +594,53 @@ class ExhaustivePathTracer(AbstractPathTracer):
         nv = objs.shape[0]
         return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=objs.device),
                            torch.zeros((nv, order), dtype=torch.int32, device=objs.device), self.confidence_threshold, keys)
+
+    def trace_beam_pruned_static(self, scene, order: int, *, max_paths: int, kappa: float = 64.0,
+                                 max_entries: int | None = None, max_records: int | None = None,
+                                 max_rows: int | None = None, max_survivors: int | None = None, pairs: bool = True,
+                                 out: dict | None = None) -> dict:
+        """:meth:`trace_beam_pruned` with STATIC output shapes and no host synchronisation
+        (``drt_trace_paths_beam_async``): the form a ``jax.ffi`` handler or a HIP graph needs (reference boundary:
+        ``wp.jax_callable(func, output_dims=...)``, _mesh.py:266-276).  Returns device tensors ``keys [max_paths]``,
+        ``vertices [max_paths, order+2, 3]``, ``objects [max_paths, order+2]`` -- valid paths first, in
+        ``masked_vertices`` order, then padding (key -1) -- and ``counts [4]`` (``[1]`` valid paths, ``[2]`` status word:
+        non-zero = a capacity overflowed, re-run larger or use :meth:`trace_beam_pruned`).  Pass the returned dict
+        back as ``out`` to reuse every buffer (capture + replay).  The mesh's primitive clusters (and its LBVH with
+        ``accel="bvh"``) are built here, outside any capture, on first use."""
+        if not 0 <= order <= 3:
+            raise ValueError("beam pruning covers orders 0..3")
+        beam = _lib.BeamParams()
+        beam.kappa = float(kappa)
+        beam.flags = 0 if pairs else _lib.DRT_BEAM_NO_PAIRS
+        beam.max_entries, beam.max_records = int(max_entries or 0), int(max_records or 0)
+        beam.max_rows, beam.max_survivors = int(max_rows or 0), int(max_survivors or 0)
+        tx = scene.transmitters.reshape(-1, 3).contiguous()
+        rx = scene.receivers.reshape(-1, 3).contiguous()
+        mesh = scene.mesh
+        dev = tx.device
+        h = mesh.handle().h
+        params = _params(self.epsilon, self.hit_tol, self.min_len, self.accel)
+        if out is None:
+            lib = _lib.load()
+            if mesh.num_primitives:
+                if not pairs:  # the handle caches ONE kind of clusters: make it the triangles' through a tiny sync call
+                    self.trace_beam_pruned(Scene_like(scene, tx[:1], rx[:1]), max(order, 1), pairs=False, max_paths=16)
+                else:
+                    _lib.call("drt_mesh_build_beam_clusters", h, stream())
+                if self.accel == "bvh":
+                    _lib.call("drt_mesh_build_bvh", h, stream())
+            nbytes = lib.drt_trace_beam_workspace_size(tx.shape[0], rx.shape[0], mesh.num_primitives, order, C.byref(beam),
+                                                       int(max_paths))
+            out = {"keys": torch.empty(max_paths, dtype=torch.int64, device=dev),
+                   "vertices": torch.empty((max_paths, order + 2, 3), dtype=torch.float32, device=dev),
+                   "objects": torch.empty((max_paths, order + 2), dtype=torch.int32, device=dev),
+                   "counts": torch.zeros(4, dtype=torch.int64, device=dev),
+                   "workspace": torch.empty(nbytes, dtype=torch.uint8, device=dev)}
+        ws = out["workspace"]
+        _lib.call("drt_trace_paths_beam_async", h, C.byref(params), C.byref(beam), ptr(tx), tx.shape[0], ptr(rx),
+                  rx.shape[0], order, int(max_paths), ptr(out["keys"]), ptr(out["vertices"]), ptr(out["objects"]),
+                  ptr(out["counts"]), ptr(ws), ws.numel(), stream())
+        return out
 
     def _beam_workspace(self, nbytes: int, dev) -> torch.Tensor:
         """One workspace per tracer, grown on demand and reused from call to call (the default list capacities

@@ -581,6 +581,27 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *params, co
                              int64_t max_paths, int64_t *keys, float *vertices, int32_t *objects,
                              int64_t *num_valid_host, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same search with STATIC shapes and NO host synchronisation or allocation: the form a jax.ffi / XLA custom-call
+ * handler or a HIP graph needs (reference boundary: wp.jax_callable(func, output_dims=...), geometry/_mesh.py:266-276,
+ * 3082-3092), like drt_trace_paths_compact_async.  ONE pass with fixed capacities instead of slices sized from counts
+ * read back: the lists are sized by `beam` (or the scene-sized defaults of drt_trace_beam_workspace_size -- the same
+ * workspace query), every stage is launched over the capacity of its input list and takes the length from a device
+ * counter, the scene scalars are computed on the device.  Orders 0..3.
+ *   keys / vertices / objects : all max_paths rows are written; the first counts_dev[1] are the valid paths in
+ *       masked_vertices order, bit-identical to drt_trace_paths_beam; the others are padding (key -1, vertices 0, objects -1)
+ *   counts_dev [4] i64 (DEVICE): [0] rows that passed the geometric checks, [1] valid paths, [2] status word
+ *       (DRT_TRACE_OVERFLOW_* | DRT_BEAM_OVERFLOW_*, 0 = complete), [3] candidate rows handed to the tracer
+ * Preconditions (they allocate / synchronise, so they cannot happen here): drt_mesh_build_beam_clusters(mesh), and
+ * drt_mesh_build_bvh(mesh) with DRT_TRACE_USE_BVH.  On overflow the rows written are valid paths, but not all of them:
+ * re-run with larger capacities (or call drt_trace_paths_beam, which slices). */
+#define DRT_BEAM_OVERFLOW_ENTRIES 4  /* level-2 prefix list (order 3) beyond max_entries */
+#define DRT_BEAM_OVERFLOW_RECORDS 8  /* records of the last expansion beyond max_records */
+#define DRT_BEAM_OVERFLOW_ROWS 16    /* candidate rows beyond max_rows (max_rows >> order pair rows in coplanar-pair mode) */
+int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *params, const drt_beam_params *beam,
+                                   const float *tx, int64_t num_tx, const float *rx, int64_t num_rx, int32_t order,
+                                   int64_t max_paths, int64_t *keys, float *vertices, int32_t *objects,
+                                   int64_t *counts_dev, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (e) collectives of the path on RCCL, no torch in the process.  One process per
  * GPU; rank 0 draws an id (drt_comm_unique_id) and hands its 128 bytes to the other ranks out of band (the

@@ -192,3 +192,99 @@ def test_capture_and_replay_trace_forward_and_vjp():
             scale = float(exp.abs().max()) + 1e-30
             assert float((got - exp).abs().max()) <= 1e-5 * scale  # float atomics: order may differ
     assert float(rtx.abs().max()) > 0
+
+
+# ------------------------------------------------------------------ drt_trace_paths_beam_async ----
+def _beam_city(assume_quads=False, boxes=30, ntx=3, nrx=40, seed=3):
+    import numpy as np
+
+    import differt_amd.geometry as G
+    import synthetic_scenes as S
+
+    V, Tr, c, h = S.manhattan(boxes, seed=seed)
+    tx, rx = S.manhattan_tx_rx(c, h, ntx, nrx, seed=seed + 1)
+    tx[:, 2] = np.linspace(3.0, 35.0, ntx, dtype=np.float32)
+    mesh = G.Mesh(V, Tr, assume_quads=assume_quads)
+    return G, mesh, torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda")
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", ["pairs", "triangles", "quads"])
+def test_beam_async_equals_sync(order, kind):
+    """One fixed-capacity pass without read-backs (drt_trace_paths_beam_async) == the slicing, synchronising entry
+    point: same count, keys, objects, vertex bits; padding rows behind; status word 0."""
+    G, mesh, tx, rx = _beam_city(assume_quads=(kind == "quads"), boxes=30 if order < 3 else 14)
+    scene = G.Scene(tx, rx, mesh)
+    tracer = G.ExhaustivePathTracer(accel="bvh")
+    pairs = kind != "triangles"
+    ref = tracer.trace_beam_pruned(scene, order, pairs=pairs)
+    assert tracer.last_beam_stats["pair_mode"] == (kind == "pairs" and order > 0)
+    n = ref.objects.shape[0]
+    cap = 4096
+    out = tracer.trace_beam_pruned_static(scene, order, max_paths=cap, pairs=pairs)
+    torch.cuda.synchronize()
+    c = out["counts"].tolist()
+    assert c[1] == n and c[2] == 0, c
+    assert torch.equal(out["keys"][:n], ref.keys) and torch.equal(out["objects"][:n], ref.objects)
+    assert torch.equal(out["vertices"][:n].view(torch.int32), ref.vertices.view(torch.int32))
+    assert bool((out["keys"][n:] == -1).all()) and bool((out["objects"][n:] == -1).all())
+    assert bool((out["vertices"][n:] == 0).all())
+    assert order == 0 or n > 0
+
+
+def test_beam_async_capture_and_replay_with_moved_transmitters():
+    """Captured once in a HIP graph, replayed after the transmitters moved IN PLACE (the buffers an XLA executable
+    would re-use): every replay equals a fresh synchronous call on the new positions -- list sizes, the error unit and
+    the receivers' box all live on the device."""
+    G, mesh, tx, rx = _beam_city(boxes=40, ntx=4, nrx=64)
+    tracer = G.ExhaustivePathTracer(accel="bvh")
+    order, cap = 2, 8192
+    scene = G.Scene(tx, rx, mesh)
+    out = tracer.trace_beam_pruned_static(scene, order, max_paths=cap)  # builds clusters / LBVH, allocates buffers
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        tracer.trace_beam_pruned_static(scene, order, max_paths=cap, out=out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        tracer.trace_beam_pruned_static(scene, order, max_paths=cap, out=out)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    seen = set()
+    for rep in range(4):
+        if rep:
+            tx.add_(torch.randn(tx.shape, device="cuda", generator=gen) * (3.0 if rep < 3 else 300.0))  # (rep 3: the magnitude, hence the unit, changes)
+        for k in ("keys", "vertices", "objects", "counts"):
+            out[k].fill_(13)
+        g.replay()
+        torch.cuda.synchronize()
+        ref = tracer.trace_beam_pruned(G.Scene(tx.clone(), rx, mesh), order)
+        n = ref.objects.shape[0]
+        c = out["counts"].tolist()
+        assert c[1] == n and c[2] == 0, (rep, c, n)
+        assert torch.equal(out["keys"][:n], ref.keys) and torch.equal(out["objects"][:n], ref.objects)
+        assert torch.equal(out["vertices"][:n].view(torch.int32), ref.vertices.view(torch.int32))
+        assert bool((out["keys"][n:] == -1).all())
+        seen.add(n)
+    assert len(seen) > 1  # the replays really saw different problems
+
+
+def test_beam_async_reports_overflow_instead_of_slicing():
+    from differt_amd import _lib
+
+    G, mesh, tx, rx = _beam_city(boxes=40, ntx=4, nrx=64)
+    scene = G.Scene(tx, rx, mesh)
+    tracer = G.ExhaustivePathTracer()
+    ref = tracer.trace_beam_pruned(scene, 2)
+    have = set(ref.keys.tolist())
+    for kw, bit in (({"max_records": 1024}, _lib.DRT_BEAM_OVERFLOW_RECORDS), ({"max_rows": 2048}, _lib.DRT_BEAM_OVERFLOW_ROWS),
+                    ({"max_survivors": 8}, _lib.DRT_TRACE_OVERFLOW_SURVIVORS)):
+        out = tracer.trace_beam_pruned_static(scene, 2, max_paths=4096, **kw)
+        torch.cuda.synchronize()
+        c = out["counts"].tolist()
+        assert c[2] & bit, (kw, c)
+        got = [k for k in out["keys"].tolist() if k >= 0]
+        assert set(got) <= have  # what is written is valid, only incomplete
+    out = tracer.trace_beam_pruned_static(scene, 2, max_paths=4)
+    torch.cuda.synchronize()
+    assert out["counts"].tolist()[2] & _lib.DRT_TRACE_OVERFLOW_PATHS and out["counts"].tolist()[1] == len(have)
