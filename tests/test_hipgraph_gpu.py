@@ -202,8 +202,13 @@ def _beam_city(assume_quads=False, boxes=30, ntx=3, nrx=40, seed=3):
     import synthetic_scenes as S
 
     V, Tr, c, h = S.manhattan(boxes, seed=seed)
-    tx, rx = S.manhattan_tx_rx(c, h, ntx, nrx, seed=seed + 1)
-    tx[:, 2] = np.linspace(3.0, 35.0, ntx, dtype=np.float32)
+    ext = float(np.abs(V[:, :2]).max()) + 10  # a ground quad: reflections off the street exist at every order
+    gv = np.array([[-ext, -ext, 0], [ext, -ext, 0], [ext, ext, 0], [-ext, ext, 0]], np.float32)
+    Tr = np.concatenate((Tr, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V)))
+    V = np.concatenate((V, gv))
+    _, rx = S.manhattan_tx_rx(c, h, 1, nrx, seed=seed + 1)
+    _, tx = S.manhattan_tx_rx(c, h, 1, ntx, seed=seed + 2)  # transmitters above street crossings too (not inside a box)
+    tx[:, 2] = np.linspace(3.0, 25.0, ntx, dtype=np.float32)
     mesh = G.Mesh(V, Tr, assume_quads=assume_quads)
     return G, mesh, torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda")
 
