@@ -101,6 +101,13 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         # search (no exhaustive count to compare with: 91 paths, re-validated by the oracle in tests/test_full_size_gpu.py)
         out["beam_pruned_order3"] = beam_leg(G, mesh, tx, rx, 3, None, reps=1)
         out["beam_pruned_order3"]["same_valid_paths_as_exhaustive"] = exhaustive_record("configs[3]")
+        # the same configs as QUAD meshes (assume_quads=True: the city is boxes, and the reference's own harness calls
+        # set_assume_quads(), tests/benchmarks/test_rt.py:162): exhaustive order 2, pruned orders 2 and 3
+        try:
+            qmesh = G.Mesh(V, Tr, assume_quads=True)
+            out["assume_quads"] = quads_legs(G, qmesh, tx, rx)
+        except Exception as exc:  # noqa: BLE001
+            out["assume_quads"] = {"error": repr(exc)}
         out["visibility_pruned"] = pruned_leg(G, mesh, tx, rx, order, nvalid)
     if rank == 0 and world == 1 and num_ranks is None and order == 2:
         # the drop-in itself: Scene.trace_paths(order, chunk_size=...) in the reference's dense layout (bench_dense.py)
@@ -197,13 +204,81 @@ def beam_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps: int 
         st = tracer.last_beam_stats
         return {"s_per_step": dt, "valid_paths": int(nv), "valid_paths_per_s": nv / dt,
                 "same_valid_paths_as_exhaustive": None if expected_valid is None else int(nv) == int(expected_valid),
-                "order": order, "kappa": 64.0,
+                "order": order, "kappa": 64.0, "assume_quads": bool(mesh.assume_quads),
+                "coplanar_pair_mode": bool(st["pair_mode"]),
                 "rows_traced": int(st["rows"]), "prefix_levels": st["levels"], "unit_m": st["unit_m"], "grazing_prefixes": st["grazing_prefixes"],
+                "kernel_ms": {"last_expansion": st["expand_last_ms"], "receiver_stage": st["emit_ms"],
+                              "row_sort_and_trace": st["trace_ms"]},
+                "roofline": beam_roofline(order, st, bool(mesh.assume_quads)),
                 "entry_point": "drt_trace_paths_beam (one native call per step)",
                 "coverage": "all n(n-1)^(order-1) candidates of every (tx, rx) pair; error bounds per mirror from its "
                             "incidence geometry (no smallest-cosine parameter)"}
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}
+
+
+def beam_roofline(order: int, st: dict, quads: bool) -> dict | None:
+    """VALU-issue roofline of the kernel that owns a pruned step (the last expansion, order >= 2): kernel time = HIP
+    events around its launches in THIS run (drt_beam_stats.expand_last_ms); executed VALU instructions per step from the
+    committed counter pass of the same step (profiles/r*/pmc_beam_expand.json, hash-stamped: `pmc_stale` when the
+    kernel sources changed since).  Peak = one wave instruction per SIMD every 2 cycles (no packed / FMA credit)."""
+    import json
+    from pathlib import Path
+
+    if order < 2 or not st.get("expand_last_ms"):
+        return None
+    recs = sorted((Path(__file__).resolve().parent / "profiles").glob("r*/pmc_beam_expand.json"))
+    out = {"bound": "valu", "kernel_ms": st["expand_last_ms"], "peak": PEAK_VALU_ISSUE, "unit": "lane-ops/s",
+           "achieved": None, "frac": None, "pmc_stale": None}
+    if not recs:
+        return out
+    try:
+        from differt_amd._srchash import is_stale
+
+        rec = json.loads(recs[-1].read_text())
+        leg = rec.get("legs", {}).get(f"order{order}{'_quads' if quads else ''}")
+        out["pmc_stale"] = is_stale(rec, "beam")
+        out["source"] = f"profiles/{recs[-1].parent.name}/pmc_beam_expand.json"
+        if leg:
+            out["kernel"] = leg.get("kernel")
+            valu = leg["SQ_INSTS_VALU_per_step"]
+            out["executed_valu_wave_instructions_per_step"] = valu
+            out["achieved"] = valu * 64 / (st["expand_last_ms"] * 1e-3)
+            out["frac"] = out["achieved"] / PEAK_VALU_ISSUE
+            for k in ("SQ_WAIT_INST_ANY_over_SQ_WAVE_CYCLES", "valu_issue_frac_from_counters"):
+                if k in leg:
+                    out[k] = leg[k]
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+def quads_legs(G, qmesh, tx, rx) -> dict:
+    import torch
+
+    nq = qmesh.num_primitives
+    tracer = G.ExhaustivePathTracer()
+
+    def step():
+        txg = torch.tensor(tx, device="cuda", requires_grad=True)
+        scene = G.Scene(txg, torch.tensor(rx, device="cuda"), qmesh)
+        paths = tracer.trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
+        torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+        return paths.objects.shape[0]
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nv = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cand = len(tx) * len(rx) * nq * (nq - 1)
+    out = {"workload": f"configs[2] / configs[3] scene as {nq} quads (assume_quads=True)",
+           "exhaustive_order2": {"s_per_step": dt, "path_candidates_per_step": cand, "path_candidates_per_s": cand / dt,
+                                 "valid_paths": int(nv)},
+           "beam_pruned_order2": beam_leg(G, qmesh, tx, rx, 2, nv),
+           "beam_pruned_order3": beam_leg(G, qmesh, tx, rx, 3, None, reps=1)}
+    return out
 
 
 def exhaustive_record(config: str) -> dict | None:

@@ -81,6 +81,10 @@ class BeamStats(C.Structure):
         ("magnitude", C.c_float),
         ("pair_mode", C.c_int32),
         ("reserved", C.c_int32),
+        ("expand_last_ms", C.c_float),
+        ("emit_ms", C.c_float),
+        ("trace_ms", C.c_float),
+        ("reserved2", C.c_float),
     ]
 
 

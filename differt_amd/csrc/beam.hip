@@ -1014,8 +1014,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (dv.dyn) rxall = dv.dyn->rxall;
     expand_clustered_body<1, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
 }
+#ifndef BEAM_S2_WAVES
+#define BEAM_S2_WAVES 0  // (3 would spill 48 / 132 B per lane; the general two-triangle form is the fallback for quads that are not
+                         // convex planar fans -- those take the q4 kernels at 4 waves per SIMD)
+#endif
+#if BEAM_S2_WAVES > 0
+#define BEAM_S2_OCC __attribute__((amdgpu_waves_per_eu(BEAM_S2_WAVES, BEAM_S2_WAVES)))
+#else
+#define BEAM_S2_OCC
+#endif
 template <int LEVEL>
-__global__ __launch_bounds__(128) void beam_expand_clustered_last_kernel_s2(
+__global__ __launch_bounds__(128) BEAM_S2_OCC void beam_expand_clustered_last_kernel_s2(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
@@ -1963,6 +1972,41 @@ static BeamLayout beam_layout(const BeamSizes &z, int64_t ntx, int64_t nrx, int6
     return L;
 }
 
+// HIP-event stopwatch for drt_beam_stats (only when the caller asked for stats): start / stop around a group of
+// launches on the call's stream, read after the next synchronisation the call makes anyway
+struct BeamTimer {
+    bool on = false;
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    bool pending = false;
+    float *acc = nullptr;
+    void init(bool enable, hipStream_t stream, float *target) {
+        s = stream;
+        acc = target;
+        on = enable && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+    }
+    ~BeamTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    void start() {
+        if (on) (void)hipEventRecord(a, s);
+    }
+    void stop() {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            pending = true;
+        }
+    }
+    void collect() {  // after a stream synchronisation
+        if (on && pending) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, a, b) == hipSuccess) *acc += ms;
+            pending = false;
+        }
+    }
+};
+
 static int32_t read_count(const unsigned long long *dev, int64_t *host, hipStream_t s) {
     unsigned long long v = 0;
     DRT_HIP(hipMemcpyAsync(&v, dev, 8, hipMemcpyDeviceToHost, s));
@@ -2328,6 +2372,10 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     if (st) st->levels[0] = ncur;
     DRT_REQUIRE(ncur < (1ll << 32), "record format holds 32-bit prefix indices");
 
+    BeamTimer t_expand, t_emit, t_trace;
+    t_expand.init(st != nullptr, s, st ? &st->expand_last_ms : nullptr);
+    t_emit.init(st != nullptr, s, st ? &st->emit_ms : nullptr);
+    t_trace.init(st != nullptr, s, st ? &st->trace_ms : nullptr);
     // ---- last level: rows of a slice of prefixes -> sort -> table -> trace ----
     int64_t nvalid = 0, slices_with_paths = 0;
     auto process = [&](const BeamEntry *src, const unsigned long long *rec, int64_t nsrc, int64_t *rows_out,
@@ -2336,19 +2384,24 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         *rows_out = 0;
         if (nsrc == 0) return DRT_OK;
         DRT_HIP(fill_bytes_async(counters, 0, 8, s));
+        t_emit.start();
 #define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, src, rec, nsrc, rx, rx_sorted, rx_index, rx_boxes, nrx, u, rows, rows_cap, counters, counters + 1, s)
         BEAM_DISPATCH2(M.kind, order, CALL);
 #undef CALL
+        t_emit.stop();
         DRT_LAUNCH_CHECK();
         int64_t r = 0;
         int32_t rc2 = read_count(counters, &r, s);
         if (rc2 != DRT_OK) return rc2;
+        t_emit.collect();
+        t_expand.collect();
         *rows_out = r;  // in the unit of rows_cap: pair rows in coplanar-pair mode
         if (r > rows_cap) {
             *fits = false;
             return DRT_OK;
         }
         if (r == 0) return DRT_OK;
+        t_trace.start();
         size_t tb = sort_keys64_temp_bytes(r);
         DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted, (size_t)r,
                                          0, key_bits_rows, s));
@@ -2383,6 +2436,9 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         rc2 = drt_trace_paths_compact(mesh, &tp, tx, ntx, rx, nrx, &c, z.max_survivors, max_paths - nvalid,
                                       reinterpret_cast<int64_t *>(slice_keys), vertices ? vertices + nvalid * k2 * 3 : nullptr,
                                       objects ? objects + nvalid * k2 : nullptr, &nv, base + L.trace_ws, L.trace_ws_bytes, stream);
+        t_trace.stop();
+        if (t_trace.on) (void)hipStreamSynchronize(s);  // (the trace synchronised already; the stop event is the only thing in flight)
+        t_trace.collect();
         if (rc2 == DRT_E_CAPACITY && nv > z.max_survivors) {
             // the survivor queue of the trace overflowed (it reports the survivor count, which a count of valid
             // paths can never exceed): the slice is too large, like one whose rows do not fit
@@ -2420,6 +2476,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         while (i0 < ncur) {
             const int64_t i1 = std::min(i0 + step, ncur);
             DRT_HIP(fill_bytes_async(counters, 0, 8, s));
+            t_expand.start();
             if (order == 2) {
 #define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall)
                 BEAM_DISPATCH2(M.kind, 1, CALL);
@@ -2429,10 +2486,12 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
                 BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
             }
+            t_expand.stop();
             DRT_LAUNCH_CHECK();
             int64_t c = 0, r = 0;
             int32_t rc2 = read_count(counters, &c, s);
             if (rc2 != DRT_OK) return rc2;
+            t_expand.collect();
             bool fits = c <= z.max_records;
             if (fits) {
                 rc2 = process(cur + i0, records, c, &r, &fits);

@@ -590,7 +590,9 @@ class ExhaustivePathTracer(AbstractPathTracer):
                                                beam, int(max_paths), self._beam_workspace)
         self.last_beam_stats = {"unit_m": st.unit_m, "magnitude": st.magnitude, "levels": [int(x) for x in st.levels[:max(order, 1)]],
                                 "rows": int(st.rows), "chunks": int(st.slices), "valid": int(st.valid),
-                                "grazing_prefixes": int(st.grazing_prefixes), "pair_mode": bool(st.pair_mode)}
+                                "grazing_prefixes": int(st.grazing_prefixes), "pair_mode": bool(st.pair_mode),
+                                "expand_last_ms": float(st.expand_last_ms), "emit_ms": float(st.emit_ms),
+                                "trace_ms": float(st.trace_ms)}
         nv = objs.shape[0]
         return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=objs.device),
                            torch.zeros((nv, order), dtype=torch.int32, device=objs.device), self.confidence_threshold, keys)

@@ -540,6 +540,10 @@ typedef struct drt_beam_stats {
     float magnitude;          /* that magnitude */
     int32_t pair_mode;        /* 1: a triangle mesh searched over its coplanar pairs (levels[] count pair prefixes) */
     int32_t reserved;
+    float expand_last_ms;     /* HIP-event time of the last expansion's kernels (all slices), */
+    float emit_ms;            /*   of the receiver stage, */
+    float trace_ms;           /*   of the fused trace of the candidate rows (sort / decode included) */
+    float reserved2;
 } drt_beam_stats;
 
 #define DRT_BEAM_EXPAND_PLAIN 1   /* expansion: every (prefix, primitive) pair tested, no cluster culling */

@@ -40,7 +40,7 @@ static T *to_device(const std::vector<T> &h) {
     return d;
 }
 
-static_assert(sizeof(drt_beam_params) == 72 && sizeof(drt_beam_stats) == 80, "layouts the ctypes binding relies on");
+static_assert(sizeof(drt_beam_params) == 72 && sizeof(drt_beam_stats) == 96, "layouts the ctypes binding relies on");
 
 int main(int argc, char **argv) {
     if (argc < 3) return 2;

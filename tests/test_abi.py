@@ -36,9 +36,9 @@ def test_struct_layouts_match_header():
     assert _lib.Candidates.order.offset == 40 and _lib.Candidates.first_map.offset == 48
     assert _lib.Candidates.num_last.offset == 72
     assert C.sizeof(_lib.EmParams) == 40 and _lib.EmParams.rx_polarization.offset == 24
-    # drt_beam_params: f32, i32, 7 x i64, ptr; drt_beam_stats: 4 + 4 x i64, 2 x f32, 2 x i32 (tests/abi/abi_beam_example.cpp asserts the same)
+    # drt_beam_params: f32, i32, 7 x i64, ptr; drt_beam_stats: 4 + 4 x i64, 2 x f32, 2 x i32, 4 x f32 (tests/abi/abi_beam_example.cpp asserts the same)
     assert C.sizeof(_lib.BeamParams) == 72 and _lib.BeamParams.stats.offset == 64 and _lib.BeamParams.shard_rank.offset == 48
-    assert C.sizeof(_lib.BeamStats) == 80 and _lib.BeamStats.unit_m.offset == 64 and _lib.BeamStats.pair_mode.offset == 72
+    assert C.sizeof(_lib.BeamStats) == 96 and _lib.BeamStats.unit_m.offset == 64 and _lib.BeamStats.pair_mode.offset == 72
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
