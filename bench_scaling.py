@@ -218,6 +218,66 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
     return out
 
 
+def emulate_shards(nshards: int = 8, *, window: int | None = None, reps: int = 2) -> dict:
+    """Shard imbalance of the two multi-GPU splits, measured on ONE GPU: every shard of `beam_sharded` (level-1
+    prefix (t, m) on rank (t n + m) mod N) and of `candidate_sharded` (one contiguous block of the rank window per
+    rank) for configs[3] (order 3) and configs[4] (order 2) is run by itself, one after the other, and timed.  The
+    slowest shard bounds the N-GPU step: `speedup_bound` = (unsharded step) / (slowest shard) -- what N GPUs can reach
+    at best before the epilogue (two all-gathers of a few KB, one all-reduce of 48 B).  Target: max / mean <= 1.15."""
+    import torch
+
+    import differt_amd.geometry as G
+    import synthetic_scenes as S
+    from differt_amd.distributed import shard_interval
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            nv = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, nv
+
+    def summary(ts, full):
+        ts = [float(t) for t in ts]
+        mean = sum(ts) / len(ts)
+        return {"per_shard_s": ts, "max_over_mean": max(ts) / mean, "unsharded_s": full,
+                "speedup_bound": full / max(ts), "sum_over_unsharded": sum(ts) / full}
+
+    out = {"shards": nshards, "note": "every shard run alone on one MI355X, sequentially; no collective is timed"}
+    for name, order in (("configs[3]", 3), ("configs[4]", 2)):
+        if name == "configs[3]":
+            V, Tr, c, h = S.manhattan(1000)
+            tx, rx = S.manhattan_tx_rx(c, h, 16, 64)
+        else:
+            V, Tr, tx, rx = S.cfg5_scene()
+        mesh = G.Mesh(V, Tr)
+        scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
+        tracer = G.ExhaustivePathTracer(accel="bvh")
+        full, nv = timed(lambda: tracer.trace_beam_pruned(scene, order).objects.shape[0])
+        ts, found = [], 0
+        for r in range(nshards):
+            t, k = timed(lambda r=r: tracer.trace_beam_pruned(scene, order, prefix_shard=(r, nshards)).objects.shape[0])
+            ts.append(t)
+            found += k
+        rec = {"beam_sharded": {**summary(ts, full), "valid_paths": int(nv), "valid_paths_over_shards": int(found)}}
+        if order == 2:
+            n = mesh.num_primitives
+            total = n * (n - 1)
+            W = min(total, int(window) if window else max(int(3.4e12 // max(rx.shape[0], 1)), 1))
+            ex = G.ExhaustivePathTracer()
+            fullc, _ = timed(lambda: ex.trace_rank_range(scene, 2, 0, W, max_survivors=1 << 22).objects.shape[0])
+            tc = []
+            for r in range(nshards):
+                lo, hi = shard_interval(W, nshards, r)
+                t, _ = timed(lambda lo=lo, hi=hi: ex.trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22).objects.shape[0])
+                tc.append(t)
+            rec["candidate_sharded"] = {**summary(tc, fullc), "window": W}
+        out[name] = rec
+    return out
+
+
 if __name__ == "__main__":
     import argparse
     import json
@@ -227,5 +287,10 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--boxes", type=int, default=20000)
     ap.add_argument("--window", type=int, default=None)
+    ap.add_argument("--emulate-shards", type=int, default=0,
+                    help="run every shard of the beam / candidate splits alone on this GPU and report the imbalance")
     a = ap.parse_args()
-    print(json.dumps(run(torch.device("cuda", 0), boxes=a.boxes, window=a.window)))
+    if a.emulate_shards:
+        print(json.dumps(emulate_shards(a.emulate_shards, window=a.window)))
+    else:
+        print(json.dumps(run(torch.device("cuda", 0), boxes=a.boxes, window=a.window)))

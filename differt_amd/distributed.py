@@ -109,7 +109,7 @@ class NativeComm:
         return recv
 
 
-_NATIVE: dict = {}
+_NATIVE: dict = {}  # process group OBJECT -> NativeComm (the key keeps the group alive: its identity cannot be reused)
 
 
 def native_comm(group=None) -> NativeComm | None:
@@ -122,16 +122,20 @@ def native_comm(group=None) -> NativeComm | None:
     world, rank = _world(group)
     if world == 1:
         return None
-    key = id(group)
-    if key not in _NATIVE:
+    key = group if group is not None else dist.group.WORLD
+    nc = _NATIVE.get(key)
+    if nc is not None and (nc.world != world or nc.rank != rank or nc.h is None):
+        nc.close()  # a re-initialised default group: never hand out a communicator of another world
+        nc = None
+    if nc is None:
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             idt = torch.tensor(list(NativeComm.unique_id()), dtype=torch.uint8, device=dev)
         dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        _NATIVE[key] = NativeComm(bytes(idt.cpu().tolist()), rank, world)
-    return _NATIVE[key]
+        nc = _NATIVE[key] = NativeComm(bytes(idt.cpu().tolist()), rank, world)
+    return nc
 
 
 def _world(group) -> tuple[int, int]:
@@ -140,34 +144,59 @@ def _world(group) -> tuple[int, int]:
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _allgather_rows(t: torch.Tensor, group) -> torch.Tensor:
+    """``[world, *t.shape]``: ONE collective -- ``drt_allgather_bytes`` under ``DRT_COMM=rccl`` on GPU tensors, else
+    ``torch.distributed`` (into one tensor where the backend can, a list otherwise)."""
+    world, _ = _world(group)
+    t = t.contiguous()
+    nc = native_comm(group)
+    if nc is not None and t.is_cuda:
+        return nc.allgather_bytes(t)
+    out = torch.empty((world, *t.shape), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out, t, group=group)
+    except (RuntimeError, NotImplementedError):  # a backend without the flat form
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t, group=group)
+        out = torch.stack(bufs)
+    return out
+
+
 def gather_paths(keys: torch.Tensor, vertices: torch.Tensor, objects: torch.Tensor,
                  key_offset: int = 0, group=None):
     """All-gather the valid paths of every rank; returns ``(keys, vertices, objects)`` identical on
     all ranks, sorted by global flat key ``(tx*num_rx + rx) * C + candidate_rank`` (the order of
     ``masked_vertices``).  ``keys`` must already be global (see ``globalize_keys``); ``key_offset``
-    is a convenience for the single-pair case."""
+    is a convenience for the single-pair case.
+
+    TWO collectives: the per-rank counts (8 bytes each; their maximum sizes the record buffer -- the one host
+    read of the epilogue), then every rank's paths as ONE block of packed records ``key | vertices | objects``
+    (8 + 16 (order + 2) bytes per path) padded to that maximum."""
     world, _ = _world(group)
     keys = keys + key_offset
     if world == 1:
         return keys, vertices, objects
-    n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=keys.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-
-    def pad(t: torch.Tensor) -> torch.Tensor:
-        out = torch.zeros((cap, *t.shape[1:]), dtype=t.dtype, device=t.device)
-        out[: t.shape[0]] = t
-        return out
-
-    outs = []
-    for t in (keys, vertices, objects):
-        bufs = [torch.zeros((cap, *t.shape[1:]), dtype=t.dtype, device=t.device) for _ in range(world)]
-        dist.all_gather(bufs, pad(t.contiguous()), group=group)
-        outs.append(torch.cat([b[:c] for b, c in zip(bufs, counts)]))
-    perm = torch.argsort(outs[0], stable=True)
-    return tuple(o[perm] for o in outs)
+    dev = keys.device
+    n = keys.shape[0]
+    counts = _allgather_rows(torch.tensor([n], dtype=torch.int64, device=dev), group).reshape(-1)
+    counts_h = counts.tolist()
+    cap = max(max(counts_h), 1)
+    k2 = vertices.shape[1]
+    rec = 8 + 12 * k2 + 4 * k2
+    block = torch.zeros((cap, rec), dtype=torch.uint8, device=dev)
+    if n:
+        block[:n, :8] = keys.contiguous().view(torch.uint8).reshape(n, 8)
+        block[:n, 8:8 + 12 * k2] = vertices.contiguous().view(torch.uint8).reshape(n, 12 * k2)
+        block[:n, 8 + 12 * k2:] = objects.contiguous().view(torch.uint8).reshape(n, 4 * k2)
+    allb = _allgather_rows(block, group)  # [world, cap, rec]
+    valid = (torch.arange(cap, device=dev)[None, :] < counts[:, None]).reshape(-1)
+    rows = allb.reshape(world * cap, rec)[valid].contiguous()
+    m = rows.shape[0]
+    out_k = rows[:, :8].contiguous().view(torch.int64).reshape(m)
+    out_v = rows[:, 8:8 + 12 * k2].contiguous().view(torch.float32).reshape(m, k2, 3)
+    out_o = rows[:, 8 + 12 * k2:].contiguous().view(torch.int32).reshape(m, k2)
+    perm = torch.argsort(out_k, stable=True)
+    return out_k[perm], out_v[perm], out_o[perm]
 
 
 def globalize_keys(local_keys: torch.Tensor, local_count: int, rank_lo: int, total: int) -> torch.Tensor:

@@ -9,6 +9,7 @@ authoring (sampling, editing, plotting, file IO) is out of scope (SURVEY.md sect
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 from dataclasses import dataclass, field, replace
 
 import numpy as np
@@ -17,6 +18,8 @@ import torch
 from .. import _lib
 from .._tensors import F32_EPS, as_f32, as_i32, device, ptr, stream
 from . import _utils
+
+_GENERATIONS = itertools.count(1)  # Mesh.generation(): one number per device snapshot, never reused
 
 __all__ = ["Mesh"]
 
@@ -159,12 +162,14 @@ class Mesh:
             )
             self._handle.key = self._handle_key()
             self._handle.src = (self.vertices, self.triangles, self.mask)
+            self._handle.generation = next(_GENERATIONS)
         return self._handle
 
     def generation(self) -> int:
         """Identity of the current device snapshot (changes whenever :meth:`handle` re-snapshots): the key
-        for anything cached per geometry outside the native handle."""
-        return id(self.handle())
+        for anything cached per geometry outside the native handle.  A process-wide counter, not ``id()``: the address
+        of a freed handle can come back with the next snapshot."""
+        return self.handle().generation
 
     # ---- reference properties ----
     @property
