@@ -107,6 +107,7 @@ class BeamParams(C.Structure):
 
 DRT_BEAM_EXPAND_PLAIN, DRT_BEAM_EMIT_PLAIN, DRT_BEAM_EMIT_CLUSTERED, DRT_BEAM_NO_PAIRS = 1, 2, 4, 8
 DRT_BEAM_OVERFLOW_ENTRIES, DRT_BEAM_OVERFLOW_RECORDS, DRT_BEAM_OVERFLOW_ROWS = 4, 8, 16
+DRT_HYBRID_PREFIX, DRT_HYBRID_RAGGED = 1, 2
 DRT_CAND_PACKED_KEYS = 4
 
 
@@ -236,6 +237,9 @@ _SIGNATURES = {
     "drt_mesh_build_beam_clusters": (_i32, [_vp, _vp]),
     "drt_trace_beam_workspace_size": (_sz, [_i64, _i64, _i64, _i32, _vp, _i64]),
     "drt_trace_paths_beam": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "drt_trace_hybrid_pairs_workspace_size": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "drt_trace_paths_hybrid_pairs": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp,
+                                          C.POINTER(_i64), C.POINTER(_i64), _vp, _sz, _vp]),
     "drt_trace_paths_beam_async": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drt_trace_paths_compact": (
         _i32,

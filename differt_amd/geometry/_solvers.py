@@ -247,6 +247,57 @@ class _TraceBeamFn(torch.autograd.Function):
         return gtx, grx, gmv, None, None, None, None, None, None
 
 
+class _TraceHybridPairsFn(torch.autograd.Function):
+    """``drt_trace_paths_hybrid_pairs``: per-pair visibility-pruned trace (CSR sets and pair offsets built by kernels in
+    the call's workspace); keys are packed, the backward is ``drt_trace_paths_vjp`` with ``DRT_CAND_PACKED_KEYS``."""
+
+    @staticmethod
+    def forward(ctx, tx, rx, mesh_vertices, mesh, order, params, vis_tx, vis_rx, flags, max_survivors, max_paths, info):
+        dev = tx.device
+        lib = _lib.load()
+        n = mesh.num_primitives
+        h = mesh.handle().h
+        while True:
+            nbytes = lib.drt_trace_hybrid_pairs_workspace_size(tx.shape[0], rx.shape[0], n, max_survivors, max_paths)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            keys = torch.empty(max_paths, dtype=torch.int64, device=dev)
+            verts = torch.empty((max_paths, order + 2, 3), dtype=torch.float32, device=dev)
+            objs = torch.empty((max_paths, order + 2), dtype=torch.int32, device=dev)
+            nv, ne = C.c_int64(0), C.c_int64(0)
+            try:
+                _lib.call("drt_trace_paths_hybrid_pairs", h, C.byref(params), ptr(tx), tx.shape[0], ptr(rx), rx.shape[0],
+                          order, ptr(vis_tx), ptr(vis_rx), flags, max_survivors, max_paths, ptr(keys), ptr(verts),
+                          ptr(objs), C.byref(nv), C.byref(ne), ptr(ws), nbytes, stream())
+                break
+            except _lib.CapacityError:  # the call reports the count that did not fit (results never depend on capacities)
+                need = int(nv.value)
+                if need > max_survivors:
+                    max_survivors = max(2 * max_survivors, need)
+                else:
+                    max_paths = max(2 * max_paths, need)
+        info["evaluated"] = int(ne.value)
+        nvalid = int(nv.value)
+        keys = keys[:nvalid].clone()
+        objs = objs[:nvalid].clone()
+        ctx.mesh, ctx.order, ctx.n, ctx.params = mesh, order, n, params
+        ctx.save_for_backward(tx, rx, keys)
+        ctx.mark_non_differentiable(objs, keys)
+        return verts[:nvalid].clone(), objs, keys
+
+    @staticmethod
+    def backward(ctx, gv, _go, _gk):
+        tx, rx, keys = ctx.saved_tensors
+        mesh = ctx.mesh
+        gtx, grx = torch.zeros_like(tx), torch.zeros_like(rx)
+        gmv = torch.zeros_like(mesh.vertices) if ctx.needs_input_grad[2] else None
+        if keys.shape[0]:
+            cands = _lib.Candidates()
+            cands.table, cands.num_nodes, cands.order = None, ctx.n, ctx.order
+            cands.reserved = _lib.DRT_CAND_PACKED_KEYS
+            _paths_vjp(mesh, ctx.params, tx, rx, cands, keys, gv.contiguous(), keys.shape[0], ctx.order, gtx, grx, gmv)
+        return gtx, grx, gmv, None, None, None, None, None, None, None, None, None
+
+
 class _TraceSmoothFn(torch.autograd.Function):
     """Smoothed tracer (_solvers.py:499-770 with ``smoothing_factor``): vertices AND the float mask are
     differentiable in (tx, rx, mesh vertices) through ``drt_trace_paths_dense_smooth_vjp``."""
@@ -777,63 +828,45 @@ class HybridPathTracer(ExhaustivePathTracer):
         paths of all pairs (pair-major, lexicographic inside a pair = ``masked_vertices`` order of the
         exhaustive tracer), differentiable like any compact trace.  Finds a subset of the exhaustive
         tracer's valid paths that is complete up to the sampling of the visibility estimate;
-        ``visibility`` takes a cached :meth:`estimate_visibility` result."""
+        ``visibility`` takes a cached :meth:`estimate_visibility` result.  ``keys`` are packed like those of
+        :meth:`trace_beam_pruned`: ``(tx*num_rx + rx) * n**order + sum_j m_j * n**(order-1-j)``."""
         if order < 2:
             return self.trace_rank_range(scene, order, max_survivors=max_survivors, max_paths=max_paths)
         mesh = scene.mesh
-        tx = scene.transmitters.reshape(-1, 3)
-        rx = scene.receivers.reshape(-1, 3)
+        tx = scene.transmitters.reshape(-1, 3).contiguous()
+        rx = scene.receivers.reshape(-1, 3).contiguous()
         vis_tx, vis_rx = self.estimate_visibility(scene) if visibility is None else visibility
-        if mesh.assume_quads:
-            vis_tx = vis_tx.reshape(vis_tx.shape[0], -1, 2).any(dim=-1)
-            vis_rx = vis_rx.reshape(vis_rx.shape[0], -1, 2).any(dim=-1)
-        middle = None
-        if mesh.mask is not None:
-            active = mesh.mask
-            if mesh.assume_quads:
-                active = active[0::2] & active[1::2]
-            vis_tx, vis_rx = vis_tx & active, vis_rx & active
-            middle = torch.nonzero(active).reshape(-1).to(torch.int32).contiguous()
-        n = mesh.num_primitives if middle is None else int(middle.shape[0])
-
-        def csr(vis):  # [V, P] bool -> (ids int32 ascending per row, offsets int64 [V + 1])
-            nz = torch.nonzero(vis)  # row-major: sorted by viewpoint, then by primitive
-            counts = vis.sum(dim=1).to(torch.int64)
-            off = torch.zeros(vis.shape[0] + 1, dtype=torch.int64, device=vis.device)
-            off[1:] = torch.cumsum(counts, 0)
-            return nz[:, 1].to(torch.int32).contiguous(), off, counts
-
-        first_ids, first_off, nf = csr(vis_tx)
-        last_ids, last_off, nl = csr(vis_rx)
-        # exact total in Python integers first: the int64 tensors below would wrap silently and rows would
-        # decode to the wrong (tx, rx) pair (the C side only sees the wrapped value)
-        exact_total = int(nf.sum().item()) * n ** (order - 2) * int(nl.sum().item())
-        if exact_total >= 2**62:
-            raise OverflowError(f"per-pair candidate spaces hold {exact_total} rows in all (>= 2**62): "
-                                "trace fewer pairs per call or lower the order")
-        sizes = (nf[:, None] * (n ** (order - 2)) * nl[None, :]).reshape(-1)  # pair-major, like the keys
-        pair_off = torch.zeros(sizes.shape[0] + 1, dtype=torch.int64, device=sizes.device)
-        pair_off[1:] = torch.cumsum(sizes, 0)
-        total = int(pair_off[-1].item())
-        self.last_num_evaluated = total
         strategy = self.pairs_strategy
-        if strategy == "auto":
-            # huge pair spaces (configs[3] order 3: 1e9 rows per pair): amortise the unranking, the mirror
-            # gathers and the forward images over the receivers and their last interactions (prefix kernel:
-            # measured 14.2 s for the plain ragged launch, 10.6 s for one launch per pair)
-            large = sizes.numel() and total / sizes.numel() > self.ragged_max_pair_size
-            strategy = "prefix" if (large and order >= 3) else "ragged"
-        if strategy == "loop":
-            return self._trace_pairs_loop(scene, order, vis_tx, vis_rx, middle, n, max_survivors, max_paths)
-        if strategy not in ("ragged", "prefix"):
+        if strategy == "loop":  # one product-space launch per pair (a debugging mapping; torch glue)
+            vt, vr = vis_tx, vis_rx
+            if mesh.assume_quads:
+                vt = vt.reshape(vt.shape[0], -1, 2).any(dim=-1)
+                vr = vr.reshape(vr.shape[0], -1, 2).any(dim=-1)
+            middle = None
+            if mesh.mask is not None:
+                active = mesh.mask
+                if mesh.assume_quads:
+                    active = active[0::2] & active[1::2]
+                vt, vr = vt & active, vr & active
+                middle = torch.nonzero(active).reshape(-1).to(torch.int32).contiguous()
+            n = mesh.num_primitives if middle is None else int(middle.shape[0])
+            return self._trace_pairs_loop(scene, order, vt, vr, middle, n, max_survivors, max_paths)
+        if strategy not in ("auto", "ragged", "prefix"):
             raise ValueError(f"unknown pairs_strategy {self.pairs_strategy!r}")
-        ragged = {"pair_offsets": pair_off, "first_offsets": first_off, "last_offsets": last_off,
-                  "small": bool(sizes.numel() == 0 or int(sizes.max().item()) < 2**32),
-                  "prefix": strategy == "prefix" and order >= 3, "max_first": int(nf.max().item()) if nf.numel() else 0}
-        desc = {"table": None, "order": order, "rank_lo": 0, "count": total, "num_nodes": n, "node_map": middle,
-                "first_map": first_ids, "last_map": last_ids, "ragged": ragged}
-        p = self._trace_compact(scene, desc, max_survivors, max_paths)
-        return p
+        # everything else -- primitive-level visibility, CSR sets, pair offsets, the ragged trace -- is ONE native call
+        # (drt_trace_paths_hybrid_pairs, csrc/hybrid.hip); this method only marshals
+        flags = {"auto": 0, "ragged": _lib.DRT_HYBRID_RAGGED, "prefix": _lib.DRT_HYBRID_PREFIX}[strategy]
+        if mesh.num_primitives and tx.shape[0] * rx.shape[0] * mesh.num_primitives ** order >= 2 ** 62:
+            raise OverflowError("tx * rx * primitives**order does not fit a 62-bit key")
+        info: dict = {}
+        params = _params(self.epsilon, self.hit_tol, self.min_len, self.accel, deterministic_grad=self.deterministic_grad)
+        verts, objs, keys = _TraceHybridPairsFn.apply(
+            tx, rx, mesh.vertices, mesh, order, params, vis_tx.to(torch.uint8).contiguous(), vis_rx.to(torch.uint8).contiguous(),
+            flags, int(max_survivors), int(max_paths), info)
+        self.last_num_evaluated = info.get("evaluated", 0)
+        nv = objs.shape[0]
+        return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=objs.device),
+                           torch.zeros((nv, order), dtype=torch.int32, device=objs.device), self.confidence_threshold, keys)
 
     def _trace_pairs_loop(self, scene, order, vis_tx, vis_rx, middle, n, max_survivors, max_paths) -> TracedPaths:
         """One GPU-unranked product-space launch per (transmitter, receiver) pair."""

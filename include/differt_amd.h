@@ -607,6 +607,30 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *para
                                    int64_t *counts_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (f2) visibility pruning PER (transmitter, receiver) pair -- reference: HybridPathTracer, geometry/_solvers.py:960-1176
+ * (which merges the visible sets over all end points, :969-973; per pair is the MI355X extension).  Pair (i, j) traces
+ * F_i x N^(order-2) x L_j: first interaction among the primitives visible from transmitter i, last one among those
+ * visible from receiver j, middle ones among the active primitives; all pairs in one ragged launch of the compact
+ * tracer.  Inputs: vis_tx u8 [num_tx, T], vis_rx u8 [num_rx, T] (device; non-zero = triangle seen, e.g. from
+ * drt_triangles_visible_from_vertex); quads count as seen when either triangle is (:1024-1031), masked primitives are
+ * dropped (:1038-1042).  The CSR sets, their offsets and the pair offsets are built by kernels in the workspace (no
+ * host enumeration; one read-back of the num_tx + num_rx set sizes).  Outputs as drt_trace_paths_compact, except
+ * keys = PACKED keys (tx num_rx + rx) n^order + sum_j m_j n^(order-1-j) (n primitives): self-describing, so
+ * drt_trace_paths_vjp takes them with DRT_CAND_PACKED_KEYS and needs none of the sets.  *num_evaluated_host (may be
+ * NULL): rows of all pair spaces.  order >= 2.  flags: 0 = choose, DRT_HYBRID_RAGGED = lane per (pair, candidate)
+ * row, DRT_HYBRID_PREFIX (order >= 3) = lane per prefix of order-1 interactions (huge pair spaces). */
+#define DRT_HYBRID_PREFIX 1
+#define DRT_HYBRID_RAGGED 2
+size_t drt_trace_hybrid_pairs_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_primitives,
+                                             int64_t max_survivors, int64_t max_paths);
+int32_t drt_trace_paths_hybrid_pairs(drt_mesh_t mesh, const drt_trace_params *params, const float *tx, int64_t num_tx,
+                                     const float *rx, int64_t num_rx, int32_t order, const uint8_t *vis_tx,
+                                     const uint8_t *vis_rx, int32_t flags, int64_t max_survivors, int64_t max_paths,
+                                     int64_t *keys, float *vertices, int32_t *objects, int64_t *num_valid_host,
+                                     int64_t *num_evaluated_host, void *workspace, size_t workspace_bytes,
+                                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (e) collectives of the path on RCCL, no torch in the process.  One process per
  * GPU; rank 0 draws an id (drt_comm_unique_id) and hands its 128 bytes to the other ranks out of band (the
  * host's rendezvous: a file, MPI, torch.distributed's store ...); every rank then calls drt_comm_init with

@@ -636,9 +636,14 @@ def test_hybrid_trace_pairs_equals_exhaustive(G, goldens, two_buildings, order, 
             np.testing.assert_array_equal(_np(alt.keys), _np(got.keys), err_msg=strategy)
     cached = solver.trace_pairs(scene, order, visibility=solver.estimate_visibility(scene))
     assert torch.equal(cached.objects, got.objects) and torch.equal(cached.vertices, got.vertices)
-    if order >= 2:  # keys of the ragged launch are global rows of the concatenated pair spaces, ascending
+    if order >= 2:  # packed keys: (tx nrx + rx) n^order + sum_j m_j n^(order-1-j), ascending = masked_vertices order
         k = _np(got.keys)
-        assert (np.diff(k) > 0).all() and k.max() < solver.last_num_evaluated
+        o = _np(got.objects).astype(np.int64)
+        n = scene.mesh.num_primitives
+        exp = o[:, 0] * rx.shape[0] + o[:, -1]
+        for j in range(order):
+            exp = exp * n + o[:, 1 + j] // (2 if assume_quads else 1)
+        assert (np.diff(k) > 0).all() and np.array_equal(k, exp) and solver.last_num_evaluated > 0
     if order >= 2:
         assert solver.last_num_evaluated < 6 * G.ExhaustivePathTracer().num_path_candidates(scene, order)
     txg = torch.tensor(tx, device="cuda", requires_grad=True)
