@@ -12,7 +12,21 @@
 // carries an RCCL (torch does) shares that copy instead of loading a second one.
 #include <dlfcn.h>
 #include <string.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL development headers still builds the whole library: the runtime
+// binding is by dlopen / dlsym anyway, and this file needs only these declarations of the stable NCCL ABI
+// (rccl.h: NCCL_UNIQUE_ID_BYTES 128; ncclSum 0, ncclMax 2, ncclMin 3; ncclUint8 1, ncclUint64 5, ncclFloat32 7).
+#include <hip/hip_runtime.h>
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7 } ncclDataType_t;
+#endif
 
 #include <mutex>
 

@@ -511,17 +511,50 @@ __global__ __launch_bounds__(256) void trace_vjp_contrib_kernel(
     }
 }
 
+// Ordered sum of every destination group in TWO levels, so that a group of g contributions costs one lane g / 256 + 256
+// dependent adds instead of g (one transmitter with 1e6 paths: 4 000 instead of 1e6): the sorted list is
+// cut into fixed chunks of 256; level 1 sums, in order, the part of a group that CONTINUES from the previous chunk
+// (at most one such run per chunk: the leading one) into carry[chunk]; level 2, one lane per group head, sums the
+// group's elements inside the head's chunk in order and then the carries of the following chunks in order.  The
+// association is fixed by the positions alone: bit-identical from run to run.
+constexpr int kVjpChunk = 256;
+__global__ __launch_bounds__(256) void trace_vjp_carry_kernel(const unsigned long long *__restrict__ dest_sorted,
+                                                              const uint32_t *__restrict__ slots_sorted,
+                                                              const float *__restrict__ vecs, int64_t n,
+                                                              float *__restrict__ carry) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;  // chunk
+    const int64_t i0 = c * kVjpChunk;
+    if (c == 0 || i0 >= n) return;
+    const unsigned long long d = dest_sorted[i0];
+    V3 acc{0, 0, 0};
+    if (d != ~0ull && dest_sorted[i0 - 1] == d) {
+        const int64_t end = (i0 + kVjpChunk < n) ? i0 + kVjpChunk : n;
+        acc = ld3(vecs + 3 * (int64_t)slots_sorted[i0]);
+        for (int64_t j = i0 + 1; j < end && dest_sorted[j] == d; ++j) acc = acc + ld3(vecs + 3 * (int64_t)slots_sorted[j]);
+    }
+    st3(carry + 3 * c, acc);
+}
+
 __global__ __launch_bounds__(256) void trace_vjp_reduce_kernel(const unsigned long long *__restrict__ dest_sorted,
                                                                const uint32_t *__restrict__ slots_sorted,
                                                                const float *__restrict__ vecs, int64_t n,
+                                                               const float *__restrict__ carry,
                                                                float *__restrict__ g_tx, float *__restrict__ g_rx,
                                                                float *__restrict__ g_vertices) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long d = dest_sorted[i];
     if (d == ~0ull || (i > 0 && dest_sorted[i - 1] == d)) return;  // not the head of a group
+    const int64_t chunk_end = (i / kVjpChunk + 1) * kVjpChunk;
     V3 acc = ld3(vecs + 3 * (int64_t)slots_sorted[i]);
-    for (int64_t j = i + 1; j < n && dest_sorted[j] == d; ++j) acc = acc + ld3(vecs + 3 * (int64_t)slots_sorted[j]);
+    int64_t j = i + 1;
+    for (; j < n && j < chunk_end && dest_sorted[j] == d; ++j) acc = acc + ld3(vecs + 3 * (int64_t)slots_sorted[j]);
+    // the group runs on into the next chunks: their leading runs were summed by trace_vjp_carry_kernel
+    for (int64_t c = chunk_end / kVjpChunk; j == c * kVjpChunk && j < n && dest_sorted[j] == d; ++c) {
+        acc = acc + ld3(carry + 3 * c);
+        const int64_t last = ((c + 1) * kVjpChunk < n ? (c + 1) * kVjpChunk : n) - 1;
+        j = (dest_sorted[last] == d) ? last + 1 : j + 1;  // (j + 1: any value off the next chunk boundary ends the loop)
+    }
     const int space = (int)(d >> 40);
     float *out = ((space == 0) ? g_tx : ((space == 1) ? g_rx : g_vertices)) + 3 * (int64_t)(d & 0xffffffffffull);
     // gradients are ACCUMULATED into the caller's buffers: the group's only writer adds its total
@@ -894,8 +927,13 @@ int32_t drt_trace_paths_vjp_ex(drt_mesh_t mesh, const drt_trace_params *pr, cons
     size_t tb = vjp_sort_temp_bytes(n);
     // radix sort is stable: inside a destination the slots stay in path order
     DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb, dest, dest_sorted, slots, slots_sorted, (size_t)n, 0, 42, L.s));
+    // (the unsorted destination keys are dead after the sort: their buffer holds the chunk carries, 12 B per 256 slots)
+    float *carry = reinterpret_cast<float *>(dest);
+    const int64_t nchunks = ceil_div(n, kVjpChunk);
+    hipLaunchKernelGGL(trace_vjp_carry_kernel, dim3((unsigned)ceil_div(nchunks, 256)), dim3(256), 0, L.s, dest_sorted,
+                       slots_sorted, vecs, n, carry);
     hipLaunchKernelGGL(trace_vjp_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, L.s, dest_sorted,
-                       slots_sorted, vecs, n, g_tx, g_rx, g_vertices);
+                       slots_sorted, vecs, n, carry, g_tx, g_rx, g_vertices);
     DRT_LAUNCH_CHECK();
     return DRT_OK;
 }

@@ -493,7 +493,8 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t num_tx, co
 
 /* The same VJP with an option for run-to-run REPRODUCIBLE gradients (hard part 6): with
  * DRT_TRACE_DETERMINISTIC_GRAD in params->flags every path writes its contributions, a stable sort groups them by
- * destination (transmitter / receiver / mesh vertex) and each group is summed in path order by one lane -- no
+ * destination (transmitter / receiver / mesh vertex) and each group is summed in a fixed two-level order (chunks of 256
+ * sorted contributions in path order, then the chunks in order: g / 256 + 256 dependent adds for a group of g) -- no
  * float atomics, bit-identical from run to run (and within rounding of the atomic version).  Without the
  * flag (or params == NULL) this is drt_trace_paths_vjp and the workspace is not touched. */
 #define DRT_TRACE_DETERMINISTIC_GRAD 4
