@@ -34,6 +34,23 @@ def bytes_per_row(order: int) -> tuple[int, int]:
     return written + 4 * order, written
 
 
+def fill_probe() -> float:
+    """Write bandwidth of THIS box right now: a 4 GiB `fill_` (torch's vectorised store kernel), GB/s.  Boxes of the pool
+    differ by ~20 % on pure-store kernels; the probe says what the dense tracer's rate has to be read against."""
+    import torch
+
+    t = torch.empty(1 << 32, dtype=torch.uint8, device="cuda")
+    t.fill_(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        t.fill_(2)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * (1 << 32) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def run(order: int = 2, num_tx: int = 1, num_rx: int = 64, chunk: int = 1 << 20, assume_quads: bool = False,
         max_chunks: int | None = None, num_boxes: int = 1000, stat_chunks: int = 8) -> dict:
     import torch
@@ -65,6 +82,7 @@ def run(order: int = 2, num_tx: int = 1, num_rx: int = 64, chunk: int = 1 << 20,
                 occ_ms.append(solver.last_stats["occlusion_ms"])
         return nvalid, rows, kernel_ms, occ_ms
 
+    torch.cuda.empty_cache()  # start from a clean caching allocator: each chunk allocates ~5.5 GB of outputs
     solver = G.ExhaustivePathTracer(chunk_size=chunk)
     sweep(solver, min(3, nchunks))  # warm-up: allocator, clocks
     torch.cuda.synchronize()
@@ -81,6 +99,7 @@ def run(order: int = 2, num_tx: int = 1, num_rx: int = 64, chunk: int = 1 << 20,
     full_rows = num_tx * num_rx * min(chunk, total)
     full = [k for k in kms[: max(1, len(kms) - (1 if nchunks == nchunks_all and total % chunk else 0))]]
     kernel_ms = sum(full) / len(full)
+    kernel_ms_all = [round(k, 4) for k in full]
     if kernel_ms <= 0:  # scratch A/B builds (DRT_DENSE_LEGACY) do not fill the stats: wall-clock numbers only
         return {"rows": rows, "valid_paths": nvalid, "s_total": dt, "candidates_per_s": rows / dt,
                 "end_to_end_GBps": algo * rows / dt / 1e9, "roofline": None}
@@ -103,6 +122,7 @@ def run(order: int = 2, num_tx: int = 1, num_rx: int = 64, chunk: int = 1 << 20,
             "bytes_written_per_candidate": written,
             "rows_per_launch": full_rows,
             "kernel_ms": kernel_ms,
+            "kernel_ms_per_launch": kernel_ms_all,
             "occlusion_kernel_ms": sum(oms) / len(oms),
             "achieved": achieved / 1e9,
             "peak": HBM_PEAK_BPS / 1e9,
@@ -112,6 +132,7 @@ def run(order: int = 2, num_tx: int = 1, num_rx: int = 64, chunk: int = 1 << 20,
             "kernel_time_source": "HIP events around the launch on its stream (drt_trace_stats), mean over "
                                   f"{len(full)} full-size launches of an untimed second pass",
             "traffic": pmc_traffic(order),
+            "box_fill_GBps": fill_probe(),
         },
     }
     return out
