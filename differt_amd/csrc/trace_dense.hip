@@ -37,8 +37,13 @@ namespace drt {
 
 enum : uint32_t { kVecVertices = 1, kVecObjects = 2, kVecTypes = 4, kVecMask = 8 };
 
+#ifdef DRT_DENSE_LAB_OCC  // lab: occupancy the register allocator targets
+#define DRT_DENSE_ATTR __attribute__((amdgpu_waves_per_eu(DRT_DENSE_LAB_OCC, DRT_DENSE_LAB_OCC)))
+#else
+#define DRT_DENSE_ATTR
+#endif
 template <int K, bool QUADS>
-__global__ __launch_bounds__(256) void trace_dense_kernel(
+__global__ __launch_bounds__(256) DRT_DENSE_ATTR void trace_dense_kernel(
     TraceArgs a, const float *__restrict__ txp, const float *__restrict__ rxp, CandSrc cs,
     unsigned long long *__restrict__ q_count, long long *__restrict__ queue, int64_t q_cap, int64_t tx_per_block,
     float *__restrict__ d_vertices, int32_t *__restrict__ d_objects, uint8_t *__restrict__ d_mask,
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256) void trace_dense_kernel(
                         flush_region_b128<64 * VDW * 4>(wv, reinterpret_cast<char *>(d_vertices + rowg * VDW), nrows * VDW * 4, lane);
                     else
                         flush_region_b32(wv, reinterpret_cast<uint32_t *>(d_vertices + rowg * VDW), nrows * VDW, lane);
+#ifndef DRT_DENSE_LAB_ONLYV  // lab: vertices only (not a valid build)
                     if (vec & kVecObjects)
                         flush_region_b128<64 * ODW * 4>(wo, reinterpret_cast<char *>(d_objects + rowg * ODW), nrows * ODW * 4, lane);
                     else
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(256) void trace_dense_kernel(
                     } else if (in_range) {
                         d_mask[rowg + lane] = (uint8_t)alive;  // stage B clears it when the path is blocked
                     }
+#endif
                 }
                 wave_lds_fence();  // flush reads precede the next iteration's staging writes
 
