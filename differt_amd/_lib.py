@@ -105,10 +105,11 @@ class BeamParams(C.Structure):
     ]
 
 
-DRT_BEAM_EXPAND_PLAIN, DRT_BEAM_EMIT_PLAIN, DRT_BEAM_EMIT_CLUSTERED, DRT_BEAM_NO_PAIRS = 1, 2, 4, 8
+DRT_BEAM_EXPAND_PLAIN, DRT_BEAM_EMIT_PLAIN, DRT_BEAM_EMIT_CLUSTERED, DRT_BEAM_NO_PAIRS, DRT_BEAM_ROWS_PLAIN = 1, 2, 4, 8, 16
 DRT_BEAM_OVERFLOW_ENTRIES, DRT_BEAM_OVERFLOW_RECORDS, DRT_BEAM_OVERFLOW_ROWS = 4, 8, 16
 DRT_HYBRID_PREFIX, DRT_HYBRID_RAGGED = 1, 2
 DRT_CAND_PACKED_KEYS = 4
+DRT_CAND_PAIR_BLOCKS = 8
 
 
 class EmParams(C.Structure):

@@ -2360,6 +2360,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     }
     const bool expand_clustered = !(flags & DRT_BEAM_EXPAND_PLAIN);
     const bool emit_clustered = (flags & DRT_BEAM_EMIT_CLUSTERED) || (!(flags & DRT_BEAM_EMIT_PLAIN) && nrx >= 128);
+    const bool pair_blocks = !(flags & DRT_BEAM_ROWS_PLAIN);
 
     DRT_HIP(fill_bytes_async(counters, 0, 256, s));
     // ---- level 1 ----
@@ -2431,6 +2432,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         c.num_candidates = table_rows;
         c.order = order;
         c.pair_offsets = reinterpret_cast<const int64_t *>(pair_offsets);
+        if (pairs && pair_blocks) c.reserved |= DRT_CAND_PAIR_BLOCKS;  // the filter stage evaluates each pair row's chain once
         int64_t nv = 0;
         const int64_t k2 = order + 2;
         rc2 = drt_trace_paths_compact(mesh, &tp, tx, ntx, rx, nrx, &c, z.max_survivors, max_paths - nvalid,
@@ -2797,6 +2799,7 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     c.num_candidates = table_rows;
     c.order = order;
     c.pair_offsets = reinterpret_cast<const int64_t *>(pair_offsets);
+    if (pairs && !(flags & DRT_BEAM_ROWS_PLAIN)) c.reserved |= DRT_CAND_PAIR_BLOCKS;
     rc = drt_trace_paths_compact_async(mesh, &tp, tx, ntx, rx, nrx, &c, z.max_survivors, max_paths,
                                        reinterpret_cast<int64_t *>(slice_keys), vertices, objects, counts_dev,
                                        base + L.trace_ws, L.trace_ws_bytes, stream);

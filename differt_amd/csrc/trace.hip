@@ -231,6 +231,127 @@ __global__ __launch_bounds__(256) void trace_filter_ragged_kernel(TraceArgs a, C
     }
 }
 
+// Stage A for a per-pair table of COPLANAR-PAIR BLOCKS (DRT_CAND_PAIR_BLOCKS, include/differt_amd.h): lane = block
+// of 2^K rows that name the triangle choices 2 q_j + bit_j(c) of one pair sequence.  Both triangles of a pair are the
+// same mirror (equal first vertex, equal unit normal up to the sign of zero components), so all rows of the block have
+// the same images and reflection points as VALUES: the image method is sums, products and guarded quotients of the
+// mirror's point and normal, none of which turns the sign of a zero into a different number, and every later decision
+// (Moller-Trumbore's ranges with its |a| > eps guard, jnp.sign of the same-side test, the squared lengths, isfinite)
+// is a comparison, which does not see that sign either.  The chain is evaluated ONCE with the even triangle's mirror,
+// Moller-Trumbore runs against both triangles of every pair, and row c survives iff its triangle passes at every
+// mirror -- the decisions trace_filter_ragged_kernel takes row by row (8 chains at order 3), the same queue of global
+// table rows.  Stage B and the emit stage read each surviving row's own triangles from the table, as before.
+template <int K>
+__global__ __launch_bounds__(256) void trace_filter_pairblocks_kernel(TraceArgs a, CandSrc cs,
+                                                                      unsigned long long *__restrict__ q_count,
+                                                                      long long *__restrict__ queue, int64_t q_cap) {
+    constexpr int COMBOS = 1 << K;
+    constexpr int C_ALT = (K >= 2 ? (1 << (K - 2)) : 0) | (K >= 4 ? (1 << (K - 4)) : 0);  // bits 0,1,0,1: never a repeat
+    const int lane = threadIdx.x & 63;
+    const int64_t nblocks = cs.count >> K;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < nblocks; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t b = b0 + threadIdx.x;
+        const bool in_range = b < nblocks;
+        const int64_t g0 = (in_range ? b : 0) << K;
+        int64_t lo = 0, hi = cs.npairs;  // pair of the block: largest lo with pair_offsets[lo] <= g0
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cs.pair_offsets[mid] <= g0) lo = mid; else hi = mid;
+        }
+        const int64_t it = lo / a.nrx, ir = lo - it * a.nrx;
+        // the pairs, from the row whose bits alternate (a padding row only when the whole block is padding)
+        int32_t q[K];
+        bool ok = in_range;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int32_t id = cs.table[(g0 + C_ALT) * K + j];
+            ok = ok && id >= 0 && (int64_t)(id | 1) < a.T;
+            q[j] = ok ? (id >> 1) : 0;
+        }
+        V3 p[K], n[K];
+        bool active = true;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int64_t s = 2 * (int64_t)q[j];
+            p[j] = ld3(a.tri_verts + 9 * s);
+            n[j] = ld3(a.normals + 3 * s);
+            if (a.mask) active = active && (a.mask[s] != 0) && (a.mask[s + 1] != 0);
+        }
+        V3 full[K + 2];
+        full[0] = ld3(a.tx + 3 * it);
+        full[K + 1] = ld3(a.rx + 3 * ir);
+        {
+            V3 path[K];
+            image_chain<K>(full[0], full[K + 1], p, n, path);
+#pragma unroll
+            for (int j = 0; j < K; ++j) full[j + 1] = path[j];
+        }
+        bool alive = ok && active;
+        // inside tests, last mirror first (the most selective); hit[j] bit t = triangle 2 q_j + t contains X_{j+1}
+        uint32_t hit[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) hit[j] = 0u;
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) {
+            if (!__any(alive)) break;
+            const V3 o = full[j];
+            const V3 d = full[j + 1] - full[j];
+            const float *tv = a.tri_verts + 18 * (int64_t)q[j];
+            float t;
+            const bool h0 = moller_trumbore(o, d, load_tri(tv), a.eps, t);
+            const bool h1 = moller_trumbore(o, d, load_tri(tv + 9), a.eps, t);
+            hit[j] = (h0 ? 1u : 0u) | (h1 ? 2u : 0u);
+            alive = alive && hit[j] != 0u;
+        }
+        if (__any(alive)) {
+            alive = alive && path_finite<K>(full);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                alive = alive && same_sign(dot(full[j] - p[j], n[j]), dot(full[j + 2] - p[j], n[j]));
+#pragma unroll
+            for (int sgm = 0; sgm <= K; ++sgm) {
+                const V3 d = full[sgm + 1] - full[sgm];
+                alive = alive && !(dot(d, d) < a.min_len);
+            }
+        }
+        if (!__any(alive)) continue;
+        // the rows of the block that survive: every mirror's chosen triangle is hit, no triangle named twice in a row
+        uint32_t rows = 0u;
+#pragma unroll
+        for (int c = 0; c < COMBOS; ++c) {
+            bool v = alive;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t bit = (uint32_t)(c >> (K - 1 - j)) & 1u;
+                v = v && ((hit[j] >> bit) & 1u);
+                if (j > 0) v = v && !(q[j] == q[j - 1] && bit == ((uint32_t)(c >> (K - j)) & 1u));
+            }
+            rows |= v ? (1u << c) : 0u;
+        }
+        // one atomic per wave; lanes take consecutive slots for their rows
+        const uint32_t mine = (uint32_t)__popc(rows);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (total == 0u) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(q_count, (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+        unsigned long long slot = base + (unsigned long long)(incl - mine);
+        uint32_t r = rows;
+        while (r) {
+            const int c = __builtin_ctz(r);
+            r &= r - 1u;
+            if ((int64_t)slot < q_cap) queue[slot] = g0 + c;
+            ++slot;
+        }
+    }
+}
+
 // Stage A for ragged per-pair spaces of order >= 3 with LARGE pair spaces: lane = PREFIX (the first K-1
 // interactions of transmitter blockIdx.y: F_tx x N^(K-2) rows), inner loops over the receivers and over
 // each receiver's visible last interactions.  The unranking, the K-1 mirror gathers and the forward images
@@ -603,6 +724,15 @@ static void launch_filter(const Launch &L, unsigned long long *qc, long long *q,
                 if (bx > 256 * 16) bx = 256 * 16;
                 hipLaunchKernelGGL((trace_filter_prefix_kernel<K, QUADS>), dim3((unsigned)(bx < 1 ? 1 : bx), (unsigned)L.a.ntx),
                                    dim3(256), 0, L.s, L.a, L.cs, qc, q, qcap);
+                return;
+            }
+        }
+        if constexpr (K >= 1 && K <= 4 && !QUADS) {
+            if (L.cs.pair_blocks) {  // coplanar-pair blocks: one lane per block of 2^K rows
+                int64_t bx = ceil_div(L.cs.count >> K, 256);
+                if (bx > 256 * 32) bx = 256 * 32;
+                hipLaunchKernelGGL((trace_filter_pairblocks_kernel<K>), dim3((unsigned)(bx < 1 ? 1 : bx)), dim3(256), 0, L.s,
+                                   L.a, L.cs, qc, q, qcap);
                 return;
             }
         }

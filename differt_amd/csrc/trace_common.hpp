@@ -39,6 +39,7 @@ struct CandSrc {
     // packed keys (DRT_CAND_PACKED_KEYS): a flat key IS the candidate -- (tx * nrx + rx) * n^K + sum_j m_j n^(K-1-j),
     // the keys drt_trace_paths_beam returns; pw[j] = n^(K-1-j), count = n^K
     int32_t packed;
+    int32_t pair_blocks;  // per-pair table made of coplanar-pair blocks of 2^K rows (DRT_CAND_PAIR_BLOCKS)
     const int64_t *pair_offsets, *first_off, *last_off;
 };
 
@@ -359,6 +360,12 @@ static int32_t make_cand_src(const drt_candidates *c, int32_t id_scale, CandSrc 
         s.ragged = 1;
         s.pair_offsets = c->pair_offsets;
         s.small = 1;
+        if (c->reserved & DRT_CAND_PAIR_BLOCKS) {
+            DRT_REQUIRE(id_scale == 1, "coplanar-pair blocks are rows of a TRIANGLE mesh (no assume_quads)");
+            DRT_REQUIRE(c->order <= 8 && (c->num_candidates & (((int64_t)1 << c->order) - 1)) == 0,
+                        "coplanar-pair blocks: the table must hold whole blocks of 2^order rows");
+            s.pair_blocks = 1;
+        }
         *out = s;
         return DRT_OK;
     }

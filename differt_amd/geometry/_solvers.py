@@ -583,7 +583,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
     def trace_beam_pruned(self, scene, order: int, *, kappa: float = 64.0, expansion: str = "auto", emit: str = "auto",
                           max_entries: int | None = None, max_records: int | None = None, max_rows: int | None = None,
                           max_survivors: int | None = None, max_paths: int = 1 << 16, probe_prefixes: int | None = None,
-                          prefix_shard: tuple[int, int] | None = None, pairs: bool = True) -> TracedPaths:
+                          prefix_shard: tuple[int, int] | None = None, pairs: bool = True,
+                          rows: str = "auto") -> TracedPaths:
         """The valid paths of the exhaustive tracer -- same objects, same ``masked_vertices`` order, identical
         vertex bits, same autograd -- without visiting ``n (n-1)**(order-1)`` candidates per pair: ONE call of
         ``drt_trace_paths_beam`` (csrc/beam.hip; reference context: the exhaustive enumeration
@@ -607,7 +608,10 @@ class ExhaustivePathTracer(AbstractPathTracer):
         prefix, so the shards' results partition the full result; rank 0 owns the line-of-sight paths.
         ``pairs=False`` (``DRT_BEAM_NO_PAIRS``) searches a triangle mesh triangle by triangle even when its triangles
         ``(2i, 2i+1)`` are coplanar pairs (same mirror bit for bit: the walls of a box city), which the search otherwise
-        runs over -- the same result either way (tested), a quarter of the level-2 prefixes."""
+        runs over -- the same result either way (tested), a quarter of the level-2 prefixes.  In that mode the exact
+        trace evaluates the image chain once per surviving pair row and tests both triangles of every pair
+        (``DRT_CAND_PAIR_BLOCKS``); ``rows="plain"`` (``DRT_BEAM_ROWS_PLAIN``) traces the ``2**order`` triangle rows one
+        by one instead -- the same result (tested)."""
         if self.smoothing_factor is not None:
             raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
         if not 0 <= order <= 3:
@@ -616,12 +620,15 @@ class ExhaustivePathTracer(AbstractPathTracer):
             raise ValueError(f"unknown expansion {expansion!r}")
         if emit not in ("auto", "plain", "clustered"):
             raise ValueError(f"unknown emit {emit!r}")
+        if rows not in ("auto", "plain"):
+            raise ValueError(f"unknown rows {rows!r}")
         beam = _lib.BeamParams()
         beam.kappa = float(kappa)
         beam.flags = ((_lib.DRT_BEAM_EXPAND_PLAIN if expansion == "plain" else 0)
                       | (_lib.DRT_BEAM_EMIT_PLAIN if emit == "plain" else 0)
                       | (_lib.DRT_BEAM_EMIT_CLUSTERED if emit == "clustered" else 0)
-                      | (0 if pairs else _lib.DRT_BEAM_NO_PAIRS))
+                      | (0 if pairs else _lib.DRT_BEAM_NO_PAIRS)
+                      | (_lib.DRT_BEAM_ROWS_PLAIN if rows == "plain" else 0))
         beam.max_entries, beam.max_records = int(max_entries or 0), int(max_records or 0)
         beam.max_rows, beam.max_survivors = int(max_rows or 0), int(max_survivors or 0)
         beam.probe_prefixes = int(probe_prefixes or 0)

@@ -551,6 +551,8 @@ typedef struct drt_beam_stats {
 #define DRT_BEAM_EMIT_PLAIN 2     /* receiver stage: lane = prefix walks the receivers (after a vote on their clusters' boxes) */
 #define DRT_BEAM_EMIT_CLUSTERED 4 /* receiver stage: Morton clusters of 64 even below 128 receivers */
 #define DRT_BEAM_NO_PAIRS 8        /* triangle meshes: search triangle by triangle even when (2i, 2i+1) are coplanar pairs */
+#define DRT_BEAM_ROWS_PLAIN 16    /* coplanar-pair mode: trace the 2^order triangle rows of a pair row one by one instead
+                                     of as one DRT_CAND_PAIR_BLOCKS block (A/B and cross-check; same result) */
 /* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on).
  * COPLANAR PAIRS (round 4): on a triangle mesh (assume_quads == 0) whose triangles 2i and 2i+1 have equal (==)
  * unit normals, first vertices and mask values -- the two halves of a wall of a box city -- both triangles are the
@@ -576,6 +578,19 @@ typedef struct drt_beam_params {
     drt_beam_stats *stats;  /* host pointer or NULL */
 } drt_beam_params;
 #define DRT_CAND_PACKED_KEYS 4 /* drt_candidates.reserved bit: keys ARE the candidates (see above) */
+/* drt_candidates.reserved bit, PER-PAIR TABLE only (table != NULL, pair_offsets != NULL, mesh without assume_quads):
+ * COPLANAR-PAIR BLOCKS.  The table consists of blocks of 2^order consecutive rows; block b enumerates the triangle
+ * choices of ONE sequence of triangle pairs (q_0 .. q_{order-1}): row b 2^order + c names triangles
+ * 2 q_j + bit_j(c), bit_j(c) = (c >> (order-1-j)) & 1, or is a padding row of -1 (a whole padding block, or a choice
+ * that names one triangle twice in a row); every pair_offsets entry is a multiple of 2^order; and triangles 2q and
+ * 2q+1 of every named pair are THE SAME MIRROR: equal (==) unit normals, equal first vertices, equal mask values
+ * (what drt_mesh_build_beam_clusters establishes before drt_trace_paths_beam searches a triangle mesh over its pairs).
+ * All 2^order rows of a block then share every image and reflection point -- the mirror (first vertex, normal) is the
+ * only thing the image method reads of a triangle, _solvers.py:552-562 -- and differ in the inside tests alone: the
+ * filter stage evaluates the chain ONCE per block and Moller-Trumbore against both triangles of each pair.  Same
+ * survivors, same keys (global table rows), same vertices as without the bit (those are computed per row from the
+ * row's own triangles). */
+#define DRT_CAND_PAIR_BLOCKS 8
 
 /* Morton clusters of the mesh's primitives (allocates, synchronises; implied by drt_trace_paths_beam) */
 int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream);

@@ -81,8 +81,8 @@ while time.time() - t0 < budget:
     st["rows_traced"] += rows
     st["valid_paths"] += len(ea)
     if st["cases"] % 4 == 0:
-        for kw in ({"expansion": "plain"}, {"emit": "clustered"}, {"emit": "plain"}, {"pairs": False}):
-            if "pairs" in kw and not pair_mode:
+        for kw in ({"expansion": "plain"}, {"emit": "clustered"}, {"emit": "plain"}, {"pairs": False}, {"rows": "plain"}):
+            if ("pairs" in kw or "rows" in kw) and not pair_mode:
                 continue
             other = tracer.trace_beam_pruned(scene, order, kappa=KAPPA, **kw)
             st["mapping_checks"] += 1

@@ -786,6 +786,51 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
 
 
 @pytest.mark.parametrize("order", [1, 2, 3])
+def test_beam_pair_blocks_equal_row_by_row_trace(G, rng, order):
+    """DRT_CAND_PAIR_BLOCKS (include/differt_amd.h): in coplanar-pair mode the filter stage evaluates the image chain once
+    per surviving pair row and Moller-Trumbore against both triangles of every pair, instead of tracing the 2^order
+    triangle rows one by one (rows="plain").  Same keys, objects and vertex bits, equal to the exhaustive tracer -- on
+    box cities whose pair normals differ in the SIGN OF ZERO components (most axis-aligned walls), with a ground quad
+    (a pair that may follow itself through its two triangles: ground - wall - ground), masks, and receivers placed on the
+    diagonal of a wall's reflection so that both triangles of a pair can pass."""
+    import synthetic_scenes as S
+
+    total = 0
+    for trial in range(4):
+        boxes = int(rng.integers(5, 30))
+        V, Tr, c, h = S.manhattan(boxes, pitch=float(rng.uniform(20, 45)), seed=int(rng.integers(1 << 30)))
+        ext = float(np.abs(V[:, :2]).max()) + 10
+        gv = np.array([[-ext, -ext, 0], [ext, -ext, 0], [ext, ext, 0], [-ext, ext, 0]], np.float32)
+        Tr = np.concatenate((Tr, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V)))
+        V = np.concatenate((V, gv))
+        tx, rx = S.manhattan_tx_rx(c, h, 2, 24, seed=int(rng.integers(1 << 30)))
+        tx[:, 2] = rng.uniform(2, 60, len(tx))
+        # mirror image of a transmitter in the ground, seen from receivers on the ground quad's diagonal x = y
+        rx[:6, 0] = rx[:6, 1]
+        mask = None
+        if trial % 2:
+            mask = rng.random(Tr.shape[0]) > 0.15
+            mask[1::2] = mask[0::2]
+        mesh = G.Mesh(V, Tr, mask=mask)
+        scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
+        tracer = G.ExhaustivePathTracer()
+        ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 22, max_paths=1 << 18)
+        blocks = tracer.trace_beam_pruned(scene, order)
+        st = dict(tracer.last_beam_stats)
+        assert st["pair_mode"]
+        plain = tracer.trace_beam_pruned(scene, order, rows="plain")
+        assert tracer.last_beam_stats["rows"] == st["rows"]
+        for got in (blocks, plain):
+            _assert_same_paths(ex, got)
+            assert torch.equal(got.keys, blocks.keys)
+        total += ex.objects.shape[0]
+    # the pair normals of these meshes do differ in zero signs (the case the kernel's argument is about)
+    nrm = mesh.normals.view(torch.int32).reshape(-1, 2, 3)
+    assert bool((nrm[:, 0] != nrm[:, 1]).any()) and bool((mesh.normals.reshape(-1, 2, 3)[:, 0] == mesh.normals.reshape(-1, 2, 3)[:, 1]).all())
+    assert total > 0
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("assume_quads", [False, True])
 @pytest.mark.parametrize("masked", [False, True])
 def test_beam_pruned_equals_exhaustive_quads_masks_orders(G, rng, order, assume_quads, masked):
