@@ -97,6 +97,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
     }
     if rank == 0 and world == 1 and num_ranks is None and order == 2:
         out["beam_pruned"] = beam_leg(G, mesh, tx, rx, order, nvalid)
+        out["beam_pruned_graph"] = beam_graph_leg(G, mesh, tx, rx, order, nvalid)
         # BASELINE configs[3]: the same scene at order 3 -- 1.02e15 candidates, reachable only through the pruned
         # search (no exhaustive count to compare with: 91 paths, re-validated by the oracle in tests/test_full_size_gpu.py)
         out["beam_pruned_order3"] = beam_leg(G, mesh, tx, rx, 3, None, reps=1)
@@ -213,6 +214,75 @@ def beam_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps: int 
                 "entry_point": "drt_trace_paths_beam (one native call per step)",
                 "coverage": "all n(n-1)^(order-1) candidates of every (tx, rx) pair; error bounds per mirror from its "
                             "incidence geometry (no smallest-cosine parameter)"}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)}
+
+
+def beam_graph_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps: int = 10, max_paths: int = 4096) -> dict:
+    """The pruned step as an XLA executable would run it (reference boundary: wp.jax_callable with fixed output_dims,
+    geometry/_mesh.py:266-276): `drt_trace_paths_beam_async` (static shapes, list sizes on the device, no host
+    synchronisation, no allocation) + the loss cotangent + `drt_trace_paths_vjp` over all `max_paths` rows (padding rows
+    carry key -1 and contribute nothing), captured ONCE in a HIP graph and replayed: forward + grad(TX) per replay,
+    no Python or host round trip inside the step."""
+    import ctypes as C
+
+    import torch
+
+    from differt_amd import _lib
+    from differt_amd._tensors import ptr, stream
+
+    try:
+        tracer = G.ExhaustivePathTracer(accel="bvh")
+        txd, rxd = torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda")
+        scene = G.Scene(txd, rxd, mesh)
+        out = tracer.trace_beam_pruned_static(scene, order, max_paths=max_paths)
+        gtx, grx = torch.zeros_like(txd), torch.zeros_like(rxd)
+        gmv = torch.zeros_like(mesh.vertices)
+        cands = _lib.Candidates()
+        cands.table, cands.num_nodes, cands.order = None, mesh.num_primitives, order
+        cands.reserved = _lib.DRT_CAND_PACKED_KEYS
+        h = mesh.handle().h
+
+        def launch():
+            tracer.trace_beam_pruned_static(scene, order, max_paths=max_paths, out=out)
+            v = out["vertices"]
+            seg = v[:, 1:] - v[:, :-1]
+            ln = torch.sqrt((seg * seg).sum(-1, keepdim=True))
+            unit = torch.where(ln > 0, seg / ln, torch.zeros_like(seg))  # d(sum of segment lengths) / d(segment)
+            cot = torch.zeros_like(v)
+            cot[:, 1:] += unit
+            cot[:, :-1] -= unit
+            gtx.zero_(); grx.zero_(); gmv.zero_()
+            _lib.call("drt_trace_paths_vjp", h, ptr(txd), txd.shape[0], ptr(rxd), rxd.shape[0], C.byref(cands),
+                      ptr(out["keys"]), ptr(cot), max_paths, ptr(gtx), ptr(grx), ptr(gmv), stream())
+
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            launch()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            launch()
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        c = out["counts"].tolist()
+        nv = int(c[1])
+        # the gradient against the synchronous autograd path
+        txg = torch.tensor(tx, device="cuda", requires_grad=True)
+        ref = tracer.trace_beam_pruned(G.Scene(txg, rxd, mesh), order)
+        torch.sqrt((torch.diff(ref.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+        scale = float(txg.grad.abs().max()) + 1e-30
+        return {"s_per_step": dt, "valid_paths": nv, "valid_paths_per_s": nv / dt, "status_word": int(c[2]),
+                "same_valid_paths_as_exhaustive": None if expected_valid is None else nv == int(expected_valid),
+                "same_keys_as_sync_entry": bool(torch.equal(out["keys"][:nv], ref.keys)),
+                "grad_tx_max_rel_diff_vs_sync": float((gtx - txg.grad).abs().max()) / scale,
+                "order": order, "max_paths": max_paths,
+                "entry_point": "drt_trace_paths_beam_async + drt_trace_paths_vjp in ONE HIP graph (capture once, replay per step)"}
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}
 
