@@ -19,6 +19,7 @@
 // The arithmetic (image chain with the reference's where-guards, inside / same-side / length / finite / active
 // checks) is the compact tracer's, bit for bit; candidates that pass go to the same stage B (occlusion), which
 // clears their mask byte when blocked.
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -35,7 +36,8 @@
 
 namespace drt {
 
-enum : uint32_t { kVecVertices = 1, kVecObjects = 2, kVecTypes = 4, kVecMask = 8 };
+enum : uint32_t { kVecVertices = 1, kVecObjects = 2, kVecTypes = 4, kVecMask = 8,
+                  kRowBlocksInterleaved = 0x100 };  // lab (DRT_DENSE_LAB_MODE=1): round 4's row-block order, for the A/B
 
 #ifdef DRT_DENSE_LAB_OCC  // lab: occupancy the register allocator targets
 #define DRT_DENSE_ATTR __attribute__((amdgpu_waves_per_eu(DRT_DENSE_LAB_OCC, DRT_DENSE_LAB_OCC)))
@@ -59,7 +61,17 @@ __global__ __launch_bounds__(256) DRT_DENSE_ATTR void trace_dense_kernel(
     uint32_t *wt = lds_t + wave * 64 * TDW;
     const int64_t it0 = (int64_t)blockIdx.y * tx_per_block;
     const int64_t it1 = (it0 + tx_per_block < a.ntx) ? it0 + tx_per_block : a.ntx;
-    for (int64_t row0 = (int64_t)blockIdx.x * 256; row0 < cs.count; row0 += (int64_t)gridDim.x * 256) {
+    // Row blocks of 256, ONE CONTIGUOUS RANGE PER XCD: workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8;
+    // the launcher keeps gridDim.x a multiple of 8 whenever it exceeds 8), so walking index rb owns row block
+    // (rb % 8) * ceil(nrb / 8) + rb / 8 -- every XCD's L2 and fabric port stream one eighth of each output array instead
+    // of every eighth 12-KiB piece of all of it.  Same rows, same bytes; measured 1.05 -> 0.96 ms with the outputs packed
+    // in one region and 0.79 -> 0.755 ms with the vertices 32 GiB away (profiles/r04/dense.md, scratch/dense_modes.py).
+    const int64_t nrb = (cs.count + 255) / 256;
+    const int64_t per_xcd = (nrb + 7) / 8;
+    for (int64_t rb = (int64_t)blockIdx.x; rb < 8 * per_xcd; rb += (int64_t)gridDim.x) {
+        const int64_t rbm = (vec & kRowBlocksInterleaved) ? rb : (rb % 8) * per_xcd + rb / 8;
+        if (rbm >= nrb) continue;  // (wave-uniform: the padding of the last XCD's range)
+        const int64_t row0 = rbm * 256;
         const int64_t row_w = row0 + wave * 64;  // wave-uniform: the wave's first row
         const int64_t left = cs.count - row_w;
         const uint32_t nrows = left >= 64 ? 64u : (left > 0 ? (uint32_t)left : 0u);
@@ -209,6 +221,7 @@ static void dense_grid(const Launch &L, dim3 *grid, int64_t *tx_per_block) {
     int64_t bx = ceil_div(L.cs.count, 256);
     if (bx > 256 * 8) bx = 256 * 8;
     if (bx < 1) bx = 1;
+    if (bx > 8) bx = (bx + 7) / 8 * 8;  // walking index % 8 == workgroup % 8 == XCD on every trip of the grid-stride loop
     int64_t by = 1;  // few candidates but many transmitters: split the tx loop over blockIdx.y
     if (bx < 1024 && L.a.ntx > 1) {
         by = ceil_div(2048, bx);
@@ -267,6 +280,7 @@ int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *pr, co
     // the 16-byte store path of an array needs every wave segment to start on a 16-byte boundary: the array does
     // and C rows are a multiple of 16 bytes (a wave's first row is a multiple of 64)
     uint32_t vec = 0;
+    if (const char *lab = getenv("DRT_DENSE_LAB_MODE")) vec |= (atoi(lab) & 1) ? kRowBlocksInterleaved : 0u;
     if (aligned16(vertices) && (C * 12 * (k + 2)) % 16 == 0) vec |= kVecVertices;
     if (aligned16(objects) && (C * 4 * (k + 2)) % 16 == 0) vec |= kVecObjects;
     if (types_out && aligned16(types_out) && (C * 4 * k) % 16 == 0) vec |= kVecTypes;
@@ -286,19 +300,20 @@ int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *pr, co
             hipLaunchKernelGGL((trace_dense_kernel<K, false>), grid, dim3(256), 0, L.s, L.a, L.a.tx, L.a.rx, \
                                L.cs, qc, q, total, tpb, vertices, objects, mask, types_in, types_out, vec);  \
         timer.mark(1);                                                                                       \
-        launch_occlusion<K, true>(L, qc, q, total, nullptr, nullptr, 0, mask);                               \
+        launch_occlusion<K, true>(L, qc, q, total, qc + 1, nullptr, 0, mask);                                \
         timer.mark(2);                                                                                       \
     } while (0)
     DRT_ORDER_SWITCH(k, CALL)
 #undef CALL
     DRT_LAUNCH_CHECK();
     if (st) {
-        unsigned long long survivors = 0;
-        DRT_HIP(hipMemcpyAsync(&survivors, qc, 8, hipMemcpyDeviceToHost, L.s));
+        unsigned long long sv[2] = {0, 0};
+        DRT_HIP(hipMemcpyAsync(sv, qc, 16, hipMemcpyDeviceToHost, L.s));
         DRT_HIP(hipStreamSynchronize(L.s));
+        const unsigned long long survivors = sv[0], blocked = sv[1];
         st->candidates = total;
         st->survivors = (int64_t)survivors;
-        st->valid = -1;  // the dense layout has no valid-path counter: sum the mask
+        st->valid = (int64_t)(survivors - blocked);
         st->filter_ms = timer.elapsed(0, 1);
         st->occlusion_ms = timer.elapsed(1, 2);
         st->sort_emit_ms = 0.0f;

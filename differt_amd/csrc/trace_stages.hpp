@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void trace_occlusion_kernel(
         __syncthreads();
         if (have && lane == 0) {
             if (DENSE) {
-                if (blocked) d_mask[flat] = 0;
+                if (blocked) {
+                    d_mask[flat] = 0;
+                    if (v_count) atomicAdd(v_count, 1ull);  // dense layout: the number of survivors the stage cleared
+                }
             } else if (!blocked) {
                 const unsigned long long slot = atomicAdd(v_count, 1ull);
                 if ((int64_t)slot < v_cap) valid[slot] = flat;
@@ -137,7 +140,10 @@ __global__ __launch_bounds__(256) void trace_occlusion_bvh_kernel(
                                            a.eps, a.thr, col);
         }
         if (DENSE) {
-            if (blocked) d_mask[flat] = 0;
+            if (blocked) {
+                d_mask[flat] = 0;
+                if (v_count) atomicAdd(v_count, 1ull);
+            }
         } else if (!blocked) {
             const unsigned long long slot = atomicAdd(v_count, 1ull);
             if ((int64_t)slot < v_cap) valid[slot] = flat;

@@ -85,9 +85,21 @@ class TracedPaths:
         m = self.mask
         return m if m.dtype == torch.bool else (m >= self.confidence_threshold)
 
+    def _attach_valid_count(self, counters: torch.Tensor) -> None:
+        """Device-side counters of the dense tracer call that produced ``mask`` (``[0]`` rows that passed the geometric
+        checks, ``[1]`` those the occlusion stage cleared): ``num_valid_paths`` reads them instead of reducing the mask,
+        for as long as ``mask`` is the tensor the kernel wrote (same storage, same version, same element count -- reshapes
+        and squeezes keep it, any in-place edit, slice or replacement falls back to the reduction)."""
+        self.__dict__["_valid_count"] = (self.mask.data_ptr(), self.mask._version, self.mask.numel(), counters)
+
     @property
     def num_valid_paths(self) -> torch.Tensor:
-        """geometry/_paths.py:264-272 (one reduction kernel over the 1-byte mask; `.sum()` would first widen it to int64)."""
+        """geometry/_paths.py:264-272 (one reduction kernel over the 1-byte mask; `.sum()` would first widen it to int64;
+        straight from the tracer's device-side counters when this object is what the dense tracer returned)."""
+        vc = self.__dict__.get("_valid_count")
+        m = self.mask
+        if vc is not None and m.dtype == torch.bool and vc[0] == m.data_ptr() and vc[1] == m._version and vc[2] == m.numel():
+            return vc[3][0] - vc[3][1]
         return torch.count_nonzero(self._bool_mask())
 
     @property
@@ -105,22 +117,29 @@ class TracedPaths:
         it = self.interaction_types
         objects = self.objects.reshape(*batch, self.path_length)
         batch = tuple(objects.shape[:-1])  # resolves a -1 (ambiguous for the empty order-0 arrays)
-        return replace(
+        out = replace(
             self,
             vertices=self.vertices.reshape(*batch, self.path_length, 3),
             objects=objects,
             mask=self.mask.reshape(*batch),
             interaction_types=None if it is None else it.reshape(*batch, self.order),
         )
+        return self._carry_valid_count(out)
+
+    def _carry_valid_count(self, out: "TracedPaths") -> "TracedPaths":
+        vc = self.__dict__.get("_valid_count")
+        if vc is not None:  # (checked against the new mask's storage / version / size when it is read)
+            out.__dict__["_valid_count"] = vc
+        return out
 
     def squeeze(self, axis: int | Sequence[int] | None = None) -> "TracedPaths":
         """geometry/_paths.py:152-194."""
         ndim = self.vertices.dim() - 2
         axis = _squeeze_axes(ndim, axis)
         it = self.interaction_types
-        return replace(self, vertices=_squeeze(self.vertices, axis, ndim), objects=_squeeze(self.objects, axis, ndim),
-                       mask=_squeeze(self.mask, axis, ndim),
-                       interaction_types=None if it is None else _squeeze(it, axis, ndim))
+        return self._carry_valid_count(replace(
+            self, vertices=_squeeze(self.vertices, axis, ndim), objects=_squeeze(self.objects, axis, ndim),
+            mask=_squeeze(self.mask, axis, ndim), interaction_types=None if it is None else _squeeze(it, axis, ndim)))
 
     def mask_duplicate_objects(self, axis: int = -1) -> "TracedPaths":
         """geometry/_paths.py:196-252: along ``axis`` only the FIRST path of every set with identical

@@ -115,6 +115,9 @@ class _TraceDenseFn(torch.autograd.Function):
             _lib.call("drt_trace_paths_dense_ex", mesh.handle().h, C.byref(params), ptr(tx), ntx, ptr(rx),
                       nrx, C.byref(cands), ptr(types), ptr(verts), ptr(objs), ptr(mask), ptr(tout), ptr(ws), nbytes,
                       stream())
+            # device-side counters of the call (include/differt_amd.h): survivors of the geometric checks, and those of
+            # them the occlusion stage cleared -- TracedPaths.num_valid_paths without a pass over the mask
+            mesh._last_dense_counts = (mask, ws[:16].view(torch.int64).clone())  # (a copy: the 8 B / row workspace is not kept alive)
         ctx.mesh, ctx.table, ctx.params = mesh, table, params
         ctx.save_for_backward(tx, rx)
         ctx.mark_non_differentiable(objs, mask, tout)
@@ -363,7 +366,13 @@ def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, inte
         params.stats = C.pointer(stats)
     verts, objs, mask, it = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table, types, params)
     # the kernel writes 0 / 1 bytes: reinterpret, do not copy
-    return TracedPaths(verts, objs, mask.view(torch.bool), it, confidence_threshold)
+    paths = TracedPaths(verts, objs, mask.view(torch.bool), it, confidence_threshold)
+    counts = getattr(mesh, "_last_dense_counts", None)
+    if counts is not None:
+        mesh._last_dense_counts = None
+        if counts[0].data_ptr() == paths.mask.data_ptr():
+            paths._attach_valid_count(counts[1])
+    return paths
 
 
 def Scene_like(scene, tx, rx):

@@ -352,7 +352,7 @@ int32_t drt_digraph_iter_next_chunk(drt_digraph_iter_t it, uint64_t max_rows, ui
  * invalid) or a rank interval of the complete graph, unranked on the GPU (no table in HBM).
  * ------------------------------------------------------------------------------------------- */
 /* Per-stage counters and HIP-event timers of one drt_trace_paths_compact call (SURVEY.md section 5,
- * "metrics" / "tracing" rows; the dense entry points fill `valid` with -1: the mask holds it).  Filled when drt_trace_params.stats is non-NULL; costs two extra
+ * "metrics" / "tracing" rows; the dense entry points count `valid` as survivors minus cleared survivors).  Filled when drt_trace_params.stats is non-NULL; costs two extra
  * stream synchronisations, so leave it NULL on the hot path. */
 typedef struct drt_trace_stats {
     int64_t candidates;     /* (tx, rx, candidate) rows evaluated by the filter stage */
@@ -426,7 +426,11 @@ typedef struct drt_candidates {
  *   vertices [Ntx,Nrx,C,order+2,3] f32 (zeroed where not finite, _solvers.py:696-699)
  *   objects  [Ntx,Nrx,C,order+2] i32  (_solvers.py:723-748)
  *   mask     [Ntx,Nrx,C] u8           (_solvers.py:715-717)
- * workspace: drt_trace_dense_workspace_size bytes. */
+ * workspace: drt_trace_dense_workspace_size bytes.  When the call's work has completed on the stream, its first two
+ * 64-bit words hold DEVICE-side counters -- [0] rows that passed the geometric checks, [1] those of them the occlusion
+ * stage cleared -- so the number of valid paths is [0] - [1] without a reduction over the mask (the reference's
+ * TracedPaths.num_valid_paths, _paths.py:264-272, is what its own harness reads after every call:
+ * tests/benchmarks/test_rt.py:151-196). */
 size_t drt_trace_dense_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_candidates);
 int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
                               int64_t num_tx, const float *rx, int64_t num_rx,

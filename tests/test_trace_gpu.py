@@ -785,6 +785,37 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
     assert torch.equal(bp.keys, exp_keys) and bool((bp.keys[1:] > bp.keys[:-1]).all())
 
 
+@pytest.mark.parametrize("accel", [None, "bvh"])
+def test_dense_num_valid_paths_from_device_counters(G, accel):
+    """The dense tracer leaves survivors / cleared-by-occlusion counters in its workspace (include/differt_amd.h);
+    TracedPaths.num_valid_paths (reference _paths.py:264-272, read by the reference's harness after every call) uses
+    them instead of reducing the mask -- the same number, through reshapes, and NOT after the mask was edited, sliced
+    or replaced."""
+    import synthetic_scenes as S
+
+    V, Tr, c, h = S.manhattan(30, seed=5)
+    tx, rx = S.manhattan_tx_rx(c, h, 3, 7, seed=6)
+    scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), G.Mesh(V, Tr))
+    total = 0
+    for order in (0, 1, 2):
+        for paths in ([scene.trace_paths(order=order, solver="exhaustive", accel=accel)] if order < 2 else
+                      list(scene.trace_paths(order=order, solver="exhaustive", accel=accel, chunk_size=4096))[:6]):
+            assert "_valid_count" in paths.__dict__ or paths.mask.numel() == 0
+            expect = int(torch.count_nonzero(paths.mask))
+            assert int(paths.num_valid_paths) == expect
+            assert int(paths.reshape(-1).num_valid_paths) == expect
+            if paths.mask.numel() > 1:
+                sl = G.TracedPaths(paths.vertices.reshape(-1, order + 2, 3)[:1], paths.objects.reshape(-1, order + 2)[:1],
+                                   paths.mask.reshape(-1)[:1])
+                sl.__dict__["_valid_count"] = paths.__dict__.get("_valid_count")  # a slice must not trust the counters
+                assert int(sl.num_valid_paths) == int(torch.count_nonzero(paths.mask.reshape(-1)[:1]))
+                flat = paths.mask.reshape(-1)
+                flat[0] = not bool(flat[0])  # in-place edit: version bump, back to the reduction
+                assert int(paths.num_valid_paths) == int(torch.count_nonzero(paths.mask))
+            total += expect
+    assert total > 0
+
+
 @pytest.mark.parametrize("order", [1, 2, 3])
 def test_beam_pair_blocks_equal_row_by_row_trace(G, rng, order):
     """DRT_CAND_PAIR_BLOCKS (include/differt_amd.h): in coplanar-pair mode the filter stage evaluates the image chain once
