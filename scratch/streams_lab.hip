@@ -71,6 +71,12 @@ int main(int argc, char **argv) {
         if (which & 8) bytes += rows * 1.0;
         printf("%-44s gap %2zu GiB which %2d delay %d xcd %d : %.3f ms  %.2f TB/s\n", name, gap >> 30, which, delay, xcd, best, bytes / best * 1e-9);
     };
+    printf("arena %p base %p (C = %lld)\n", (void *)arena, (void *)base, (long long)C);
+    if (argc > 2) {  // scan: where does the second region begin?
+        for (size_t g : {0, 4, 8, 12, 16, 20, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 40})
+            run("all four streams, XCD row ranges", g * G, 15, 0, 1);
+        return 0;
+    }
     for (size_t gap : {(size_t)0, 32 * G}) {
         run("all four streams", gap, 15, 0, 0);
         run("all four streams, XCD row ranges", gap, 15, 0, 1);
