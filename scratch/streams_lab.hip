@@ -40,6 +40,23 @@ __global__ __launch_bounds__(256) void streams_kernel(char *v, char *o, char *t,
     }
 }
 
+// wave-exit form: one workgroup per (group of `ppb` planes, row block), plane-major launch order -- the chip-wide write
+// order is then (almost) the memory order of each array, like a fill
+__global__ __launch_bounds__(256) void streams_exit_kernel(char *v, char *o, char *t, char *m, int64_t C, int planes, int which,
+                                                           int ppb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nrb = C / 256;
+    const int64_t pg = blockIdx.x / nrb, rb = blockIdx.x % nrb;
+    const int64_t row = rb * 256 + wave * 64;
+    for (int p = (int)pg * ppb; p < (int)(pg + 1) * ppb && p < planes; ++p) {
+        const int64_t g = (int64_t)p * C + row;
+        if (which & 1) wave_store<3072>(v + g * 48, lane, (uint32_t)p);
+        if (which & 2) wave_store<1024>(o + g * 16, lane, (uint32_t)p);
+        if (which & 4) wave_store<512>(t + g * 8, lane, (uint32_t)p);
+        if ((which & 8) && lane < 4) __builtin_nontemporal_store(u4{1, 1, 1, 1}, reinterpret_cast<u4 *>(m + g) + lane);
+    }
+}
+
 int main(int argc, char **argv) {
     const int64_t C = argc > 1 ? atoll(argv[1]) : (1 << 20);
     const int planes = 64;
@@ -72,6 +89,36 @@ int main(int argc, char **argv) {
         printf("%-44s gap %2zu GiB which %2d delay %d xcd %d : %.3f ms  %.2f TB/s\n", name, gap >> 30, which, delay, xcd, best, bytes / best * 1e-9);
     };
     printf("arena %p base %p (C = %lld)\n", (void *)arena, (void *)base, (long long)C);
+    auto run_exit = [&](const char *name, size_t gap, int which, int ppb) {
+        auto up = [](size_t x) { return (x + (2u << 20) - 1) / (2u << 20) * (2u << 20); };
+        char *v = base, *o = base + up(rows * 48) + gap, *t = o + up(rows * 16), *m = t + up(rows * 8);
+        float best = 1e9f;
+        const int64_t nblocks = (C / 256) * ((planes + ppb - 1) / ppb);
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL(streams_exit_kernel, dim3((unsigned)nblocks), dim3(256), 0, 0, v, o, t, m, C, planes, which, ppb);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (rep && ms < best) best = ms;
+        }
+        double bytes = 0;
+        if (which & 1) bytes += rows * 48.0;
+        if (which & 2) bytes += rows * 16.0;
+        if (which & 4) bytes += rows * 8.0;
+        if (which & 8) bytes += rows * 1.0;
+        printf("%-44s gap %2zu GiB which %2d planes/block %2d : %.3f ms  %.2f TB/s\n", name, gap >> 30, which, ppb, best, bytes / best * 1e-9);
+    };
+    if (argc > 2 && argv[2][0] == 'e') {
+        for (int ppb : {1, 2, 4, 8, 16, 64}) {
+            run_exit("wave-exit form, all four streams", 0, 15, ppb);
+            run_exit("wave-exit form, vertices only", 0, 1, ppb);
+        }
+        run("persistent, all four, XCD", 0, 15, 0, 1);
+        run("persistent, vertices only, XCD", 0, 1, 0, 1);
+        return 0;
+    }
     if (argc > 2) {  // scan: where does the second region begin?
         for (size_t g : {0, 4, 8, 12, 16, 20, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 40})
             run("all four streams, XCD row ranges", g * G, 15, 0, 1);
