@@ -1258,8 +1258,16 @@ __device__ __forceinline__ bool receiver_inside(const BeamCtx<SCALE, ORDER> &c, 
 }
 
 // lane = level-ORDER prefix, loop over the receivers
+#ifndef BEAM_EMIT_WAVES
+#define BEAM_EMIT_WAVES 0
+#endif
+#if BEAM_EMIT_WAVES > 0
+#define BEAM_EMIT_OCC __attribute__((amdgpu_waves_per_eu(BEAM_EMIT_WAVES, BEAM_EMIT_WAVES)))
+#else
+#define BEAM_EMIT_OCC
+#endif
 template <int SCALE, int ORDER>
-__global__ __launch_bounds__(256) void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in,
+__global__ __launch_bounds__(256) BEAM_EMIT_OCC void beam_emit_kernel(BeamMesh M, const BeamEntry *__restrict__ in,
                                                         const unsigned long long *__restrict__ rec, int64_t n_in,
                                                         const float *__restrict__ rx_sorted,
                                                         const int32_t *__restrict__ rx_index,
