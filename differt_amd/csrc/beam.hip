@@ -1276,17 +1276,22 @@ __global__ __launch_bounds__(256) BEAM_EMIT_OCC void beam_emit_kernel(BeamMesh M
                                                         unsigned long long *__restrict__ count,
                                                         unsigned long long *__restrict__ grazing, BeamDev dv) {
     beam_dev_apply(dv, M, u, n_in);
-    if ((int64_t)blockIdx.x * 256 >= n_in) return;
     __shared__ unsigned long long wbuf[4][kBeamWaveBuf];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int wcount = 0;
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long ngraz = 0;  // wave-uniform
+    // PERSISTENT: a wave walks groups of 64 prefixes and keeps its staging buffer across them.  A wave emits ~4 rows per
+    // group at configs[3]; one group per wave meant one returning atomic per wave on the ONE row counter plus one per
+    // grazing prefix on the statistics counter -- 7.9e6 same-address atomics per step, and the L2 atomic unit, not the
+    // arithmetic, set the kernel's 37 ms (the lesson of beam_flush, one level up).
+    for (int64_t g0 = (int64_t)blockIdx.x * 256; g0 < n_in; g0 += (int64_t)gridDim.x * 256) {
+    const int64_t g = g0 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
     BeamCtx<SCALE, ORDER> ctx;
     emit_setup<SCALE, ORDER>(M, in, rec, g, have, u, e, ctx);
-    if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);  // every test of this prefix is off (informational)
+    ngraz += (unsigned long long)__popcll(__ballot(have && !(e.esum < kInf)));  // every test of this prefix is off (informational)
     const int nrx32 = (int)nrx;  // < 2^31: the 62-bit row key bounds it
     const int nclusters = (nrx32 + 63) / 64;
     long long tail = 0;  // sum_j id_j n^(k-1-j)
@@ -1342,7 +1347,9 @@ __global__ __launch_bounds__(256) BEAM_EMIT_OCC void beam_emit_kernel(BeamMesh M
             }
         }
     }
+    }  // groups
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+    if (ngraz && lane == 0) atomicAdd(grazing, ngraz);
 }
 
 // beam_emit for MANY receivers: the receivers arrive sorted along a Morton curve in clusters of 64 with an
@@ -1357,12 +1364,13 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
     int64_t nrx, float u, long long *__restrict__ rows, int64_t cap, unsigned long long *__restrict__ count,
     unsigned long long *__restrict__ grazing, BeamDev dv) {
     beam_dev_apply(dv, M, u, n_in);
-    if ((int64_t)blockIdx.x * 128 >= n_in) return;
     __shared__ unsigned long long wbuf[2][kBeamWaveBuf];
     int wcount = 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    unsigned long long ngraz = 0;
+    for (int64_t g0 = (int64_t)blockIdx.x * 128; g0 < n_in; g0 += (int64_t)gridDim.x * 128) {  // persistent, see beam_emit_kernel
+    const int64_t g = g0 + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
     BeamCtx<SCALE, ORDER> ctx;
@@ -1373,7 +1381,7 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
         tail = tail * (long long)M.nprim + (long long)(have ? e.id[j] : 0);
         npow *= (long long)M.nprim;
     }
-    if (have && !(e.esum < kInf)) atomicAdd(grazing, 1ull);
+    ngraz += (unsigned long long)__popcll(__ballot(have && !(e.esum < kInf)));
     const int tx = entry_tx(e);
     const int64_t nclusters = (nrx + 63) / 64;
     for (int64_t cl = 0; cl < nclusters; ++cl) {
@@ -1397,7 +1405,9 @@ __global__ __launch_bounds__(128) void beam_emit_clustered_kernel(
                                      wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
         }
     }
+    }  // groups
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, reinterpret_cast<unsigned long long *>(rows), cap, count);
+    if (ngraz && lane == 0) atomicAdd(grazing, ngraz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2066,18 +2076,24 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
     }
 }
 
+#ifndef BEAM_EMIT_BLOCKS
+#define BEAM_EMIT_BLOCKS (256 * 16)
+#endif
+constexpr int64_t kBeamEmitBlocks = BEAM_EMIT_BLOCKS;  // workgroups of 256 (twice as many of 128) of the receiver stage
+
 template <int SCALE, int ORDER>
 static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, const unsigned long long *rec,
                         int64_t n_in, const float *rx, const float *rx_sorted, const int32_t *rx_index,
                         const float *rx_boxes, int64_t nrx, float u, long long *rows, int64_t cap,
                         unsigned long long *count, unsigned long long *grazing, hipStream_t s,
                         BeamDev dv = BeamDev{nullptr, nullptr}) {
+    // persistent grids: a few workgroups per CU slot, every wave walks many groups of prefixes
     if (clustered)
-        hipLaunchKernelGGL((beam_emit_clustered_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 128)), dim3(128), 0,
-                           s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing, dv);
+        hipLaunchKernelGGL((beam_emit_clustered_kernel<SCALE, ORDER>), dim3((unsigned)std::min<int64_t>(ceil_div(n_in, 128), kBeamEmitBlocks * 2)),
+                           dim3(128), 0, s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing, dv);
     else
-        hipLaunchKernelGGL((beam_emit_kernel<SCALE, ORDER>), dim3((unsigned)ceil_div(n_in, 256)), dim3(256), 0, s, M, in,
-                           rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing, dv);
+        hipLaunchKernelGGL((beam_emit_kernel<SCALE, ORDER>), dim3((unsigned)std::min<int64_t>(ceil_div(n_in, 256), kBeamEmitBlocks)),
+                           dim3(256), 0, s, M, in, rec, n_in, rx_sorted, rx_index, rx_boxes, nrx, u, rows, cap, count, grazing, dv);
 }
 
 #define BEAM_DISPATCH2(SC, K, CALL) /* SC = primitive shape (BeamMesh::kind) */ \
