@@ -2036,6 +2036,15 @@ static int32_t read_count(const unsigned long long *dev, int64_t *host, hipStrea
 // `dv`: device-side scalars / list size (async entry point; then n_in is the list's CAPACITY and sizes the grid);
 // `last`: the last expansion (receiver-box child filter; with dv.dyn the receivers' box comes from the device and a box
 // that is off lets every child pass)
+// Workgroups (of 2 waves) a clustered expansion aims for by splitting the cluster range over blockIdx.y.  2 048 (one
+// round of the chip) left the launch to its slowest waves -- the survivors per (wave, cluster range) vary widely:
+// configs[4]'s last expansion (782 x 3 workgroups) 19.4 ms, with 32 768: 12.0 ms (step 0.0317 -> 0.024 s); configs[2] 1.38 ->
+// 1.02 ms; configs[3] 163.6 -> 157 ms; 131 072 the same, 524 288 slower again (the prefix contexts are rebuilt per split).
+#ifndef BEAM_EXPAND_BLOCKS
+#define BEAM_EXPAND_BLOCKS 32768
+#endif
+constexpr int64_t kBeamExpandBlocks = BEAM_EXPAND_BLOCKS;
+
 template <int SCALE, int LEVEL>
 static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool clustered, const BeamEntry *in, int64_t n_in,
                           float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s,
@@ -2043,7 +2052,7 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
                           bool last = false) {
     if (clustered) {
         const int64_t bx = ceil_div(n_in, 128);
-        int64_t by = ceil_div(2048, bx);  // few prefixes: split the cluster range so that the launch fills the chip
+        int64_t by = ceil_div(kBeamExpandBlocks, bx);  // few prefixes: split the cluster range so that the launch fills the chip
         if (by > C.nclusters) by = C.nclusters;
         if (by > 65535) by = 65535;
         if (by < 1) by = 1;
