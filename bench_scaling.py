@@ -60,7 +60,7 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
         out["ranks_seen_by_backend"] = dist.get_world_size()
 
     # ---------------------------------------------------------------- candidate-rank sharding ----
-    tracer = G.ExhaustivePathTracer()
+    tracer = G.ExhaustivePathTracer(accel="bvh")  # survivors' occlusion on the LBVH (200k triangles)
     rx_d = torch.tensor(rx, device=dev)
 
     def step():
