@@ -508,6 +508,13 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
 }
 
 constexpr int kBeamTile = 128;         // primitives per LDS tile of the plain expansion
+// Threads per workgroup of the clustered expansion.  Its waves never synchronise, and a workgroup's resources are held
+// until its LAST wave ends: with two waves per workgroup the faster one's slot idles while its partner finishes (the
+// survivors per wave vary widely) -- one wave per workgroup: configs[3] last expansion 157.4 -> 154.0 ms, same box.
+#ifndef BEAM_EXPAND_WG
+#define BEAM_EXPAND_WG 64
+#endif
+constexpr int kExpandWG = BEAM_EXPAND_WG;
 constexpr int kBeamWaveBuf = 192;      // records staged per wave before one flush (>= 128: a flush moves 64+)
 #ifndef BEAM_WAVE_BUF_BIG
 #define BEAM_WAVE_BUF_BIG 512
@@ -787,17 +794,17 @@ __device__ __forceinline__ void expand_clustered_body(
     int64_t clusters_per_split, const RxAll &rxall) {
     // 8 KiB per wave: a flush every ~960 records (with 192 the flush atomics -- all on ONE address -- were half
     // of the kernel's time at configs[3])
-    __shared__ unsigned long long wbuf[2][kBeamWaveBufBig];
+    __shared__ unsigned long long wbuf[kExpandWG / 64][kBeamWaveBufBig];
     // the cluster's triangle planes, staged per wave: lane k brings plane k with one coalesced load (in flight one
     // cluster ahead), the 64 prefixes of the wave then read them back as LDS broadcasts.  As 64 scalar loads per
     // (wave, cluster) this loop was half of the kernel's time (profiles/r03/beam.md): 157 KiB of planes per wave
     // do not live in the 16-KiB scalar cache
     using Sh = Shape<SCALE>;
-    __shared__ __attribute__((aligned(16))) float4 lds_planes[2][64 * Sh::NP];
+    __shared__ __attribute__((aligned(16))) float4 lds_planes[kExpandWG / 64][64 * Sh::NP];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if ((int64_t)blockIdx.x * 128 >= n_in) return;  // a grid sized for the list's CAPACITY (async entry point)
-    const int64_t g = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if ((int64_t)blockIdx.x * kExpandWG >= n_in) return;  // a grid sized for the list's CAPACITY (async entry point)
+    const int64_t g = (int64_t)blockIdx.x * kExpandWG + threadIdx.x;
     const bool have = g < n_in;
     BeamEntry e{};
     if (have) e = in[g];
@@ -809,8 +816,8 @@ __device__ __forceinline__ void expand_clustered_body(
     // kept lanes park (record, plane of the new mirror, its shape factor) in a wave-private LDS queue, and whenever
     // 64 wait, lane = parked child gathers its parent's apex / narrowest pyramid from the parent's lane
     // (ds_bpermute) and decides.  At configs[3] three quarters of the 7.1e9 children go no further.
-    __shared__ unsigned long long raw_rec[2][128];
-    __shared__ float raw_f[2][5][128];
+    __shared__ unsigned long long raw_rec[kExpandWG / 64][128];
+    __shared__ float raw_f[kExpandWG / 64][5][128];
     constexpr bool filter_on = FILTER;
     float rho0[Sh::NP][Sh::NF];
     float sig_sum = kInf;
@@ -818,7 +825,7 @@ __device__ __forceinline__ void expand_clustered_body(
     int rawcount = 0;
     const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
     const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
-    const unsigned long long gbase = (unsigned long long)((int64_t)blockIdx.x * 128 + wave * 64);
+    const unsigned long long gbase = (unsigned long long)((int64_t)blockIdx.x * kExpandWG + wave * 64);
     int wcount = 0;
     // the last n parked children (n <= 64): lane = child
     auto filter_parked = [&](int n) {
@@ -995,7 +1002,7 @@ __device__ __forceinline__ void expand_clustered_body(
     if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
 }
 template <int SCALE, int LEVEL>
-__global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_kernel(
+__global__ __launch_bounds__(kExpandWG) BEAM_EXPAND_OCC void beam_expand_clustered_kernel(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split, BeamDev dv) {
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(128) BEAM_EXPAND_OCC void beam_expand_clustered_ker
 // occupancy attribute, 128 and no scratch with it (4 waves per SIMD: 0.69 against 0.76 s at configs[3]); quads keep
 // the compiler's own choice (the attribute would spill there).
 template <int LEVEL>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void beam_expand_clustered_last_kernel_s1(
+__global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void beam_expand_clustered_last_kernel_s1(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
@@ -1024,7 +1031,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define BEAM_S2_OCC
 #endif
 template <int LEVEL>
-__global__ __launch_bounds__(128) BEAM_S2_OCC void beam_expand_clustered_last_kernel_s2(
+__global__ __launch_bounds__(kExpandWG) BEAM_S2_OCC void beam_expand_clustered_last_kernel_s2(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
@@ -1034,7 +1041,7 @@ __global__ __launch_bounds__(128) BEAM_S2_OCC void beam_expand_clustered_last_ke
 }
 // convex planar fan quads (shape 4): one 4-face pyramid and four vertices per primitive
 template <int LEVEL>
-__global__ __launch_bounds__(128) BEAM_Q4_OCC void beam_expand_clustered_last_kernel_q4(
+__global__ __launch_bounds__(kExpandWG) BEAM_Q4_OCC void beam_expand_clustered_last_kernel_q4(
     BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in, int64_t n_in, float u,
     unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
@@ -2051,8 +2058,8 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
                           const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f}, BeamDev dv = BeamDev{nullptr, nullptr},
                           bool last = false) {
     if (clustered) {
-        const int64_t bx = ceil_div(n_in, 128);
-        int64_t by = ceil_div(kBeamExpandBlocks, bx);  // few prefixes: split the cluster range so that the launch fills the chip
+        const int64_t bx = ceil_div(n_in, kExpandWG);
+        int64_t by = ceil_div(kBeamExpandBlocks * 128 / kExpandWG, bx);  // few prefixes: split the cluster range so that the launch fills the chip
         if (by > C.nclusters) by = C.nclusters;
         if (by > 65535) by = 65535;
         if (by < 1) by = 1;
@@ -2060,16 +2067,16 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
         by = ceil_div(C.nclusters, cps);
         if (rxall.on || (last && dv.dyn)) {
             if constexpr (SCALE == 1)
-                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s1<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
+                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s1<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(kExpandWG),
                                    0, s, M, C, in, n_in, u, out, cap, count, cps, rxall, dv);
             else if constexpr (SCALE == 2)
-                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s2<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
+                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_s2<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(kExpandWG),
                                    0, s, M, C, in, n_in, u, out, cap, count, cps, rxall, dv);
             else
-                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_q4<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128),
+                hipLaunchKernelGGL((beam_expand_clustered_last_kernel_q4<LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(kExpandWG),
                                    0, s, M, C, in, n_in, u, out, cap, count, cps, rxall, dv);
         } else {
-            hipLaunchKernelGGL((beam_expand_clustered_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(128), 0,
+            hipLaunchKernelGGL((beam_expand_clustered_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(kExpandWG), 0,
                                s, M, C, in, n_in, u, out, cap, count, cps, dv);
         }
     } else {
