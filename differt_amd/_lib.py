@@ -84,7 +84,7 @@ class BeamStats(C.Structure):
         ("expand_last_ms", C.c_float),
         ("emit_ms", C.c_float),
         ("trace_ms", C.c_float),
-        ("reserved2", C.c_float),
+        ("next_probe_prefixes", C.c_float),
     ]
 
 

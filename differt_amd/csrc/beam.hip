@@ -2511,6 +2511,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     // slice first), so that the records of a slice and its rows fit their buffers; a slice that overflows is
     // retried smaller.  LEVEL = order - 1.
     int64_t step_hint = (bp && bp->probe_prefixes > 0) ? bp->probe_prefixes : 4096;  // carried from list to list
+    double hint_min = 4e18;  // smallest slice size any slice of this call suggested: what the NEXT call can start with
     int64_t done = 0;
     auto last_expansion = [&](const BeamEntry *cur, int64_t ncur, int64_t *records_total) -> int32_t {
         int64_t i0 = 0;
@@ -2559,6 +2560,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             const double row_budget = (double)std::min(rows_cap, z.max_survivors);
             const double fan = std::max({(double)c / per / (double)z.max_records, (double)r / per / row_budget, 1e-18});
             double next = 0.5 / fan;
+            hint_min = std::min(hint_min, next);
             if (done > 1) next = std::min(next, 4.0 * (double)step);
             step_hint = (int64_t)std::max(1.0, std::min(next, 4e18));
             step = std::min<int64_t>(step_hint, ncur);
@@ -2660,6 +2662,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         st->rows = total_rows;
         st->pair_mode = pairs ? 1 : 0;
         st->slices = nslices;
+        st->next_probe_prefixes = (hint_min < 4e18) ? (float)std::max(1.0, std::min(hint_min, 1073741824.0)) : 0.0f;
         st->valid = nvalid;
     }
     return DRT_OK;

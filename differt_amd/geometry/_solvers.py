@@ -10,6 +10,7 @@ on the GPU -- no candidate table is ever built -- and returns only the valid pat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections.abc import Iterator, Sequence
 from dataclasses import dataclass
 from typing import TYPE_CHECKING, Any
@@ -640,7 +641,13 @@ class ExhaustivePathTracer(AbstractPathTracer):
                       | (_lib.DRT_BEAM_ROWS_PLAIN if rows == "plain" else 0))
         beam.max_entries, beam.max_records = int(max_entries or 0), int(max_records or 0)
         beam.max_rows, beam.max_survivors = int(max_rows or 0), int(max_survivors or 0)
-        beam.probe_prefixes = int(probe_prefixes or 0)
+        # slice size of the last expansion: the caller's, else what the previous call on this (mesh, order, end-point
+        # counts) had settled on (drt_beam_stats.next_probe_prefixes) -- a loop that moves its transmitters starts with
+        # full-size slices instead of a 4096-prefix probe; only a hint (an overflowing slice is retried smaller)
+        hint_key = (scene.mesh.generation(), order, bool(pairs), int(scene.transmitters.reshape(-1, 3).shape[0]),
+                    int(scene.receivers.reshape(-1, 3).shape[0]), float(kappa), prefix_shard)
+        hints = self.__dict__.setdefault("_beam_probe_hints", {})
+        beam.probe_prefixes = int(probe_prefixes or (0 if os.environ.get("DRT_BEAM_NO_HINT") else hints.get(hint_key, 0)))
         if prefix_shard is not None:
             srank, sworld = int(prefix_shard[0]), int(prefix_shard[1])
             if sworld <= 0 or not 0 <= srank < sworld:
@@ -660,6 +667,10 @@ class ExhaustivePathTracer(AbstractPathTracer):
                                 "grazing_prefixes": int(st.grazing_prefixes), "pair_mode": bool(st.pair_mode),
                                 "expand_last_ms": float(st.expand_last_ms), "emit_ms": float(st.emit_ms),
                                 "trace_ms": float(st.trace_ms)}
+        if order >= 2 and st.next_probe_prefixes >= 1.0:
+            if len(hints) > 64:
+                hints.clear()
+            hints[hint_key] = int(st.next_probe_prefixes)
         nv = objs.shape[0]
         return TracedPaths(verts, objs, torch.ones(nv, dtype=torch.bool, device=objs.device),
                            torch.zeros((nv, order), dtype=torch.int32, device=objs.device), self.confidence_threshold, keys)

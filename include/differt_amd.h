@@ -548,7 +548,11 @@ typedef struct drt_beam_stats {
     float expand_last_ms;     /* HIP-event time of the last expansion's kernels (all slices), */
     float emit_ms;            /*   of the receiver stage, */
     float trace_ms;           /*   of the fused trace of the candidate rows (sort / decode included) */
-    float reserved2;
+    float next_probe_prefixes; /* the smallest slice size any slice of this call suggested (prefixes per slice of the last
+                                  expansion, from the measured fan-out; 0 = no slice ran): pass it as drt_beam_params.probe_prefixes
+                                  of the NEXT call on a similar scene (a training loop that moves its transmitters) and
+                                  that call starts with full-size slices instead of a 4096-prefix probe.  Only a hint:
+                                  a slice that overflows is retried smaller, results never depend on it. */
 } drt_beam_stats;
 
 #define DRT_BEAM_EXPAND_PLAIN 1   /* expansion: every (prefix, primitive) pair tested, no cluster culling */

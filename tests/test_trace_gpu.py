@@ -785,6 +785,34 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
     assert torch.equal(bp.keys, exp_keys) and bool((bp.keys[1:] > bp.keys[:-1]).all())
 
 
+def test_beam_slice_hint_carried_between_calls(G, monkeypatch):
+    """drt_beam_stats.next_probe_prefixes: the tracer object starts its next call on the same (mesh, order, end-point
+    counts) with the slice size the previous call measured instead of a 4096-prefix probe -- fewer slices, the same paths
+    (a hint only: a slice that overflows is retried smaller); DRT_BEAM_NO_HINT switches it off."""
+    import synthetic_scenes as S
+
+    V, Tr, c, h = S.manhattan(700, seed=9)
+    tx, rx = S.manhattan_tx_rx(c, h, 2, 16, seed=10)
+    mesh = G.Mesh(V, Tr)
+    tracer = G.ExhaustivePathTracer(accel="bvh")
+    scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
+    first = tracer.trace_beam_pruned(scene, 2)
+    s1 = dict(tracer.last_beam_stats)
+    assert s1["chunks"] >= 2 and tracer._beam_probe_hints  # 2 x 3500 prefixes: a probe slice and the rest
+    moved = G.Scene(torch.tensor(tx + np.float32(0.25), device="cuda"), torch.tensor(rx, device="cuda"), mesh)
+    second = tracer.trace_beam_pruned(moved, 2)
+    s2 = dict(tracer.last_beam_stats)
+    assert s2["chunks"] < s1["chunks"]
+    monkeypatch.setenv("DRT_BEAM_NO_HINT", "1")
+    ref = tracer.trace_beam_pruned(moved, 2)
+    assert tracer.last_beam_stats["chunks"] == s1["chunks"]
+    _assert_same_paths(ref, second)
+    assert torch.equal(ref.keys, second.keys) and first.objects.shape[1] == 4
+    # an absurd hint is harmless: the oversized slice is retried smaller
+    huge = tracer.trace_beam_pruned(moved, 2, probe_prefixes=1 << 40, max_records=1 << 16)
+    _assert_same_paths(ref, huge)
+
+
 @pytest.mark.parametrize("accel", [None, "bvh"])
 def test_dense_num_valid_paths_from_device_counters(G, accel):
     """The dense tracer leaves survivors / cleared-by-occlusion counters in its workspace (include/differt_amd.h);
