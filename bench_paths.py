@@ -238,7 +238,18 @@ def beam_graph_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps
         tracer = G.ExhaustivePathTracer(accel="bvh")
         txd, rxd = torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda")
         scene = G.Scene(txd, rxd, mesh)
-        out = tracer.trace_beam_pruned_static(scene, order, max_paths=max_paths)
+        # static capacities as a deployment would fix them: twice what one synchronous call measured on this scene
+        # (the one-pass form launches every stage over the CAPACITY of its input list; an overflow is reported in
+        # counts[2], never silent)
+        tracer.trace_beam_pruned(scene, order)
+        st0 = tracer.last_beam_stats
+        p2 = lambda v: 1 << max(int(v) - 1, 1).bit_length()  # noqa: E731
+        caps = {"max_records": p2(2 * st0["levels"][-1]), "max_rows": p2(2 * st0["rows"]),
+                # rows that pass the geometric checks: about one triangle row per pair row in coplanar-pair mode
+                "max_survivors": p2(max(st0["rows"] // 2, 1 << 20))}
+        if order >= 3:
+            caps["max_entries"] = p2(2 * st0["levels"][-2])
+        out = tracer.trace_beam_pruned_static(scene, order, max_paths=max_paths, **caps)
         gtx, grx = torch.zeros_like(txd), torch.zeros_like(rxd)
         gmv = torch.zeros_like(mesh.vertices)
         cands = _lib.Candidates()
@@ -247,7 +258,7 @@ def beam_graph_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps
         h = mesh.handle().h
 
         def launch():
-            tracer.trace_beam_pruned_static(scene, order, max_paths=max_paths, out=out)
+            tracer.trace_beam_pruned_static(scene, order, max_paths=max_paths, out=out, **caps)
             v = out["vertices"]
             seg = v[:, 1:] - v[:, :-1]
             ln = torch.sqrt((seg * seg).sum(-1, keepdim=True))
@@ -284,7 +295,7 @@ def beam_graph_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps
                 "same_valid_paths_as_exhaustive": None if expected_valid is None else nv == int(expected_valid),
                 "same_keys_as_sync_entry": bool(torch.equal(out["keys"][:nv], ref.keys)),
                 "grad_tx_max_rel_diff_vs_sync": float((gtx - txg.grad).abs().max()) / scale,
-                "order": order, "max_paths": max_paths,
+                "order": order, "max_paths": max_paths, "capacities": caps,
                 "entry_point": "drt_trace_paths_beam_async + drt_trace_paths_vjp in ONE HIP graph (capture once, replay per step)"}
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}

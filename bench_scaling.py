@@ -215,6 +215,14 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
         }
     except Exception as exc:  # noqa: BLE001
         out["beam_sharded"] = {"error": repr(exc)}
+    if world == 1:
+        # the same complete problem as ONE HIP graph (static shapes, no host synchronisation): bench_paths.beam_graph_leg
+        try:
+            from bench_paths import beam_graph_leg
+
+            out["beam_graph"] = beam_graph_leg(G, mesh, tx, rx, 2, out.get("beam_sharded", {}).get("valid_paths"))
+        except Exception as exc:  # noqa: BLE001
+            out["beam_graph"] = {"error": repr(exc)}
     return out
 
 

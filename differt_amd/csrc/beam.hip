@@ -58,6 +58,7 @@
 #include "common.hpp"
 #include "geom.hpp"
 #include "mesh.hpp"
+#include "sort_safe.hpp"
 
 #pragma clang fp contract(off)
 
@@ -1847,26 +1848,34 @@ static BeamMesh beam_mesh_pairs(drt_mesh_t m) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// (temporary storage: enough for rocPRIM's default configuration AND for the capture-safe one of sort_safe.hpp -- the
+// synchronous and the asynchronous entry point share one workspace layout)
 static size_t sort_pairs_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
-    size_t bytes = 0;
+    size_t bytes = 0, safe = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                     (uint32_t *)nullptr, (size_t)n, 0, 32, nullptr);
-    return bytes;
+    (void)rocprim::radix_sort_pairs<CaptureSafeSort>(nullptr, safe, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                     (uint32_t *)nullptr, (size_t)n, 0, 32, nullptr);
+    return std::max(bytes, safe);
 }
 static size_t sort_keys64_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
-    size_t bytes = 0;
+    size_t bytes = 0, safe = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                    (size_t)n, 0, 64, nullptr);
-    return bytes;
+    (void)rocprim::radix_sort_keys<CaptureSafeSort>(nullptr, safe, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                                    (size_t)n, 0, 64, nullptr);
+    return std::max(bytes, safe);
 }
 static size_t sort_pairs64_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
-    size_t bytes = 0;
+    size_t bytes = 0, safe = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 64, nullptr);
-    return bytes;
+    (void)rocprim::radix_sort_pairs<CaptureSafeSort>(nullptr, safe, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 64, nullptr);
+    return std::max(bytes, safe);
 }
 
 // Morton order of `n` items (means of `group` consecutive points): sorted ids in `*ids_out`, bounds
@@ -1895,7 +1904,8 @@ static int32_t morton_order(const float *pts, int64_t n, int32_t group, char *tm
     hipLaunchKernelGGL(morton_kernel, grid, dim3(256), 0, s, pts, n, group, bounds, keys, ids);
     DRT_LAUNCH_CHECK();
     size_t tb = sort_pairs_temp_bytes(n);
-    DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb, keys, keys_sorted, ids, ids_sorted, (size_t)n, 0, 30, s));
+    // (capture-safe configuration: the receivers' order is computed inside drt_trace_paths_beam_async)
+    DRT_HIP(rocprim::radix_sort_pairs<CaptureSafeSort>(sort_tmp, tb, keys, keys_sorted, ids, ids_sorted, (size_t)n, 0, 30, s));
     return DRT_OK;
 }
 
@@ -2818,8 +2828,8 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
                        reinterpret_cast<unsigned long long *>(rows), c4, rows_cap);
     DRT_LAUNCH_CHECK();
     size_t tb = sort_keys64_temp_bytes(rows_cap);
-    DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted, (size_t)rows_cap,
-                                     0, 63, s));
+    DRT_HIP(rocprim::radix_sort_keys<CaptureSafeSort>(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted,
+                                                      (size_t)rows_cap, 0, 63, s));  // sort_safe.hpp
     const unsigned long long *row_keys = rows_sorted;
     if (pairs) {
         const dim3 ge((unsigned)ceil_div(table_rows, 256));
@@ -2857,8 +2867,8 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
             auto *tmp_rows = reinterpret_cast<uint32_t *>(base + L.merge_rows);
             hipLaunchKernelGGL(iota_kernel, dim3((unsigned)ceil_div(max_paths, 256)), dim3(256), 0, s, iota, max_paths);
             size_t tb2 = sort_pairs64_temp_bytes(max_paths);
-            DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb2, reinterpret_cast<unsigned long long *>(keys), mk, iota, perm,
-                                              (size_t)max_paths, 0, 64, s));  // padding keys (-1) sort last
+            DRT_HIP(rocprim::radix_sort_pairs<CaptureSafeSort>(sort_tmp, tb2, reinterpret_cast<unsigned long long *>(keys), mk, iota,
+                                                               perm, (size_t)max_paths, 0, 64, s));  // padding keys (-1) sort last
             auto copy = [&](const void *src, void *dst, int64_t words) {
                 hipLaunchKernelGGL(copy_u32_kernel, dim3((unsigned)ceil_div(words, 256)), dim3(256), 0, s,
                                    reinterpret_cast<const uint32_t *>(src), words, reinterpret_cast<uint32_t *>(dst));

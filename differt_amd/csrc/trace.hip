@@ -41,6 +41,7 @@ __device__ unsigned long long drt_dbg_counts[8];
 #include "tri_tile.hpp"
 #include "bvh.hpp"
 #include "trace_common.hpp"
+#include "sort_safe.hpp"
 #include "trace_stages.hpp"
 
 #pragma clang fp contract(off)
@@ -751,12 +752,14 @@ static void launch_filter(const Launch &L, unsigned long long *qc, long long *q,
                        L.a.rx, L.cs, qc, q, qcap, tpb);
 }
 
-static size_t sort_temp_bytes(int64_t n) {
+static size_t sort_temp_bytes(int64_t n) {  // enough for the default and for the capture-safe configuration (sort_safe.hpp)
     if (n <= 0) return 0;
-    size_t bytes = 0;
+    size_t bytes = 0, safe = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr,
                                    (unsigned long long *)nullptr, (size_t)n, 0, 64, nullptr);
-    return bytes;
+    (void)rocprim::radix_sort_keys<CaptureSafeSort>(nullptr, safe, (unsigned long long *)nullptr,
+                                                    (unsigned long long *)nullptr, (size_t)n, 0, 64, nullptr);
+    return bytes > safe ? bytes : safe;
 }
 
 }  // namespace drt
@@ -960,9 +963,9 @@ int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *p
     }
     if (max_paths > 0) {
         size_t tmp_bytes = sort_temp_bytes(max_paths);
-        DRT_HIP(rocprim::radix_sort_keys(sort_tmp, tmp_bytes, reinterpret_cast<unsigned long long *>(q2),
-                                         reinterpret_cast<unsigned long long *>(keys), (size_t)max_paths, 0,
-                                         64, L.s));
+        DRT_HIP(rocprim::radix_sort_keys<CaptureSafeSort>(sort_tmp, tmp_bytes, reinterpret_cast<unsigned long long *>(q2),
+                                                          reinterpret_cast<unsigned long long *>(keys), (size_t)max_paths,
+                                                          0, 64, L.s));
     }
     const int64_t rows = max_paths > 0 ? max_paths : 1;  // one thread at least: it writes the counts
 #define CALL(K)                                                                                        \
@@ -1004,8 +1007,8 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t ntx, const
 static size_t vjp_sort_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                    (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 42, nullptr);
+    (void)rocprim::radix_sort_pairs<CaptureSafeSort>(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 42, nullptr);
     return bytes;
 }
 
@@ -1056,7 +1059,8 @@ int32_t drt_trace_paths_vjp_ex(drt_mesh_t mesh, const drt_trace_params *pr, cons
     DRT_LAUNCH_CHECK();
     size_t tb = vjp_sort_temp_bytes(n);
     // radix sort is stable: inside a destination the slots stay in path order
-    DRT_HIP(rocprim::radix_sort_pairs(sort_tmp, tb, dest, dest_sorted, slots, slots_sorted, (size_t)n, 0, 42, L.s));
+    // (capture-safe configuration, sort_safe.hpp: this entry point may sit in a HIP graph next to the asynchronous tracers)
+    DRT_HIP(rocprim::radix_sort_pairs<CaptureSafeSort>(sort_tmp, tb, dest, dest_sorted, slots, slots_sorted, (size_t)n, 0, 42, L.s));
     // (the unsorted destination keys are dead after the sort: their buffer holds the chunk carries, 12 B per 256 slots)
     float *carry = reinterpret_cast<float *>(dest);
     const int64_t nchunks = ceil_div(n, kVjpChunk);

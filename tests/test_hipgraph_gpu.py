@@ -274,6 +274,40 @@ def test_beam_async_capture_and_replay_with_moved_transmitters():
     assert len(seen) > 1  # the replays really saw different problems
 
 
+def test_beam_async_graph_replays_with_sorts_beyond_2e20_keys():
+    """Regression (round 4): rocPRIM's radix sort takes its one-sweep algorithm above 2^20 items and resets its buffers
+    with hipMemsetAsync -- memset NODES under capture, which replay once and then fill garbage on this ROCm: the second
+    replay of a captured drt_trace_paths_beam_async on a 200 000-triangle mesh died with a memory aperture violation.
+    Every sort of a capturable entry point now uses the merge-sort configuration (csrc/sort_safe.hpp).  Here: a row
+    capacity of 2^23 (2^21 pair rows > 2^20 keys in the captured sort), five replays, each equal to the synchronous call."""
+    G, mesh, tx, rx = _beam_city(boxes=600, ntx=2, nrx=48, seed=5)
+    tracer = G.ExhaustivePathTracer(accel="bvh")
+    order, cap = 2, 4096
+    scene = G.Scene(tx, rx, mesh)
+    caps = {"max_records": 1 << 22, "max_rows": 1 << 23, "max_survivors": 1 << 21}
+    out = tracer.trace_beam_pruned_static(scene, order, max_paths=cap, **caps)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        tracer.trace_beam_pruned_static(scene, order, max_paths=cap, out=out, **caps)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        tracer.trace_beam_pruned_static(scene, order, max_paths=cap, out=out, **caps)
+    ref = tracer.trace_beam_pruned(scene, order)
+    n = ref.objects.shape[0]
+    assert n > 0
+    for rep in range(5):
+        for k in ("keys", "vertices", "objects", "counts"):
+            out[k].fill_(13)
+        g.replay()
+        torch.cuda.synchronize()
+        c = out["counts"].tolist()
+        assert c[1] == n and c[2] == 0, (rep, c, n)
+        assert torch.equal(out["keys"][:n], ref.keys) and torch.equal(out["objects"][:n], ref.objects)
+        assert torch.equal(out["vertices"][:n].view(torch.int32), ref.vertices.view(torch.int32))
+
+
 def test_beam_async_reports_overflow_instead_of_slicing():
     from differt_amd import _lib
 
