@@ -499,7 +499,7 @@ int32_t drt_mesh_triangles_visible_from_vertex(drt_mesh_t m, const float *vertic
     if (rc != DRT_OK) return rc;
     hipStream_t s = as_stream(stream);
     const uint8_t *mask = m->has_mask ? m->mask : nullptr;
-    DRT_HIP(hipMemsetAsync(visible_out, 0, (size_t)B * (size_t)T, s));
+    DRT_HIP(fill_bytes_async(visible_out, 0, (size_t)B * (size_t)T, s));  // (a kernel: memset nodes do not survive graph replay, core.hip)
     launch_frustum_kernel(vertices, B, m->tri_verts, T, mask, frustum_workspace, s);
     DRT_LAUNCH_CHECK();
     hipLaunchKernelGGL(bvh_visibility_kernel, dim3((unsigned)ceil_div(num_rays, 256), (unsigned)B),

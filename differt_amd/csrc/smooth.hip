@@ -507,7 +507,7 @@ int32_t drt_ray_intersect_any_triangle_smooth(const float *o, const float *d, in
     if (R == 0) return DRT_OK;
     DRT_REQUIRE(out, "out is null");
     if (T == 0) {  // _utils.py:1441-1450
-        DRT_HIP(hipMemsetAsync(out, 0, (size_t)R * sizeof(float), as_stream(stream)));
+        DRT_HIP(fill_bytes_async(out, 0, (size_t)R * sizeof(float), as_stream(stream)));
         return DRT_OK;
     }
     DRT_REQUIRE(o && d && tv, "null pointer");

@@ -369,7 +369,7 @@ int32_t drt_triangles_visible_from_vertex(const float *vertices, int64_t B, cons
     DRT_REQUIRE(vertices && tv && visible_out && frustum_workspace, "null pointer");
     DRT_REQUIRE(B <= 65535, "at most 65535 viewing vertices per call");
     hipStream_t s = as_stream(stream);
-    DRT_HIP(hipMemsetAsync(visible_out, 0, (size_t)B * (size_t)T, s));
+    DRT_HIP(fill_bytes_async(visible_out, 0, (size_t)B * (size_t)T, s));  // (a kernel: memset nodes do not survive graph replay, core.hip)
     hipLaunchKernelGGL(frustum_kernel, dim3((unsigned)B), dim3(256), 0, s, vertices, B, tv, T, active,
                        frustum_workspace);
     DRT_LAUNCH_CHECK();
