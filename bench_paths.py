@@ -105,6 +105,9 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         # search (no exhaustive count to compare with: 91 paths, re-validated by the oracle in tests/test_full_size_gpu.py)
         out["beam_pruned_order3"] = beam_leg(G, mesh, tx, rx, 3, None, reps=1)
         out["beam_pruned_order3"]["same_valid_paths_as_exhaustive"] = exhaustive_record("configs[3]")
+        # configs[3] in ONE pass and one HIP graph (29 GiB of workspace at capacities of twice the measured list sizes:
+        # what 288 GB of HBM are for)
+        out["beam_pruned_order3_graph"] = beam_graph_leg(G, mesh, tx, rx, 3, out["beam_pruned_order3"].get("valid_paths"), reps=2)
         # the same configs as QUAD meshes (assume_quads=True: the city is boxes, and the reference's own harness calls
         # set_assume_quads(), tests/benchmarks/test_rt.py:162): exhaustive order 2, pruned orders 2 and 3
         try:
