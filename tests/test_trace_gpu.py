@@ -845,6 +845,85 @@ def test_dense_num_valid_paths_from_device_counters(G, accel):
 
 
 @pytest.mark.parametrize("order", [1, 2, 3])
+def test_pair_blocks_through_the_c_abi_with_a_hand_built_table(G, rng, order):
+    """DRT_CAND_PAIR_BLOCKS as a documented feature of drt_trace_paths_compact (include/differt_amd.h), independent of the
+    beam search: a per-pair table whose blocks of 2^order rows enumerate the triangle choices 2 q_j + bit_j(c) of pair
+    sequences -- sequences of valid paths and random ones, pairs that follow themselves (padding rows where a triangle
+    would repeat), whole padding blocks, an empty (tx, rx) pair -- gives the same keys, objects and vertex bits with and
+    without the bit."""
+    import ctypes as C
+
+    import differt_amd._lib as lib
+    import synthetic_scenes as S
+    from differt_amd._tensors import ptr, stream
+    from differt_amd.geometry._solvers import _params
+
+    V, Tr, c, h = S.manhattan(18, seed=31)
+    ext = float(np.abs(V[:, :2]).max()) + 10
+    gv = np.array([[-ext, -ext, 0], [ext, -ext, 0], [ext, ext, 0], [-ext, ext, 0]], np.float32)
+    Tr = np.concatenate((Tr, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V)))
+    V = np.concatenate((V, gv))
+    tx, rx = S.manhattan_tx_rx(c, h, 2, 6, seed=32)
+    tx[:, 2] = np.float32(float(h.max()) + 20.0)  # above every roof: ground and roof reflections exist at every order
+    mesh = G.Mesh(V, Tr)
+    txd, rxd = torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda")
+    scene = G.Scene(txd, rxd, mesh)
+    tracer = G.ExhaustivePathTracer()
+    valid = tracer.trace_beam_pruned(scene, order)  # (builds the pair clusters: establishes the precondition)
+    assert tracer.last_beam_stats["pair_mode"]
+    nq, ntx, nrx, K = Tr.shape[0] // 2, len(tx), len(rx), order
+    blocks = {p: [] for p in range(ntx * nrx)}
+    for o in valid.objects.cpu().tolist():  # pair sequences of the valid paths
+        blocks[o[0] * nrx + o[-1]].append(tuple(t // 2 for t in o[1:-1]))
+    for p in range(ntx * nrx):
+        if p == 3:
+            blocks[p] = []  # an empty pair
+            continue
+        for _ in range(40):
+            q = tuple(int(x) for x in rng.integers(0, nq, K))
+            blocks[p].append(q)
+        if K >= 2:
+            blocks[p].append((nq - 1,) * K)  # the ground pair following itself
+        blocks[p].append(None)  # a whole padding block
+    rows, offsets = [], [0]
+    for p in range(ntx * nrx):
+        for q in blocks[p]:
+            for cc in range(1 << K):
+                if q is None:
+                    rows.append([-1] * K)
+                    continue
+                ids = [2 * q[j] + ((cc >> (K - 1 - j)) & 1) for j in range(K)]
+                rows.append([-1] * K if any(ids[j] == ids[j - 1] for j in range(1, K)) else ids)
+        offsets.append(len(rows))
+    table = torch.tensor(rows, dtype=torch.int32, device="cuda")
+    pair_off = torch.tensor(offsets, dtype=torch.int64, device="cuda")
+    L = lib.load()
+    cap_s, cap_p = 1 << 16, 1 << 12
+    nb = L.drt_trace_compact_workspace_size(cap_s, cap_p)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    params = _params(None, None, None)
+    res = []
+    for flag in (0, lib.DRT_CAND_PAIR_BLOCKS):
+        cands = lib.Candidates()
+        cands.table, cands.num_candidates, cands.order = table.data_ptr(), table.shape[0], K
+        cands.pair_offsets = pair_off.data_ptr()
+        cands.reserved = flag
+        k = torch.empty(cap_p, dtype=torch.int64, device="cuda")
+        v = torch.empty((cap_p, K + 2, 3), dtype=torch.float32, device="cuda")
+        o = torch.empty((cap_p, K + 2), dtype=torch.int32, device="cuda")
+        nv = C.c_int64(0)
+        lib.call("drt_trace_paths_compact", mesh.handle().h, C.byref(params), ptr(txd), ntx, ptr(rxd), nrx, C.byref(cands),
+                 cap_s, cap_p, ptr(k), ptr(v), ptr(o), C.byref(nv), ptr(ws), nb, stream())
+        n = int(nv.value)
+        res.append((n, k[:n].clone(), v[:n].clone(), o[:n].clone()))
+    (n0, k0, v0, o0), (n1, k1, v1, o1) = res
+    expected = {tuple(o) for o in valid.objects.cpu().tolist() if o[0] * nrx + o[-1] != 3}  # (pair 3 was emptied above)
+    assert n0 == n1 and n0 >= len(expected) > 0  # (a valid sequence may appear twice: once found, once drawn)
+    assert torch.equal(k0, k1) and torch.equal(o0, o1) and torch.equal(v0.view(torch.int32), v1.view(torch.int32))
+    assert expected <= set(map(tuple, o0.cpu().tolist()))
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
 def test_beam_pair_blocks_equal_row_by_row_trace(G, rng, order):
     """DRT_CAND_PAIR_BLOCKS (include/differt_amd.h): in coplanar-pair mode the filter stage evaluates the image chain once
     per surviving pair row and Moller-Trumbore against both triangles of every pair, instead of tracing the 2^order
