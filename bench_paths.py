@@ -315,15 +315,18 @@ def beam_roofline(order: int, st: dict, quads: bool) -> dict | None:
     if order < 2 or not st.get("expand_last_ms"):
         return None
     recs = sorted((Path(__file__).resolve().parent / "profiles").glob("r*/pmc_beam_expand.json"))
-    out = {"bound": "valu", "kernel_ms": st["expand_last_ms"], "peak": PEAK_VALU_ISSUE, "unit": "lane-ops/s",
-           "achieved": None, "frac": None, "pmc_stale": None}
+    out = {"bound": "valu", "kernel_ms": st["expand_last_ms"], "peak": PEAK_VALU_ISSUE, "peak_fma_flops": PEAK_FP32_FMA,
+           "unit": "lane-ops/s", "achieved": None, "frac": None, "frac_of_157TF": None, "pmc_stale": None}
     if not recs:
         return out
     try:
         from differt_amd._srchash import is_stale
 
         rec = json.loads(recs[-1].read_text())
-        leg = rec.get("legs", {}).get(f"order{order}{'_quads' if quads else ''}")
+        legs = rec.get("legs", {})
+        # a quad mesh and a triangle mesh in coplanar-pair mode run the same `_q4` kernel over the same n/2 primitives:
+        # the counter pass of either describes both when only one was collected
+        leg = legs.get(f"order{order}{'_quads' if quads else ''}") or legs.get(f"order{order}")
         out["pmc_stale"] = is_stale(rec, "beam")
         out["source"] = f"profiles/{recs[-1].parent.name}/pmc_beam_expand.json"
         if leg:
@@ -332,6 +335,7 @@ def beam_roofline(order: int, st: dict, quads: bool) -> dict | None:
             out["executed_valu_wave_instructions_per_step"] = valu
             out["achieved"] = valu * 64 / (st["expand_last_ms"] * 1e-3)
             out["frac"] = out["achieved"] / PEAK_VALU_ISSUE
+            out["frac_of_157TF"] = out["achieved"] / PEAK_FP32_FMA
             for k in ("SQ_WAIT_INST_ANY_over_SQ_WAVE_CYCLES", "valu_issue_frac_from_counters"):
                 if k in leg:
                     out[k] = leg[k]

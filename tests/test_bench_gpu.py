@@ -1,4 +1,5 @@
-"""bench.py contract (one JSON line with `roofline`; N > 1 under torch.distributed.run) on the GPU box.
+"""bench.py contract (one COMPACT JSON line with `roofline`, every leg in full in a sidecar file; N > 1 under
+torch.distributed.run) on the GPU box.
 
 The two-rank case uses the DRT_BENCH_SHARE_GPU test hook (both ranks on cuda:0 over gloo): it checks
 the sharding / barrier / all-reduce / rank-0 JSON plumbing, not performance.
@@ -25,13 +26,24 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 
 def _last_json(out: str) -> dict:
+    """The line as the driver reads it (the last line of an 8 KB stdout tail) + the sidecar's legs merged in."""
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out
-    return json.loads(lines[0])
+    assert len(lines[0]) < 4000, len(lines[0])
+    d = json.loads(out[-8000:].splitlines()[-1])
+    assert d == json.loads(lines[0])
+    full = json.loads((ROOT / d["full"]).read_text() if not os.path.isabs(d["full"]) else Path(d["full"]).read_text())
+    for k in ("metric", "value", "n_gpus", "steps", "warmup"):
+        assert full[k] == pytest.approx(d[k], rel=1e-5), k
+    d["strong_scaling"] = full.get("strong_scaling")
+    d["prewarm_ms"] = full["prewarm_ms"]
+    d["full_record"] = full
+    return d
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, "bench.py", *COMMON], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "bench.py", "--full-json", "/tmp/drt_bench_full_n1.json", *COMMON], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
@@ -62,7 +74,8 @@ def _check_strong(sc: dict, world: int):
 def test_two_ranks_share_gpu():
     env = dict(os.environ, DRT_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", *COMMON]
+           "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--full-json", "/tmp/drt_bench_full_n2.json",
+           *COMMON]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)  # rank 0 only
@@ -87,3 +100,37 @@ def test_two_ranks_share_gpu():
         assert two["beam_sharded"]["checksum_keys"] == one["beam_sharded"]["checksum_keys"]
         g1, g2 = one["beam_sharded"]["grad_tx_absmax"], two["beam_sharded"]["grad_tx_absmax"]
         assert abs(g1 - g2) <= 1e-5 * max(abs(g1), 1e-30)
+
+
+def test_default_command_line_is_parseable_by_the_driver():
+    """The DEFAULT command as the driver runs it (`--steps 20 --warmup 5`, paths ON): ONE JSON line under 4 000
+    characters that the last line of an 8 KB stdout tail parses to, carrying `roofline`, `cpu_baseline`, the paths
+    half of the BASELINE metric, and the sidecar with every leg (the r04 line was 20 KB)."""
+    side = Path("/tmp/drt_bench_full_default.json")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--full-json", str(side)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = r.stdout[-8000:].splitlines()[-1]
+    assert len(line) < 4000, len(line)
+    d = json.loads(line)
+    assert KEYS <= set(d) and d["full"] == str(side)
+    assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["value"] > 0
+    pm = d["paths_metric"]
+    assert pm["unit"] == "valid order-2 paths/s (fwd+grad)" and pm["config"] == "configs[2]" and pm["value"] > 0
+    assert pm["same_as_exhaustive"] is True
+    ps = d["paths"]
+    for k in ("cfg2_fwdgrad_s", "cfg3_s", "cfg4_s", "dense_api_frac", "cfg3_expand_valu_frac", "cfg3_expand_frac_of_157TF"):
+        assert ps[k] is not None and ps[k] > 0, (k, ps)
+    assert ps["same_as_exhaustive"] is True
+    for v in d.values():  # numbers and short identifiers only: no prose in the line
+        assert not isinstance(v, str) or len(v) < 100
+    full = json.loads(side.read_text())
+    # every VALU roofline block states both denominators, and no fraction is null
+    def walk(o):
+        if isinstance(o, dict):
+            if o.get("bound") == "valu":
+                assert o.get("frac") is not None and o.get("frac_of_157TF") is not None, o
+            for v in o.values():
+                walk(v)
+    walk(full)
