@@ -65,7 +65,7 @@ DRT_TRACE_USE_BVH = 1
 DRT_TRACE_SKIP_OCCLUSION = 2
 DRT_TRACE_DETERMINISTIC_GRAD = 4
 DRT_TRACE_OVERFLOW_SURVIVORS, DRT_TRACE_OVERFLOW_PATHS = 1, 2
-ABI_VERSION = 6  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
+ABI_VERSION = 7  # DRT_ABI_VERSION of include/differt_amd.h this binding was written against
 
 
 class BeamStats(C.Structure):
@@ -80,7 +80,7 @@ class BeamStats(C.Structure):
         ("unit_m", C.c_float),
         ("magnitude", C.c_float),
         ("pair_mode", C.c_int32),
-        ("reserved", C.c_int32),
+        ("paired_primitives", C.c_int32),
         ("expand_last_ms", C.c_float),
         ("emit_ms", C.c_float),
         ("trace_ms", C.c_float),
@@ -236,6 +236,9 @@ _SIGNATURES = {
     "drt_trace_vjp_workspace_size": (_sz, [_i64, _i32]),
     "drt_trace_paths_vjp_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drt_mesh_build_beam_clusters": (_i32, [_vp, _vp]),
+    "drt_mesh_build_beam_clusters_ex": (_i32, [_vp, _i32, _vp]),
+    "drt_mesh_beam_pairing": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "drt_mesh_beam_pairing_table": (_i32, [_vp, _vp, _i64, _vp]),
     "drt_trace_beam_workspace_size": (_sz, [_i64, _i64, _i64, _i32, _vp, _i64]),
     "drt_trace_paths_beam": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drt_trace_hybrid_pairs_workspace_size": (_sz, [_i64, _i64, _i64, _i64, _i64]),
@@ -294,7 +297,7 @@ _SIGNATURES = {
 }
 
 # functions whose int32 result is NOT a status code
-_NOT_STATUS = {"drt_abi_version", "drt_mesh_has_bvh", "drt_comm_rank", "drt_comm_world"}
+_NOT_STATUS = {"drt_abi_version", "drt_mesh_has_bvh", "drt_comm_rank", "drt_comm_world", "drt_mesh_beam_pairing"}
 
 _LIB = None
 

@@ -54,6 +54,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "common.hpp"
 #include "geom.hpp"
@@ -95,7 +96,13 @@ struct BeamMesh {
     float inv_2m;   // 1 / (2 M), M = largest coordinate magnitude of mesh, transmitters and receivers
     int32_t self_loops;  // coplanar-pair mode of a TRIANGLE mesh: a pair may follow itself (its two triangles are
                          // different candidates of the triangle-level space; assume_quads has no such candidate)
+    const int32_t *pair_tri;  // [nprim,2] pair mode: the real triangles of a primitive (second -1: a single triangle, which
+                              // may NOT follow itself); null otherwise
 };
+// may primitive p follow a prefix whose last mirror is m?
+__device__ __forceinline__ bool may_follow(const BeamMesh &M, int32_t p, int32_t m) {
+    return p != m || (M.self_loops && M.pair_tri[2 * (int64_t)p + 1] >= 0);
+}
 // The error unit u = kappa ulp(M) assumes operands within 2 M (differences of scene points, images one reflection
 // away).  Images of images can reach (2k+1) M, and float32 rounding grows with the operand: a prefix whose apex lies
 // beyond 2 M scales its unit by |apex|_inf / (2 M).
@@ -245,13 +252,20 @@ __device__ __forceinline__ float min_faces(const float (&v)[NF]) {
     if constexpr (NF == 4) m = __builtin_fminf(m, v[3]);
     return m;
 }
-__device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, float delta, V3 &n_out, float &g_out) {
+// `third` (and, for a quadrilateral, `third2`): the polygon's other vertices; they fix which side of the face is
+// "inside".  A quadrilateral passes BOTH: a convex quad has them on the same side (their sum has that sign), and a
+// triangle laid out as the degenerate quad (v0, v1, v2, v2) -- a single triangle among the coplanar pairs of a
+// triangle soup, drt_mesh::pair_* -- has one of the two ON the face's own edge, where the triple product is rounding
+// noise next to the other one's value.
+template <bool TWO>
+__device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, float delta, V3 &n_out, float &g_out) {
     // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded forms (~12 instructions each, five per face,
     // three faces per pyramid, up to three pyramids per prefix): these are margins, and the 2e-6 |x - I|_1 in the
     // slope covers the rounding of the normalisation and of <x - I, n_f>; rho is rounded DOWN by the 0.9999
     const V3 N = cross(a - I, b - I);
     const float len = __builtin_amdgcn_sqrtf(fdot(N, N));
-    const float s = fdot(third - I, N);
+    float s = fdot(third - I, N);
+    if constexpr (TWO) s += fdot(third2 - I, N);
     const V3 e = b - a;
     const float el = __builtin_amdgcn_sqrtf(fdot(e, e));
     const float rho = (el > 0.0f) ? 0.9999f * len * __builtin_amdgcn_rcpf(el) : 0.0f;
@@ -267,7 +281,8 @@ template <int NF>
 __device__ __forceinline__ PyrN<NF> make_pyr(V3 I, const V3 (&v)[NF], float delta) {
     PyrN<NF> P;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) pyr_face(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], delta, P.n[f], P.g[f]);
+    for (int f = 0; f < NF; ++f)
+        pyr_face<NF == 4>(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], v[(f + 3) % NF], delta, P.n[f], P.g[f]);
     return P;
 }
 
@@ -631,7 +646,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
             for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pl[t][q] = lds_pl[j][t][q];
-            const bool cand = have && (c != m || M.self_loops);
+            const bool cand = have && may_follow(M, c, m);
             const bool keep = cand && !prim_pruned<SCALE, LEVEL>(ctx, vx, pl, lds_sg[j], cand);
             beam_stage<kBeamWaveBuf>(keep, ((unsigned long long)(uint32_t)g << 32) | (uint32_t)c, wbuf[wave], wcount,
                                      lane, out, cap, count);
@@ -962,12 +977,13 @@ __device__ __forceinline__ void expand_clustered_body(
         // ---- transposed: lane = primitive of the cluster ----
         const int64_t pos = cl * 64 + lane;
         const bool act = p >= 0 && prim_active(M, p);
+        const bool self_ok = p >= 0 && may_follow(M, p, p);
         const float sg = C.sigma[pos];
         while (todo) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
             const BeamCtx<SCALE, LEVEL> cx = lane_bcast<SCALE, LEVEL>(ctx, l);
-            const bool cand = act && (p != __builtin_amdgcn_readlane(m, l) || M.self_loops);
+            const bool cand = act && (p != __builtin_amdgcn_readlane(m, l) || self_ok);
             const bool keep = cand && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg, cand);
 #ifdef BEAM_LAB_COUNT
             {
@@ -1666,51 +1682,158 @@ __global__ __launch_bounds__(256) void pair_offsets_kernel(const unsigned long l
     offsets[p] = lo * mult;  // (mult: table rows per sorted row, 2^ORDER in coplanar-pair mode)
 }
 
-// ---- coplanar-pair mode (a triangle mesh searched over its n/2 pairs) ------------------------------------------
-// What the triangle pairs (2i, 2i+1) of a mesh are, for ALL pairs at once:
-// flag[0] stays 1 when every pair has EQUAL unit normals, the same first vertex (float equality: +0 == -0 -- the cross
-// product of axis-aligned edges yields zeros of either sign -- and a NaN equals nothing) and the same mask value: both
-// triangles then are THE SAME MIRROR for the reference (plane point and normal feed image_of_vertex / the ray-plane
-// step, _solvers.py:552-562; the sign of a zero component changes no value there, only the sign of a zero result),
-// every image and reflection point of a candidate has the same value whichever of the two it names, and only the
-// inside test tells them apart.  The exact trace of a triangle row uses that triangle's own normal, zeros' signs
-// included.  A triangle mesh with flag[0] is searched over its pairs.
-// flag[1] stays 1 when every pair moreover is a CONVEX PLANAR FAN QUAD (struct Shape, shape 4): second triangle =
-// (v0, v2, v3) of the first one's (v0, v1, v2), every corner of v0 v1 v2 v3 turns the way the normal says by at least
-// sin = 1e-3 (a clear margin: a corner that is flat or reflex within rounding falls back to the two-triangle form).
-__global__ __launch_bounds__(256) void pair_shape_kernel(const float *__restrict__ tv, const float *__restrict__ normals,
-                                                         const uint8_t *__restrict__ mask, int64_t npairs,
-                                                         uint32_t *__restrict__ flag) {
+// ---- primitive shapes of an assume_quads mesh ------------------------------------------------------------------
+// flag[0] stays 1 when every quad (2i, 2i+1) is a CONVEX PLANAR FAN QUAD (struct Shape, shape 4): equal (==) unit
+// normals and first vertices (float equality: +0 == -0 -- the cross product of axis-aligned edges yields zeros of
+// either sign -- and a NaN equals nothing), second triangle = (v0, v2, v3) of the first one's (v0, v1, v2), every corner
+// of v0 v1 v2 v3 turning the way the normal says by at least sin = 1e-3 (a clear margin: a corner that is flat or reflex
+// within rounding falls back to the two-triangle form, shape 2).
+__device__ __forceinline__ bool fan_quad_convex(V3 n, const V3 (&q)[4]) {
+    bool quad = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const V3 e0 = q[(k + 1) % 4] - q[k], e1 = q[(k + 2) % 4] - q[(k + 1) % 4];
+        const float turn = fdot(cross(e0, e1), n);
+        const float scale = __builtin_sqrtf(fdot(e0, e0) * fdot(e1, e1));
+        quad = quad && (turn > 1e-3f * scale) && is_finite(scale);
+    }
+    return quad;
+}
+__global__ __launch_bounds__(256) void quad_shape_kernel(const float *__restrict__ tv, const float *__restrict__ normals,
+                                                         int64_t nquads, uint32_t *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npairs) return;
+    if (i >= nquads) return;
     const float *a = normals + 6 * i, *b = a + 3;
     const float *va = tv + 18 * i, *vb = va + 9;
     const bool same_plane = a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && va[0] == vb[0] && va[1] == vb[1] && va[2] == vb[2];
-    bool pair_ok = same_plane;
-    if (mask) pair_ok = pair_ok && ((mask[2 * i] != 0) == (mask[2 * i + 1] != 0));
-    if (!pair_ok) atomicAnd(flag, 0u);
     bool quad = same_plane && va[6] == vb[3] && va[7] == vb[4] && va[8] == vb[5];  // shared diagonal v0 - v2
     if (quad) {
-        const V3 n = ld3(a);
         const V3 q[4] = {ld3(va), ld3(va + 3), ld3(va + 6), ld3(vb + 6)};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const V3 e0 = q[(k + 1) % 4] - q[k], e1 = q[(k + 2) % 4] - q[(k + 1) % 4];
-            const float turn = fdot(cross(e0, e1), n);
-            const float scale = __builtin_sqrtf(fdot(e0, e0) * fdot(e1, e1));
-            quad = quad && (turn > 1e-3f * scale) && is_finite(scale);
-        }
+        quad = fan_quad_convex(ld3(a), q);
     }
-    if (!quad) atomicAnd(flag + 1, 0u);
+    if (!quad) atomicAnd(flag, 0u);
 }
 
-// sorted packed PAIR rows ((tx nrx + rx) nq^K + sum q_j nq^(K-1-j)) -> the 2^K triangle rows of each, in place of
-// rows_decode: table rows [i 2^K + c] = triangle ids 2 q_j + bit_j(c) (a repeated pair row, or a combination that
-// names the same triangle twice in a row -- not a candidate of the reference's graph, graph.rs:400-470 -- becomes a
-// padding row of -1) and tri_keys[i 2^K + c] = the triangle-level packed key, what drt_trace_paths_beam returns.
+// ---- coplanar pairs of a triangle soup -------------------------------------------------------------------------
+// Two triangles A = (v0, v1, v2) and B = (v0, v2, v3) with EQUAL (==) unit normals, the same first vertex and the same
+// mask value are THE SAME MIRROR for the reference (plane point and normal are all the image method reads of a triangle,
+// _solvers.py:552-562; the sign of a zero component changes no value there, only the sign of a zero result): every
+// image and reflection point of a candidate has the same value whichever of the two it names, and only the inside test
+// tells them apart.  When moreover v0 v1 v2 v3 is convex (fan_quad_convex) the pair is searched as ONE shape-4 primitive.
+// Round 4 took the pairs (2i, 2i+1) and gave up on the whole mesh when one of them failed; the reference's real meshes
+// (tests/golden/bruxelles.npz: walls are fans of two, roofs are ear-clipped polygons, in no particular order) pair
+// 36 of 7 103 that way.  pair_candidate_kernel answers, for EVERY triangle A, which triangle B follows it around the
+// shared first vertex (succ[A] = the lowest such B, or -1) -- 5 829 pairs on bruxelles after the host's matching.
+// Keys are bit patterns with -0 folded into +0 (float equality); a NaN coordinate or normal pairs with nothing.
+struct PairKey {
+    uint32_t w[6];  // v0, then the diagonal's other end (A: v2, B: v1)
+};
+__device__ __forceinline__ uint32_t fold_zero(float x) { return __float_as_uint(x + 0.0f); }
+__global__ __launch_bounds__(256) void pair_keys_kernel(const float *__restrict__ tv, int64_t T, uint64_t *__restrict__ hash_second,
+                                                        uint32_t *__restrict__ ids) {
+    // hash of (v0, v1): the key a triangle is found under as the SECOND triangle of a fan
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float *v = tv + 9 * t;
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        h ^= (uint64_t)fold_zero(v[k]);
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    hash_second[t] = h;
+    ids[t] = (uint32_t)t;
+}
+// succ[a] = lowest b != a with hash/second-key equal to a's (v0, v2), equal normals, masks, convex union
+__global__ __launch_bounds__(256) void pair_candidate_kernel(const float *__restrict__ tv, const float *__restrict__ normals,
+                                                             const uint8_t *__restrict__ mask, int64_t T,
+                                                             const uint64_t *__restrict__ sorted_hash,
+                                                             const uint32_t *__restrict__ sorted_ids,
+                                                             int32_t *__restrict__ succ) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= T) return;
+    const float *va = tv + 9 * a;
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        h ^= (uint64_t)fold_zero(va[k < 3 ? k : k + 3]);  // (v0, v2)
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    int64_t lo = 0, hi = T;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sorted_hash[mid] < h) lo = mid + 1; else hi = mid;
+    }
+    int32_t best = -1;
+    const V3 na = ld3(normals + 3 * a);
+    for (int64_t i = lo; i < T && sorted_hash[i] == h; ++i) {
+        const int64_t b = (int64_t)sorted_ids[i];
+        if (b == a) continue;
+        const float *vb = tv + 9 * b;
+        const V3 nb = ld3(normals + 3 * b);
+        bool ok = va[0] == vb[0] && va[1] == vb[1] && va[2] == vb[2] && va[6] == vb[3] && va[7] == vb[4] && va[8] == vb[5] &&
+                  na.x == nb.x && na.y == nb.y && na.z == nb.z;
+        if (mask) ok = ok && ((mask[a] != 0) == (mask[b] != 0));
+        if (ok) {
+            const V3 q[4] = {ld3(va), ld3(va + 3), ld3(va + 6), ld3(vb + 6)};
+            ok = fan_quad_convex(na, q);
+        }
+        if (ok && (best < 0 || (int32_t)b < best)) best = (int32_t)b;
+    }
+    succ[a] = best;
+}
+// the virtual mesh of 2 P triangles the kernels read in pair mode (drt_mesh::pair_*)
+__global__ __launch_bounds__(256) void pair_gather_kernel(const float *__restrict__ tv, const float *__restrict__ normals,
+                                                          const float *__restrict__ shape, const uint8_t *__restrict__ mask,
+                                                          const int32_t *__restrict__ pair_tri, int64_t P,
+                                                          float *__restrict__ ptv, float *__restrict__ pn,
+                                                          float *__restrict__ ps, uint8_t *__restrict__ pm) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int64_t t0 = pair_tri[2 * p], t1 = pair_tri[2 * p + 1];
+    const float *a = tv + 9 * t0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ptv[18 * p + k] = a[k];
+    if (t1 >= 0) {
+        const float *b = tv + 9 * t1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ptv[18 * p + 9 + k] = b[k];
+    } else {  // (v0, v2, v2): shape_vertex<4> reads the quad (v0, v1, v2, v2)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ptv[18 * p + 9 + k] = a[k];
+            ptv[18 * p + 12 + k] = a[6 + k];
+            ptv[18 * p + 15 + k] = a[6 + k];
+        }
+    }
+    const int64_t s1 = t1 >= 0 ? t1 : t0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pn[6 * p + k] = normals[3 * t0 + k];
+        pn[6 * p + 3 + k] = normals[3 * s1 + k];
+    }
+    ps[2 * p] = shape[t0];
+    ps[2 * p + 1] = shape[s1];
+    if (pm) {
+        pm[2 * p] = mask[t0];
+        pm[2 * p + 1] = mask[s1];
+    }
+}
+
+// sorted packed PRIMITIVE rows ((tx nrx + rx) nq^K + sum q_j nq^(K-1-j)) of pair mode -> the 2^K triangle rows of each,
+// in place of rows_decode: table row [i 2^K + c] names triangle pair_tri[q_j][bit_j(c)] at mirror j, and tri_keys[i 2^K + c]
+// is its triangle-level packed key (over the T triangles of the mesh), what drt_trace_paths_beam returns.  Padding:
+//   a repeated primitive row (or a sentinel of the fixed-capacity list): the whole block is -1;
+//   a combination that names the absent second triangle of a single, or one triangle twice in a row (not a candidate of
+//   the reference's graph, graph.rs:400-470): the row is padding for every consumer (all ids < 0), but an id that exists
+//   is stored as -2 - id, so that the pair-block filter (trace_filter_pairblocks_kernel) can still read both triangles
+//   of every primitive from the block's first and last row.
 template <int ORDER>
 __global__ __launch_bounds__(256) void rows_expand_pairs_kernel(const unsigned long long *__restrict__ rows, int64_t n,
-                                                                unsigned long long nq, int32_t *__restrict__ table,
+                                                                unsigned long long nq, const int32_t *__restrict__ pair_tri,
+                                                                unsigned long long T, int32_t *__restrict__ table,
                                                                 unsigned long long *__restrict__ tri_keys) {
     constexpr int COMBOS = 1 << ORDER;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1718,23 +1841,25 @@ __global__ __launch_bounds__(256) void rows_expand_pairs_kernel(const unsigned l
     const int64_t i = g >> ORDER;
     const int c = (int)(g & (COMBOS - 1));
     const unsigned long long key = rows[i];
-    bool bad = (i > 0 && rows[i - 1] == key) || key >= kRowSentinel;
+    const bool dead = (i > 0 && rows[i - 1] == key) || key >= kRowSentinel;  // the whole block
+    bool bad = dead;
     unsigned long long rest = key;
     int32_t id[ORDER];
 #pragma unroll
     for (int j = ORDER - 1; j >= 0; --j) {
         const unsigned long long q = rest / nq;
-        id[j] = (int32_t)(rest - q * nq) * 2 + ((c >> (ORDER - 1 - j)) & 1);
+        id[j] = dead ? -1 : pair_tri[2 * (rest - q * nq) + ((c >> (ORDER - 1 - j)) & 1)];
+        bad = bad || id[j] < 0;
         rest = q;
     }
 #pragma unroll
     for (int j = 1; j < ORDER; ++j) bad = bad || (id[j] == id[j - 1]);
-    unsigned long long tk = rest;  // the pair index
+    unsigned long long tk = rest;  // the (tx, rx) pair index
 #pragma unroll
-    for (int j = 0; j < ORDER; ++j) tk = tk * (2ull * nq) + (unsigned long long)id[j];
+    for (int j = 0; j < ORDER; ++j) tk = tk * T + (unsigned long long)(id[j] < 0 ? 0 : id[j]);
 #pragma unroll
-    for (int j = 0; j < ORDER; ++j) table[g * ORDER + j] = bad ? -1 : id[j];
-    tri_keys[g] = (key >= kRowSentinel) ? ~0ull : tk;
+    for (int j = 0; j < ORDER; ++j) table[g * ORDER + j] = !bad ? id[j] : ((dead || id[j] < 0) ? -1 : -2 - id[j]);
+    tri_keys[g] = bad ? ~0ull : tk;
 }
 
 // keys of the slice's trace are rows of its table: back to packed rows
@@ -1834,16 +1959,36 @@ static BeamMesh beam_mesh(drt_mesh_t m) {
     M.nprim = m->num_triangles / M.scale;
     M.inv_2m = 0.0f;  // set by the driver once the scene magnitude is known (0: no rescaling)
     M.self_loops = 0;
+    M.pair_tri = nullptr;
     return M;
 }
-// the same mesh searched over its coplanar triangle pairs (drt_mesh::beam_pairs == 1)
+// the same TRIANGLE mesh searched over the primitives of the pairing pass (drt_mesh::pair_state == 1): the virtual
+// mesh of 2 P triangles, every primitive a shape-4 quad (a single triangle: the degenerate quad v0 v1 v2 v2)
 static BeamMesh beam_mesh_pairs(drt_mesh_t m) {
-    BeamMesh M = beam_mesh(m);
+    BeamMesh M;
+    M.tv = m->pair_tv;
+    M.normals = m->pair_normals;
+    M.shape = m->pair_shape;
+    M.mask = m->has_mask ? m->pair_mask : nullptr;
     M.scale = 2;
-    M.kind = (m->beam_quad4 == 1) ? 4 : 2;
-    M.nprim = m->num_triangles / 2;
+    M.kind = 4;
+    M.nprim = m->pair_prims;
+    M.inv_2m = 0.0f;
     M.self_loops = 1;
+    M.pair_tri = m->pair_tri;
     return M;
+}
+static BeamClusters beam_clusters_of(const drt_mesh::BeamCache &b) {
+    BeamClusters C;
+    C.order = b.order;
+    C.verts = b.verts;
+    C.planes = b.planes;
+    C.uplanes = b.uplanes;
+    C.sigma = b.sigma;
+    C.boxes = b.boxes;
+    C.subboxes = b.subboxes;
+    C.nclusters = b.clusters;
+    return C;
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -2148,47 +2293,150 @@ extern "C" void drt_debug_beam_counts(unsigned long long *out, int reset) {
 
 extern "C" {
 
-// Clusters for the search's primitives: quads of an assume_quads mesh, triangles, or -- `allow_pairs` and the mesh
-// qualifies (pairable_kernel) -- the coplanar pairs of a triangle mesh.  Cached in the handle per primitive kind; a
-// call that asks for the other kind of the same mesh rebuilds (only A/B runs and tests do that).
-static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stream) {
+// A triangle mesh is searched over the pairing pass's primitives when at least this fraction of its triangles found a
+// partner: a single triangle costs more as a degenerate quad (4 vertices x 4 faces per pyramid test instead of 3 x 3),
+// and the lists shrink like (P / T)^level.
+constexpr double kPairMinFraction = 0.30;
+
+// The pairing pass (once per mesh): candidate successors on the GPU (pair_candidate_kernel), a matching along the fans
+// on the host (chains A -> B -> C ... around a shared first vertex: heads first, then whatever is left -- cycles), the
+// primitive table and the virtual mesh back on the GPU.
+static int32_t pair_triangles(drt_mesh_t mesh, hipStream_t s) {
+    mesh->pair_state = 0;
+    const int64_t T = mesh->num_triangles;
+    if (T < 2 || mesh->assume_quads) return DRT_OK;
+    const size_t a8 = align_up((size_t)T * 8, 256), a4 = align_up((size_t)T * 4, 256);
+    size_t tb = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                    (uint32_t *)nullptr, (size_t)T, 0, 64, nullptr);
+    char *tmp = nullptr;
+    DRT_HIP(hipMalloc(&tmp, 2 * a8 + 3 * a4 + align_up(tb, 256)));
+    auto *hash = reinterpret_cast<uint64_t *>(tmp), *hash_sorted = reinterpret_cast<uint64_t *>(tmp + a8);
+    auto *ids = reinterpret_cast<uint32_t *>(tmp + 2 * a8), *ids_sorted = reinterpret_cast<uint32_t *>(tmp + 2 * a8 + a4);
+    auto *succ_dev = reinterpret_cast<int32_t *>(tmp + 2 * a8 + 2 * a4);
+    char *sort_tmp = tmp + 2 * a8 + 3 * a4;
+    const dim3 grid((unsigned)ceil_div(T, 256));
+    std::vector<int32_t> succ((size_t)T);
+    hipLaunchKernelGGL(pair_keys_kernel, grid, dim3(256), 0, s, mesh->tri_verts, T, hash, ids);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(sort_tmp, tb, hash, hash_sorted, ids, ids_sorted, (size_t)T, 0, 64, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pair_candidate_kernel, grid, dim3(256), 0, s, mesh->tri_verts, mesh->normals,
+                           mesh->has_mask ? mesh->mask : nullptr, T, hash_sorted, ids_sorted, succ_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(succ.data(), succ_dev, (size_t)T * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        mesh->pair_state = -1;
+        return fail(DRT_E_HIP, "triangle pairing pass failed: %s", hipGetErrorString(e));
+    }
+    std::vector<int32_t> partner((size_t)T, -1);  // of a FIRST triangle: its second; of a second triangle: -2
+    std::vector<uint8_t> has_pred((size_t)T, 0);
+    for (int64_t a = 0; a < T; ++a)
+        if (succ[a] >= 0) has_pred[succ[a]] = 1;
+    int64_t quads = 0;
+    auto walk = [&](int64_t a) {
+        while (a >= 0 && partner[a] == -1) {
+            const int64_t b = succ[a];
+            if (b < 0 || partner[b] != -1) break;
+            partner[a] = (int32_t)b;
+            partner[b] = -2;
+            ++quads;
+            a = succ[b];
+        }
+    };
+    for (int64_t a = 0; a < T; ++a)
+        if (!has_pred[a]) walk(a);
+    for (int64_t a = 0; a < T; ++a) walk(a);
+    if ((double)(2 * quads) < kPairMinFraction * (double)T) return DRT_OK;  // pair_state 0: triangle by triangle
+    const int64_t P = T - quads;
+    std::vector<int32_t> table((size_t)(2 * P));
+    int64_t p = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        if (partner[t] == -2) continue;
+        table[2 * p] = (int32_t)t;
+        table[2 * p + 1] = partner[t];  // -1: a single triangle
+        ++p;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align_up(bytes, 256);
+        return at;
+    };
+    const size_t o_tri = take((size_t)P * 8), o_tv = take((size_t)P * 72), o_n = take((size_t)P * 24), o_s = take((size_t)P * 8),
+                 o_m = take((size_t)P * 2);
+    char *blob = nullptr;
+    DRT_HIP(hipMalloc(&blob, off));
+    auto *pair_tri = reinterpret_cast<int32_t *>(blob + o_tri);
+    e = hipMemcpyAsync(pair_tri, table.data(), (size_t)P * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pair_gather_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, s, mesh->tri_verts, mesh->normals,
+                           mesh->shape, mesh->has_mask ? mesh->mask : nullptr, pair_tri, P,
+                           reinterpret_cast<float *>(blob + o_tv), reinterpret_cast<float *>(blob + o_n),
+                           reinterpret_cast<float *>(blob + o_s), reinterpret_cast<uint8_t *>(blob + o_m));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // (`table` is read by the copy until here)
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        mesh->pair_state = -1;
+        return fail(DRT_E_HIP, "triangle pairing pass failed: %s", hipGetErrorString(e));
+    }
+    mesh->pair_blob = blob;
+    mesh->pair_tri = pair_tri;
+    mesh->pair_tv = reinterpret_cast<float *>(blob + o_tv);
+    mesh->pair_normals = reinterpret_cast<float *>(blob + o_n);
+    mesh->pair_shape = reinterpret_cast<float *>(blob + o_s);
+    mesh->pair_mask = reinterpret_cast<uint8_t *>(blob + o_m);
+    mesh->pair_prims = P;
+    mesh->pair_quads = quads;
+    mesh->pair_state = 1;
+    return DRT_OK;
+}
+
+// Clusters for the search's primitives -- slot 0: the caller's (triangles, or the quads of an assume_quads mesh);
+// slot 1 (`allow_pairs`, a triangle mesh, enough pairs): the primitives of the pairing pass.  Each slot is built once
+// and kept until drt_mesh_destroy: NOT thread-safe against other calls on the same handle while it builds (header).
+// `*slot_out`: the slot a search with these flags uses.
+static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stream, int *slot_out = nullptr) {
     DRT_REQUIRE(mesh, "mesh is null");
     hipStream_t s = as_stream(stream);
-    if (mesh->beam_pairs < 0) {  // examine the triangle pairs once per mesh
-        mesh->beam_pairs = 0;
+    if (mesh->assume_quads && mesh->beam_quad4 < 0) {  // examine the quads once per mesh
         mesh->beam_quad4 = 0;
         const int64_t T = mesh->num_triangles;
-        if (T >= 2 && T % 2 == 0) {
-            uint32_t *flag = nullptr, h[2] = {0, 0};
-            DRT_HIP(hipMalloc(&flag, 8));
-            const uint32_t ones[2] = {1, 1};
-            hipError_t e = hipMemcpyAsync(flag, ones, 8, hipMemcpyHostToDevice, s);
+        if (T >= 2) {
+            uint32_t *flag = nullptr, h = 0;
+            DRT_HIP(hipMalloc(&flag, 4));
+            const uint32_t one = 1;
+            hipError_t e = hipMemcpyAsync(flag, &one, 4, hipMemcpyHostToDevice, s);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(pair_shape_kernel, dim3((unsigned)ceil_div(T / 2, 256)), dim3(256), 0, s, mesh->tri_verts,
-                                   mesh->normals, mesh->has_mask ? mesh->mask : nullptr, T / 2, flag);
+                hipLaunchKernelGGL(quad_shape_kernel, dim3((unsigned)ceil_div(T / 2, 256)), dim3(256), 0, s, mesh->tri_verts,
+                                   mesh->normals, T / 2, flag);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             (void)hipFree(flag);
             if (e != hipSuccess) {
-                mesh->beam_pairs = -1;
-                return fail(DRT_E_HIP, "triangle-pair shape check failed: %s", hipGetErrorString(e));
+                mesh->beam_quad4 = -1;
+                return fail(DRT_E_HIP, "quad shape check failed: %s", hipGetErrorString(e));
             }
-            mesh->beam_pairs = h[0] ? 1 : 0;
-            mesh->beam_quad4 = h[1] ? 1 : 0;
+            mesh->beam_quad4 = h ? 1 : 0;
         }
     }
-    const bool pairs = !mesh->assume_quads && allow_pairs && mesh->beam_pairs == 1;
-    const BeamMesh M = pairs ? beam_mesh_pairs(mesh) : beam_mesh(mesh);
-    const int32_t want = M.kind + (pairs ? 16 : 0);  // what the cached clusters were built for
-    if (mesh->beam_blob && mesh->beam_scale == want) return DRT_OK;
-    if (mesh->beam_blob) {  // built for the other primitive kind
-        DRT_HIP(hipStreamSynchronize(s));
-        (void)hipFree(mesh->beam_blob);
-        mesh->beam_blob = nullptr;
-        mesh->beam_scale = 0;
+    if (!mesh->assume_quads && allow_pairs && mesh->pair_state < 0) {
+        const int32_t rcp = pair_triangles(mesh, s);
+        if (rcp != DRT_OK) return rcp;
     }
+    const bool pairs = !mesh->assume_quads && allow_pairs && mesh->pair_state == 1;
+    const int slot = pairs ? 1 : 0;
+    if (slot_out) *slot_out = slot;
+    const BeamMesh M = pairs ? beam_mesh_pairs(mesh) : beam_mesh(mesh);
+    drt_mesh::BeamCache &B = mesh->beam[slot];
+    if (B.blob && B.kind == M.kind) return DRT_OK;
     if (M.nprim == 0) return DRT_OK;
     const int64_t ncl = ceil_div(M.nprim, 64), pp = ncl * 64, sc = M.scale;
     const int64_t nv = (M.kind == 1) ? 3 : (M.kind == 2 ? 6 : 4), np = (M.kind == 2) ? 2 : 1;
@@ -2232,17 +2480,17 @@ static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stre
         if (rc == DRT_OK) {
             float mag;
             memcpy(&mag, &mag_bits, 4);
-            mesh->beam_max_abs = mag;
-            mesh->beam_order = order;
-            mesh->beam_verts = verts;
-            mesh->beam_planes = planes;
-            mesh->beam_uplanes = uplanes;
-            mesh->beam_sigma = sigma;
-            mesh->beam_boxes = boxes;
-            mesh->beam_subboxes = subboxes;
-            mesh->beam_clusters = ncl;
-            mesh->beam_blob = blob;
-            mesh->beam_scale = want;
+            mesh->beam_max_abs = mag;  // (the same vertices in either slot)
+            B.order = order;
+            B.verts = verts;
+            B.planes = planes;
+            B.uplanes = uplanes;
+            B.sigma = sigma;
+            B.boxes = boxes;
+            B.subboxes = subboxes;
+            B.clusters = ncl;
+            B.kind = M.kind;
+            B.blob = blob;
         }
     }
     (void)hipFree(tmp);
@@ -2251,6 +2499,21 @@ static int32_t build_beam_clusters(drt_mesh_t mesh, bool allow_pairs, void *stre
 }
 
 int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream) { return build_beam_clusters(mesh, true, stream); }
+int32_t drt_mesh_build_beam_clusters_ex(drt_mesh_t mesh, int32_t allow_pairs, void *stream) {
+    return build_beam_clusters(mesh, allow_pairs != 0, stream);
+}
+int32_t drt_mesh_beam_pairing_table(drt_mesh_t mesh, int32_t *table_out, int64_t num_primitives, void *stream) {
+    DRT_REQUIRE(mesh && mesh->pair_state == 1, "the mesh is not in pair mode (drt_mesh_beam_pairing)");
+    DRT_REQUIRE(table_out && num_primitives == mesh->pair_prims, "table_out must hold [num_primitives, 2] int32");
+    DRT_HIP(hipMemcpyAsync(table_out, mesh->pair_tri, (size_t)num_primitives * 8, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return DRT_OK;
+}
+int32_t drt_mesh_beam_pairing(drt_mesh_t mesh, int64_t *num_primitives, int64_t *num_pairs) {
+    DRT_REQUIRE(mesh, "mesh is null");
+    if (num_primitives) *num_primitives = mesh->pair_state == 1 ? mesh->pair_prims : 0;
+    if (num_pairs) *num_pairs = mesh->pair_state == 1 ? mesh->pair_quads : 0;
+    return mesh->pair_state;
+}
 
 size_t drt_trace_beam_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_primitives, int32_t order,
                                      const drt_beam_params *bp, int64_t max_paths) {
@@ -2334,13 +2597,14 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     char *sort_tmp = base + L.sort_tmp;
     auto *slice_keys = reinterpret_cast<long long *>(base + L.slice_keys);
 
-    int32_t rc = build_beam_clusters(mesh, !(flags & DRT_BEAM_NO_PAIRS), stream);
+    int slot = 0;
+    int32_t rc = build_beam_clusters(mesh, !(flags & DRT_BEAM_NO_PAIRS), stream, &slot);
     if (rc != DRT_OK) return rc;
     // Coplanar-pair mode: a triangle mesh whose triangles (2i, 2i+1) are the same mirror is searched over its n/2
     // pairs with the quad kernels (pyramid of a pair = union of its triangles' pyramids: what keeps a triangle
     // sequence keeps its pair sequence; a pair may follow itself), a quarter of the level-2 prefixes of a box city;
     // every surviving pair row is then split into its 2^order triangle rows, which the exact trace decides.
-    const bool pairs = !mesh->assume_quads && mesh->beam_scale >= 16;
+    const bool pairs = slot == 1;
     int key_bits_rows = key_bits;  // bits of the keys the row sort sees
     int64_t rows_cap = z.max_rows;
     M = pairs ? beam_mesh_pairs(mesh) : beam_mesh(mesh);  // (the shape of the pairs is known only now)
@@ -2355,15 +2619,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         while (key_bits_rows < 64 && ((unsigned __int128)1 << key_bits_rows) < tq) ++key_bits_rows;
         rows_cap = std::max<int64_t>(z.max_rows >> order, 1);  // the split needs 2^order table rows per pair row
     }
-    BeamClusters C;
-    C.order = mesh->beam_order;
-    C.verts = mesh->beam_verts;
-    C.planes = mesh->beam_planes;
-    C.uplanes = mesh->beam_uplanes;
-    C.sigma = mesh->beam_sigma;
-    C.boxes = mesh->beam_boxes;
-    C.subboxes = mesh->beam_subboxes;
-    C.nclusters = mesh->beam_clusters;
+    const BeamClusters C = beam_clusters_of(mesh->beam[slot]);
 
     // receivers: Morton clusters (also yields the largest |coordinate| of the receivers); transmitters: bounds only
     uint32_t *rx_ids = nullptr, *rx_bounds = nullptr;
@@ -2464,9 +2720,9 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             table_rows = r << order;
             const dim3 ge((unsigned)ceil_div(table_rows, 256));
             auto *tri_keys = reinterpret_cast<unsigned long long *>(rows);
-            if (order == 1) hipLaunchKernelGGL(rows_expand_pairs_kernel<1>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, table, tri_keys);
-            else if (order == 2) hipLaunchKernelGGL(rows_expand_pairs_kernel<2>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, table, tri_keys);
-            else hipLaunchKernelGGL(rows_expand_pairs_kernel<3>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, table, tri_keys);
+            if (order == 1) hipLaunchKernelGGL(rows_expand_pairs_kernel<1>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.pair_tri, (unsigned long long)mesh->num_triangles, table, tri_keys);
+            else if (order == 2) hipLaunchKernelGGL(rows_expand_pairs_kernel<2>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.pair_tri, (unsigned long long)mesh->num_triangles, table, tri_keys);
+            else hipLaunchKernelGGL(rows_expand_pairs_kernel<3>, ge, dim3(256), 0, s, rows_sorted, r, (unsigned long long)M.nprim, M.pair_tri, (unsigned long long)mesh->num_triangles, table, tri_keys);
             row_keys = tri_keys;
         } else {
             const dim3 gr((unsigned)ceil_div(r, 256));
@@ -2671,6 +2927,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
         st->grazing_prefixes = gz;
         st->rows = total_rows;
         st->pair_mode = pairs ? 1 : 0;
+        st->paired_primitives = pairs ? (int32_t)std::min<int64_t>(mesh->pair_quads, 2147483647) : 0;
         st->slices = nslices;
         st->next_probe_prefixes = (hint_min < 4e18) ? (float)std::max(1.0, std::min(hint_min, 1073741824.0)) : 0.0f;
         st->valid = nvalid;
@@ -2725,11 +2982,15 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     const BeamLayout L = beam_layout(z, ntx, nrx, nprim_caller, order, max_paths);
     if (!ws || ws_bytes < L.total) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", L.total);
     DRT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15u) == 0, "workspace must be 16-byte aligned");
-    DRT_REQUIRE(M.nprim == 0 || mesh->beam_blob,
+    // the slot a synchronous call with these flags uses (drt_mesh_build_beam_clusters examines the triangle pairs and
+    // builds that one; drt_mesh_build_beam_clusters_ex(mesh, 0, ...) builds the triangle-by-triangle slot)
+    const bool pairs = !mesh->assume_quads && !(flags & DRT_BEAM_NO_PAIRS) && mesh->pair_state == 1;
+    const int slot = pairs ? 1 : 0;
+    DRT_REQUIRE(M.nprim == 0 || mesh->assume_quads || (flags & DRT_BEAM_NO_PAIRS) || mesh->pair_state >= 0,
                 "the primitive clusters must exist before a no-allocation call: drt_mesh_build_beam_clusters(mesh) once");
-    const bool pairs = !mesh->assume_quads && mesh->beam_scale >= 16;
-    DRT_REQUIRE(M.nprim == 0 || !((flags & DRT_BEAM_NO_PAIRS) && pairs),
-                "DRT_BEAM_NO_PAIRS, but the cached clusters are those of the coplanar pairs (rebuilding would allocate)");
+    DRT_REQUIRE(M.nprim == 0 || mesh->beam[slot].blob,
+                "the primitive clusters of this search (pairs / DRT_BEAM_NO_PAIRS) must exist before a no-allocation call: "
+                "drt_mesh_build_beam_clusters[_ex](mesh) once");
     if ((tp.flags & DRT_TRACE_USE_BVH) && mesh->num_triangles > 0)
         DRT_REQUIRE(drt_mesh_has_bvh(mesh), "DRT_TRACE_USE_BVH: build the LBVH before a no-allocation call (drt_mesh_build_bvh)");
     char *base = reinterpret_cast<char *>(ws);
@@ -2764,15 +3025,7 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     const int64_t rows_cap = pairs ? std::max<int64_t>(z.max_rows >> order, 1) : z.max_rows;
     const int64_t table_rows = pairs ? (rows_cap << order) : rows_cap;
     DRT_REQUIRE(ntx * M.nprim < (1ll << 32) && z.max_entries < (1ll << 32), "record format holds 32-bit prefix indices");
-    BeamClusters C;
-    C.order = mesh->beam_order;
-    C.verts = mesh->beam_verts;
-    C.planes = mesh->beam_planes;
-    C.uplanes = mesh->beam_uplanes;
-    C.sigma = mesh->beam_sigma;
-    C.boxes = mesh->beam_boxes;
-    C.subboxes = mesh->beam_subboxes;
-    C.nclusters = mesh->beam_clusters;
+    const BeamClusters C = beam_clusters_of(mesh->beam[slot]);
 
     uint32_t *rx_ids = nullptr, *rx_bounds = nullptr;
     int32_t rc = morton_order(rx, nrx, 1, base + L.morton, &rx_ids, &rx_bounds, s);
@@ -2834,9 +3087,9 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     if (pairs) {
         const dim3 ge((unsigned)ceil_div(table_rows, 256));
         auto *tri_keys = reinterpret_cast<unsigned long long *>(rows);
-        if (order == 1) hipLaunchKernelGGL(rows_expand_pairs_kernel<1>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, table, tri_keys);
-        else if (order == 2) hipLaunchKernelGGL(rows_expand_pairs_kernel<2>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, table, tri_keys);
-        else hipLaunchKernelGGL(rows_expand_pairs_kernel<3>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, table, tri_keys);
+        if (order == 1) hipLaunchKernelGGL(rows_expand_pairs_kernel<1>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, M.pair_tri, (unsigned long long)mesh->num_triangles, table, tri_keys);
+        else if (order == 2) hipLaunchKernelGGL(rows_expand_pairs_kernel<2>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, M.pair_tri, (unsigned long long)mesh->num_triangles, table, tri_keys);
+        else hipLaunchKernelGGL(rows_expand_pairs_kernel<3>, ge, dim3(256), 0, s, rows_sorted, rows_cap, (unsigned long long)M.nprim, M.pair_tri, (unsigned long long)mesh->num_triangles, table, tri_keys);
         row_keys = tri_keys;
     } else {
         const dim3 gr((unsigned)ceil_div(rows_cap, 256));

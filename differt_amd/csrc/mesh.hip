@@ -117,7 +117,9 @@ int32_t drt_mesh_destroy(drt_mesh_t m) {
     (void)hipFree(m->mask);
     (void)hipFree(m->bvh_nodes);
     (void)hipFree(m->bvh_leaf_ids);
-    (void)hipFree(m->beam_blob);
+    (void)hipFree(m->beam[0].blob);
+    (void)hipFree(m->beam[1].blob);
+    (void)hipFree(m->pair_blob);
     delete m;
     return DRT_OK;
 }

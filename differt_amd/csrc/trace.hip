@@ -233,21 +233,23 @@ __global__ __launch_bounds__(256) void trace_filter_ragged_kernel(TraceArgs a, C
 }
 
 // Stage A for a per-pair table of COPLANAR-PAIR BLOCKS (DRT_CAND_PAIR_BLOCKS, include/differt_amd.h): lane = block
-// of 2^K rows that name the triangle choices 2 q_j + bit_j(c) of one pair sequence.  Both triangles of a pair are the
-// same mirror (equal first vertex, equal unit normal up to the sign of zero components), so all rows of the block have
-// the same images and reflection points as VALUES: the image method is sums, products and guarded quotients of the
-// mirror's point and normal, none of which turns the sign of a zero into a different number, and every later decision
-// (Moller-Trumbore's ranges with its |a| > eps guard, jnp.sign of the same-side test, the squared lengths, isfinite)
-// is a comparison, which does not see that sign either.  The chain is evaluated ONCE with the even triangle's mirror,
-// Moller-Trumbore runs against both triangles of every pair, and row c survives iff its triangle passes at every
-// mirror -- the decisions trace_filter_ragged_kernel takes row by row (8 chains at order 3), the same queue of global
-// table rows.  Stage B and the emit stage read each surviving row's own triangles from the table, as before.
+// of 2^K rows that name the triangle choices (first or second triangle, bit_j(c)) of one sequence of primitives, each a
+// pair of triangles that are the same mirror (equal first vertex, equal unit normal up to the sign of zero components)
+// or a single triangle.  All rows of the block have the same images and reflection points as VALUES: the image method
+// is sums, products and guarded quotients of the mirror's point and normal, none of which turns the sign of a zero into
+// a different number, and every later decision (Moller-Trumbore's ranges with its |a| > eps guard, jnp.sign of the
+// same-side test, the squared lengths, isfinite) is a comparison, which does not see that sign either.  The chain is
+// evaluated ONCE with the first triangle's mirror, Moller-Trumbore runs against both triangles of every pair, and row c
+// survives iff its triangle passes at every mirror -- the decisions trace_filter_ragged_kernel takes row by row (8 chains
+// at order 3), the same queue of global table rows.  Stage B and the emit stage read each surviving row's own triangles
+// from the table, as before.  The block's FIRST row names the first triangles, its LAST row the second ones; an id of a
+// padding row is stored as -2 - id (beam.hip, rows_expand_pairs_kernel), -1 = no such triangle / a whole padding block.
+__device__ __forceinline__ int32_t pairblock_id(int32_t x) { return (x >= 0) ? x : ((x == -1) ? -1 : -2 - x); }
 template <int K>
 __global__ __launch_bounds__(256) void trace_filter_pairblocks_kernel(TraceArgs a, CandSrc cs,
                                                                       unsigned long long *__restrict__ q_count,
                                                                       long long *__restrict__ queue, int64_t q_cap) {
     constexpr int COMBOS = 1 << K;
-    constexpr int C_ALT = (K >= 2 ? (1 << (K - 2)) : 0) | (K >= 4 ? (1 << (K - 4)) : 0);  // bits 0,1,0,1: never a repeat
     const int lane = threadIdx.x & 63;
     const int64_t nblocks = cs.count >> K;
     for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < nblocks; b0 += (int64_t)gridDim.x * 256) {
@@ -260,23 +262,23 @@ __global__ __launch_bounds__(256) void trace_filter_pairblocks_kernel(TraceArgs 
             if (cs.pair_offsets[mid] <= g0) lo = mid; else hi = mid;
         }
         const int64_t it = lo / a.nrx, ir = lo - it * a.nrx;
-        // the pairs, from the row whose bits alternate (a padding row only when the whole block is padding)
-        int32_t q[K];
+        int32_t t0[K], t1[K];  // the two triangles of every primitive (t1 = -1: a single triangle)
         bool ok = in_range;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int32_t id = cs.table[(g0 + C_ALT) * K + j];
-            ok = ok && id >= 0 && (int64_t)(id | 1) < a.T;
-            q[j] = ok ? (id >> 1) : 0;
+            t0[j] = pairblock_id(cs.table[g0 * K + j]);
+            t1[j] = pairblock_id(cs.table[(g0 + COMBOS - 1) * K + j]);
+            ok = ok && t0[j] >= 0 && (int64_t)t0[j] < a.T && (int64_t)t1[j] < a.T;
+            if (!ok) t0[j] = 0, t1[j] = -1;
         }
         V3 p[K], n[K];
         bool active = true;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int64_t s = 2 * (int64_t)q[j];
+            const int64_t s = (int64_t)t0[j];
             p[j] = ld3(a.tri_verts + 9 * s);
             n[j] = ld3(a.normals + 3 * s);
-            if (a.mask) active = active && (a.mask[s] != 0) && (a.mask[s + 1] != 0);
+            if (a.mask) active = active && (a.mask[s] != 0) && (t1[j] < 0 || a.mask[t1[j]] != 0);
         }
         V3 full[K + 2];
         full[0] = ld3(a.tx + 3 * it);
@@ -297,10 +299,11 @@ __global__ __launch_bounds__(256) void trace_filter_pairblocks_kernel(TraceArgs 
             if (!__any(alive)) break;
             const V3 o = full[j];
             const V3 d = full[j + 1] - full[j];
-            const float *tv = a.tri_verts + 18 * (int64_t)q[j];
             float t;
-            const bool h0 = moller_trumbore(o, d, load_tri(tv), a.eps, t);
-            const bool h1 = moller_trumbore(o, d, load_tri(tv + 9), a.eps, t);
+            const bool h0 = moller_trumbore(o, d, load_tri(a.tri_verts + 9 * (int64_t)t0[j]), a.eps, t);
+            // (a single triangle: the test runs on the first triangle again and is masked -- no divergent branch)
+            const bool h1 = moller_trumbore(o, d, load_tri(a.tri_verts + 9 * (int64_t)(t1[j] >= 0 ? t1[j] : t0[j])), a.eps, t) &&
+                            t1[j] >= 0;
             hit[j] = (h0 ? 1u : 0u) | (h1 ? 2u : 0u);
             alive = alive && hit[j] != 0u;
         }
@@ -325,7 +328,10 @@ __global__ __launch_bounds__(256) void trace_filter_pairblocks_kernel(TraceArgs 
             for (int j = 0; j < K; ++j) {
                 const uint32_t bit = (uint32_t)(c >> (K - 1 - j)) & 1u;
                 v = v && ((hit[j] >> bit) & 1u);
-                if (j > 0) v = v && !(q[j] == q[j - 1] && bit == ((uint32_t)(c >> (K - j)) & 1u));
+                if (j > 0) {  // no triangle named twice in a row
+                    const uint32_t pbit = (uint32_t)(c >> (K - j)) & 1u;
+                    v = v && ((bit ? t1[j] : t0[j]) != (pbit ? t1[j - 1] : t0[j - 1]));
+                }
             }
             rows |= v ? (1u << c) : 0u;
         }

@@ -171,6 +171,20 @@ class Mesh:
         of a freed handle can come back with the next snapshot."""
         return self.handle().generation
 
+    def beam_pairing(self) -> dict:
+        """What the pruned tracer's pairing pass makes of this (triangle) mesh (``drt_mesh_build_beam_clusters`` +
+        ``drt_mesh_beam_pairing``; built on first use, cached in the native handle): ``pair_mode`` -- the search runs
+        over ``primitives`` < ``num_triangles`` primitives, ``pairs`` of them coplanar triangle pairs (two triangles
+        ``(v0, v1, v2)``, ``(v0, v2, v3)`` anywhere in the mesh that are the same mirror for the reference, convex
+        union) -- or triangle by triangle (too few pairs, or ``assume_quads``, whose quads are the primitives)."""
+        h = self.handle().h
+        if self.triangles.shape[0]:
+            _lib.call("drt_mesh_build_beam_clusters", h, stream())
+        prims, pairs = C.c_int64(0), C.c_int64(0)
+        state = _lib.load().drt_mesh_beam_pairing(h, C.byref(prims), C.byref(pairs))
+        return {"pair_mode": state == 1, "primitives": int(prims.value) if state == 1 else self.num_primitives,
+                "pairs": int(pairs.value)}
+
     # ---- reference properties ----
     @property
     def num_triangles(self) -> int:

@@ -616,9 +616,12 @@ class ExhaustivePathTracer(AbstractPathTracer):
         ``(t * n + m) % world == rank``: the multi-GPU split of
         ``differt_amd.distributed.trace_beam_pruned_sharded`` -- every valid path has exactly one level-1
         prefix, so the shards' results partition the full result; rank 0 owns the line-of-sight paths.
-        ``pairs=False`` (``DRT_BEAM_NO_PAIRS``) searches a triangle mesh triangle by triangle even when its triangles
-        ``(2i, 2i+1)`` are coplanar pairs (same mirror bit for bit: the walls of a box city), which the search otherwise
-        runs over -- the same result either way (tested), a quarter of the level-2 prefixes.  In that mode the exact
+        ``pairs=False`` (``DRT_BEAM_NO_PAIRS``) searches a triangle mesh triangle by triangle even when the pairing pass
+        found coplanar pairs (two triangles ``(v0, v1, v2)``, ``(v0, v2, v3)`` anywhere in the mesh with equal unit
+        normals, first vertices and mask values and a convex union: the same mirror bit for bit -- the walls of a box
+        city, the walls and consecutive roof ears of the reference's bruxelles.obj), which the search otherwise runs
+        over as single primitives -- the same result either way (tested), a quarter of the level-2 prefixes on a box
+        city.  In that mode the exact
         trace evaluates the image chain once per surviving pair row and tests both triangles of every pair
         (``DRT_CAND_PAIR_BLOCKS``); ``rows="plain"`` (``DRT_BEAM_ROWS_PLAIN``) traces the ``2**order`` triangle rows one
         by one instead -- the same result (tested)."""
@@ -665,6 +668,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
         self.last_beam_stats = {"unit_m": st.unit_m, "magnitude": st.magnitude, "levels": [int(x) for x in st.levels[:max(order, 1)]],
                                 "rows": int(st.rows), "chunks": int(st.slices), "valid": int(st.valid),
                                 "grazing_prefixes": int(st.grazing_prefixes), "pair_mode": bool(st.pair_mode),
+                                "paired_primitives": int(st.paired_primitives),
                                 "expand_last_ms": float(st.expand_last_ms), "emit_ms": float(st.emit_ms),
                                 "trace_ms": float(st.trace_ms)}
         if order >= 2 and st.next_probe_prefixes >= 1.0:
@@ -703,10 +707,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
         if out is None:
             lib = _lib.load()
             if mesh.num_primitives:
-                if not pairs:  # the handle caches ONE kind of clusters: make it the triangles' through a tiny sync call
-                    self.trace_beam_pruned(Scene_like(scene, tx[:1], rx[:1]), max(order, 1), pairs=False, max_paths=16)
-                else:
-                    _lib.call("drt_mesh_build_beam_clusters", h, stream())
+                # (the handle keeps both kinds of clusters once built, each at a fixed address: a captured graph stays valid)
+                _lib.call("drt_mesh_build_beam_clusters_ex", h, 1 if pairs else 0, stream())
                 if self.accel == "bvh":
                     _lib.call("drt_mesh_build_bvh", h, stream())
             nbytes = lib.drt_trace_beam_workspace_size(tx.shape[0], rx.shape[0], mesh.num_primitives, order, C.byref(beam),
@@ -716,6 +718,18 @@ class ExhaustivePathTracer(AbstractPathTracer):
                    "objects": torch.empty((max_paths, order + 2), dtype=torch.int32, device=dev),
                    "counts": torch.zeros(4, dtype=torch.int64, device=dev),
                    "workspace": torch.empty(nbytes, dtype=torch.uint8, device=dev)}
+        else:  # reused buffers: the C side writes max_paths rows into whatever it is given
+            need = _lib.load().drt_trace_beam_workspace_size(tx.shape[0], rx.shape[0], mesh.num_primitives, order,
+                                                             C.byref(beam), int(max_paths))
+            want = {"keys": ((max_paths,), torch.int64), "vertices": ((max_paths, order + 2, 3), torch.float32),
+                    "objects": ((max_paths, order + 2), torch.int32), "counts": ((4,), torch.int64)}
+            for name, (shape, dtype) in want.items():
+                t = out[name]
+                if tuple(t.shape) != shape or t.dtype != dtype or t.device != dev or not t.is_contiguous():
+                    raise ValueError(f"out[{name!r}] must be a contiguous {dtype} tensor of shape {shape} on {dev}, "
+                                     f"got {tuple(t.shape)} {t.dtype} {t.device}")
+            if out["workspace"].numel() < need or out["workspace"].device != dev:
+                raise ValueError(f"out['workspace'] holds {out['workspace'].numel()} bytes, this call needs {need}")
         ws = out["workspace"]
         _lib.call("drt_trace_paths_beam_async", h, C.byref(params), C.byref(beam), ptr(tx), tx.shape[0], ptr(rx),
                   rx.shape[0], order, int(max_paths), ptr(out["keys"]), ptr(out["vertices"]), ptr(out["objects"]),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRT_ABI_VERSION 6
+#define DRT_ABI_VERSION 7
 
 enum {
     DRT_OK = 0,
@@ -543,8 +543,9 @@ typedef struct drt_beam_stats {
                                  (they were kept, never dropped) -- informational */
     float unit_m;             /* u = kappa * ulp(largest coordinate magnitude), metres */
     float magnitude;          /* that magnitude */
-    int32_t pair_mode;        /* 1: a triangle mesh searched over its coplanar pairs (levels[] count pair prefixes) */
-    int32_t reserved;
+    int32_t pair_mode;        /* 1: a triangle mesh searched over the primitives of the pairing pass (levels[] count
+                                 prefixes of those primitives) */
+    int32_t paired_primitives; /* pair mode: primitives that are coplanar PAIRS (the others are single triangles) */
     float expand_last_ms;     /* HIP-event time of the last expansion's kernels (all slices), */
     float emit_ms;            /*   of the receiver stage, */
     float trace_ms;           /*   of the fused trace of the candidate rows (sort / decode included) */
@@ -558,15 +559,21 @@ typedef struct drt_beam_stats {
 #define DRT_BEAM_EXPAND_PLAIN 1   /* expansion: every (prefix, primitive) pair tested, no cluster culling */
 #define DRT_BEAM_EMIT_PLAIN 2     /* receiver stage: lane = prefix walks the receivers (after a vote on their clusters' boxes) */
 #define DRT_BEAM_EMIT_CLUSTERED 4 /* receiver stage: Morton clusters of 64 even below 128 receivers */
-#define DRT_BEAM_NO_PAIRS 8        /* triangle meshes: search triangle by triangle even when (2i, 2i+1) are coplanar pairs */
-#define DRT_BEAM_ROWS_PLAIN 16    /* coplanar-pair mode: trace the 2^order triangle rows of a pair row one by one instead
+#define DRT_BEAM_NO_PAIRS 8        /* triangle meshes: search triangle by triangle even when the pairing pass found pairs */
+#define DRT_BEAM_ROWS_PLAIN 16    /* coplanar-pair mode: trace the 2^order triangle rows of a primitive row one by one instead
                                      of as one DRT_CAND_PAIR_BLOCKS block (A/B and cross-check; same result) */
 /* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on).
- * COPLANAR PAIRS (round 4): on a triangle mesh (assume_quads == 0) whose triangles 2i and 2i+1 have equal (==)
- * unit normals, first vertices and mask values -- the two halves of a wall of a box city -- both triangles are the
- * same mirror for the reference's arithmetic, so the prefix search runs over the n/2 PAIRS (a quarter of the level-2
- * prefixes) and every surviving pair row is split into its 2^order triangle rows for the exact trace.  Same paths,
- * same keys / order / vertex bits; levels[] and grazing_prefixes of drt_beam_stats then count pair prefixes. */
+ * COPLANAR PAIRS (round 4; per primitive and for triangle soups since round 5, ABI 7): on a triangle mesh
+ * (assume_quads == 0) two triangles A = (v0, v1, v2) and B = (v0, v2, v3) -- ANYWHERE in the triangle array -- with equal
+ * (==) unit normals, the same first vertex and the same mask value are the same mirror for the reference's arithmetic
+ * (plane point and normal are all the image method reads of a triangle, _solvers.py:552-562); when v0 v1 v2 v3 is convex
+ * they are searched as ONE primitive with one 4-face pyramid.  drt_mesh_build_beam_clusters runs the pairing pass (a
+ * matching along the fans around shared first vertices: the two halves of a wall, consecutive ears of a roof polygon);
+ * triangles without a partner stay single-triangle primitives in the same list; when at least 30 % of the triangles
+ * found a partner the prefix search runs over these P < n primitives, and every surviving primitive row is split into
+ * its (at most 2^order) triangle rows for the exact trace.  Same paths, same keys / order / vertex bits as the
+ * triangle-by-triangle search (DRT_BEAM_NO_PAIRS); levels[] and grazing_prefixes of drt_beam_stats then count
+ * prefixes of primitives.  The reference's bruxelles.obj (14 206 triangles): 5 829 pairs, 8 377 primitives. */
 
 typedef struct drt_beam_params {
     float kappa;            /* error unit u = kappa * ulp(M); <= 0: default 64 = the worst-case rounding count of
@@ -588,20 +595,36 @@ typedef struct drt_beam_params {
 #define DRT_CAND_PACKED_KEYS 4 /* drt_candidates.reserved bit: keys ARE the candidates (see above) */
 /* drt_candidates.reserved bit, PER-PAIR TABLE only (table != NULL, pair_offsets != NULL, mesh without assume_quads):
  * COPLANAR-PAIR BLOCKS.  The table consists of blocks of 2^order consecutive rows; block b enumerates the triangle
- * choices of ONE sequence of triangle pairs (q_0 .. q_{order-1}): row b 2^order + c names triangles
- * 2 q_j + bit_j(c), bit_j(c) = (c >> (order-1-j)) & 1, or is a padding row of -1 (a whole padding block, or a choice
- * that names one triangle twice in a row); every pair_offsets entry is a multiple of 2^order; and triangles 2q and
- * 2q+1 of every named pair are THE SAME MIRROR: equal (==) unit normals, equal first vertices, equal mask values
- * (what drt_mesh_build_beam_clusters establishes before drt_trace_paths_beam searches a triangle mesh over its pairs).
- * All 2^order rows of a block then share every image and reflection point -- the mirror (first vertex, normal) is the
+ * choices of ONE sequence of primitives (q_0 .. q_{order-1}), each a pair of triangles (first, second) or a single
+ * triangle: row b 2^order + c names, at mirror j, the first (bit_j(c) = 0) or second (1) triangle of q_j, with
+ * bit_j(c) = (c >> (order-1-j)) & 1.  A row that is not a candidate (it names the missing second triangle of a single,
+ * or one triangle twice in a row) is a PADDING row: all its ids are negative -- -1 for a triangle that does not exist,
+ * -2 - id for one that does, so that the block's first and last row always show both triangles of every primitive; a
+ * whole padding block is all -1.  Every pair_offsets entry is a multiple of 2^order; and the two triangles of every
+ * pair are THE SAME MIRROR: equal (==) unit normals, equal first vertices, equal mask values (what
+ * drt_mesh_build_beam_clusters establishes before drt_trace_paths_beam searches a triangle mesh over its pairs).
+ * All rows of a block then share every image and reflection point -- the mirror (first vertex, normal) is the
  * only thing the image method reads of a triangle, _solvers.py:552-562 -- and differ in the inside tests alone: the
  * filter stage evaluates the chain ONCE per block and Moller-Trumbore against both triangles of each pair.  Same
  * survivors, same keys (global table rows), same vertices as without the bit (those are computed per row from the
  * row's own triangles). */
 #define DRT_CAND_PAIR_BLOCKS 8
 
-/* Morton clusters of the mesh's primitives (allocates, synchronises; implied by drt_trace_paths_beam) */
+/* Morton clusters of the mesh's primitives (allocates, synchronises; implied by drt_trace_paths_beam).  On a triangle
+ * mesh the first call also runs the pairing pass.  The handle keeps up to two sets of clusters -- the pairing pass's
+ * primitives and (`allow_pairs` = 0, what a DRT_BEAM_NO_PAIRS search uses) the plain triangles -- each built once and
+ * never freed or moved before drt_mesh_destroy: a captured HIP graph may hold their addresses.
+ * THREADS: these calls (and the first drt_trace_paths_beam / drt_mesh_build_bvh on a handle, which imply them) WRITE
+ * to the handle; they must not run concurrently with any other call on the same handle.  Once built, any number of host
+ * threads may trace through one handle on their own streams (tests/abi/abi_threads.cpp). */
 int32_t drt_mesh_build_beam_clusters(drt_mesh_t mesh, void *stream);
+int32_t drt_mesh_build_beam_clusters_ex(drt_mesh_t mesh, int32_t allow_pairs, void *stream);
+/* What the pairing pass found: returns -1 (not run yet), 0 (too few pairs: the search runs triangle by triangle) or
+ * 1 (pair mode), and the number of primitives / of pairs among them (0 unless pair mode).  Not a status code. */
+int32_t drt_mesh_beam_pairing(drt_mesh_t mesh, int64_t *num_primitives, int64_t *num_pairs);
+/* pair mode: the primitive table, i32 [num_primitives, 2] (DEVICE): the two triangles of each primitive, second = -1
+ * for a single triangle; every triangle of the mesh appears exactly once */
+int32_t drt_mesh_beam_pairing_table(drt_mesh_t mesh, int32_t *table_out, int64_t num_primitives, void *stream);
 size_t drt_trace_beam_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_primitives, int32_t order,
                                      const drt_beam_params *beam, int64_t max_paths);
 int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *params, const drt_beam_params *beam,

@@ -12,6 +12,11 @@ Outputs (committed):
   reference_goldens.json  the known-answer tables of the reference's tests, as plain numbers, each
                           with the file:line it comes from.
 
+  bruxelles.npz, manhattan.npz, manhattan_small.npz
+                          geometry arrays (vertices f32[V,3], triangles i32[T,3]) of the reference's in-tree
+                          meshes docs/source/notebooks/*.obj read by the same rule -- bruxelles.obj is the mesh
+                          of the reference's own benchmark harness (differt/tests/benchmarks/fixtures.py:43-68).
+
 Fixtures are data (inputs + expected outputs), never reference source text.
 """
 
@@ -19,6 +24,8 @@ from __future__ import annotations
 
 import json
 from pathlib import Path
+
+import numpy as np
 
 REF = Path("/root/reference")
 OUT = Path(__file__).resolve().parent
@@ -55,6 +62,13 @@ def main() -> None:
             }
         )
     )
+
+    for name in ("bruxelles", "manhattan", "manhattan_small"):
+        mv, mt, msk = read_obj_triangles_only(REF / "docs/source/notebooks" / f"{name}.obj")
+        # float32 as Mesh.from_core makes them (ME: jnp.asarray of the core mesh's f32 vertices), int32 indices
+        np.savez_compressed(OUT / f"{name}.npz", vertices=np.asarray(mv, np.float32), triangles=np.asarray(mt, np.int32),
+                            skipped_non_triangle_faces=np.int32(msk))
+        print(f"wrote {OUT / (name + '.npz')} ({len(mv)} vertices, {len(mt)} triangles, {msk} skipped)")
 
     goldens = {
         # differt/tests/geometry/fixtures.py:64-71

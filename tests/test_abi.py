@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert not unbound, f"declared in the header but no ctypes signature: {unbound}"
     stale = [s for s in _lib._SIGNATURES if s not in declared]
     assert not stale, f"ctypes signature without a declaration in the header: {stale}"
-    assert L.drt_abi_version() == _lib.ABI_VERSION == 6
+    assert L.drt_abi_version() == _lib.ABI_VERSION == 7
     assert f"#define DRT_ABI_VERSION {_lib.ABI_VERSION}" in _lib.HEADER_PATH.read_text()
 
 

@@ -18,7 +18,8 @@ MEMSET_ALLOWED = {
     "trace.hip": 1,  # drt_trace_paths_compact (reads its counters back)
 }
 DEFAULT_SORT_ALLOWED = {
-    "beam.hip": 5,   # three temp-size queries + the two sorts of the SYNCHRONOUS drt_trace_paths_beam
+    "beam.hip": 7,   # three temp-size queries + the two sorts of the SYNCHRONOUS drt_trace_paths_beam + query and sort of
+                     # the pairing pass (pair_triangles: allocates, synchronises, once per mesh)
     "bvh.hip": 2,    # drt_mesh_build_bvh
     "trace.hip": 2,  # temp-size query + the sort of the SYNCHRONOUS drt_trace_paths_compact
 }
