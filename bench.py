@@ -169,7 +169,9 @@ def compact_line(full: dict, sidecar: str | None) -> dict:
         if isinstance(real, dict) and "error" not in real:
             summ["bruxelles_order2_s"] = _get(real, "bruxelles", "beam_order2", "s_per_step")
             summ["bruxelles_order3_s"] = _get(real, "bruxelles", "beam_order3", "s_per_step")
-            summ["bruxelles_pair_prims"] = _get(real, "bruxelles", "paired_primitives")
+            summ["bruxelles_order3_triangles_s"] = _get(real, "bruxelles", "beam_order3_triangles", "s_per_step")
+            summ["bruxelles_pairs"] = _get(real, "bruxelles", "paired_primitives")
+            summ["bruxelles_same_as_exhaustive"] = _get(real, "bruxelles", "beam_order2", "same_valid_paths_as_exhaustive")
         out["paths"] = {k: _r(v) for k, v in summ.items()}
     elif isinstance(p, dict):
         out["paths"] = {"error": str(p["error"])[:200]}

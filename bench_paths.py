@@ -124,6 +124,14 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
             out["reference_api"] = bench_dense.legs()
         except Exception as exc:  # noqa: BLE001
             out["reference_api"] = {"error": repr(exc)}
+    if rank == 0 and world == 1 and num_ranks is None and order == 2:
+        # the reference's own meshes (bruxelles.obj = the mesh of its benchmark harness): harness shapes + pruned orders 2 / 3
+        try:
+            import bench_real
+
+            out["real_meshes"] = bench_real.run()
+        except Exception as exc:  # noqa: BLE001
+            out["real_meshes"] = {"error": repr(exc)}
     if cpu_sample and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_sample_rate(V, Tr, tx, rx, order, n)
     return out

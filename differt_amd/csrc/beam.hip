@@ -379,7 +379,7 @@ __device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, cons
     float h = kInf;
 #pragma unroll
     for (int t = 0; t < Sh::NP; ++t) h = fminf(h, plane_dist(c.I, V3{pl[t][0], pl[t][1], pl[t][2]}, pl[t][3]));
-#ifdef BEAM_LAB_NO_PRIM_EPS
+#if defined(DRT_LAB) && defined(BEAM_LAB_NO_PRIM_EPS)
     const float eps_c = 0.0f * (sigma + D2 + h);
 #else
     const float eps_c = beam_eps(c.u, sigma, __builtin_amdgcn_sqrtf(D2) * 1.000001f, h);
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
 // the work drops from one ~150-instruction test per primitive to one box test per 64 primitives plus full-lane
 // tests of the clusters its cones actually reach.
 // ---------------------------------------------------------------------------------------------
-#ifdef BEAM_LAB_COUNT
+#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
 __device__ unsigned long long beam_dbg[8];  // [0] box tests, [1] surviving pairs, [2] pairs with >= 1 child, [3] children, [4..6] pairs by bound, [7] sub-boxes passing
 #endif
 struct BeamClusters {
@@ -909,7 +909,7 @@ __device__ __forceinline__ void expand_clustered_body(
         // bound of the candidates' own eps over the cluster: smallest plane distance of the apex over the
         // cluster's triangles (the SAME expression the per-primitive test evaluates), farthest box corner
         float hmin = kInf;
-#ifndef BEAM_LAB_NO_HMIN
+#if !(defined(DRT_LAB) && defined(BEAM_LAB_NO_HMIN))
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the LDS writes above precede the reads below
         __builtin_amdgcn_wave_barrier();
         // non-negative floats order like their bit patterns, NaN patterns lie above +inf: an unsigned integer minimum
@@ -931,7 +931,7 @@ __device__ __forceinline__ void expand_clustered_body(
         const V3 far = V3{fmaxf(__builtin_fabsf(ctx.I.x - lo[0]), __builtin_fabsf(ctx.I.x - hi[0])),
                           fmaxf(__builtin_fabsf(ctx.I.y - lo[1]), __builtin_fabsf(ctx.I.y - hi[1])),
                           fmaxf(__builtin_fabsf(ctx.I.z - lo[2]), __builtin_fabsf(ctx.I.z - hi[2]))};
-#ifdef BEAM_LAB_NO_HMIN
+#if defined(DRT_LAB) && defined(BEAM_LAB_NO_HMIN)
         const float eps_max = 0.0f;
 #else
         const float eps_max = beam_eps(ctx.u, bx[6], margin_len(far) * 1.0001f, hmin);  // ctx.u: the prefix's own unit
@@ -946,7 +946,7 @@ __device__ __forceinline__ void expand_clustered_body(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float slo[3] = {sb[6 * q], sb[6 * q + 1], sb[6 * q + 2]}, shi[3] = {sb[6 * q + 3], sb[6 * q + 4], sb[6 * q + 5]};
-#ifdef BEAM_LAB_COUNT
+#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
                 const bool sq = !box_pruned<SCALE, LEVEL>(ctx, slo, shi, eps_max);
                 sub = sub || sq;
                 const unsigned long long sv = __ballot(alive && sq);
@@ -958,7 +958,7 @@ __device__ __forceinline__ void expand_clustered_body(
             alive = alive && sub;
         }
         unsigned long long todo = __ballot(alive);
-#ifdef BEAM_LAB_COUNT
+#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
         if (lane == 0) {
             atomicAdd(&beam_dbg[0], (unsigned long long)__popcll(__ballot(have)));
             atomicAdd(&beam_dbg[1], (unsigned long long)__popcll(todo));
@@ -985,7 +985,7 @@ __device__ __forceinline__ void expand_clustered_body(
             const BeamCtx<SCALE, LEVEL> cx = lane_bcast<SCALE, LEVEL>(ctx, l);
             const bool cand = act && (p != __builtin_amdgcn_readlane(m, l) || self_ok);
             const bool keep = cand && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg, cand);
-#ifdef BEAM_LAB_COUNT
+#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
             {
                 const unsigned long long kv = __ballot(keep);
                 if (lane == 0) {
@@ -2280,7 +2280,7 @@ static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, 
 
 }  // namespace
 
-#ifdef BEAM_LAB_COUNT
+#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
 extern "C" void drt_debug_beam_counts(unsigned long long *out, int reset) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(drt::beam_dbg), sizeof(unsigned long long) * 8);
@@ -2376,7 +2376,8 @@ static int32_t pair_triangles(drt_mesh_t mesh, hipStream_t s) {
         hipLaunchKernelGGL(pair_gather_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, s, mesh->tri_verts, mesh->normals,
                            mesh->shape, mesh->has_mask ? mesh->mask : nullptr, pair_tri, P,
                            reinterpret_cast<float *>(blob + o_tv), reinterpret_cast<float *>(blob + o_n),
-                           reinterpret_cast<float *>(blob + o_s), reinterpret_cast<uint8_t *>(blob + o_m));
+                           reinterpret_cast<float *>(blob + o_s),
+                           mesh->has_mask ? reinterpret_cast<uint8_t *>(blob + o_m) : nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);  // (`table` is read by the copy until here)

@@ -52,11 +52,11 @@ constexpr int kDenseStageDwords = 5 * 64 * 4;  // LDS triangle staging per wave:
 // one wait state, and LLVM's hazard recogniser does not look inside inline asm -- the `s_nop 0` covers it
 // whatever the scheduler places after the store (one issue cycle per 1-KiB wave store).
 __device__ __forceinline__ void store_nt_b128(char *base, uint32_t off, f32x4 v) {
-#if defined(DRT_LAB_AGPR_STORE)
+#if defined(DRT_LAB) && defined(DRT_LAB_AGPR_STORE)
     // experiment: the same store sourced from accumulation registers -- separates "the store's
     // data movement blocks the SIMD's VALU issue" from "VGPR read-port contention"
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "a"(v), "s"(base) : "memory");
-#elif defined(DRT_LAB_SETPRIO)
+#elif defined(DRT_LAB) && defined(DRT_LAB_SETPRIO)
     asm volatile("s_setprio 3\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0\n\ts_setprio 0" : : "v"(off), "v"(v), "s"(base) : "memory");
 #else
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
@@ -594,11 +594,15 @@ static int32_t dense_launch(const float *ro, const float *rd, int64_t R, const f
     // Measured on the literal configs[1] launch (256 rays, inside a HIP graph, with the LDS-staged triangle
     // loads): 7.5 / 7.4 / 9.2 us at 640 / 1280 / 2560 blocks; 1024 rays: 20.1 / 17.9 / 18.5 us
     // (profiles/r02/literal_lab.txt).  Upper bound 32: 0.806 ms vs 0.83 ms at 64 on the bench shape.
-    static const int64_t target_blocks = [] {  // experiment hook: DRT_DENSE_BLOCKS=<n> (default 1280)
+#ifdef DRT_LAB  // lab builds only (-DDRT_LAB): DRT_DENSE_BLOCKS=<n>
+    static const int64_t target_blocks = [] {
         const char *e = getenv("DRT_DENSE_BLOCKS");
         const long v = e ? atol(e) : 0;
         return (int64_t)(v > 0 ? v : 1280);
     }();
+#else
+    constexpr int64_t target_blocks = 1280;
+#endif
     int64_t rpb = (R * cols * B) / target_blocks;
     if (rpb < 1) rpb = 1;
     if (rpb > 32) rpb = 32;
@@ -609,12 +613,15 @@ static int32_t dense_launch(const float *ro, const float *rd, int64_t R, const f
     DRT_REQUIRE(T <= (1ll << 24), "too many triangles per row for one launch (%lld)", (long long)T);
     dim3 grid((unsigned)rows, (unsigned)cols, (unsigned)B);
     hipStream_t s = as_stream(stream);
-    // coalesced LDS staging of the triangles needs 16-B aligned rows of 4 triangles (experiment hook:
-    // DRT_DENSE_STAGE=0 keeps the direct per-lane loads)
+    // coalesced LDS staging of the triangles needs 16-B aligned rows of 4 triangles
+#ifdef DRT_LAB  // lab builds only: DRT_DENSE_STAGE=0 keeps the direct per-lane loads
     static const bool stage_ok = [] {
         const char *e = getenv("DRT_DENSE_STAGE");
         return !(e && e[0] == '0');
     }();
+#else
+    constexpr bool stage_ok = true;
+#endif
     // worth it only when a block walks few rays (configs[1]: 8.0 -> 7.4 us; at 32 rays per block the direct
     // loads hide behind the other blocks' arithmetic and staging costs 1 %: profiles/r02/literal_lab.txt)
     const int stage = (stage_ok && rpb <= kDenseGroup && (reinterpret_cast<uintptr_t>(tv) & 15) == 0 &&

@@ -35,9 +35,9 @@ __device__ __forceinline__ T *uniform_ptr(T *p) {
 // than 64 bits followed by a VALU write of its data VGPRs needs one wait state, and LLVM's hazard recogniser does
 // not look inside inline asm -- the `s_nop 0` covers it.
 __device__ __forceinline__ void nt_store_b128(char *base, uint32_t off, st_u32x4 v) {
-#if defined(DRT_STORE_LAB_PLAIN)  // lab: the same store without the nontemporal hint
+#if defined(DRT_LAB) && defined(DRT_STORE_LAB_PLAIN)  // lab: the same store without the nontemporal hint
     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
-#elif defined(DRT_STORE_LAB_SC)   // lab: system-coherent write-through hints
+#elif defined(DRT_LAB) && defined(DRT_STORE_LAB_SC)   // lab: system-coherent write-through hints
     asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");
 #else
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(off), "v"(v), "s"(base) : "memory");

@@ -39,7 +39,7 @@ namespace drt {
 enum : uint32_t { kVecVertices = 1, kVecObjects = 2, kVecTypes = 4, kVecMask = 8,
                   kRowBlocksInterleaved = 0x100 };  // lab (DRT_DENSE_LAB_MODE=1): round 4's row-block order, for the A/B
 
-#ifdef DRT_DENSE_LAB_OCC  // lab: occupancy the register allocator targets
+#if defined(DRT_LAB) && defined(DRT_DENSE_LAB_OCC)  // lab: occupancy the register allocator targets
 #define DRT_DENSE_ATTR __attribute__((amdgpu_waves_per_eu(DRT_DENSE_LAB_OCC, DRT_DENSE_LAB_OCC)))
 #else
 #define DRT_DENSE_ATTR
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) DRT_DENSE_ATTR void trace_dense_kernel(
                         flush_region_b128<64 * VDW * 4>(wv, reinterpret_cast<char *>(d_vertices + rowg * VDW), nrows * VDW * 4, lane);
                     else
                         flush_region_b32(wv, reinterpret_cast<uint32_t *>(d_vertices + rowg * VDW), nrows * VDW, lane);
-#ifndef DRT_DENSE_LAB_ONLYV  // lab: vertices only (not a valid build)
+#if !(defined(DRT_LAB) && defined(DRT_DENSE_LAB_ONLYV))  // lab: vertices only (not a valid build)
                     if (vec & kVecObjects)
                         flush_region_b128<64 * ODW * 4>(wo, reinterpret_cast<char *>(d_objects + rowg * ODW), nrows * ODW * 4, lane);
                     else
@@ -280,7 +280,9 @@ int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *pr, co
     // the 16-byte store path of an array needs every wave segment to start on a 16-byte boundary: the array does
     // and C rows are a multiple of 16 bytes (a wave's first row is a multiple of 64)
     uint32_t vec = 0;
+#ifdef DRT_LAB  // lab builds only: DRT_DENSE_LAB_MODE=1 walks the row blocks in round 4's interleaved order
     if (const char *lab = getenv("DRT_DENSE_LAB_MODE")) vec |= (atoi(lab) & 1) ? kRowBlocksInterleaved : 0u;
+#endif
     if (aligned16(vertices) && (C * 12 * (k + 2)) % 16 == 0) vec |= kVecVertices;
     if (aligned16(objects) && (C * 4 * (k + 2)) % 16 == 0) vec |= kVecObjects;
     if (types_out && aligned16(types_out) && (C * 4 * k) % 16 == 0) vec |= kVecTypes;

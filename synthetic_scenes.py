@@ -73,3 +73,36 @@ def cfg5_scene(num_boxes: int = 20000, rx_side: int = 32, pitch: float = 40.0):
     rx = np.stack(np.meshgrid(c0[0] + g + pitch / 2, c0[1] + g + pitch / 2, indexing="ij"), -1).reshape(-1, 2)
     rx = np.column_stack((rx, np.full(len(rx), 1.5))).astype(np.float32)
     return V, Tr, tx, rx
+
+
+def load_real_mesh(name: str):
+    """The reference's in-tree meshes as committed geometry arrays (tests/golden/<name>.npz, written by
+    tests/golden/make_golden.py from docs/source/notebooks/<name>.obj with the reader rule of
+    differt-core/src/geometry/mesh.rs:399-429): vertices f32[V,3], triangles i32[T,3]."""
+    from pathlib import Path
+
+    d = np.load(Path(__file__).resolve().parent / "tests" / "golden" / f"{name}.npz")
+    return d["vertices"].astype(np.float32), d["triangles"].astype(np.int32)
+
+
+def outdoor_end_points(G, V, Tr, num_tx: int, num_rx: int, seed: int = 7):
+    """End points for a real city mesh (no street grid to place them on): transmitters 5 m above the highest roof and
+    at 40 % of that height, receivers at 1.5 m, all in the open -- random points of the central 90 % of the footprint
+    whose upward ray hits nothing (`G` = differt_amd.geometry: the first-hit query runs on the GPU)."""
+    rng = np.random.default_rng(seed)
+    lo, hi = V.min(0), V.max(0)
+    c, e = (lo + hi) / 2, (hi - lo) / 2
+    mesh = G.Mesh(V, Tr)
+
+    def outdoor(n, z):
+        out = []
+        while len(out) < n:
+            p = np.concatenate([c[:2] + rng.uniform(-0.45, 0.45, (256, 2)) * 2 * e[:2], np.full((256, 1), z)], 1).astype(np.float32)
+            up = np.tile(np.array([[0, 0, 1]], np.float32), (256, 1))
+            idx, _ = mesh.first_triangle_hit_by_ray(p, up)
+            out.extend(p[idx.cpu().numpy() < 0].tolist())
+        return np.asarray(out[:n], np.float32)
+
+    ntop = max(num_tx // 2, 1)
+    tx = np.concatenate([outdoor(ntop, float(hi[2]) + 5.0), outdoor(num_tx - ntop, 0.4 * float(hi[2]))])[:num_tx]
+    return tx, outdoor(num_rx, 1.5)

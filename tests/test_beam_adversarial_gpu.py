@@ -281,8 +281,10 @@ def test_degenerate_meshes(G, assume_quads):
 def test_coplanar_pair_mode_engages_and_equals_the_triangle_search(G, rng):
     """A triangle mesh whose triangles (2i, 2i+1) are the same mirror (equal unit normal and first vertex: the walls
     and roofs of box cities) is searched over its n/2 pairs: half the level-1 prefixes, the same keys / objects /
-    vertex bits / gradients as the triangle-by-triangle search and as the exhaustive tracer, masks included; a mesh
-    with ONE perturbed wall, or a mask that splits a pair, falls back to the triangle search."""
+    vertex bits / gradients as the triangle-by-triangle search and as the exhaustive tracer, masks included; in a mesh
+    with perturbed walls, or a mask that splits a pair, THOSE triangles stay single primitives among the pairs (round 4
+    gave the whole mesh up) -- and a permutation of the triangle array changes nothing: the pairing pass finds the
+    partners wherever they are."""
     V, Tr, c, h = S.manhattan(14, seed=5)
     tx, rx = S.manhattan_tx_rx(c, h, 3, 24, seed=6)
     tx[:, 2] = rng.uniform(2, 40, len(tx))
@@ -313,10 +315,26 @@ def test_coplanar_pair_mode_engages_and_equals_the_triangle_search(G, rng):
             if ga is not None:
                 torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-6)
         assert order == 1 or a.objects.shape[0] > 0
+    npairs = Tr.shape[0] // 2
     V2 = V.copy()
-    V2[Tr[7, 2], 0] += np.float32(0.25)  # one wall no longer planar: the whole mesh is searched by triangles
-    for Vx, mk in ((V2, None), (V, split_mask)):
-        a, sa, _, scene = run(Vx, Tr, mk, 2, True)
-        assert not sa["pair_mode"]
-        ex = tracer.trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
-        assert torch.equal(a.objects, ex.objects)
+    V2[Tr[7, 2], 0] += np.float32(0.25)  # the walls that share this vertex are no longer planar quads
+    perm = rng.permutation(Tr.shape[0])  # the same soup in no particular order
+    for Vx, Trx, mk, lost in ((V2, Tr, None, None), (V, Tr, split_mask, 1), (V, Tr[perm], None, 0),
+                              (V, Tr[perm], pair_mask[perm], 0)):
+        for order in (2, 3):
+            a, sa, _, scene = run(Vx, Trx, mk, order, True)
+            assert sa["pair_mode"]
+            if lost is None:
+                assert npairs - 4 <= sa["paired_primitives"] < npairs
+            else:
+                assert sa["paired_primitives"] == npairs - lost
+            ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+            assert torch.equal(a.objects, ex.objects) and torch.equal(a.vertices.view(torch.int32), ex.vertices.view(torch.int32))
+            b = tracer.trace_beam_pruned(scene, order, rows="plain")
+            assert torch.equal(b.objects, ex.objects) and torch.equal(a.keys, b.keys)
+    # too few pairs to pay: the search runs triangle by triangle (30 % of the triangles must have found a partner)
+    few = np.concatenate([np.arange(0, 20), np.arange(20, Tr.shape[0], 2)])  # 10 pairs + the first halves of the others: 25 %
+    a, sa, _, scene = run(V, Tr[few], None, 2, True)
+    assert not sa["pair_mode"] and sa["paired_primitives"] == 0
+    ex = tracer.trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
+    assert torch.equal(a.objects, ex.objects)

@@ -21,6 +21,7 @@ import pytest
 import torch
 
 import oracle as orc
+import synthetic_scenes as S
 
 pytestmark = pytest.mark.gpu
 
@@ -36,8 +37,7 @@ def G():
 
 
 def load(name):
-    d = np.load(GOLDEN / f"{name}.npz")
-    return d["vertices"].astype(np.float32), d["triangles"].astype(np.int32)
+    return S.load_real_mesh(name)
 
 
 def _np(t):
@@ -49,25 +49,7 @@ def _bits(a):
 
 
 def end_points(G, V, Tr, ntx, nrx, seed=7):
-    """Transmitters above the roofs and at mid height over streets, receivers at 1.5 m in the open: random points of
-    the central part of the mesh whose upward ray hits nothing (not under a roof)."""
-    rng = np.random.default_rng(seed)
-    lo, hi = V.min(0), V.max(0)
-    c, e = (lo + hi) / 2, (hi - lo) / 2
-    mesh = G.Mesh(V, Tr)
-
-    def outdoor(n, z):
-        out = []
-        while len(out) < n:
-            p = np.concatenate([c[:2] + rng.uniform(-0.45, 0.45, (256, 2)) * 2 * e[:2], np.full((256, 1), z)], 1).astype(np.float32)
-            up = np.tile(np.array([[0, 0, 1]], np.float32), (256, 1))
-            idx, _ = mesh.first_triangle_hit_by_ray(p, up)
-            out.extend(p[_np(idx) < 0].tolist())
-        return np.asarray(out[:n], np.float32)
-
-    ntop = max(ntx // 2, 1)
-    tx = np.concatenate([outdoor(ntop, float(hi[2]) + 5.0), outdoor(ntx - ntop, 0.4 * float(hi[2]))])[:ntx]
-    return tx, outdoor(nrx, 1.5)
+    return S.outdoor_end_points(G, V, Tr, ntx, nrx, seed)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -105,7 +87,7 @@ def test_tracer_vs_oracle_around_real_paths(G, name):
     """(a) Candidate tables built around the valid order-1 / order-2 paths of the scene (found by the pruned search),
     plus random rows: dense and compact tracer == the C oracle (mask, objects, vertex bits)."""
     V, Tr = load(name)
-    tx, rx = end_points(G, V, Tr, 2, 6)
+    tx, rx = end_points(G, V, Tr, 6, 40)
     mesh = G.Mesh(V, Tr)
     scene = G.Scene(tx, rx, mesh)
     tracer = G.ExhaustivePathTracer()
@@ -194,16 +176,21 @@ def test_queries_on_the_harness_rays(G, name):
     mask = rng.random(Tr.shape[0]) < 0.5
     centre = V.mean(0)
     origin = (centre + np.array([0, 0, 10.0], np.float32)).astype(np.float32)
-    d = _np(G.fibonacci_lattice(10_000)).astype(np.float32)
-    o = np.broadcast_to(origin, d.shape).copy()
+    lattice = _np(G.fibonacci_lattice(10_000)).astype(np.float32)
     mesh = G.Mesh(V, Tr, mask=mask)
     tv = V[Tr]
-    e_any = orc.ray_intersect_any_triangle(o, d, tv, active_triangles=mask)
-    e_idx, e_t = orc.first_triangle_hit_by_ray(o, d, tv, active_triangles=mask)
-    for accel in (None, "bvh"):
-        got = mesh.ray_intersect_any_triangle(o, d, accel=accel)
-        np.testing.assert_array_equal(_np(got), e_any)
-        idx, t = mesh.first_triangle_hit_by_ray(o, d, accel=accel)
-        np.testing.assert_array_equal(_np(idx), e_idx)
-        np.testing.assert_array_equal(_bits(_np(t)), _bits(e_t))
-    assert 0 < e_any.sum() < e_any.size
+    # the harness's literal call (unit directions: the any-hit operator tests the SEGMENT o -> o + d, so nearly nothing
+    # is blocked) and the same lattice as 1 km segments
+    for scale in (1.0, 1000.0):
+        d = (lattice * np.float32(scale)).astype(np.float32)
+        o = np.broadcast_to(origin, d.shape).copy()
+        e_any = orc.ray_intersect_any_triangle(o, d, tv, active_triangles=mask)
+        e_idx, e_t = orc.first_triangle_hit_by_ray(o, d, tv, active_triangles=mask)
+        for accel in (None, "bvh"):
+            got = mesh.ray_intersect_any_triangle(o, d, accel=accel)
+            np.testing.assert_array_equal(_np(got), e_any)
+            idx, t = mesh.first_triangle_hit_by_ray(o, d, accel=accel)
+            np.testing.assert_array_equal(_np(idx), e_idx)
+            np.testing.assert_array_equal(_bits(_np(t)), _bits(e_t))
+        assert 0 < (e_idx >= 0).sum() < e_idx.size
+    assert 0 < e_any.sum() < e_any.size  # the long segments
