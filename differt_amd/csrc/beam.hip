@@ -354,63 +354,190 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
     }
 }
 
+#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
+// [0] box tests, [1] surviving pairs, [2] pairs with >= 1 child, [3] children, [4..6] pairs by bound, [7] sub-boxes passing,
+// [8 + 2 s] passes that reach stage s of the per-primitive test (0: first pyramid, 1: second, ...), [9 + 2 s] lanes still alive there
+__device__ unsigned long long beam_dbg[16];
+#endif
+// What prim_pruned reads of a prefix, in the order it reads it: the head (apex, last mirror's plane, unit, side of the
+// previous point set) first, the pyramids one at a time, last mirror first.  Two views of one BeamCtx:
+//   CtxOwn    the lane's own prefix (plain expansion: lane = prefix);
+//   CtxBcast  the prefix of lane `l` of the wave, broadcast lane-to-wave with v_readlane AS IT IS NEEDED: a pass of
+//             the transposed stage that ends at the side test or after the first pyramid (most do: 44 % of the
+//             (prefix, cluster) pairs that reach it have no child at all) fetches 11 or 27 words instead of all 43.
+//             The reads are `asm volatile`: the compiler otherwise hoists every v_readlane to the top of the pass
+//             (they have no side effects) and spills the scalar registers that hold them.
+__device__ __forceinline__ float lane_bcast_pinned(float x, int l) {
+    uint32_t r;
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(r) : "v"(x), "s"(l));
+    return __uint_as_float(r);
+}
+__device__ __forceinline__ V3 lane_bcast_pinned(V3 v, int l) {
+    return V3{lane_bcast_pinned(v.x, l), lane_bcast_pinned(v.y, l), lane_bcast_pinned(v.z, l)};
+}
+template <int SCALE, int LEVEL>
+struct CtxOwn {
+    const BeamCtx<SCALE, LEVEL> &c;
+    __device__ __forceinline__ V3 I() const { return c.I; }
+    __device__ __forceinline__ V3 pm() const { return c.pm; }
+    __device__ __forceinline__ V3 nm() const { return c.nm; }
+    __device__ __forceinline__ float u() const { return c.u; }
+    __device__ __forceinline__ int side_prev() const { return c.side_prev; }
+    __device__ __forceinline__ PyrN<Shape<SCALE>::NF> pyr(int j, int t) const { return c.pyr[j][t]; }
+};
+template <int SCALE, int LEVEL>
+struct CtxBcast {
+    const BeamCtx<SCALE, LEVEL> &c;
+    int l;  // wave-uniform
+    __device__ __forceinline__ V3 I() const { return lane_bcast_pinned(c.I, l); }
+    __device__ __forceinline__ V3 pm() const { return lane_bcast_pinned(c.pm, l); }
+    __device__ __forceinline__ V3 nm() const { return lane_bcast_pinned(c.nm, l); }
+    __device__ __forceinline__ float u() const { return lane_bcast_pinned(c.u, l); }
+    __device__ __forceinline__ int side_prev() const { return (int)__float_as_uint(lane_bcast_pinned(__uint_as_float((uint32_t)c.side_prev), l)); }
+    __device__ __forceinline__ PyrN<Shape<SCALE>::NF> pyr(int j, int t) const {
+        PyrN<Shape<SCALE>::NF> P;
+#pragma unroll
+        for (int f = 0; f < Shape<SCALE>::NF; ++f) {
+            P.g[f] = lane_bcast_pinned(c.pyr[j][t].g[f], l);
+            P.n[f] = lane_bcast_pinned(c.pyr[j][t].n[f], l);
+        }
+        return P;
+    }
+};
+
 // true: primitive (vertices vx, per-triangle planes pl = (n, d), shape factor sigma) cannot follow this prefix.
 // The side test and the pyramids in turn, the prefix's own (last) mirror first; the wave leaves as soon as none of
 // its lanes is still a candidate (same tests, same result for every lane that matters: a lane that failed one
 // test is pruned whatever the others say) -- 44 % of the (prefix, cluster) pairs that pass the box tests have no
 // child at all (debug counters, profiles/r03/beam.md).
-template <int SCALE, int LEVEL>
-__device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, const V3 (&vx)[Shape<SCALE>::NV],
-                                            const float (&pl)[Shape<SCALE>::NP][4], float sigma, bool lane_on = true) {
+// separated by the pyramids P[0..NP) of ONE mirror (apex cI): for EACH pyramid SOME face has all vertices outside, i.e. the
+// smallest of its face maxima (over the vertices, of <x - I, n_f> + g |x - I|_1) is below the threshold `base`
+template <int SCALE>
+__device__ __forceinline__ bool pyramids_separate(const PyrN<Shape<SCALE>::NF> (&P)[Shape<SCALE>::NP], V3 cI,
+                                                  const V3 (&vx)[Shape<SCALE>::NV], float base) {
     using Sh = Shape<SCALE>;
+    float worst = -kInf;  // max over the pyramids of min over the faces
+#pragma unroll
+    for (int t = 0; t < Sh::NP; ++t) {
+        float m[Sh::NF];
+#pragma unroll
+        for (int f = 0; f < Sh::NF; ++f) m[f] = -kInf;
+#pragma unroll
+        for (int k = 0; k < Sh::NV; ++k) {
+            const V3 w = vx[k] - cI;
+            const float wl = l1_len(w);  // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
+#pragma unroll
+            for (int f = 0; f < Sh::NF; ++f) m[f] = fmaxf(m[f], __builtin_fmaf(P[t].g[f], wl, fdot(w, P[t].n[f])));
+        }
+        worst = fmaxf(worst, min_faces<Sh::NF>(m));
+    }
+    return worst < base;
+}
+
+// FIRST STAGE of the per-primitive test: the side test, the candidate's own error bound and the pyramid over the
+// prefix's last mirror, in ONE walk over the vertices (counters, order 3 of configs[3]: 96 % of the passes of the
+// transposed stage reach that pyramid -- the side test alone empties 4 % of them -- so testing for an early exit before
+// it cost more than it saved, and the differences x - I were computed twice).  Returns "pruned"; `base_out` = the
+// threshold of the pyramid tests of the remaining mirrors, -inf (nothing separates) for NaN geometry or a candidate seen
+// at grazing incidence.
+template <int SCALE, int LEVEL, class View>
+__device__ __forceinline__ bool prim_stage1(const View &cv, const V3 (&vx)[Shape<SCALE>::NV],
+                                            const float (&pl)[Shape<SCALE>::NP][4], float sigma, V3 &cI_out, float &base_out) {
+    using Sh = Shape<SCALE>;
+    const V3 cI = cv.I(), cpm = cv.pm(), cnm = cv.nm();
+    const float cu = cv.u();
+    const int cside = cv.side_prev();
+#if defined(DRT_LAB) && defined(BEAM_LAB_FIRST_PYRAMID_0)
+    constexpr int J1 = 0;  // lab: the narrowest pyramid (earliest mirror) first -- measured: 4.7e9 instead of 1.8e9 lanes survive it
+#else
+    constexpr int J1 = LEVEL - 1;
+#endif
+    PyrN<Sh::NF> P1[Sh::NP];
+#pragma unroll
+    for (int t = 0; t < Sh::NP; ++t) P1[t] = cv.pyr(J1, t);
+    float m1[Sh::NP][Sh::NF];
+#pragma unroll
+    for (int t = 0; t < Sh::NP; ++t)
+#pragma unroll
+        for (int f = 0; f < Sh::NF; ++f) m1[t][f] = -kInf;
     float dmin = kInf, dmax = -kInf, D2 = 0.0f;
     bool nan = false;
 #pragma unroll
     for (int k = 0; k < Sh::NV; ++k) {
         const V3 x = vx[k];
-        const float d = fdot(x - c.pm, c.nm);
+        const float d = fdot(x - cpm, cnm);
         dmin = fminf(dmin, d);
         dmax = fmaxf(dmax, d);
-        const V3 w = x - c.I;
-        const float chk = d + l1_len(w);  // NaN vertex, plane or apex (the maxima below ignore NaNs): never prune
+        const V3 w = x - cI;
+        const float wl = l1_len(w);  // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
+        const float chk = d + wl;    // NaN vertex, plane or apex (the maxima below ignore NaNs): never prune
         nan = nan || !(chk == chk);
         D2 = fmaxf(D2, fdot(w, w));
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t)
+#pragma unroll
+            for (int f = 0; f < Sh::NF; ++f)
+                m1[t][f] = fmaxf(m1[t][f], __builtin_fmaf(P1[t].g[f], wl, fdot(w, P1[t].n[f])));
     }
     float h = kInf;
 #pragma unroll
-    for (int t = 0; t < Sh::NP; ++t) h = fminf(h, plane_dist(c.I, V3{pl[t][0], pl[t][1], pl[t][2]}, pl[t][3]));
+    for (int t = 0; t < Sh::NP; ++t) h = fminf(h, plane_dist(cI, V3{pl[t][0], pl[t][1], pl[t][2]}, pl[t][3]));
 #if defined(DRT_LAB) && defined(BEAM_LAB_NO_PRIM_EPS)
     const float eps_c = 0.0f * (sigma + D2 + h);
 #else
-    const float eps_c = beam_eps(c.u, sigma, __builtin_amdgcn_sqrtf(D2) * 1.000001f, h);
+    const float eps_c = beam_eps(cu, sigma, __builtin_amdgcn_sqrtf(D2) * 1.000001f, h);
 #endif
-    const float base = -(2.0f * eps_c + c.u);  // -inf for a candidate seen at grazing incidence: nothing separates
-    const int side_c = side_of_range(dmin, dmax, eps_c + 2.0f * c.u);
-    bool pruned = !nan && (c.side_prev * side_c == -1);
-    // separated by a pyramid: for EACH of the mirror's pyramids SOME face has all vertices outside, i.e. the
-    // smallest of its face maxima (over the vertices, of <x - I, n_f> + g |x - I|_1) is below the threshold
+    const float base = -(2.0f * eps_c + cu);  // -inf for a candidate seen at grazing incidence: nothing separates
+    const int side_c = side_of_range(dmin, dmax, eps_c + 2.0f * cu);
+    bool pruned = !nan && (cside * side_c == -1);
+    float worst = -kInf;  // max over the pyramids of min over the faces
 #pragma unroll
-    for (int j = LEVEL - 1; j >= 0; --j) {
+    for (int t = 0; t < Sh::NP; ++t) worst = fmaxf(worst, min_faces<Sh::NF>(m1[t]));
+    pruned = pruned || (!nan && worst < base);
+    cI_out = cI;
+    base_out = nan ? -kInf : base;
+    return pruned;
+}
+
+// true: primitive (vertices vx, per-triangle planes pl = (n, d), shape factor sigma) cannot follow this prefix: the
+// first stage, then the earlier mirrors' pyramids in turn; the wave leaves as soon as none of its lanes is still a
+// candidate (same tests, same result for every lane that matters: a lane that failed one test is pruned whatever the
+// others say).
+template <int SCALE, int LEVEL, class View>
+__device__ __forceinline__ bool prim_pruned_view(const View &cv, const V3 (&vx)[Shape<SCALE>::NV],
+                                                 const float (&pl)[Shape<SCALE>::NP][4], float sigma, bool lane_on) {
+    using Sh = Shape<SCALE>;
+    V3 cI;
+    float base;
+    bool pruned = prim_stage1<SCALE, LEVEL>(cv, vx, pl, sigma, cI, base);
+#pragma unroll
+    for (int jj = LEVEL - 2; jj >= 0; --jj) {
+#if defined(DRT_LAB) && defined(BEAM_LAB_FIRST_PYRAMID_0)
+        const int j = jj + 1;
+#else
+        const int j = jj;
+#endif
         if (!__any(lane_on && !pruned)) return true;  // nobody left in this wave: the caller keeps no lane
-        float worst = -kInf;  // max over the pyramids of min over the faces
-#pragma unroll
-        for (int t = 0; t < Sh::NP; ++t) {
-            float m[Sh::NF];
-#pragma unroll
-            for (int f = 0; f < Sh::NF; ++f) m[f] = -kInf;
-#pragma unroll
-            for (int k = 0; k < Sh::NV; ++k) {
-                const V3 w = vx[k] - c.I;       // (recomputed per pyramid: 6 instructions, no array of differences to keep)
-                const float wl = l1_len(w);     // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
-#pragma unroll
-                for (int f = 0; f < Sh::NF; ++f)
-                    m[f] = fmaxf(m[f], __builtin_fmaf(c.pyr[j][t].g[f], wl, fdot(w, c.pyr[j][t].n[f])));
+#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
+        {
+            const unsigned long long av = __ballot(lane_on && !pruned);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&beam_dbg[8 + 2 * (LEVEL - 1 - jj)], 1ull);
+                atomicAdd(&beam_dbg[9 + 2 * (LEVEL - 1 - jj)], (unsigned long long)__popcll(av));
             }
-            worst = fmaxf(worst, min_faces<Sh::NF>(m));
         }
-        pruned = pruned || (!nan && worst < base);
+#endif
+        PyrN<Sh::NF> P[Sh::NP];
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t) P[t] = cv.pyr(j, t);
+        pruned = pruned || pyramids_separate<SCALE>(P, cI, vx, base);
     }
     return pruned;
+}
+template <int SCALE, int LEVEL>
+__device__ __forceinline__ bool prim_pruned(const BeamCtx<SCALE, LEVEL> &c, const V3 (&vx)[Shape<SCALE>::NV],
+                                            const float (&pl)[Shape<SCALE>::NP][4], float sigma, bool lane_on = true) {
+    return prim_pruned_view<SCALE, LEVEL>(CtxOwn<SCALE, LEVEL>{c}, vx, pl, sigma, lane_on);
 }
 
 // true: NO primitive inside the box [lo, hi] whose own bound is <= eps_max can follow this prefix (the box form
@@ -665,9 +792,6 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(BeamMesh M, const Beam
 // the work drops from one ~150-instruction test per primitive to one box test per 64 primitives plus full-lane
 // tests of the clusters its cones actually reach.
 // ---------------------------------------------------------------------------------------------
-#if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
-__device__ unsigned long long beam_dbg[8];  // [0] box tests, [1] surviving pairs, [2] pairs with >= 1 child, [3] children, [4..6] pairs by bound, [7] sub-boxes passing
-#endif
 struct BeamClusters {
     const int32_t *order;
     const float *verts, *planes, *uplanes, *sigma, *boxes, *subboxes;
@@ -829,15 +953,34 @@ __device__ __forceinline__ void expand_clustered_body(
     build_ctx<SCALE, LEVEL>(M, e, u, have, ctx);
     // last expansion: children are tested against the receivers' box before their records are written -- not in
     // the transposed loop (one test per pass would cost as much as the pass), but on FULL waves of kept children:
-    // kept lanes park (record, plane of the new mirror, its shape factor) in a wave-private LDS queue, and whenever
-    // 64 wait, lane = parked child gathers its parent's apex / narrowest pyramid from the parent's lane
-    // (ds_bpermute) and decides.  At configs[3] three quarters of the 7.1e9 children go no further.
+    // kept lanes park their record in a wave-private LDS queue, and whenever 64 wait, lane = parked child gathers its
+    // parent's apex / narrowest pyramid from the parent's lane (ds_bpermute) and decides.  At configs[3] three quarters of
+    // the children go no further.
+    // Level 2 (order 3) parks EARLIER: after the first stage of the per-primitive test.  The pyramid over the prefix's
+    // first mirror is the very pyramid the child filter starts from, and in the transposed loop it ran on 12 of 64 lanes
+    // (counters, configs[3]: 1.55e8 of 2.6e8 passes reach it with 1.8e9 lanes alive): lane = parked candidate re-reads
+    // its vertices / plane from the sorted arrays (by position), runs that pyramid with its own threshold and, if it is
+    // still a candidate, the receiver-box test -- both on full waves, the parent's data gathered once for both.
+    constexpr bool kTwoStage = FILTER && LEVEL == 2;
     __shared__ unsigned long long raw_rec[kExpandWG / 64][128];
-    __shared__ float raw_f[kExpandWG / 64][5][128];
+    __shared__ float raw_f[kExpandWG / 64][kTwoStage ? 2 : 5][128];  // two-stage: (sorted position, threshold)
     constexpr bool filter_on = FILTER;
-    float rho0[Sh::NP][Sh::NF];
-    float sig_sum = kInf;
-    if (filter_on) first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum);
+    // what the child filter needs of the PARENT besides its context (per face of the narrowest pyramid the distance of
+    // the apex from the edge line, and the sum of the shape factors): read once per 64 parked children, by the child's
+    // lane from the parent's slot -- kept in LDS, not in five registers that would be live across the whole cluster loop
+    __shared__ float lds_rho[kExpandWG / 64][Sh::NP * Sh::NF + 1][64];
+    if (filter_on) {
+        float rho0[Sh::NP][Sh::NF];
+        float sig_sum = kInf;
+        first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum);
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t)
+#pragma unroll
+            for (int f = 0; f < Sh::NF; ++f) lds_rho[wave][t * Sh::NF + f][lane] = rho0[t][f];
+        lds_rho[wave][Sh::NP * Sh::NF][lane] = sig_sum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     int rawcount = 0;
     const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
     const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
@@ -846,14 +989,11 @@ __device__ __forceinline__ void expand_clustered_body(
     // the last n parked children (n <= 64): lane = child
     auto filter_parked = [&](int n) {
         const int j = rawcount - n + lane;
-        const bool mine = lane < n;
+        bool mine = lane < n;
         const unsigned long long rec = mine ? raw_rec[wave][j] : 0ull;
-        const V3 nc = mine ? V3{raw_f[wave][0][j], raw_f[wave][1][j], raw_f[wave][2][j]} : V3{0, 0, 1};
-        const float dc = mine ? raw_f[wave][3][j] : 0.0f;
-        const float sgc = mine ? raw_f[wave][4][j] : 1.0f;
         const int l = (int)((rec >> 32) - gbase) & 63;  // the parent's lane
         const V3 I2 = V3{__shfl(ctx.I.x, l, 64), __shfl(ctx.I.y, l, 64), __shfl(ctx.I.z, l, 64)};
-        const float sp = __shfl(sig_sum, l, 64);
+        const float sp = lds_rho[wave][Sh::NP * Sh::NF][l];
         V3 n0[Sh::NP][Sh::NF];
         float rh[Sh::NP][Sh::NF];
 #pragma unroll
@@ -862,47 +1002,89 @@ __device__ __forceinline__ void expand_clustered_body(
             for (int f = 0; f < Sh::NF; ++f) {
                 n0[t][f] = V3{__shfl(ctx.pyr[0][t].n[f].x, l, 64), __shfl(ctx.pyr[0][t].n[f].y, l, 64),
                               __shfl(ctx.pyr[0][t].n[f].z, l, 64)};
-                rh[t][f] = __shfl(rho0[t][f], l, 64);
+                rh[t][f] = lds_rho[wave][t * Sh::NF + f][l];
             }
+        V3 nc{0, 0, 1};
+        float dc = 0.0f, sgc = 1.0f;
+        if constexpr (kTwoStage) {
+            const int64_t pos = mine ? (int64_t)__float_as_uint(raw_f[wave][0][j]) : 0;  // (position 0 always exists)
+            const float base = raw_f[wave][1][j & 127];
+            V3 vq[Sh::NV];
+#pragma unroll
+            for (int k = 0; k < Sh::NV; ++k) vq[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));
+            const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP];
+            nc = V3{q.x, q.y, q.z};
+            dc = q.w;
+            sgc = C.sigma[pos];
+            PyrN<Sh::NF> P0[Sh::NP];
+#pragma unroll
+            for (int t = 0; t < Sh::NP; ++t)
+#pragma unroll
+                for (int f = 0; f < Sh::NF; ++f) {
+                    P0[t].n[f] = n0[t][f];
+                    P0[t].g[f] = __shfl(ctx.pyr[0][t].g[f], l, 64);
+                }
+            mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);
+        } else {
+            nc = mine ? V3{raw_f[wave][0][j], raw_f[wave][1][j], raw_f[wave][2][j]} : V3{0, 0, 1};
+            dc = mine ? raw_f[wave][3][j] : 0.0f;
+            sgc = mine ? raw_f[wave][4][j] : 1.0f;
+        }
         // (rxall.on == 0 -- a non-finite receiver, known only on the device in the async entry point: every child passes)
         const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, sp, nc, dc, sgc));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
     };
-    // software pipeline: the next cluster's primitive id and vertices (sorted copy, no indirection) are in
-    // flight while this cluster is tested -- fetched whether or not the cluster will be hit (the mesh lives in L2)
-    int32_t p_next = -1;
-    V3 vx_next[Sh::NV];
-    float pl_next[Sh::NP][4], uq_next[Sh::NP][4];  // (plain floats: float4 arrays captured by the lambda stayed in scratch)
+    // The cluster's primitive ids, vertices and planes (sorted copy, no indirection; fetched whether or not the cluster
+    // will be hit: the mesh lives in L2).  kAhead: one cluster AHEAD, in flight while this cluster is tested.  The
+    // order-3 quad kernel instead loads the CURRENT cluster's right after the plane-distance loop: the ~350 VALU
+    // instructions of the box stage hide the L2 latency, and the 17 registers of the look-ahead copy were the ones the
+    // allocator spilled (16 VGPRs, 60 B of scratch per lane in round 4).
+    constexpr bool kAhead = !(SCALE == 4 && LEVEL >= 2);
+    int32_t p_ld = -1;
+    V3 vx_ld[Sh::NV];
+    float pl_ld[Sh::NP][4];  // (plain floats: float4 arrays captured by the lambda stayed in scratch)
     auto fetch = [&](int64_t c) {
         const int64_t cc = (c < cl_end) ? c : cl_end - 1;  // the last trip re-reads its own cluster
         const int64_t pos = cc * 64 + lane;
-        p_next = (pos < M.nprim) ? C.order[pos] : -1;
+        p_ld = (pos < M.nprim) ? C.order[pos] : -1;
 #pragma unroll
-        for (int k = 0; k < Sh::NV; ++k) vx_next[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));  // padded to whole clusters
+        for (int k = 0; k < Sh::NV; ++k) vx_ld[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));  // padded to whole clusters
 #pragma unroll
         for (int t = 0; t < Sh::NP; ++t) {
             const float4 a = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP + t];
-            const float4 b = reinterpret_cast<const float4 *>(C.uplanes)[pos * Sh::NP + t];
-            pl_next[t][0] = a.x; pl_next[t][1] = a.y; pl_next[t][2] = a.z; pl_next[t][3] = a.w;
-            uq_next[t][0] = b.x; uq_next[t][1] = b.y; uq_next[t][2] = b.z; uq_next[t][3] = b.w;
+            pl_ld[t][0] = a.x; pl_ld[t][1] = a.y; pl_ld[t][2] = a.z; pl_ld[t][3] = a.w;
         }
     };
-    if (cl_begin < cl_end) fetch(cl_begin);
+    // the cluster's distinct planes go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, LDS
+    // address = wave base + lane * 16, no staging registers): issued as soon as the previous cluster's planes have been
+    // read, landed by the time the next trip needs them
+    auto fetch_planes = [&](int64_t c) {
+        const int64_t cc = (c < cl_end) ? c : cl_end - 1;
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const float4 *>(C.uplanes) +
+                                                                  (cc * 64 * Sh::NP + t * 64 + lane)),
+                (__attribute__((address_space(3))) void *)(&lds_planes[wave][t * 64]), 16, 0, 0);
+    };
+    if (cl_begin < cl_end) {
+        if (kAhead) fetch(cl_begin);
+        fetch_planes(cl_begin);
+    }
     for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
-        const int32_t p = p_next;
+        int32_t p = -1;
         V3 vx[Sh::NV];
         float pl[Sh::NP][4];
+        if (kAhead) {
+            p = p_ld;
 #pragma unroll
-        for (int k = 0; k < Sh::NV; ++k) vx[k] = vx_next[k];
+            for (int k = 0; k < Sh::NV; ++k) vx[k] = vx_ld[k];
 #pragma unroll
-        for (int t = 0; t < Sh::NP; ++t) {
+            for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pl[t][q] = pl_next[t][q];
-            // wave-private: ordered by the wave's own LDS queue
-            lds_planes[wave][lane * Sh::NP + t] = float4{uq_next[t][0], uq_next[t][1], uq_next[t][2], uq_next[t][3]};
+                for (int q = 0; q < 4; ++q) pl[t][q] = pl_ld[t][q];
         }
-        fetch(cl + 1);
         // ---- lane = prefix: box of the cluster (wave-uniform scalar loads) ----
         const float *bx = C.boxes + 8 * cl;
         const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
@@ -910,7 +1092,9 @@ __device__ __forceinline__ void expand_clustered_body(
         // cluster's triangles (the SAME expression the per-primitive test evaluates), farthest box corner
         float hmin = kInf;
 #if !(defined(DRT_LAB) && defined(BEAM_LAB_NO_HMIN))
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the LDS writes above precede the reads below
+        // this cluster's planes (global_load_lds, issued a trip ago) have landed: every vector-memory operation in flight
+        // here is at least that old (this trip's loads are issued below, after the loop that reads the planes)
+        __builtin_amdgcn_s_waitcnt(/*vmcnt 0; expcnt, lgkmcnt: no wait*/ 0x0f70);
         __builtin_amdgcn_wave_barrier();
         // non-negative floats order like their bit patterns, NaN patterns lie above +inf: an unsigned integer minimum
         // is fminf here, without the NaN-quieting and unordered-compare code the float form expands to (measured:
@@ -926,8 +1110,19 @@ __device__ __forceinline__ void expand_clustered_body(
             hbits = (b < hbits) ? b : hbits;
         }
         hmin = __uint_as_float(hbits);
-        __builtin_amdgcn_wave_barrier();  // reads done before the next cluster's writes
+        __builtin_amdgcn_wave_barrier();  // reads done before the next cluster's planes arrive
+        fetch_planes(cl + 1);
 #endif
+        fetch(kAhead ? cl + 1 : cl);
+        if (!kAhead) {
+            p = p_ld;
+#pragma unroll
+            for (int k = 0; k < Sh::NV; ++k) vx[k] = vx_ld[k];
+#pragma unroll
+            for (int t = 0; t < Sh::NP; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pl[t][q] = pl_ld[t][q];
+        }
         const V3 far = V3{fmaxf(__builtin_fabsf(ctx.I.x - lo[0]), __builtin_fabsf(ctx.I.x - hi[0])),
                           fmaxf(__builtin_fabsf(ctx.I.y - lo[1]), __builtin_fabsf(ctx.I.y - hi[1])),
                           fmaxf(__builtin_fabsf(ctx.I.z - lo[2]), __builtin_fabsf(ctx.I.z - hi[2]))};
@@ -982,9 +1177,15 @@ __device__ __forceinline__ void expand_clustered_body(
         while (todo) {
             const int l = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const BeamCtx<SCALE, LEVEL> cx = lane_bcast<SCALE, LEVEL>(ctx, l);
             const bool cand = act && (p != __builtin_amdgcn_readlane(m, l) || self_ok);
-            const bool keep = cand && !prim_pruned<SCALE, LEVEL>(cx, vx, pl, sg, cand);
+            bool keep;
+            float base1 = 0.0f;
+            if constexpr (kTwoStage) {
+                V3 unused;
+                keep = cand && !prim_stage1<SCALE, LEVEL>(CtxBcast<SCALE, LEVEL>{ctx, l}, vx, pl, sg, unused, base1);
+            } else {
+                keep = cand && !prim_pruned_view<SCALE, LEVEL>(CtxBcast<SCALE, LEVEL>{ctx, l}, vx, pl, sg, cand);
+            }
 #if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
             {
                 const unsigned long long kv = __ballot(keep);
@@ -1001,11 +1202,16 @@ __device__ __forceinline__ void expand_clustered_body(
                     if (keep) {
                         const int j = rawcount + __popcll(vote & ((1ull << lane) - 1ull));
                         raw_rec[wave][j] = record;
-                        raw_f[wave][0][j] = pl[0][0];
-                        raw_f[wave][1][j] = pl[0][1];
-                        raw_f[wave][2][j] = pl[0][2];
-                        raw_f[wave][3][j] = pl[0][3];
-                        raw_f[wave][4][j] = sg;
+                        if constexpr (kTwoStage) {
+                            raw_f[wave][0][j] = __uint_as_float((uint32_t)pos);  // cl * 64 + lane < 2^31 primitives
+                            raw_f[wave][1][j] = base1;
+                        } else {
+                            raw_f[wave][0][j] = pl[0][0];
+                            raw_f[wave][1][j] = pl[0][1];
+                            raw_f[wave][2][j] = pl[0][2];
+                            raw_f[wave][3][j] = pl[0][3];
+                            raw_f[wave][4][j] = sg;
+                        }
                     }
                     rawcount += __popcll(vote);
                     if (rawcount >= 64) filter_parked(64);
@@ -2283,9 +2489,9 @@ static void launch_emit(const BeamMesh &M, bool clustered, const BeamEntry *in, 
 #if defined(DRT_LAB) && defined(BEAM_LAB_COUNT)
 extern "C" void drt_debug_beam_counts(unsigned long long *out, int reset) {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(drt::beam_dbg), sizeof(unsigned long long) * 8);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(drt::beam_dbg), sizeof(unsigned long long) * 16);
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(drt::beam_dbg), z, sizeof(z));
     }
 }

@@ -49,7 +49,7 @@ def test_single_gpu_line():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
     rf = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] == "hbm"
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5  # (the line carries 6 significant digits)
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
     assert "strong_headline" not in d  # N = 1: the line is the plain single-GPU bench
     assert d["prewarm_ms"] > 0 and d["roofline"]["pmc_stale"] in (True, False)
@@ -86,7 +86,8 @@ def test_two_ranks_share_gpu():
     heads = {h["leg"]: h for h in d["strong_headline"]}
     assert set(heads) == {"beam_sharded", "candidate_sharded"}
     for leg, h in heads.items():
-        assert h["n_gpus"] == 2 and h["scaling"] == "strong" and h["s_per_step"] == d["strong_scaling"][leg]["s_per_step"]
+        assert h["n_gpus"] == 2 and h["scaling"] == "strong"
+        assert h["s_per_step"] == pytest.approx(d["strong_scaling"][leg]["s_per_step"], rel=1e-4)  # (5 significant digits in the line)
     ref = Path(os.environ.get("DRT_BENCH_N1_JSON", "/tmp/drt_bench_n1.json"))
     if ref.exists():  # same fixed work as the single-rank run: same valid paths, same first hits, same gradient
         one = json.loads(ref.read_text())
