@@ -223,6 +223,12 @@ _SIGNATURES = {
         [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _vp, _vp, _vp, _vp,
          _vp, _vp, _sz, _vp],
     ),
+    "drt_trace_dense_capped_workspace_size": (_sz, [_i64]),
+    "drt_trace_paths_dense_capped": (
+        _i32,
+        [_vp, C.POINTER(TraceParams), _vp, _i64, _vp, _i64, C.POINTER(Candidates), _vp, _vp, _vp, _vp,
+         _vp, _i64, _vp, _sz, _vp],
+    ),
     "drt_trace_compact_workspace_size": (_sz, [_i64, _i64]),
     "drt_comm_unique_id": (_i32, [_vp]),
     "drt_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
@@ -235,6 +241,8 @@ _SIGNATURES = {
     "drt_allgather_bytes": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "drt_trace_vjp_workspace_size": (_sz, [_i64, _i32]),
     "drt_trace_paths_vjp_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "drt_sort_u64_workspace_size": (_sz, [_i64, _i32]),
+    "drt_sort_u64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _sz, _vp]),
     "drt_mesh_build_beam_clusters": (_i32, [_vp, _vp]),
     "drt_mesh_build_beam_clusters_ex": (_i32, [_vp, _i32, _vp]),
     "drt_mesh_beam_pairing": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -258,7 +258,8 @@ __device__ __forceinline__ float min_faces(const float (&v)[NF]) {
 // triangle soup, drt_mesh::pair_* -- has one of the two ON the face's own edge, where the triple product is rounding
 // noise next to the other one's value.
 template <bool TWO>
-__device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, float delta, V3 &n_out, float &g_out) {
+__device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, float delta, bool apex_off_plane, V3 &n_out,
+                                         float &g_out) {
     // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded forms (~12 instructions each, five per face,
     // three faces per pyramid, up to three pyramids per prefix): these are margins, and the 2e-6 |x - I|_1 in the
     // slope covers the rounding of the normalisation and of <x - I, n_f>; rho is rounded DOWN by the 0.9999
@@ -270,19 +271,34 @@ __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, 
     const float el = __builtin_amdgcn_sqrtf(fdot(e, e));
     const float rho = (el > 0.0f) ? 0.9999f * len * __builtin_amdgcn_rcpf(el) : 0.0f;
     const float g = 1.0101f * delta * __builtin_amdgcn_rcpf(rho - delta) + 2e-6f;
-    const bool on = (rho > 1.05f * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
+    const bool on = apex_off_plane && (rho > 1.05f * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
     const float inv = __builtin_amdgcn_rcpf(len);
     const float sc = on ? ((s > 0.0f) ? inv : -inv) : 0.0f;
     n_out = on ? N * sc : V3{0, 0, 0};  // (0 * inf = NaN for a huge N: the select, not the product, zeroes it)
     g_out = on ? g : 0.0f;
 }
 // pyramid over the polygon v[0..NF): face f spans the edge v[f] -> v[f+1]; the vertex after that edge fixes "inside"
+// distance of the apex from the polygon's plane (through v0, v1, v2); NaN for a degenerate polygon
+__device__ __forceinline__ float apex_plane_distance(V3 I, V3 v0, V3 v1, V3 v2) {
+    const V3 Np = cross(v1 - v0, v2 - v0);
+    return __builtin_fabsf(fdot(I - v0, Np)) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fdot(Np, Np)));
+}
+// A pyramid has an inside only while its apex is CLEARLY off the polygon's plane.  An apex within the lateral tolerance
+// delta of that plane -- a transmitter placed in a wall plane up to rounding, seen at 89 degrees from the reflection
+// point 2 mm away -- may lie on either side of it as far as the reference's arithmetic can tell, the cone over the
+// polygon flips with the side, and the triple product that orients each face is rounding noise: the whole pyramid is
+// OFF (never separates).  Round 5: found by the ROTATED stress cities (20 lost paths in 620 076 scenes, every one a
+// transmitter within 0.2 ulp(M) of a wall plane 3-4 km from the origin; tests/golden/beam_cases/flat_pyramid_*.npz) --
+// on axis-aligned walls the triple product of such an apex is exactly 0 and the face test `s != 0` caught it, which is
+// why four rounds of box cities never saw it.  (The header of this file always said "h_P <= 2.1 S: off"; the
+// implementation had kept only the distance from the edge LINES.)
 template <int NF>
 __device__ __forceinline__ PyrN<NF> make_pyr(V3 I, const V3 (&v)[NF], float delta) {
     PyrN<NF> P;
+    const bool apex_off_plane = apex_plane_distance(I, v[0], v[1], v[2]) * 0.9999f > 1.05f * delta;  // (NaN: off)
 #pragma unroll
     for (int f = 0; f < NF; ++f)
-        pyr_face<NF == 4>(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], v[(f + 3) % NF], delta, P.n[f], P.g[f]);
+        pyr_face<NF == 4>(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], v[(f + 3) % NF], delta, apex_off_plane, P.n[f], P.g[f]);
     return P;
 }
 
@@ -803,12 +819,15 @@ struct BeamClusters {
 // mirrors' shape factors
 template <int SCALE, int LEVEL>
 __device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamEntry &e, V3 I, bool have, float ulp_m,
-                                                  float (&rho)[Shape<SCALE>::NP][Shape<SCALE>::NF], float &sig_sum) {
+                                                  float (&rho)[Shape<SCALE>::NP][Shape<SCALE>::NF], float &sig_sum,
+                                                  float (&hp)[Shape<SCALE>::NP]) {
     using Sh = Shape<SCALE>;
 #pragma unroll
-    for (int t = 0; t < Sh::NP; ++t)
+    for (int t = 0; t < Sh::NP; ++t) {
+        hp[t] = 0.0f;  // distance of the apex from the unfolded first mirror's plane (a reflection does not change it)
 #pragma unroll
         for (int f = 0; f < Sh::NF; ++f) rho[t][f] = 0.0f;
+    }
     sig_sum = kInf;
     if (!have) return;
     sig_sum = 0.0f;
@@ -840,6 +859,7 @@ __device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamE
         // the sum of the |N_f|, and a reflection moves each point by a few ulp(M'), M' <= 3 M.  Below
         // 64 ulp(M) sum |N_f| (or the rounding of the product itself, far from the scene) the pyramid counts as flat:
         // rho = 0 for its faces, never "on" in child_misses_receivers.
+        hp[t] = apex_plane_distance(I, v[0], v[1], v[2]);
         V3 w[Sh::NF];
 #pragma unroll
         for (int k = 0; k < Sh::NF; ++k) w[k] = v[k] - I;
@@ -877,7 +897,8 @@ template <int SCALE>
 __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const BeamMesh &M, float u0, V3 I2,
                                                        const V3 (&n0)[Shape<SCALE>::NP][Shape<SCALE>::NF],
                                                        const float (&rho)[Shape<SCALE>::NP][Shape<SCALE>::NF],
-                                                       float sig_parent, V3 nc, float dc, float sig_c) {
+                                                       const float (&hp)[Shape<SCALE>::NP], float sig_parent, V3 nc, float dc,
+                                                       float sig_c) {
     using Sh = Shape<SCALE>;
     const float s2 = 2.0f * __builtin_fmaf(nc.x, I2.x, __builtin_fmaf(nc.y, I2.y, __builtin_fmaf(nc.z, I2.z, -dc)));
     const V3 I3 = V3{I2.x - nc.x * s2, I2.y - nc.y * s2, I2.z - nc.z * s2};
@@ -889,9 +910,14 @@ __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const Be
     const V3 w = ce - I3;
     const float wl = l1_len(w) + ((he.x + he.y) + he.z);
     const float thr = -1.1f * uc;
+    // the receiver stage switches the child's whole pyramid off when ITS apex lies within 1.05 delta of the polygon's
+    // plane (make_pyr); that distance equals the parent's up to the rounding of one more reflection (a few ulp(M') of
+    // position), so this stage needs the parent's distance clear of the threshold by that much, whatever kappa is
+    const float hp_slack = 64.0f * rx.ulp_m * mag_scale(M, I3);
     bool all_t = true;
 #pragma unroll
     for (int t = 0; t < Sh::NP; ++t) {
+        const bool apex_off_plane = hp[t] * 0.999f > 1.06f * delta + hp_slack;  // (NaN: off)
         float v[Sh::NF];
 #pragma unroll
         for (int f = 0; f < Sh::NF; ++f) {
@@ -900,7 +926,7 @@ __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const Be
             const V3 nr = V3{n.x - nc.x * k2, n.y - nc.y * k2, n.z - nc.z * k2};
             const float r = rho[t][f] * 0.999f;
             const float g = 1.0101f * delta * __builtin_amdgcn_rcpf(r - delta) + 2.1e-4f;
-            const bool on = r > 1.06f * delta;  // otherwise the child's face may be off: it never separates
+            const bool on = apex_off_plane && r > 1.06f * delta;  // otherwise the child's face may be off: it never separates
             const float smax = fdot(w, nr) + ((__builtin_fabsf(nr.x) * he.x + __builtin_fabsf(nr.y) * he.y) +
                                               __builtin_fabsf(nr.z) * he.z);
             const float val = __builtin_fmaf(g, wl, smax);
@@ -968,11 +994,13 @@ __device__ __forceinline__ void expand_clustered_body(
     // what the child filter needs of the PARENT besides its context (per face of the narrowest pyramid the distance of
     // the apex from the edge line, and the sum of the shape factors): read once per 64 parked children, by the child's
     // lane from the parent's slot -- kept in LDS, not in five registers that would be live across the whole cluster loop
-    __shared__ float lds_rho[kExpandWG / 64][Sh::NP * Sh::NF + 1][64];
+    __shared__ float lds_rho[kExpandWG / 64][Sh::NP * Sh::NF + 1 + Sh::NP][64];
     if (filter_on) {
-        float rho0[Sh::NP][Sh::NF];
+        float rho0[Sh::NP][Sh::NF], hp0[Sh::NP];
         float sig_sum = kInf;
-        first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum);
+        first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum, hp0);
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t) lds_rho[wave][Sh::NP * Sh::NF + 1 + t][lane] = hp0[t];
 #pragma unroll
         for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
@@ -995,15 +1023,17 @@ __device__ __forceinline__ void expand_clustered_body(
         const V3 I2 = V3{__shfl(ctx.I.x, l, 64), __shfl(ctx.I.y, l, 64), __shfl(ctx.I.z, l, 64)};
         const float sp = lds_rho[wave][Sh::NP * Sh::NF][l];
         V3 n0[Sh::NP][Sh::NF];
-        float rh[Sh::NP][Sh::NF];
+        float rh[Sh::NP][Sh::NF], hpp[Sh::NP];
 #pragma unroll
-        for (int t = 0; t < Sh::NP; ++t)
+        for (int t = 0; t < Sh::NP; ++t) {
+            hpp[t] = lds_rho[wave][Sh::NP * Sh::NF + 1 + t][l];
 #pragma unroll
             for (int f = 0; f < Sh::NF; ++f) {
                 n0[t][f] = V3{__shfl(ctx.pyr[0][t].n[f].x, l, 64), __shfl(ctx.pyr[0][t].n[f].y, l, 64),
                               __shfl(ctx.pyr[0][t].n[f].z, l, 64)};
                 rh[t][f] = lds_rho[wave][t * Sh::NF + f][l];
             }
+        }
         V3 nc{0, 0, 1};
         float dc = 0.0f, sgc = 1.0f;
         if constexpr (kTwoStage) {
@@ -1031,7 +1061,7 @@ __device__ __forceinline__ void expand_clustered_body(
             sgc = mine ? raw_f[wave][4][j] : 1.0f;
         }
         // (rxall.on == 0 -- a non-finite receiver, known only on the device in the async entry point: every child passes)
-        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, sp, nc, dc, sgc));
+        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, hpp, sp, nc, dc, sgc));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
     };
@@ -2212,21 +2242,17 @@ static size_t sort_pairs_temp_bytes(int64_t n) {
 }
 static size_t sort_keys64_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
-    size_t bytes = 0, safe = 0;
+    size_t bytes = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                    (size_t)n, 0, 64, nullptr);
-    (void)rocprim::radix_sort_keys<CaptureSafeSort>(nullptr, safe, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                                    (size_t)n, 0, 64, nullptr);
-    return std::max(bytes, safe);
+    return std::max(bytes, capture_safe_sort_temp_bytes(n, false));
 }
 static size_t sort_pairs64_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
-    size_t bytes = 0, safe = 0;
+    size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 64, nullptr);
-    (void)rocprim::radix_sort_pairs<CaptureSafeSort>(nullptr, safe, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 64, nullptr);
-    return std::max(bytes, safe);
+    return std::max(bytes, capture_safe_sort_temp_bytes(n, true));
 }
 
 // Morton order of `n` items (means of `group` consecutive points): sorted ids in `*ids_out`, bounds
@@ -3288,8 +3314,8 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
                        reinterpret_cast<unsigned long long *>(rows), c4, rows_cap);
     DRT_LAUNCH_CHECK();
     size_t tb = sort_keys64_temp_bytes(rows_cap);
-    DRT_HIP(rocprim::radix_sort_keys<CaptureSafeSort>(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted,
-                                                      (size_t)rows_cap, 0, 63, s));  // sort_safe.hpp
+    DRT_HIP(capture_safe_sort(sort_tmp, tb, reinterpret_cast<unsigned long long *>(rows), rows_sorted, nullptr, nullptr, rows_cap, 0,
+                              63, s));  // sort_safe.hpp / radix_sort.hip: kernels only
     const unsigned long long *row_keys = rows_sorted;
     if (pairs) {
         const dim3 ge((unsigned)ceil_div(table_rows, 256));
@@ -3327,8 +3353,8 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
             auto *tmp_rows = reinterpret_cast<uint32_t *>(base + L.merge_rows);
             hipLaunchKernelGGL(iota_kernel, dim3((unsigned)ceil_div(max_paths, 256)), dim3(256), 0, s, iota, max_paths);
             size_t tb2 = sort_pairs64_temp_bytes(max_paths);
-            DRT_HIP(rocprim::radix_sort_pairs<CaptureSafeSort>(sort_tmp, tb2, reinterpret_cast<unsigned long long *>(keys), mk, iota,
-                                                               perm, (size_t)max_paths, 0, 64, s));  // padding keys (-1) sort last
+            DRT_HIP(capture_safe_sort(sort_tmp, tb2, reinterpret_cast<unsigned long long *>(keys), mk, iota, perm, max_paths, 0, 64,
+                                      s));  // padding keys (-1) sort last
             auto copy = [&](const void *src, void *dst, int64_t words) {
                 hipLaunchKernelGGL(copy_u32_kernel, dim3((unsigned)ceil_div(words, 256)), dim3(256), 0, s,
                                    reinterpret_cast<const uint32_t *>(src), words, reinterpret_cast<uint32_t *>(dst));

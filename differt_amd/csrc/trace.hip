@@ -758,13 +758,12 @@ static void launch_filter(const Launch &L, unsigned long long *qc, long long *q,
                        L.a.rx, L.cs, qc, q, qcap, tpb);
 }
 
-static size_t sort_temp_bytes(int64_t n) {  // enough for the default and for the capture-safe configuration (sort_safe.hpp)
+static size_t sort_temp_bytes(int64_t n) {  // enough for the default and for the capture-safe sorts (sort_safe.hpp)
     if (n <= 0) return 0;
-    size_t bytes = 0, safe = 0;
+    size_t bytes = 0;
     (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr,
                                    (unsigned long long *)nullptr, (size_t)n, 0, 64, nullptr);
-    (void)rocprim::radix_sort_keys<CaptureSafeSort>(nullptr, safe, (unsigned long long *)nullptr,
-                                                    (unsigned long long *)nullptr, (size_t)n, 0, 64, nullptr);
+    const size_t safe = capture_safe_sort_temp_bytes(n, false);
     return bytes > safe ? bytes : safe;
 }
 
@@ -969,9 +968,8 @@ int32_t drt_trace_paths_compact_async(drt_mesh_t mesh, const drt_trace_params *p
     }
     if (max_paths > 0) {
         size_t tmp_bytes = sort_temp_bytes(max_paths);
-        DRT_HIP(rocprim::radix_sort_keys<CaptureSafeSort>(sort_tmp, tmp_bytes, reinterpret_cast<unsigned long long *>(q2),
-                                                          reinterpret_cast<unsigned long long *>(keys), (size_t)max_paths,
-                                                          0, 64, L.s));
+        DRT_HIP(capture_safe_sort(sort_tmp, tmp_bytes, reinterpret_cast<unsigned long long *>(q2),
+                                  reinterpret_cast<unsigned long long *>(keys), nullptr, nullptr, max_paths, 0, 64, L.s));
     }
     const int64_t rows = max_paths > 0 ? max_paths : 1;  // one thread at least: it writes the counts
 #define CALL(K)                                                                                        \
@@ -1012,10 +1010,7 @@ int32_t drt_trace_paths_vjp(drt_mesh_t mesh, const float *tx, int64_t ntx, const
 
 static size_t vjp_sort_temp_bytes(int64_t n) {
     if (n <= 0) return 0;
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs<CaptureSafeSort>(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 42, nullptr);
-    return bytes;
+    return capture_safe_sort_temp_bytes(n, true);
 }
 
 size_t drt_trace_vjp_workspace_size(int64_t num_paths, int32_t order) {
@@ -1066,7 +1061,7 @@ int32_t drt_trace_paths_vjp_ex(drt_mesh_t mesh, const drt_trace_params *pr, cons
     size_t tb = vjp_sort_temp_bytes(n);
     // radix sort is stable: inside a destination the slots stay in path order
     // (capture-safe configuration, sort_safe.hpp: this entry point may sit in a HIP graph next to the asynchronous tracers)
-    DRT_HIP(rocprim::radix_sort_pairs<CaptureSafeSort>(sort_tmp, tb, dest, dest_sorted, slots, slots_sorted, (size_t)n, 0, 42, L.s));
+    DRT_HIP(capture_safe_sort(sort_tmp, tb, dest, dest_sorted, slots, slots_sorted, n, 0, 42, L.s));
     // (the unsorted destination keys are dead after the sort: their buffer holds the chunk carries, 12 B per 256 slots)
     float *carry = reinterpret_cast<float *>(dest);
     const int64_t nchunks = ceil_div(n, kVjpChunk);

@@ -235,6 +235,11 @@ static void dense_grid(const Launch &L, dim3 *grid, int64_t *tx_per_block) {
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// counter word [2] = status: the survivor queue overflowed (drt_trace_paths_dense_capped)
+__global__ void dense_status_kernel(unsigned long long *__restrict__ qc, int64_t qcap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (int64_t)qc[0] > qcap) qc[2] |= (unsigned long long)DRT_TRACE_OVERFLOW_SURVIVORS;
+}
+
 }  // namespace drt
 
 using namespace drt;
@@ -245,11 +250,23 @@ size_t drt_trace_dense_workspace_size(int64_t ntx, int64_t nrx, int64_t C) {
     if (ntx <= 0 || nrx <= 0 || C <= 0) return 64;
     return 64 + (size_t)ntx * (size_t)nrx * (size_t)C * 8;
 }
+size_t drt_trace_dense_capped_workspace_size(int64_t max_survivors) {
+    return 64 + (size_t)(max_survivors > 0 ? max_survivors : 0) * 8;
+}
 
 int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx, int64_t ntx,
                                  const float *rx, int64_t nrx, const drt_candidates *cands,
                                  const int32_t *types_in, float *vertices, int32_t *objects, uint8_t *mask,
                                  int32_t *types_out, void *ws, size_t ws_bytes, void *stream) {
+    // the worst case: every row survives the geometric checks
+    return drt_trace_paths_dense_capped(mesh, pr, tx, ntx, rx, nrx, cands, types_in, vertices, objects, mask, types_out, -1, ws,
+                                        ws_bytes, stream);
+}
+
+int32_t drt_trace_paths_dense_capped(drt_mesh_t mesh, const drt_trace_params *pr, const float *tx, int64_t ntx,
+                                     const float *rx, int64_t nrx, const drt_candidates *cands,
+                                     const int32_t *types_in, float *vertices, int32_t *objects, uint8_t *mask,
+                                     int32_t *types_out, int64_t max_survivors, void *ws, size_t ws_bytes, void *stream) {
     DRT_REQUIRE(mesh && pr && cands, "null argument");
     DRT_REQUIRE(ntx >= 0 && nrx >= 0, "negative size");
     DRT_REQUIRE(nrx < (1ll << 31), "too many receivers for one launch");
@@ -271,7 +288,10 @@ int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *pr, co
     const int64_t total = ntx * nrx * C;
     if (total == 0) return DRT_OK;  // SV:566-573
     DRT_REQUIRE(tx && rx && vertices && objects && mask, "null pointer");
-    const size_t need = drt_trace_dense_workspace_size(ntx, nrx, C);
+    // survivor queue: `max_survivors` entries (< 0: one per row, the worst case); a queue that overflows sets bit
+    // DRT_TRACE_OVERFLOW_SURVIVORS of the workspace's third counter word -- never silent
+    const int64_t qcap = (max_survivors < 0 || max_survivors > total) ? total : max_survivors;
+    const size_t need = drt_trace_dense_capped_workspace_size(qcap);
     if (!ws || ws_bytes < need) return fail(DRT_E_CAPACITY, "workspace too small: need %zu bytes", need);
     auto *qc = reinterpret_cast<unsigned long long *>(ws);
     auto *q = reinterpret_cast<long long *>(reinterpret_cast<char *>(ws) + 64);
@@ -297,16 +317,18 @@ int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *pr, co
     do {                                                                                                     \
         if (L.quads)                                                                                         \
             hipLaunchKernelGGL((trace_dense_kernel<K, true>), grid, dim3(256), 0, L.s, L.a, L.a.tx, L.a.rx,  \
-                               L.cs, qc, q, total, tpb, vertices, objects, mask, types_in, types_out, vec);  \
+                               L.cs, qc, q, qcap, tpb, vertices, objects, mask, types_in, types_out, vec);   \
         else                                                                                                 \
             hipLaunchKernelGGL((trace_dense_kernel<K, false>), grid, dim3(256), 0, L.s, L.a, L.a.tx, L.a.rx, \
-                               L.cs, qc, q, total, tpb, vertices, objects, mask, types_in, types_out, vec);  \
+                               L.cs, qc, q, qcap, tpb, vertices, objects, mask, types_in, types_out, vec);   \
         timer.mark(1);                                                                                       \
-        launch_occlusion<K, true>(L, qc, q, total, qc + 1, nullptr, 0, mask);                                \
+        launch_occlusion<K, true>(L, qc, q, qcap, qc + 1, nullptr, 0, mask);                                 \
         timer.mark(2);                                                                                       \
     } while (0)
     DRT_ORDER_SWITCH(k, CALL)
 #undef CALL
+    if (qcap < total)
+        hipLaunchKernelGGL(dense_status_kernel, dim3(1), dim3(64), 0, L.s, qc, qcap);
     DRT_LAUNCH_CHECK();
     if (st) {
         unsigned long long sv[2] = {0, 0};

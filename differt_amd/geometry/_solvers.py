@@ -108,6 +108,7 @@ class _TraceDenseFn(torch.autograd.Function):
         objs = torch.empty((ntx, nrx, Cn, k + 2), dtype=torch.int32, device=dev)
         mask = torch.empty((ntx, nrx, Cn), dtype=torch.uint8, device=dev)
         tout = torch.empty((ntx, nrx, Cn, k), dtype=torch.int32, device=dev)
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)
         if ntx * nrx * Cn:
             lib = _lib.load()
             nbytes = lib.drt_trace_dense_workspace_size(ntx, nrx, Cn)
@@ -117,15 +118,17 @@ class _TraceDenseFn(torch.autograd.Function):
                       nrx, C.byref(cands), ptr(types), ptr(verts), ptr(objs), ptr(mask), ptr(tout), ptr(ws), nbytes,
                       stream())
             # device-side counters of the call (include/differt_amd.h): survivors of the geometric checks, and those of
-            # them the occlusion stage cleared -- TracedPaths.num_valid_paths without a pass over the mask
-            mesh._last_dense_counts = (mask, ws[:16].view(torch.int64).clone())  # (a copy: the 8 B / row workspace is not kept alive)
+            # them the occlusion stage cleared -- TracedPaths.num_valid_paths without a pass over the mask.  A fifth,
+            # non-differentiable OUTPUT of this function (a 16-byte copy: the 8 B / row workspace is not kept alive),
+            # not a side channel on the mesh object: two tracers that share a mesh cannot swap counts.
+            counts.copy_(ws[:16].view(torch.int64))
         ctx.mesh, ctx.table, ctx.params = mesh, table, params
         ctx.save_for_backward(tx, rx)
-        ctx.mark_non_differentiable(objs, mask, tout)
-        return verts, objs, mask, tout
+        ctx.mark_non_differentiable(objs, mask, tout, counts)
+        return verts, objs, mask, tout, counts
 
     @staticmethod
-    def backward(ctx, gv, _go, _gm, _gt):
+    def backward(ctx, gv, _go, _gm, _gt, _gc):
         tx, rx = ctx.saved_tensors
         mesh, table = ctx.mesh, ctx.table
         n = gv.numel() // (3 * (table.shape[1] + 2))
@@ -365,14 +368,11 @@ def _trace_path_candidates(mesh, tx_vertices, rx_vertices, path_candidates, inte
     params = _params(epsilon, hit_tol, min_len, accel, deterministic_grad=deterministic_grad)
     if stats is not None:  # drt_trace_stats of the dense call: HIP-event kernel times, one stream synchronisation
         params.stats = C.pointer(stats)
-    verts, objs, mask, it = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table, types, params)
+    verts, objs, mask, it, counts = _TraceDenseFn.apply(tx, rx, mesh.vertices, mesh, table, types, params)
     # the kernel writes 0 / 1 bytes: reinterpret, do not copy
     paths = TracedPaths(verts, objs, mask.view(torch.bool), it, confidence_threshold)
-    counts = getattr(mesh, "_last_dense_counts", None)
-    if counts is not None:
-        mesh._last_dense_counts = None
-        if counts[0].data_ptr() == paths.mask.data_ptr():
-            paths._attach_valid_count(counts[1])
+    if mask.numel():
+        paths._attach_valid_count(counts)
     return paths
 
 
@@ -511,7 +511,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
                     for i in range(nchunks):
                         lo, hi = i * eff, min((i + 1) * eff, total)
                         if pad_chunks and hi - lo < eff:  # _solvers.py:912-918
-                            c = torch.full((eff, order), -1, dtype=torch.int32, device=dev)
+                            # (the reference pads with -1 and THEN doubles quad ids, :912-925: padding rows of a quad mesh are -2)
+                            c = torch.full((eff, order), -2 if quads else -1, dtype=torch.int32, device=dev)
                         else:
                             c = torch.empty((hi - lo, order), dtype=torch.int32, device=dev)
                         _lib.call("drt_candidates_fill", n, order, lo, hi, ptr(node_map), 2 if quads else 1, ptr(c),
@@ -777,16 +778,14 @@ class HybridPathTracer(ExhaustivePathTracer):
     Visibility is merged over all transmitters (receivers), as in the reference (:969-973)."""
 
     num_rays: int = int(1e6)
-    ragged_max_pair_size: float = 2e7
-    """:meth:`trace_pairs`, ``pairs_strategy="auto"``: mean rows per pair above which (order >= 3) the prefix
-    kernel replaces the plain ragged launch."""
     sample_triangles: bool = False
     """Extension (needs ``accel="bvh"``): complement the lattice visibility estimate with interior sample points
     of every face (``Mesh.triangles_visible_from_vertex(sample_triangles=True)``)."""
     pairs_strategy: str = "auto"
     """``"auto"``, ``"ragged"`` (one lane per (pair, candidate) row), ``"prefix"`` (order >= 3: one lane per
     first ``order - 1`` interactions, inner loops over receivers and last interactions) or ``"loop"`` (one
-    product-space launch per pair)."""
+    product-space launch per pair).  ``"auto"`` takes the prefix kernel at order >= 3 above a mean of 2e7 rows per pair
+    (decided inside ``drt_trace_paths_hybrid_pairs``, csrc/hybrid.hip, where the row count is known)."""
 
     def _graph(self, scene):
         mesh = scene.mesh
@@ -877,6 +876,14 @@ class HybridPathTracer(ExhaustivePathTracer):
         tx = scene.transmitters.reshape(-1, 3).contiguous()
         rx = scene.receivers.reshape(-1, 3).contiguous()
         vis_tx, vis_rx = self.estimate_visibility(scene) if visibility is None else visibility
+        # a cached estimate must be THIS scene's: the native call indexes vis[v * T + f] unconditionally
+        for name, vis, pts in (("transmitters", vis_tx, tx), ("receivers", vis_rx, rx)):
+            want = (pts.shape[0], mesh.num_triangles)
+            if not isinstance(vis, torch.Tensor) or tuple(vis.shape) != want or vis.device != tx.device \
+                    or vis.dtype not in (torch.bool, torch.uint8):
+                raise ValueError(f"visibility of the {name} must be a bool / uint8 tensor of shape {want} on {tx.device} "
+                                 f"(estimate_visibility of this scene), got "
+                                 f"{tuple(vis.shape) if isinstance(vis, torch.Tensor) else type(vis).__name__}")
         strategy = self.pairs_strategy
         if strategy == "loop":  # one product-space launch per pair (a debugging mapping; torch glue)
             vt, vr = vis_tx, vis_rx

@@ -432,6 +432,14 @@ typedef struct drt_candidates {
  * TracedPaths.num_valid_paths, _paths.py:264-272, is what its own harness reads after every call:
  * tests/benchmarks/test_rt.py:151-196). */
 size_t drt_trace_dense_workspace_size(int64_t num_tx, int64_t num_rx, int64_t num_candidates);
+/* FIXED-CAPACITY survivor queue (round 5; what an XLA binding allocates as a result buffer on every call): the workspace
+ * above is the worst case, 8 B per (tx, rx, candidate) row -- 512 MB for a 2^20-row chunk x 64 pairs -- although 1e-5 of
+ * the rows survive the geometric checks.  drt_trace_paths_dense_capped takes `max_survivors` instead (< 0: the worst
+ * case) and a workspace of drt_trace_dense_capped_workspace_size(max_survivors) = 64 + 8 max_survivors bytes.  Same
+ * outputs.  The counter block gains a third 64-bit word: [2] status, DRT_TRACE_OVERFLOW_SURVIVORS when more rows passed
+ * the geometric checks than the queue holds -- the occlusion stage then has not seen the rows beyond the capacity (their
+ * mask entries are still set): re-run with a larger capacity.  Counter [0] is the true number of survivors either way. */
+size_t drt_trace_dense_capped_workspace_size(int64_t max_survivors);
 int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
                               int64_t num_tx, const float *rx, int64_t num_rx,
                               const drt_candidates *cands, float *vertices, int32_t *objects,
@@ -449,6 +457,12 @@ int32_t drt_trace_paths_dense_ex(drt_mesh_t mesh, const drt_trace_params *params
                                  const drt_candidates *cands, const int32_t *interaction_types_in,
                                  float *vertices, int32_t *objects, uint8_t *mask,
                                  int32_t *interaction_types_out, void *workspace, size_t workspace_bytes,
+                                 void *stream);
+int32_t drt_trace_paths_dense_capped(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
+                                 int64_t num_tx, const float *rx, int64_t num_rx,
+                                 const drt_candidates *cands, const int32_t *interaction_types_in,
+                                 float *vertices, int32_t *objects, uint8_t *mask,
+                                 int32_t *interaction_types_out, int64_t max_survivors, void *workspace, size_t workspace_bytes,
                                  void *stream);
 
 /* Compacted output: only valid paths, in the order of TracedPaths.masked_vertices
@@ -609,6 +623,17 @@ typedef struct drt_beam_params {
  * survivors, same keys (global table rows), same vertices as without the bit (those are computed per row from the
  * row's own triangles). */
 #define DRT_CAND_PAIR_BLOCKS 8
+
+/* ---------------------------------------------------------------------------------------------
+ * Capture-safe stable radix sort of device u64 keys, optionally with a u32 payload (csrc/radix_sort.hip): what the
+ * asynchronous entry points sort their rows with, exported for hosts that build their own capturable pipelines
+ * (library radix sorts reset their state with hipMemsetAsync, and memset nodes of a captured HIP graph do not replay
+ * reliably on ROCm 7.x).  Kernels only, no allocation, no synchronisation; bits [begin_bit, end_bit) of the keys
+ * decide, 8 per pass; keys_in / values_in are left intact; n < 2^31.
+ * ------------------------------------------------------------------------------------------- */
+size_t drt_sort_u64_workspace_size(int64_t n, int32_t with_values);
+int32_t drt_sort_u64(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *values_in, uint32_t *values_out, int64_t n,
+                     int32_t begin_bit, int32_t end_bit, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Morton clusters of the mesh's primitives (allocates, synchronises; implied by drt_trace_paths_beam).  On a triangle
  * mesh the first call also runs the pairing pass.  The handle keeps up to two sets of clusters -- the pairing pass's

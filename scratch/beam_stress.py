@@ -52,10 +52,21 @@ while time.time() - t0 < budget:
         V, tx, rx = (V + off).astype(np.float32), (tx + off).astype(np.float32), (rx + off).astype(np.float32)
         st["far_from_origin"] = st.get("far_from_origin", 0) + 1
     assume_quads = bool(rng.random() < 0.4)
+    # round 5: half of the cities are ROTATED (any yaw, tilt <= 10 degrees; a new float32 scene: nothing axis-aligned any
+    # more), and triangle meshes are shuffled / thinned so that the pairing pass must find partners anywhere in the array
+    # and single triangles sit among the pairs
+    if "--no-rotate" not in sys.argv and rng.random() < 0.5:
+        V, tx, rx = S.rotate_points(S.random_rotation(rng), V, tx, rx)
+        st["rotated"] = st.get("rotated", 0) + 1
+    if not assume_quads and rng.random() < 0.4:
+        keep = np.flatnonzero(rng.random(Tr.shape[0]) > rng.choice([0.0, 0.1, 0.3]))
+        if len(keep) >= 4:
+            Tr = Tr[rng.permutation(keep)]
+            st["shuffled"] = st.get("shuffled", 0) + 1
     mask = None
     if rng.random() < 0.3:
         mask = rng.random(Tr.shape[0]) > 0.15
-        if assume_quads or rng.random() < 0.5:  # pairwise masks keep a triangle mesh searchable over its coplanar pairs
+        if assume_quads or (rng.random() < 0.5 and Tr.shape[0] % 2 == 0):  # pairwise masks (pairs of an unshuffled mesh stay pairs)
             mask[1::2] = mask[0::2]
     mesh = G.Mesh(V, Tr, mask=mask, assume_quads=assume_quads)
     n = mesh.num_primitives
@@ -74,6 +85,14 @@ while time.time() - t0 < budget:
     ba = [tuple(o) for o in bp.objects.cpu().tolist()]
     st["missed"] += len(set(ea) - set(ba))
     st["extra"] += len(set(ba) - set(ea))
+    if set(ea) != set(ba) and st.get("saved_cases", 0) < 40:  # keep the scene: a lost path must be reproducible
+        import os
+        os.makedirs("gpurun_out/stress_mismatch", exist_ok=True)
+        st["saved_cases"] = st.get("saved_cases", 0) + 1
+        np.savez(f"gpurun_out/stress_mismatch/missed_case{st['cases']}_k{KAPPA:g}.npz", V=V, Tr=Tr, tx=tx, rx=rx,
+                 mask=np.zeros(0, bool) if mask is None else mask, order=order, assume_quads=assume_quads,
+                 missed=np.asarray(sorted(set(ea) - set(ba)), np.int64).reshape(-1, order + 2),
+                 extra=np.asarray(sorted(set(ba) - set(ea)), np.int64).reshape(-1, order + 2), pair_mode=pair_mode)
     if ea == ba and ex.vertices.shape == bp.vertices.shape:
         st["vertex_mismatch"] += int((ex.vertices.view(torch.int32) != bp.vertices.view(torch.int32)).any(dim=(-1, -2)).sum())
     st["cases"] += 1

@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 import differt_amd.geometry as G  # noqa: E402
 import synthetic_scenes as S  # noqa: E402
 
-which = [a for a in sys.argv[1:] if a.startswith("cfg")] or ["cfg3", "cfg4"]
+which = [a for a in sys.argv[1:] if a.startswith(("cfg", "bruxelles"))] or ["cfg3", "cfg4"]
 EXPANSION = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--expansion=")), "auto")
 EMIT = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--emit=")), "auto")
 KAPPA = float(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--kappa=")), "64"))
@@ -62,3 +62,8 @@ if "cfg3" in which or "cfg4" in which:
 if "cfg5" in which:
     V, Tr, tx, rx = S.cfg5_scene()
     run("configs[4]", V, Tr, tx, rx, 2)
+for w in which:  # the reference's own mesh (tests/golden/bruxelles.npz): 16 TX x 64 RX in the open, order 2 / 3
+    if w.startswith("bruxelles"):
+        V, Tr = S.load_real_mesh("bruxelles")
+        tx, rx = S.outdoor_end_points(G, V, Tr, 16, 64)
+        run(f"bruxelles order {w[-1]}", V, Tr, tx, rx, int(w[-1]))

@@ -12,7 +12,7 @@ import differt_amd.geometry as G  # noqa: E402
 import oracle as orc  # noqa: E402
 import synthetic_scenes as S  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+budget = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 60.0
 rng = np.random.default_rng(31)
 st = {"cases": 0, "candidate_evals": 0, "valid_paths": 0, "mask_mismatch": 0, "vertex_mismatch": 0,
       "object_mismatch": 0, "compact_mismatch": 0}
@@ -29,6 +29,9 @@ while time.time() - t0 < budget:
     ntx, nrx = int(rng.integers(1, 4)), int(rng.integers(1, 5))
     tx, rx = S.manhattan_tx_rx(c, h, min(ntx, boxes), nrx, seed=int(rng.integers(1 << 30)), pitch=pitch)
     tx[:, 2] = rng.uniform(2, 40, len(tx))
+    if "--no-rotate" not in sys.argv and rng.random() < 0.5:  # round 5: rotated cities (any yaw, tilt <= 10 degrees)
+        V, tx, rx = S.rotate_points(S.random_rotation(rng), V, tx, rx)
+        st["rotated"] = st.get("rotated", 0) + 1
     quads = bool(rng.random() < 0.3)
     mask = (rng.random(Tr.shape[0]) > 0.1) if rng.random() < 0.4 else None
     if mask is not None and quads:

@@ -106,3 +106,22 @@ def outdoor_end_points(G, V, Tr, num_tx: int, num_rx: int, seed: int = 7):
     ntop = max(num_tx // 2, 1)
     tx = np.concatenate([outdoor(ntop, float(hi[2]) + 5.0), outdoor(num_tx - ntop, 0.4 * float(hi[2]))])[:num_tx]
     return tx, outdoor(num_rx, 1.5)
+
+
+def random_rotation(rng, max_tilt_deg: float = 10.0) -> np.ndarray:
+    """A rotation (float64 3x3): any yaw about z, then a tilt of at most `max_tilt_deg` about a horizontal axis --
+    walls are no longer axis-aligned, roofs no longer horizontal: dot products keep all three terms, images are
+    inexact, association order and contraction become visible (every scene-level parity case so far was
+    axis-aligned)."""
+    yaw, tilt, azim = rng.uniform(0, 2 * np.pi), np.deg2rad(rng.uniform(0, max_tilt_deg)), rng.uniform(0, 2 * np.pi)
+    cz, sz = np.cos(yaw), np.sin(yaw)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1.0]])
+    a = np.array([np.cos(azim), np.sin(azim), 0.0])  # tilt axis (Rodrigues)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    Rt = np.eye(3) + np.sin(tilt) * K + (1 - np.cos(tilt)) * (K @ K)
+    return Rt @ Rz
+
+
+def rotate_points(R: np.ndarray, *arrays):
+    """Apply R (float64) to float32 point arrays, rounding the result to float32 (the rotated scene is a NEW float32 scene)."""
+    return tuple((np.asarray(a, np.float64) @ R.T).astype(np.float32) for a in arrays)

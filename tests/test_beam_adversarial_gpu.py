@@ -180,7 +180,9 @@ def test_child_filter_keeps_what_the_receiver_stage_keeps(G):
         st_plain = dict(tracer.last_beam_stats)
         assert st_auto["rows"] == st_plain["rows"]
         if not pairs:
-            assert st_auto["rows"] == int(d["rows_other"])
+            # (2 682 rows when the case was captured; since round 5 a pyramid whose apex lies within the lateral tolerance
+            # of its polygon's plane is off as a whole -- make_pyr -- so this scene, a transmitter IN a wall plane, keeps more)
+            assert st_auto["rows"] >= int(d["rows_other"])
         assert st_auto["levels"][-1] < st_plain["levels"][-1]  # the filter does drop children here
         for r in (auto, plain):
             assert torch.equal(r.objects, ex.objects)
@@ -338,3 +340,31 @@ def test_coplanar_pair_mode_engages_and_equals_the_triangle_search(G, rng):
     assert not sa["pair_mode"] and sa["paired_primitives"] == 0
     ex = tracer.trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
     assert torch.equal(a.objects, ex.objects)
+
+
+@pytest.mark.parametrize("case", sorted(p.name for p in (Path(__file__).parent / "golden" / "beam_cases").glob("flat_pyramid_*.npz")))
+def test_apex_in_the_mirror_plane_on_rotated_geometry(G, case):
+    """Lost paths captured by the ROTATED stress cities of round 5 (scratch/beam_stress.py; 20 in 620 076 scenes at
+    kappa = 64): a transmitter within 0.2 ulp(M) of a wall plane, 3-4 km from the origin, reflection point 1-4 mm away at
+    88.8 degrees of incidence.  The apex (the transmitter's image) may lie on either side of the mirror's plane as far as
+    the reference's arithmetic can tell; the pyramid over the mirror flips with the side, and the triple product that
+    orients its faces is rounding noise -- on axis-aligned walls it is exactly 0 and `s != 0` switched the faces off,
+    which is why four rounds of box cities never lost such a path.  make_pyr now switches a pyramid off while its apex
+    is within the lateral tolerance of the polygon's plane: pruned == exhaustive in every mapping."""
+    d = np.load(Path(__file__).parent / "golden" / "beam_cases" / case)
+    mask = d["mask"] if d["mask"].size else None
+    mesh = G.Mesh(d["V"], d["Tr"], mask=mask, assume_quads=bool(d["assume_quads"]))
+    scene = G.Scene(torch.as_tensor(d["tx"], device="cuda"), torch.as_tensor(d["rx"], device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    order = int(d["order"])
+    ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    lost = {tuple(r) for r in d["missed"].tolist()}
+    assert lost <= {tuple(r) for r in ex.objects.cpu().tolist()}  # the exhaustive tracer still finds what the search had lost
+    ref_rows = None
+    for kw in ({}, {"pairs": False}, {"expansion": "plain"}, {"emit": "plain"}, {"emit": "clustered"}, {"kappa": 1.0}):
+        bp = tracer.trace_beam_pruned(scene, order, **kw)
+        assert torch.equal(bp.objects, ex.objects), (case, kw)
+        assert torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32)), (case, kw)
+        if kw in ({}, {"expansion": "plain"}, {"emit": "plain"}, {"emit": "clustered"}):
+            ref_rows = ref_rows if ref_rows is not None else tracer.last_beam_stats["rows"]
+            assert tracer.last_beam_stats["rows"] == ref_rows, (case, kw)

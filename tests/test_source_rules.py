@@ -47,9 +47,14 @@ def test_capturable_entry_points_use_the_safe_configuration():
     beam = (CSRC / "beam.hip").read_text()
     i = beam.index("int32_t drt_trace_paths_beam_async(")
     body = beam[i:]
-    assert "radix_sort_keys<CaptureSafeSort>" in body and "radix_sort_pairs<CaptureSafeSort>" in body
+    assert body.count("capture_safe_sort(") >= 2
     assert not re.search(r"rocprim::radix_sort_(?:keys|pairs)\s*\(", re.sub(r"//[^\n]*", "", body))
     trace = (CSRC / "trace.hip").read_text()
     j = trace.index("int32_t drt_trace_paths_compact_async(")
     k = trace.index("\n}\n", j)
-    assert "radix_sort_keys<CaptureSafeSort>" in trace[j:k]
+    assert "capture_safe_sort(" in trace[j:k]
+    # the dispatcher itself: the library's own radix sort (kernels only) or rocPRIM's merge-sort configuration
+    safe = re.sub(r"//[^\n]*", "", (CSRC / "sort_safe.hpp").read_text())
+    assert "radix_sort_u64(" in safe and "radix_sort_keys<CaptureSafeSort>" in safe and "radix_sort_pairs<CaptureSafeSort>" in safe
+    own = re.sub(r"//[^\n]*", "", (CSRC / "radix_sort.hip").read_text())
+    assert "hipMemset" not in own and "rocprim::" not in own

@@ -47,6 +47,7 @@ def test_fused_tracer_vs_oracle_stress():
     assert st["cases"] > 5 and st["candidate_evals"] > 1e4
     assert st["mask_mismatch"] == 0 and st["vertex_mismatch"] == 0 and st["object_mismatch"] == 0, st
     assert st["compact_mismatch"] == 0, st
+    assert st.get("rotated", 0) > 2  # half of the cities are rotated (round 5): not only axis-aligned geometry
 
 
 def test_hybrid_candidate_space_stress():
@@ -62,6 +63,7 @@ def test_beam_pruning_vs_exhaustive_stress():
     assert st["cases"] > 50 and st["valid_paths"] > 0 and st["mapping_checks"] > 0
     assert st["rows_traced"] < st["exhaustive_candidates"] / 10
     assert st["missed"] == 0 and st["extra"] == 0 and st["vertex_mismatch"] == 0 and st["mapping_row_mismatch"] == 0, st
+    assert st.get("rotated", 0) > 10 and st.get("shuffled", 0) > 5  # rotated cities, shuffled / thinned triangle arrays
 
 
 def test_bvh_vs_brute_force_stress():

@@ -133,7 +133,8 @@ def test_chunk_iterator_is_gpu_filled_and_equals_host_enumeration(G, rng, order,
         assert all(tuple(c.shape) == (cs, order) for c, _ in padded)
         flat = np.concatenate([_np(c) for c, _ in padded])
         np.testing.assert_array_equal(flat[:exp.shape[0]], exp)
-        assert (flat[exp.shape[0]:] == -1).all()
+        # the reference pads with -1 and THEN doubles quad ids (_solvers.py:912-925): -2 on a quad mesh, host path alike
+        assert (flat[exp.shape[0]:] == (-2 if assume_quads else -1)).all()
 
 
 def test_padded_chunk_rows_are_invalid_and_zero(G):
@@ -243,3 +244,50 @@ def test_image_method_vjp_with_shared_rows(G, rng, k):
         assert tuple(g_s[i].shape) == ref.shape
         tol = 1e-5 * np.abs(per).sum(axis=0).max()
         np.testing.assert_allclose(_np(g_s[i]), ref, rtol=0, atol=tol)
+
+
+def test_capped_survivor_queue(G):
+    """drt_trace_paths_dense_capped (round 5): a survivor queue of `max_survivors` entries instead of one per row -- the
+    same four arrays and counters when it fits, bit DRT_TRACE_OVERFLOW_SURVIVORS of the third counter word when it does
+    not (never silent), and the true survivor count either way."""
+    import ctypes as C
+
+    from differt_amd import _lib
+    from differt_amd._tensors import ptr, stream
+    from differt_amd.geometry._solvers import _params, _table_candidates
+
+    V, Tr, tx, rx, scene = _city(G, boxes=12, ntx=3, nrx=4)
+    n = scene.mesh.num_primitives
+    table = torch.as_tensor(orc.generate_all_path_candidates(n, 2).astype(np.int32), device="cuda")
+    ref = scene.trace_paths(path_candidates=table)
+    txd, rxd = scene.transmitters.reshape(-1, 3).contiguous(), scene.receivers.reshape(-1, 3).contiguous()
+    ntx, nrx, (Cn, k) = txd.shape[0], rxd.shape[0], table.shape
+    params = _params(None, None, None, None)
+    cands = _table_candidates(table)
+    lib = _lib.load()
+
+    def run(max_survivors):
+        verts = torch.empty((ntx, nrx, Cn, k + 2, 3), dtype=torch.float32, device="cuda")
+        objs = torch.empty((ntx, nrx, Cn, k + 2), dtype=torch.int32, device="cuda")
+        mask = torch.empty((ntx, nrx, Cn), dtype=torch.uint8, device="cuda")
+        tout = torch.empty((ntx, nrx, Cn, k), dtype=torch.int32, device="cuda")
+        nbytes = lib.drt_trace_dense_capped_workspace_size(max_survivors)
+        assert nbytes == 64 + 8 * max(max_survivors, 0)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        _lib.call("drt_trace_paths_dense_capped", scene.mesh.handle().h, C.byref(params), ptr(txd), ntx, ptr(rxd), nrx,
+                  C.byref(cands), None, ptr(verts), ptr(objs), ptr(mask), ptr(tout), max_survivors, ptr(ws), nbytes, stream())
+        torch.cuda.synchronize()
+        return verts, objs, mask, ws[:24].view(torch.int64).cpu().numpy()
+
+    survivors = None
+    for cap in (ntx * nrx * Cn, 4096):
+        verts, objs, mask, cnt = run(cap)
+        assert torch.equal(mask.bool(), ref.mask) and torch.equal(objs, ref.objects)
+        assert torch.equal(verts.view(torch.int32), ref.vertices.view(torch.int32))
+        assert cnt[2] == 0 and cnt[0] - cnt[1] == int(ref.mask.sum())
+        survivors = int(cnt[0])
+    assert 8 < survivors <= 4096  # the small capacity above was a real bound, and the next one overflows
+    verts, objs, mask, cnt = run(8)
+    assert cnt[2] == _lib.DRT_TRACE_OVERFLOW_SURVIVORS and cnt[0] == survivors
+    # what the first 8 queue entries decided is right; rows beyond the queue keep the geometric verdict (mask set)
+    assert bool((mask.bool() | ~ref.mask).all())
