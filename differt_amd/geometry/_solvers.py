@@ -467,6 +467,15 @@ class ExhaustivePathTracer(AbstractPathTracer):
         """``(candidates i32[C, order], interaction_types i32[C, order])`` (_solvers.py:803-848)."""
         if isinstance(order, Sequence):
             raise NotImplementedError("ExhaustivePathTracer does not support multiple orders yet.")
+        if order == 0:
+            # the one direct path from -> to, whatever the graph between them looks like (complete, masked or visibility-
+            # pruned: insert_from_and_to_nodes(direct_path=True), graph.rs) -- no 7 000 x 7 000 adjacency matrix for it
+            # (the reference's harness traces orders 0 and 1 on bruxelles.obj, tests/benchmarks/test_rt.py:151-196)
+            cands = torch.empty((1, 0), dtype=torch.int32, device=device())
+            return cands, torch.zeros_like(cands)
+        fast = self._fast_candidates(scene, order)
+        if fast is not None:
+            return fast, torch.zeros_like(fast)
         if type(self) is ExhaustivePathTracer and order >= 1:
             # complete graph (optionally over the active primitives only): the table is unranked on
             # the GPU, no host enumeration and no host->device copy (reference: _solvers.py:817-843)
@@ -485,6 +494,9 @@ class ExhaustivePathTracer(AbstractPathTracer):
         if scene.mesh.assume_quads:
             cands = 2 * cands  # _solvers.py:842-843
         return cands, torch.zeros_like(cands)
+
+    def _fast_candidates(self, scene, order):  # noqa: ARG002 - subclasses with a pruned graph override
+        return None
 
     def generate_path_candidates_chunks_iter(self, scene, order, *args, chunk_size=None,
                                              pad_chunks=False, **kwargs):
@@ -806,6 +818,22 @@ class HybridPathTracer(ExhaustivePathTracer):
                 mask = mask[0::2] & mask[1::2]
             graph.filter_by_mask(mask.cpu().numpy(), fast_mode=True)
         return graph, from_, to
+
+    def _fast_candidates(self, scene, order):
+        """Orders 1 and 2 of the pruned DiGraph (_solvers.py:1013-1056) without building it on the host: a path
+        from -> n_1 -> .. -> n_k -> to exists iff n_1 is visible from a transmitter, n_k from a receiver, every n_i is
+        active and consecutive nodes differ (a complete graph has no self loops) -- enumerated in the DiGraph's
+        lexicographic order (graph.rs:400-470) with two torch ops on the device.  Higher orders: the host iterator."""
+        if order not in (1, 2):
+            return None
+        first, last, _middle, both = self._visible_sets(scene)
+        scale = 2 if scene.mesh.assume_quads else 1
+        if order == 1:
+            return (torch.nonzero(both).reshape(-1).to(torch.int32) * scale).reshape(-1, 1).contiguous()
+        if first.shape[0] * last.shape[0] >= 2 ** 27:
+            return None
+        rows = torch.cartesian_prod(first, last).reshape(-1, 2)  # (first-major: lexicographic)
+        return (rows[rows[:, 0] != rows[:, 1]] * scale).contiguous()
 
     def _visible_sets(self, scene):
         """Primitive index lists (device int32, ascending): first interactions (visible from a

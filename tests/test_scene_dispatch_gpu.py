@@ -245,3 +245,26 @@ def test_trace_paths_beam_solver_equals_compact_exhaustive(G, two_buildings, gol
         scene.trace_paths(2, solver="beam", chunk_size=10)
     with pytest.raises(ValueError):
         scene.trace_paths(4, solver="beam")
+
+
+@pytest.mark.parametrize("assume_quads", [False, True])
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_fast_candidate_paths_equal_the_host_graph(G, canyon, assume_quads, with_mask):
+    """Order 0 (every tracer) and orders 1-2 of the hybrid tracer are enumerated on the device without the host DiGraph
+    (what the reference's harness runs on bruxelles.obj: orders 0 and 1, tests/benchmarks/test_rt.py:151-196): the same
+    rows in the same order as DiGraph.all_paths_array over the pruned graph (_solvers.py:1013-1056, graph.rs:400-470)."""
+    mesh = canyon.mesh.set_assume_quads(assume_quads)
+    if with_mask:
+        m = torch.ones(mesh.num_triangles, dtype=torch.bool, device="cuda")
+        m[4:10] = False
+        mesh = mesh.set_mask(m)
+    scene = canyon.with_mesh(mesh)
+    for solver in (G.HybridPathTracer(num_rays=20_000), G.ExhaustivePathTracer(disconnect_inactive_triangles=True),
+                   G.ExhaustivePathTracer()):
+        for order in (0, 1, 2):
+            got, types = solver.generate_path_candidates(scene, order)
+            graph, from_, to = solver._graph(scene)
+            arr = np.asarray(graph.all_paths_array(from_, to, order + 2, include_from_and_to=False)).astype(np.int32)
+            exp = arr.reshape(arr.shape[0], order) * (2 if assume_quads else 1)
+            assert tuple(got.shape) == exp.shape and got.dtype == torch.int32 and tuple(types.shape) == exp.shape
+            np.testing.assert_array_equal(got.cpu().numpy(), exp)
