@@ -260,8 +260,8 @@ def _exhaustive_pairs_module():
     import importlib.util
     from pathlib import Path
 
-    spec = importlib.util.spec_from_file_location("exhaustive_pairs",
-                                                  Path(__file__).resolve().parents[1] / "scratch" / "exhaustive_pairs.py")
+    # tests/exhaustive_pairs_check.py (scratch/exhaustive_pairs.py is its command line)
+    spec = importlib.util.spec_from_file_location("exhaustive_pairs_check", Path(__file__).resolve().parent / "exhaustive_pairs_check.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
