@@ -188,6 +188,11 @@ def compact_line(full: dict, sidecar: str | None) -> dict:
     return out
 
 
+def _progress(msg: str) -> None:
+    """Leg markers on stderr (the line on stdout stays the only thing there): a leg that dies is then named."""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-json", default=None, help="sidecar with every leg in full (default gpurun_out/bench_full.json)")
@@ -435,6 +440,7 @@ def main() -> None:
         except Exception as exc:  # noqa: BLE001 - an extra leg never costs the headline line
             result["cfg2_batched"] = {"error": repr(exc)}
 
+    _progress("headline done")
     if not args.no_paths:  # every rank takes part: the candidate-rank space is sharded over the GPUs
         paths = None
         try:
@@ -449,6 +455,7 @@ def main() -> None:
         if rank == 0 and paths is not None:
             result["paths"] = paths
 
+    _progress("paths done")
     if not args.no_scaling:  # every rank takes part: configs[4], total work fixed, split over the ranks
         try:
             import bench_scaling
@@ -471,6 +478,7 @@ def main() -> None:
                                       "scaling": "strong", "valid_paths": rec.get("valid_paths")})
                 result["strong_headline"] = heads
 
+    _progress("scaling done")
     if rank == 0 and not args.no_paths:
         try:
             import bench_queries

@@ -98,16 +98,26 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
         "grad_tx_finite": bool(torch.isfinite(grad).all().item()),
         "grad_tx_absmax": float(grad.abs().max().item()),
     }
+    import sys
+
+    def note(msg):
+        print(f"[bench_paths] {msg}", file=sys.stderr, flush=True)
+
     if rank == 0 and world == 1 and num_ranks is None and order == 2:
+        note("exhaustive done")
         out["beam_pruned"] = beam_leg(G, mesh, tx, rx, order, nvalid)
+        note("beam_pruned done")
         out["beam_pruned_graph"] = beam_graph_leg(G, mesh, tx, rx, order, nvalid)
+        note("beam_pruned_graph done")
         # BASELINE configs[3]: the same scene at order 3 -- 1.02e15 candidates, reachable only through the pruned
         # search (no exhaustive count to compare with: 91 paths, re-validated by the oracle in tests/test_full_size_gpu.py)
         out["beam_pruned_order3"] = beam_leg(G, mesh, tx, rx, 3, None, reps=1)
         out["beam_pruned_order3"]["same_valid_paths_as_exhaustive"] = exhaustive_record("configs[3]")
         # configs[3] in ONE pass and one HIP graph (29 GiB of workspace at capacities of twice the measured list sizes:
         # what 288 GB of HBM are for)
+        note("beam_pruned_order3 done")
         out["beam_pruned_order3_graph"] = beam_graph_leg(G, mesh, tx, rx, 3, out["beam_pruned_order3"].get("valid_paths"), reps=2)
+        note("beam_pruned_order3_graph done")
         # the same configs as QUAD meshes (assume_quads=True: the city is boxes, and the reference's own harness calls
         # set_assume_quads(), tests/benchmarks/test_rt.py:162): exhaustive order 2, pruned orders 2 and 3
         try:
@@ -115,7 +125,9 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
             out["assume_quads"] = quads_legs(G, qmesh, tx, rx)
         except Exception as exc:  # noqa: BLE001
             out["assume_quads"] = {"error": repr(exc)}
+        note("assume_quads done")
         out["visibility_pruned"] = pruned_leg(G, mesh, tx, rx, order, nvalid)
+        note("visibility_pruned done")
     if rank == 0 and world == 1 and num_ranks is None and order == 2:
         # the drop-in itself: Scene.trace_paths(order, chunk_size=...) in the reference's dense layout (bench_dense.py)
         try:
@@ -124,6 +136,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
             out["reference_api"] = bench_dense.legs()
         except Exception as exc:  # noqa: BLE001
             out["reference_api"] = {"error": repr(exc)}
+        note("reference_api done")
     if rank == 0 and world == 1 and num_ranks is None and order == 2:
         # the reference's own meshes (bruxelles.obj = the mesh of its benchmark harness): harness shapes + pruned orders 2 / 3
         try:
@@ -132,6 +145,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
             out["real_meshes"] = bench_real.run()
         except Exception as exc:  # noqa: BLE001
             out["real_meshes"] = {"error": repr(exc)}
+        note("real_meshes done")
     if cpu_sample and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_sample_rate(V, Tr, tx, rx, order, n)
     return out
@@ -281,6 +295,10 @@ def beam_graph_leg(G, mesh, tx, rx, order: int, expected_valid: int | None, reps
             _lib.call("drt_trace_paths_vjp", h, ptr(txd), txd.shape[0], ptr(rxd), rxd.shape[0], C.byref(cands),
                       ptr(out["keys"]), ptr(cot), max_paths, ptr(gtx), ptr(grx), ptr(gmv), stream())
 
+        # (the first static call above is still in flight on the current stream and owns `out`: the warm-up on the side
+        # stream must not start before it has finished -- two instances on one workspace corrupt each other's lists; found
+        # in round 5 as an intermittent memory fault of this leg once the row sort addressed its scatter by counters)
+        torch.cuda.synchronize()
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             launch()

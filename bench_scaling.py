@@ -35,6 +35,11 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
     from differt_amd.distributed import (allreduce_grads, gather_paths, shard_interval,
                                          trace_rank_range_sharded)
 
+    def note(msg):
+        import sys
+
+        print(f"[bench_scaling] rank {rank}: {msg}", file=sys.stderr, flush=True)
+
     def barrier():
         if dist is not None and world > 1:
             dist.barrier()
@@ -104,6 +109,7 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
     except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
         err = repr(exc)
         out["candidate_sharded"] = {"error": err}
+    note("candidate_sharded done")
 
     # ---------------------------------------------------------------- triangle-block sharding ----
     try:
@@ -169,6 +175,7 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
         }
     except Exception as exc:  # noqa: BLE001
         out["triangle_block"] = {"error": repr(exc)}
+    note("triangle_block done")
 
     # ------------------------------------------------- full coverage: beam pruning, prefix-sharded ----
     # The COMPLETE configs[4] problem (every candidate of every pair, guarantee of DESIGN.md section 9), split
@@ -215,6 +222,7 @@ def run(dev, rank: int = 0, world: int = 1, dist=None, *, boxes: int = 20000, rx
         }
     except Exception as exc:  # noqa: BLE001
         out["beam_sharded"] = {"error": repr(exc)}
+    note("beam_sharded done")
     if world == 1:
         # the same complete problem as ONE HIP graph (static shapes, no host synchronisation): bench_paths.beam_graph_leg
         try:

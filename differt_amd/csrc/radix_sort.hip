@@ -154,8 +154,12 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const unsigned l
         if (idx < n) {
             const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
             const uint32_t pos = cnt[wave][d] + off[r];
-            keys_out[pos] = key[r];
-            if (VALUES) vals_out[pos] = val[r];
+            // (pos < n by construction; the compare costs nothing next to the store and turns a caller's misuse -- two
+            // calls in flight on ONE workspace overwrite each other's counters -- into wrong output instead of a wild write)
+            if ((int64_t)pos < n) {
+                keys_out[pos] = key[r];
+                if (VALUES) vals_out[pos] = val[r];
+            }
         }
     }
 }

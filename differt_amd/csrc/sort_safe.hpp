@@ -27,7 +27,11 @@ size_t radix_sort_u64_temp_bytes(int64_t n, bool values);
 hipError_t radix_sort_u64(void *tmp, size_t tmp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
                           const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int begin_bit, int end_bit, hipStream_t s);
 
+#if defined(DRT_LAB) && defined(DRT_LAB_OWN_SORT_MIN)  // lab: A/B against rocPRIM's merge sort (a huge value disables the own sort)
+constexpr int64_t kOwnSortMin = DRT_LAB_OWN_SORT_MIN;
+#else
 constexpr int64_t kOwnSortMin = 1 << 15;
+#endif
 
 inline size_t capture_safe_sort_temp_bytes(int64_t n, bool values) {
     if (n <= 0) return 0;

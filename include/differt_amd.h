@@ -667,6 +667,8 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *params, co
  *       masked_vertices order, bit-identical to drt_trace_paths_beam; the others are padding (key -1, vertices 0, objects -1)
  *   counts_dev [4] i64 (DEVICE): [0] rows that passed the geometric checks, [1] valid paths, [2] status word
  *       (DRT_TRACE_OVERFLOW_* | DRT_BEAM_OVERFLOW_*, 0 = complete), [3] candidate rows handed to the tracer
+ * The workspace (and the outputs) belong to ONE call in flight: a second call on another stream must not start before the
+ * first has finished -- the stages address their lists through device-side counters in the workspace.
  * Preconditions (they allocate / synchronise, so they cannot happen here): drt_mesh_build_beam_clusters(mesh), and
  * drt_mesh_build_bvh(mesh) with DRT_TRACE_USE_BVH.  On overflow the rows written are valid paths, but not all of them:
  * re-run with larger capacities (or call drt_trace_paths_beam, which slices). */
