@@ -11,6 +11,7 @@ sys.path.insert(0, ".")
 from differt_amd._srchash import source_hash  # noqa: E402
 
 src, dst = Path("gpurun_out/prof_r05"), Path("profiles/r05")
+ONLY_TRAFFIC = "--traffic-only" in sys.argv
 dst.mkdir(parents=True, exist_ok=True)
 (dst / "raw").mkdir(exist_ok=True)
 
@@ -58,7 +59,7 @@ def _big(pattern, name):
     vals = []
     for fn in find(pattern):
         for r in csv.DictReader(open(fn)):
-            if "mt_dense_aligned_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name and int(r["Grid_Size"]) > 10_000_000:
+            if "mt_dense_aligned_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name and int(r["Grid_Size"]) == 5242880:
                 vals.append(float(r["Counter_Value"]))
     return vals
 fv, wv = _big("pmcmt_fetch_size_counter_collection.csv", "FETCH_SIZE"), _big("pmcmt_write_size_counter_collection.csv", "WRITE_SIZE")
