@@ -63,6 +63,22 @@ while time.time() - t0 < budget:
         if len(keep) >= 4:
             Tr = Tr[rng.permutation(keep)]
             st["shuffled"] = st.get("shuffled", 0) + 1
+    # round 5, after the flat-pyramid finding: end points placed IN the plane of a random triangle of the (possibly rotated)
+    # mesh -- a float32 point of the plane, i.e. within a fraction of an ulp of it -- or a hair off it along the normal,
+    # inside or just outside the triangle's outline: incidences of 90 degrees up to rounding on walls at any angle
+    if "--no-in-plane" not in sys.argv and rng.random() < 0.25:
+        def in_plane_point():
+            t = V[Tr[int(rng.integers(0, Tr.shape[0]))]].astype(np.float64)
+            w = rng.dirichlet((1.0, 1.0, 1.0)) * rng.choice([1.0, 1.0, 1.3]) - rng.choice([0.0, 0.0, 0.1])
+            nrm = np.cross(t[1] - t[0], t[2] - t[1])
+            nrm /= max(np.linalg.norm(nrm), 1e-30)
+            return (w @ t / max(w.sum(), 1e-9) + nrm * float(rng.choice([0.0, 0.0, 1e-6, -1e-5, 1e-4, -1e-3]))).astype(np.float32)
+        if rng.random() < 0.7:
+            tx[int(rng.integers(0, len(tx)))] = in_plane_point()
+        if rng.random() < 0.5:
+            for k in rng.choice(len(rx), size=min(len(rx), 2), replace=False):
+                rx[k] = in_plane_point()
+        st["in_plane_points"] = st.get("in_plane_points", 0) + 1
     mask = None
     if rng.random() < 0.3:
         mask = rng.random(Tr.shape[0]) > 0.15

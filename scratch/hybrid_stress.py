@@ -29,6 +29,9 @@ while time.time() - t0 < budget:
     ntx, nrx = int(rng.integers(1, 4)), int(rng.integers(1, 5))
     tx, rx = S.manhattan_tx_rx(c, h, min(ntx, boxes), nrx, seed=int(rng.integers(1 << 30)), pitch=pitch)
     tx[:, 2] = rng.uniform(2, 40, len(tx))
+    if rng.random() < 0.5:  # round 5: rotated cities (any yaw, tilt <= 10 degrees)
+        V, tx, rx = S.rotate_points(S.random_rotation(rng), V, tx, rx)
+        st["rotated"] = st.get("rotated", 0) + 1
     quads = bool(rng.random() < 0.4)
     mask = (rng.random(Tr.shape[0]) > 0.15) if rng.random() < 0.5 else None
     if mask is not None and quads:

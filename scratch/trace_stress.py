@@ -25,6 +25,9 @@ while time.time() - t0 < budget:
     tx, rx = S.manhattan_tx_rx(c, h, ntx, nrx, seed=int(rng.integers(1 << 30)))
     if rng.random() < 0.5:  # low TX -> more multi-bounce street-level paths
         tx[:, 2] = rng.uniform(2, 15, ntx)
+    if rng.random() < 0.5:  # round 5: rotated cities (any yaw, tilt <= 10 degrees)
+        V, tx, rx = S.rotate_points(S.random_rotation(rng), V, tx, rx)
+        st["rotated"] = st.get("rotated", 0) + 1
     quads = bool(rng.random() < 0.3)
     mask = (rng.random(Tr.shape[0]) > 0.05) if rng.random() < 0.4 else None
     if mask is not None and quads:
