@@ -184,6 +184,8 @@ def compact_line(full: dict, sidecar: str | None) -> dict:
         out["ranks_seen_by_backend"] = sc.get("ranks_seen_by_backend")
     if "strong_headline" in full:
         out["strong_headline"] = [{k: _r(v) for k, v in h.items()} for h in full["strong_headline"]]
+    if full.get("legs_error"):
+        out["legs_error"] = str(full["legs_error"])[:160]
     out["full"] = sidecar
     return out
 
@@ -191,6 +193,82 @@ def compact_line(full: dict, sidecar: str | None) -> dict:
 def _progress(msg: str) -> None:
     """Leg markers on stderr (the line on stdout stays the only thing there): a leg that dies is then named."""
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def run_legs(args, dev, rank: int, world: int, dist) -> dict:
+    """Every leg besides the headline: {"paths", "strong_scaling", "strong_headline" (N > 1), "queries"}."""
+    out: dict = {}
+    if not args.no_paths:  # every rank takes part: the candidate-rank space is sharded over the GPUs
+        paths = None
+        try:
+            import bench_paths
+
+            paths = bench_paths.run(dev, cpu_sample=not args.no_cpu_baseline, rank=rank, world=world,
+                                    dist=dist)
+        except ImportError:
+            pass
+        except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
+            paths = {"error": repr(exc)}
+        if rank == 0 and paths is not None:
+            out["paths"] = paths
+
+    _progress("paths done")
+    if not args.no_scaling:  # every rank takes part: configs[4], total work fixed, split over the ranks
+        try:
+            import bench_scaling
+
+            sc = bench_scaling.run(dev, rank=rank, world=world, dist=dist, boxes=args.cfg5_boxes,
+                                   window=args.cfg5_window, rx_side=args.cfg5_rx_side)
+        except Exception as exc:  # noqa: BLE001
+            sc = {"error": repr(exc)}
+        if rank == 0:
+            out["strong_scaling"] = sc
+            if world > 1 and isinstance(sc, dict):
+                # the north-star scaling claim (>= 6x at 8 GPUs) is about FIXED total work: surface those
+                # legs at the top level so that a SCALE run shows them without digging (`value` above stays
+                # the weak-scaling dense operator, identical to the single-GPU bench at N = 1)
+                heads = []
+                for leg in ("beam_sharded", "candidate_sharded"):
+                    rec = sc.get(leg)
+                    if isinstance(rec, dict) and rec.get("s_per_step") is not None:
+                        heads.append({"leg": leg, "s_per_step": rec["s_per_step"], "n_gpus": world,
+                                      "scaling": "strong", "valid_paths": rec.get("valid_paths")})
+                out["strong_headline"] = heads
+
+    _progress("scaling done")
+    if rank == 0 and not args.no_paths:
+        try:
+            import bench_queries
+
+            out["queries"] = bench_queries.run(dev)
+        except Exception as exc:  # noqa: BLE001
+            out["queries"] = {"error": repr(exc)}
+
+    return out
+
+
+def legs_in_child(args) -> dict:
+    """run_legs in a child process (one GPU): its JSON, or {"legs_error": ...} when the child died."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        outp = Path(tmp) / "legs.json"
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--legs-child", str(outp), "--cfg5-boxes", str(args.cfg5_boxes),
+               "--cfg5-rx-side", str(args.cfg5_rx_side)]
+        if args.cfg5_window is not None:
+            cmd += ["--cfg5-window", str(args.cfg5_window)]
+        for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-paths", args.no_paths), ("--no-scaling", args.no_scaling)):
+            if on:
+                cmd.append(flag)
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, timeout=1500)  # (its stderr = ours: the progress markers)
+            if r.returncode == 0 and outp.exists():
+                return json.loads(outp.read_text())
+            return {"legs_error": f"the legs process exited with code {r.returncode} (negative: killed by that signal); "
+                                  "the last [bench] marker on stderr names the leg"}
+        except subprocess.TimeoutExpired:
+            return {"legs_error": "the legs process did not finish within 1500 s"}
 
 
 def main() -> None:
@@ -209,6 +287,8 @@ def main() -> None:
     ap.add_argument("--cfg5-boxes", type=int, default=20000, help="boxes of the configs[4] city (10 triangles each)")
     ap.add_argument("--cfg5-window", type=int, default=None, help="candidate ranks per pair of the strong-scaling leg")
     ap.add_argument("--cfg5-rx-side", type=int, default=32)
+    ap.add_argument("--legs-in-process", action="store_true", help="run the extra legs in this process even on one GPU")
+    ap.add_argument("--legs-child", default=None, help=argparse.SUPPRESS)  # internal: run the legs only, write their JSON here
     args = ap.parse_args()
 
     import torch
@@ -238,6 +318,9 @@ def main() -> None:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     lib.require_device()
     dev = torch.device("cuda", local_rank)
+    if args.legs_child:  # the child of legs_in_child(): legs only, JSON to the given path, nothing on stdout
+        Path(args.legs_child).write_text(json.dumps(run_legs(args, dev, 0, 1, None)))
+        return
 
     R, T = args.rays, args.triangles
     o_h, d_h, tv_h = make_cfg2(R, T, seed=1234 + rank)
@@ -441,51 +524,18 @@ def main() -> None:
             result["cfg2_batched"] = {"error": repr(exc)}
 
     _progress("headline done")
-    if not args.no_paths:  # every rank takes part: the candidate-rank space is sharded over the GPUs
-        paths = None
-        try:
-            import bench_paths
-
-            paths = bench_paths.run(dev, cpu_sample=not args.no_cpu_baseline, rank=rank, world=world,
-                                    dist=dist)
-        except ImportError:
-            pass
-        except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
-            paths = {"error": repr(exc)}
-        if rank == 0 and paths is not None:
-            result["paths"] = paths
-
-    _progress("paths done")
-    if not args.no_scaling:  # every rank takes part: configs[4], total work fixed, split over the ranks
-        try:
-            import bench_scaling
-
-            sc = bench_scaling.run(dev, rank=rank, world=world, dist=dist, boxes=args.cfg5_boxes,
-                                   window=args.cfg5_window, rx_side=args.cfg5_rx_side)
-        except Exception as exc:  # noqa: BLE001
-            sc = {"error": repr(exc)}
+    # The other legs (image-method traces, real meshes, configs[4], queries).  On ONE GPU they run in a child process: a
+    # leg that takes the process down (a GPU memory fault aborts it -- round 5 met one, in the bench's own graph leg)
+    # then costs its own numbers, not the headline line.  Under torch.distributed (N > 1) they run here: they shard
+    # over the ranks and use the process group.
+    if world == 1 and not args.legs_in_process:
+        del t_out, hit_out
+        torch.cuda.empty_cache()
+        result.update(legs_in_child(args))
+    else:
+        legs = run_legs(args, dev, rank, world, dist)  # (every rank takes part; rank 0 holds the record)
         if rank == 0:
-            result["strong_scaling"] = sc
-            if world > 1 and isinstance(sc, dict):
-                # the north-star scaling claim (>= 6x at 8 GPUs) is about FIXED total work: surface those
-                # legs at the top level so that a SCALE run shows them without digging (`value` above stays
-                # the weak-scaling dense operator, identical to the single-GPU bench at N = 1)
-                heads = []
-                for leg in ("beam_sharded", "candidate_sharded"):
-                    rec = sc.get(leg)
-                    if isinstance(rec, dict) and rec.get("s_per_step") is not None:
-                        heads.append({"leg": leg, "s_per_step": rec["s_per_step"], "n_gpus": world,
-                                      "scaling": "strong", "valid_paths": rec.get("valid_paths")})
-                result["strong_headline"] = heads
-
-    _progress("scaling done")
-    if rank == 0 and not args.no_paths:
-        try:
-            import bench_queries
-
-            result["queries"] = bench_queries.run(dev)
-        except Exception as exc:  # noqa: BLE001
-            result["queries"] = {"error": repr(exc)}
+            result.update(legs)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(T)

@@ -56,3 +56,27 @@ def test_random_rotation_is_a_rotation_with_bounded_tilt():
         assert R[2, 2] >= np.cos(np.deg2rad(10.0)) - 1e-12  # the z axis tilts by at most 10 degrees
     (p,) = S.rotate_points(np.eye(3), np.array([[1.5, 2.5, 3.5]], np.float32))
     assert p.dtype == np.float32 and np.array_equal(p, np.array([[1.5, 2.5, 3.5]], np.float32))
+
+
+def test_a_dead_legs_process_costs_its_legs_not_the_line(monkeypatch, tmp_path):
+    """On one GPU the extra legs run in a child process (bench.legs_in_child): a child that dies -- a GPU memory fault
+    aborts the process -- yields `legs_error`, and the line with the headline, roofline and cpu_baseline is still built."""
+    import subprocess
+    import types
+
+    args = types.SimpleNamespace(cfg5_boxes=400, cfg5_rx_side=4, cfg5_window=None, no_cpu_baseline=True, no_paths=False,
+                                 no_scaling=False)
+
+    def dead(cmd, **kw):
+        assert "--legs-child" in cmd and "--no-cpu-baseline" in cmd
+        return subprocess.CompletedProcess(cmd, -6)  # SIGABRT
+
+    monkeypatch.setattr(subprocess, "run", dead)
+    legs = bench.legs_in_child(args)
+    assert "legs_error" in legs and "-6" in legs["legs_error"]
+    full = json.loads((ROOT / "profiles" / "r04" / "bench_driver.json").read_text())
+    for k in ("paths", "strong_scaling", "queries"):
+        full.pop(k)
+    full.update(legs)
+    d = json.loads(json.dumps(bench.compact_line(full, None)))
+    assert d["legs_error"].startswith("the legs process exited") and d["value"] > 0 and "roofline" in d and "paths" not in d
