@@ -22,7 +22,8 @@ stream), "cpu_baseline" (the CPU oracle timed on this box's host cores on a boun
 N=1 only), "paths_metric" (the second half of BASELINE.json's metric: valid order-2 paths/s, fwd +
 grad, configs[2]) and a flat numeric "paths" summary.  Every leg in full (image-method trace, real
 meshes, strong-scaling legs, queries) goes to the sidecar named by "full" (default
-gpurun_out/bench_full.json, `--full-json PATH` to move it).
+gpurun_out/bench_full.json, `--full-json PATH` to move it).  On one GPU those legs run in a child process
+(`--legs-in-process` keeps them here): a leg that takes its process down costs its own numbers ("legs_error"), not the line.
 """
 
 from __future__ import annotations
