@@ -106,6 +106,7 @@ class BeamParams(C.Structure):
 
 
 DRT_BEAM_EXPAND_PLAIN, DRT_BEAM_EMIT_PLAIN, DRT_BEAM_EMIT_CLUSTERED, DRT_BEAM_NO_PAIRS, DRT_BEAM_ROWS_PLAIN = 1, 2, 4, 8, 16
+DRT_BEAM_EXPAND_FUSED = 32
 DRT_BEAM_OVERFLOW_ENTRIES, DRT_BEAM_OVERFLOW_RECORDS, DRT_BEAM_OVERFLOW_ROWS = 4, 8, 16
 DRT_HYBRID_PREFIX, DRT_HYBRID_RAGGED = 1, 2
 DRT_CAND_PACKED_KEYS = 4

@@ -130,6 +130,7 @@ struct BeamDyn {
 struct BeamDev {
     const BeamDyn *dyn;
     const unsigned long long *n;
+    int64_t n_off = 0;  // the launch covers entries [n_off, n_off + its size argument) of the list whose length is *n
 };
 __device__ __forceinline__ void beam_dev_apply(const BeamDev &dv, BeamMesh &M, float &u, int64_t &n) {
     if (dv.dyn) {
@@ -137,7 +138,8 @@ __device__ __forceinline__ void beam_dev_apply(const BeamDev &dv, BeamMesh &M, f
         M.inv_2m = dv.dyn->inv_2m;
     }
     if (dv.n) {
-        const int64_t nd = (int64_t)*dv.n;
+        int64_t nd = (int64_t)*dv.n - dv.n_off;
+        nd = nd < 0 ? 0 : nd;
         n = nd < n ? nd : n;
     }
 }
@@ -1303,6 +1305,263 @@ __global__ __launch_bounds__(kExpandWG) BEAM_Q4_OCC void beam_expand_clustered_l
     expand_clustered_body<4, LEVEL, true>(M, C, in, n_in, u, out, cap, count, clusters_per_split, rxall);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The order-3 last expansion in TWO kernels (round 5).  The fused kernel above keeps the 64 prefix contexts of a wave in
+// 43 VGPRs per lane for its box stage (lane = prefix) and reads them back lane-to-wave with 27-43 v_readlane per pass of
+// its transposed stage (lane = primitive): 128 VGPRs, 4 waves per SIMD, 0.55 of the VALU issue ceiling with 43 % of the
+// wave-cycles waiting.  The two stages want different register files, so they are two launches:
+//   beam_boxes_kernel         lane = prefix: builds each prefix's context ONCE, writes it to a table in global memory
+//                             (kCtxWords floats per prefix, L2-resident for the wave that reads it back), runs the box
+//                             stage over every cluster and writes the 64-bit "which prefixes reach this cluster" mask
+//                             per (wave of prefixes, cluster);
+//   beam_expand_pairs_kernel  lane = primitive: walks the clusters whose mask is not empty; the prefix of a pass comes
+//                             through the SCALAR unit (s_load of its table entry: no v_readlane, no VALU port), the
+//                             cluster's vertices are loaded only for clusters that are hit; first stage of the
+//                             per-primitive test, survivors parked, second pyramid + receiver-box filter on full waves
+//                             (the parent's entry read per lane from the table) -- about 60 VGPRs, 8 waves per SIMD.
+// Same tests, same functions, same records as the fused kernel (DRT_BEAM_EXPAND_FUSED keeps that one: cross-check).
+// ---------------------------------------------------------------------------------------------
+template <int SCALE, int LEVEL>
+struct CtxTab {
+    using Sh = Shape<SCALE>;
+    // float offsets of one entry; every group starts on a 16-byte boundary
+    static constexpr int kI = 0, kU = 3, kPm = 4, kSide = 7, kNm = 8, kSig = 11, kM = 12;  // head: 16 floats
+    static constexpr int kPyr = 16;                                    // [LEVEL][NP][NF] x (n.x, n.y, n.z, g)
+    static constexpr int kRho = kPyr + 4 * LEVEL * Sh::NP * Sh::NF;    // [NP][NF] rho of the FIRST mirror's pyramid
+    static constexpr int kHp = kRho + Sh::NP * Sh::NF;                 // [NP]
+    static constexpr int kWords = (kHp + Sh::NP + 3) / 4 * 4;
+};
+
+template <int SCALE, int LEVEL>
+__global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamClusters C, const BeamEntry *__restrict__ in,
+                                                               int64_t n_in, float u, float *__restrict__ ctxtab,
+                                                               unsigned long long *__restrict__ masks,
+                                                               int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
+    using Sh = Shape<SCALE>;
+    using Tab = CtxTab<SCALE, LEVEL>;
+    beam_dev_apply(dv, M, u, n_in);
+    if (dv.dyn) rxall = dv.dyn->rxall;
+    __shared__ __attribute__((aligned(16))) float4 lds_planes[kExpandWG / 64][64 * Sh::NP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if ((int64_t)blockIdx.x * kExpandWG >= n_in) return;  // a grid sized for the list's CAPACITY (async entry point)
+    const int64_t g = (int64_t)blockIdx.x * kExpandWG + threadIdx.x;
+    const bool have = g < n_in;
+    BeamEntry e{};
+    if (have) e = in[g];
+    BeamCtx<SCALE, LEVEL> ctx;
+    build_ctx<SCALE, LEVEL>(M, e, u, have, ctx);
+    if (blockIdx.y == 0) {  // the table entry of this prefix (every lane writes one: lanes beyond the list hold "off" contexts)
+        float rho0[Sh::NP][Sh::NF], hp0[Sh::NP];
+        float sig_sum = kInf;
+        first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum, hp0);
+        float4 *t = reinterpret_cast<float4 *>(ctxtab + g * Tab::kWords);
+        t[0] = float4{ctx.I.x, ctx.I.y, ctx.I.z, ctx.u};
+        t[1] = float4{ctx.pm.x, ctx.pm.y, ctx.pm.z, __uint_as_float((uint32_t)ctx.side_prev)};
+        t[2] = float4{ctx.nm.x, ctx.nm.y, ctx.nm.z, sig_sum};
+        t[3] = float4{__uint_as_float((uint32_t)(have ? e.id[LEVEL - 1] : -1)), 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < LEVEL; ++j)
+#pragma unroll
+            for (int tt = 0; tt < Sh::NP; ++tt)
+#pragma unroll
+                for (int f = 0; f < Sh::NF; ++f) {
+                    const PyrN<Sh::NF> &P = ctx.pyr[j][tt];
+                    t[Tab::kPyr / 4 + (j * Sh::NP + tt) * Sh::NF + f] = float4{P.n[f].x, P.n[f].y, P.n[f].z, P.g[f]};
+                }
+        float *tf = ctxtab + g * Tab::kWords;
+#pragma unroll
+        for (int tt = 0; tt < Sh::NP; ++tt) {
+            tf[Tab::kHp + tt] = hp0[tt];
+#pragma unroll
+            for (int f = 0; f < Sh::NF; ++f) tf[Tab::kRho + tt * Sh::NF + f] = rho0[tt][f];
+        }
+    }
+    const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
+    const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
+    auto fetch_planes = [&](int64_t c) {
+        const int64_t cc = (c < cl_end) ? c : cl_end - 1;
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const float4 *>(C.uplanes) +
+                                                                  (cc * 64 * Sh::NP + t * 64 + lane)),
+                (__attribute__((address_space(3))) void *)(&lds_planes[wave][t * 64]), 16, 0, 0);
+    };
+    if (cl_begin < cl_end) fetch_planes(cl_begin);
+    unsigned long long *mrow = masks + (int64_t)blockIdx.x * C.nclusters;
+    for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
+        // (the box stage of expand_clustered_body, statement for statement: the same `todo`)
+        const float *bx = C.boxes + 8 * cl;
+        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        __builtin_amdgcn_s_waitcnt(/*vmcnt 0; expcnt, lgkmcnt: no wait*/ 0x0f70);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t hbits = 0x7f800000u;
+        const int nplanes = __builtin_amdgcn_readfirstlane((int)bx[7]);
+#pragma unroll 8
+        for (int k = 0; k < nplanes; ++k) {
+            const float4 q = lds_planes[wave][k];
+            float sd = __builtin_fmaf(q.x, ctx.I.x, __builtin_fmaf(q.y, ctx.I.y, __builtin_fmaf(q.z, ctx.I.z, -q.w)));
+            asm volatile("" : "+v"(sd));
+            const uint32_t b = __float_as_uint(sd) & 0x7fffffffu;
+            hbits = (b < hbits) ? b : hbits;
+        }
+        const float hmin = __uint_as_float(hbits);
+        __builtin_amdgcn_wave_barrier();
+        fetch_planes(cl + 1);
+        const V3 far = V3{fmaxf(__builtin_fabsf(ctx.I.x - lo[0]), __builtin_fabsf(ctx.I.x - hi[0])),
+                          fmaxf(__builtin_fabsf(ctx.I.y - lo[1]), __builtin_fabsf(ctx.I.y - hi[1])),
+                          fmaxf(__builtin_fabsf(ctx.I.z - lo[2]), __builtin_fabsf(ctx.I.z - hi[2]))};
+        const float eps_max = beam_eps(ctx.u, bx[6], margin_len(far) * 1.0001f, hmin);
+        bool alive = have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max);
+        if (__any(alive)) {
+            const float *sb = C.subboxes + 24 * cl;
+            bool sub = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float slo[3] = {sb[6 * q], sb[6 * q + 1], sb[6 * q + 2]}, shi[3] = {sb[6 * q + 3], sb[6 * q + 4], sb[6 * q + 5]};
+                sub = sub || !box_pruned<SCALE, LEVEL>(ctx, slo, shi, eps_max);
+            }
+            alive = alive && sub;
+        }
+        const unsigned long long todo = __ballot(alive);
+        if (lane == 0) mrow[cl] = todo;
+    }
+}
+
+// the prefix of a pass, read from its table entry through the scalar unit (wave-uniform address, read-only memory)
+template <int SCALE, int LEVEL>
+struct CtxScalar {
+    using Tab = CtxTab<SCALE, LEVEL>;
+    const float *__restrict__ t;  // wave-uniform
+    __device__ __forceinline__ V3 I() const { return V3{t[Tab::kI], t[Tab::kI + 1], t[Tab::kI + 2]}; }
+    __device__ __forceinline__ V3 pm() const { return V3{t[Tab::kPm], t[Tab::kPm + 1], t[Tab::kPm + 2]}; }
+    __device__ __forceinline__ V3 nm() const { return V3{t[Tab::kNm], t[Tab::kNm + 1], t[Tab::kNm + 2]}; }
+    __device__ __forceinline__ float u() const { return t[Tab::kU]; }
+    __device__ __forceinline__ int side_prev() const { return (int)__float_as_uint(t[Tab::kSide]); }
+    __device__ __forceinline__ PyrN<Shape<SCALE>::NF> pyr(int j, int tt) const {
+        PyrN<Shape<SCALE>::NF> P;
+#pragma unroll
+        for (int f = 0; f < Shape<SCALE>::NF; ++f) {
+            const float *q = t + Tab::kPyr + 4 * ((j * Shape<SCALE>::NP + tt) * Shape<SCALE>::NF + f);
+            P.n[f] = V3{q[0], q[1], q[2]};
+            P.g[f] = q[3];
+        }
+        return P;
+    }
+};
+
+#ifndef BEAM_PAIRS_WAVES_MIN
+#define BEAM_PAIRS_WAVES_MIN 6
+#endif
+#ifndef BEAM_PAIRS_WAVES_MAX
+#define BEAM_PAIRS_WAVES_MAX 8
+#endif
+template <int SCALE, int LEVEL>
+__global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(BEAM_PAIRS_WAVES_MIN, BEAM_PAIRS_WAVES_MAX))) void beam_expand_pairs_kernel(
+    BeamMesh M, BeamClusters C, const float *__restrict__ ctxtab, const unsigned long long *__restrict__ masks, int64_t n_in,
+    float u, unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
+    int64_t clusters_per_split, RxAll rxall, BeamDev dv, int64_t rec_off) {
+    // (rec_off: position of this launch's first prefix in the list the records index -- a launch covers one chunk of it)
+    static_assert(LEVEL == 2, "the two-kernel expansion is the order-3 (level-2) last expansion");
+    using Sh = Shape<SCALE>;
+    using Tab = CtxTab<SCALE, LEVEL>;
+    beam_dev_apply(dv, M, u, n_in);
+    if (dv.dyn) rxall = dv.dyn->rxall;
+    __shared__ unsigned long long wbuf[kExpandWG / 64][kBeamWaveBufBig];
+    __shared__ unsigned long long raw_rec[kExpandWG / 64][128];
+    __shared__ float raw_f[kExpandWG / 64][2][128];  // (sorted position, threshold)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if ((int64_t)blockIdx.x * kExpandWG >= n_in) return;
+    const unsigned long long gbase = (unsigned long long)((int64_t)blockIdx.x * kExpandWG + wave * 64);
+    const float *__restrict__ tab = ctxtab + (int64_t)gbase * Tab::kWords;  // the 64 entries of this wave's prefixes
+    const unsigned long long *__restrict__ mrow = masks + (int64_t)blockIdx.x * C.nclusters;
+    int rawcount = 0, wcount = 0;
+    // the last n parked candidates (n <= 64): lane = candidate; its parent's entry comes per lane from the table
+    auto filter_parked = [&](int n) {
+        const int j = rawcount - n + lane;
+        bool mine = lane < n;
+        const unsigned long long rec = mine ? raw_rec[wave][j] : 0ull;
+        const int l = (int)((rec >> 32) - (unsigned long long)rec_off - gbase) & 63;
+        const float *__restrict__ pe = tab + (int64_t)l * Tab::kWords;
+        const float4 h0 = reinterpret_cast<const float4 *>(pe)[0];
+        const V3 I2 = V3{h0.x, h0.y, h0.z};
+        const float sp = pe[Tab::kSig];
+        V3 n0[Sh::NP][Sh::NF];
+        float rh[Sh::NP][Sh::NF], hpp[Sh::NP];
+        PyrN<Sh::NF> P0[Sh::NP];
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t) {
+            hpp[t] = pe[Tab::kHp + t];
+#pragma unroll
+            for (int f = 0; f < Sh::NF; ++f) {
+                const float4 q = reinterpret_cast<const float4 *>(pe + Tab::kPyr)[t * Sh::NF + f];  // pyramid 0
+                n0[t][f] = V3{q.x, q.y, q.z};
+                P0[t].n[f] = n0[t][f];
+                P0[t].g[f] = q.w;
+                rh[t][f] = pe[Tab::kRho + t * Sh::NF + f];
+            }
+        }
+        const int64_t pos = mine ? (int64_t)__float_as_uint(raw_f[wave][0][j]) : 0;  // (position 0 always exists)
+        const float base = raw_f[wave][1][j & 127];
+        V3 vq[Sh::NV];
+#pragma unroll
+        for (int k = 0; k < Sh::NV; ++k) vq[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));
+        const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP];
+        const V3 nc = V3{q.x, q.y, q.z};
+        const float dc = q.w, sgc = C.sigma[pos];
+        mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);
+        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, hpp, sp, nc, dc, sgc));
+        rawcount -= n;
+        beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
+    };
+    const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
+    const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
+    for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
+        unsigned long long todo = mrow[cl];  // (scalar load)
+        if (todo == 0) continue;
+        const int64_t pos = cl * 64 + lane;
+        const int32_t p = (pos < M.nprim) ? C.order[pos] : -1;
+        V3 vx[Sh::NV];
+        float pl[Sh::NP][4];
+#pragma unroll
+        for (int k = 0; k < Sh::NV; ++k) vx[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));  // padded to whole clusters
+#pragma unroll
+        for (int t = 0; t < Sh::NP; ++t) {
+            const float4 a = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP + t];
+            pl[t][0] = a.x; pl[t][1] = a.y; pl[t][2] = a.z; pl[t][3] = a.w;
+        }
+        const bool act = p >= 0 && prim_active(M, p);
+        const bool self_ok = p >= 0 && may_follow(M, p, p);
+        const float sg = C.sigma[pos];
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float *__restrict__ te = tab + (int64_t)l * Tab::kWords;  // wave-uniform: scalar loads
+            const int32_t m = (int32_t)__float_as_uint(te[Tab::kM]);
+            const bool cand = act && (p != m || self_ok);
+            V3 unused;
+            float base1 = 0.0f;
+            const bool keep = cand && !prim_stage1<SCALE, LEVEL>(CtxScalar<SCALE, LEVEL>{te}, vx, pl, sg, unused, base1);
+            const unsigned long long record = (((unsigned long long)rec_off + gbase + (unsigned long long)l) << 32) | (uint32_t)p;
+            const unsigned long long vote = __ballot(keep);
+            if (vote) {
+                if (keep) {
+                    const int j = rawcount + __popcll(vote & ((1ull << lane) - 1ull));
+                    raw_rec[wave][j] = record;
+                    raw_f[wave][0][j] = __uint_as_float((uint32_t)pos);
+                    raw_f[wave][1][j] = base1;
+                }
+                rawcount += __popcll(vote);
+                if (rawcount >= 64) filter_parked(64);
+            }
+        }
+    }
+    if (rawcount > 0) filter_parked(rawcount);
+    if (wcount > 0) beam_flush(wbuf[wave], wcount, lane, out, cap, count);
+}
+
 // (source prefix, primitive) record -> child prefix: image of the apex in the new mirror, side of the parent's
 // last mirror w.r.t. the new mirror's plane, error sum extended by the new mirror's own bound
 template <int LEVEL>  // level of the PARENT
@@ -2298,12 +2557,14 @@ namespace {
 struct BeamLayout {  // byte offsets into the caller's workspace
     size_t counters, rx_sorted, rx_index, rx_boxes, morton, entries1, entries2, records, rows, rows_sorted, table,
         pair_offsets, sort_tmp, trace_ws, trace_ws_bytes, slice_keys, merge_keys, merge_perm, merge_iota, merge_rows,
-        total;
+        ctx_table, ctx_masks, total;
 };
 
 struct BeamSizes {
     int64_t max_entries, max_records, max_rows, max_survivors;
+    int64_t ctx_cap;  // prefixes per launch of the two-kernel order-3 expansion (context table + cluster masks); 0: order < 3
 };
+constexpr int64_t kCtxWordsMax = 72;  // CtxTab<2, 2>::kWords, the largest entry (shape known only once the clusters exist)
 
 // Default list capacities, sized from the scene (results never depend on them: a slice that overflows is retried
 // smaller, drt_trace_paths_beam; round 3 took 2^26 / 2^27 / 2^26 / 2^22 whatever the scene = 5.5 GiB of workspace
@@ -2343,6 +2604,14 @@ static BeamSizes beam_sizes(const drt_beam_params *bp, int64_t ntx, int64_t nrx,
     const int64_t d_rows = std::min(clamp64(z.max_records / 2, (int64_t)1 << 18, (int64_t)1 << 26), std::max<int64_t>(row_bound, 64));
     z.max_rows = (bp && bp->max_rows > 0) ? bp->max_rows : d_rows;
     z.max_survivors = (bp && bp->max_survivors > 0) ? bp->max_survivors : std::min<int64_t>((int64_t)1 << 22, z.max_rows);
+    // order 3: the last expansion runs over slices / chunks of at most ctx_cap level-2 prefixes (288 B of context per
+    // prefix, 8 B of mask per (64 prefixes, cluster): at most 2^21 prefixes, masks of at most 256 MiB)
+    z.ctx_cap = 0;
+    if (order >= 3) {
+        const int64_t ncl = ceil_div(nprim > 0 ? nprim : 1, 64);
+        const int64_t by_masks = std::max<int64_t>(64, ((int64_t)1 << 25) / ncl * 64);  // 2^28 B / 8 B per mask word
+        z.ctx_cap = std::max<int64_t>(64, std::min({std::min(z.max_entries, z.max_records), (int64_t)1 << 21, by_masks}) / 64 * 64);
+    }
     return z;
 }
 
@@ -2380,6 +2649,8 @@ static BeamLayout beam_layout(const BeamSizes &z, int64_t ntx, int64_t nrx, int6
     L.merge_perm = take((size_t)max_paths * 4);
     L.merge_iota = take((size_t)max_paths * 4);
     L.merge_rows = take((size_t)max_paths * (size_t)k2 * 12);
+    L.ctx_table = take((size_t)z.ctx_cap * (size_t)kCtxWordsMax * 4);
+    L.ctx_masks = take((size_t)(z.ctx_cap / 64) * (size_t)ceil_div(nprim > 0 ? nprim : 1, 64) * 8);
     L.total = off;
     return L;
 }
@@ -2439,11 +2710,41 @@ static int32_t read_count(const unsigned long long *dev, int64_t *host, hipStrea
 #endif
 constexpr int64_t kBeamExpandBlocks = BEAM_EXPAND_BLOCKS;
 
+// context table + masks of the two-kernel order-3 expansion (null: the fused kernel)
+struct SplitWs {
+    float *ctxtab = nullptr;
+    unsigned long long *masks = nullptr;
+    int64_t cap = 0;
+};
+
 template <int SCALE, int LEVEL>
 static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool clustered, const BeamEntry *in, int64_t n_in,
                           float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s,
                           const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f}, BeamDev dv = BeamDev{nullptr, nullptr},
-                          bool last = false) {
+                          bool last = false, SplitWs sw = SplitWs{}) {
+    if constexpr (LEVEL == 2 && SCALE != 2) {  // (shape 2, the rare two-arbitrary-triangles quad, stays on the fused kernel)
+        if (clustered && sw.ctxtab && (rxall.on || (last && dv.dyn))) {
+            // two launches per chunk of at most sw.cap prefixes: box stage (lane = prefix) -> contexts + masks, then the
+            // per-primitive stage (lane = primitive, prefix through the scalar unit); the chunks append to one record list
+            for (int64_t i0 = 0; i0 < n_in; i0 += sw.cap) {
+                const int64_t n = std::min(sw.cap, n_in - i0);
+                const int64_t bx = ceil_div(n, kExpandWG);
+                int64_t by = ceil_div(kBeamExpandBlocks * 128 / kExpandWG, bx);
+                if (by > C.nclusters) by = C.nclusters;
+                if (by > 65535) by = 65535;
+                if (by < 1) by = 1;
+                const int64_t cps = ceil_div(C.nclusters, by);
+                by = ceil_div(C.nclusters, cps);
+                BeamDev dc = dv;
+                dc.n_off = dv.n_off + i0;
+                hipLaunchKernelGGL((beam_boxes_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(kExpandWG), 0, s, M, C,
+                                   in + i0, n, u, sw.ctxtab, sw.masks, cps, rxall, dc);
+                hipLaunchKernelGGL((beam_expand_pairs_kernel<SCALE, LEVEL>), dim3((unsigned)bx, (unsigned)by), dim3(kExpandWG), 0, s, M,
+                                   C, sw.ctxtab, sw.masks, n, u, out, cap, count, cps, rxall, dc, i0);
+            }
+            return;
+        }
+    }
     if (clustered) {
         const int64_t bx = ceil_div(n_in, kExpandWG);
         int64_t by = ceil_div(kBeamExpandBlocks * 128 / kExpandWG, bx);  // few prefixes: split the cluster range so that the launch fills the chip
@@ -2900,6 +3201,9 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     const bool expand_clustered = !(flags & DRT_BEAM_EXPAND_PLAIN);
     const bool emit_clustered = (flags & DRT_BEAM_EMIT_CLUSTERED) || (!(flags & DRT_BEAM_EMIT_PLAIN) && nrx >= 128);
     const bool pair_blocks = !(flags & DRT_BEAM_ROWS_PLAIN);
+    SplitWs split_ws;  // order 3: the last expansion as two kernels (DRT_BEAM_EXPAND_FUSED: the single fused kernel)
+    if (order == 3 && z.ctx_cap > 0 && !(flags & DRT_BEAM_EXPAND_FUSED))
+        split_ws = SplitWs{reinterpret_cast<float *>(base + L.ctx_table), reinterpret_cast<unsigned long long *>(base + L.ctx_masks), z.ctx_cap};
 
     DRT_HIP(fill_bytes_async(counters, 0, 256, s));
     // ---- level 1 ----
@@ -3024,7 +3328,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
                 BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
             } else {
-#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall)
+#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall, BeamDev{nullptr, nullptr}, true, split_ws)
                 BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
             }
@@ -3271,6 +3575,9 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     hipLaunchKernelGGL(point_bounds_kernel, dim3((unsigned)ceil_div(ntx, 256)), dim3(256), 0, s, tx, ntx, 1, tx_bounds);
     const bool expand_clustered = !(flags & DRT_BEAM_EXPAND_PLAIN);
     const bool emit_clustered = (flags & DRT_BEAM_EMIT_CLUSTERED) || (!(flags & DRT_BEAM_EMIT_PLAIN) && nrx >= 128);
+    SplitWs split_ws;
+    if (order == 3 && z.ctx_cap > 0 && !(flags & DRT_BEAM_EXPAND_FUSED))
+        split_ws = SplitWs{reinterpret_cast<float *>(base + L.ctx_table), reinterpret_cast<unsigned long long *>(base + L.ctx_masks), z.ctx_cap};
     hipLaunchKernelGGL(beam_dyn_kernel, dim3(1), dim3(64), 0, s, rx_bounds, tx_bounds, mesh->beam_max_abs, kappa,
                        expand_clustered ? 1 : 0, dyn);
     DRT_HIP(fill_bytes_async(counters, 0, 128, s));
@@ -3299,7 +3606,7 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
 #undef CALL
         hipLaunchKernelGGL(beam_finish_kernel<1>, dim3((unsigned)ceil_div(cap2, 256)), dim3(256), 0, s, M, entries1, records,
                            cap2, u0, entries2, BeamDev{dyn, c2});
-#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, entries2, cap2, u0, records, z.max_records, c3, s, rx_off, BeamDev{dyn, c2}, true)
+#define CALL(SC, K) launch_expand<SC, 2>(M, C, expand_clustered, entries2, cap2, u0, records, z.max_records, c3, s, rx_off, BeamDev{dyn, c2}, true, split_ws)
         BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
         last_src = entries2;

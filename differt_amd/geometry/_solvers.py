@@ -623,7 +623,8 @@ class ExhaustivePathTracer(AbstractPathTracer):
         primitive ids).  Orders 0..3.
 
         ``expansion``: ``"clustered"`` (= ``"auto"``: primitives in Morton clusters of 64, box test per (prefix,
-        cluster)) or ``"plain"`` (every pair tested); ``emit``: ``"plain"``, ``"clustered"`` (receivers in Morton
+        cluster); at order 3 the last expansion runs as two kernels, ``"fused"`` keeps it in one) or ``"plain"`` (every
+        pair tested); ``emit``: ``"plain"``, ``"clustered"`` (receivers in Morton
         clusters) or ``"auto"`` (clustered from 128 receivers on) -- the same rows either way.
         ``prefix_shard=(rank, world)`` keeps the level-1 prefixes (transmitter ``t``, first mirror ``m``) with
         ``(t * n + m) % world == rank``: the multi-GPU split of
@@ -642,7 +643,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
             raise NotImplementedError("the smoothed mode is dense by nature: use trace_path_candidates")
         if not 0 <= order <= 3:
             raise ValueError("beam pruning covers orders 0..3")
-        if expansion not in ("auto", "clustered", "plain"):
+        if expansion not in ("auto", "clustered", "plain", "fused"):
             raise ValueError(f"unknown expansion {expansion!r}")
         if emit not in ("auto", "plain", "clustered"):
             raise ValueError(f"unknown emit {emit!r}")
@@ -651,6 +652,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
         beam = _lib.BeamParams()
         beam.kappa = float(kappa)
         beam.flags = ((_lib.DRT_BEAM_EXPAND_PLAIN if expansion == "plain" else 0)
+                      | (_lib.DRT_BEAM_EXPAND_FUSED if expansion == "fused" else 0)
                       | (_lib.DRT_BEAM_EMIT_PLAIN if emit == "plain" else 0)
                       | (_lib.DRT_BEAM_EMIT_CLUSTERED if emit == "clustered" else 0)
                       | (0 if pairs else _lib.DRT_BEAM_NO_PAIRS)

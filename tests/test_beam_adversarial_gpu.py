@@ -52,7 +52,7 @@ def check(G, V, Tr, tx, rx, orders=(1, 2, 3), assume_quads=False, kappas=(64.0,)
     for order in orders:
         ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
         for kappa in kappas:
-            for expansion in ("auto", "plain"):
+            for expansion in ("auto", "plain") + (("fused",) if order == 3 else ()):  # order 3: two kernels vs the fused one
                 # triangle meshes of boxes are searched over their coplanar pairs by default: both forms
                 for pairs in ((True, False) if not assume_quads else (True,)):
                     bp = tracer.trace_beam_pruned(scene, order, kappa=kappa, expansion=expansion, max_paths=1 << 18,
@@ -368,3 +368,35 @@ def test_apex_in_the_mirror_plane_on_rotated_geometry(G, case):
         if kw in ({}, {"expansion": "plain"}, {"emit": "plain"}, {"emit": "clustered"}):
             ref_rows = ref_rows if ref_rows is not None else tracer.last_beam_stats["rows"]
             assert tracer.last_beam_stats["rows"] == ref_rows, (case, kw)
+
+
+def test_order3_two_kernel_expansion_in_chunks(G, rng):
+    """Order 3: the last expansion runs as two launches per chunk of at most `ctx_cap` level-2 prefixes (context table +
+    cluster masks in the workspace; csrc/beam.hip, beam_boxes_kernel / beam_expand_pairs_kernel).  Small capacities force
+    many chunks / slices in the synchronous entry, a capacity above 2^21 two chunks in the asynchronous one: the same
+    paths as the exhaustive tracer and as the fused kernel (`expansion="fused"`), the same rows."""
+    V, Tr, c, h = S.manhattan(14, seed=11)
+    tx, rx = S.manhattan_tx_rx(c, h, 2, 12, seed=12)
+    tx[:, 2] = rng.uniform(2, 40, len(tx))
+    R = S.random_rotation(rng)
+    V, tx, rx = S.rotate_points(R, V, tx, rx)
+    scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(rx, device="cuda"), G.Mesh(V, Tr))
+    tracer = G.ExhaustivePathTracer()
+    ex = tracer.trace_rank_range(scene, 3, max_survivors=1 << 24, max_paths=1 << 20)
+    assert ex.objects.shape[0] > 0
+    ref = tracer.trace_beam_pruned(scene, 3, expansion="fused")
+    rows = tracer.last_beam_stats["rows"]
+    for kw in ({}, {"max_entries": 320, "max_records": 1 << 14}, {"max_entries": 64, "max_records": 1 << 13}, {"pairs": False, "max_entries": 192}):
+        bp = tracer.trace_beam_pruned(scene, 3, **kw)
+        assert torch.equal(bp.objects, ex.objects) and torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32)), kw
+        assert torch.equal(bp.keys, ref.keys)
+        if "pairs" not in kw:
+            assert tracer.last_beam_stats["rows"] == rows, kw
+    # asynchronous entry, capacity of the level-2 list above 2^21: two chunks, most of their workgroups beyond the list
+    cap = ex.objects.shape[0] + 8
+    out = tracer.trace_beam_pruned_static(scene, 3, max_paths=cap, max_entries=(1 << 21) + 4096, max_records=1 << 22, max_rows=1 << 20)
+    torch.cuda.synchronize()
+    cnt = out["counts"].tolist()
+    assert cnt[2] == 0 and cnt[1] == ex.objects.shape[0]
+    assert torch.equal(out["keys"][:cnt[1]], ref.keys) and torch.equal(out["objects"][:cnt[1]], ex.objects)
+    assert torch.equal(out["vertices"][:cnt[1]].view(torch.int32), ex.vertices.view(torch.int32))
