@@ -117,16 +117,22 @@ for leg, key, cfg in (("cfg4", "order3", "configs[3], triangle mesh (coplanar-pa
                       ("cfg4quads", "order3_quads", "configs[3], assume_quads"),
                       ("cfg3", "order2", "configs[2], triangle mesh (coplanar-pair mode)"),
                       ("bruxelles3", "bruxelles_order3", "bruxelles.obj (14 206 triangles -> 8 376 primitives of the pairing pass), 16 TX x 64 RX, order 3")):
-    c = counters(f"pmcbeam_{leg}_*counter_collection.csv", "beam_expand_clustered_last_kernel")
+    # the last expansion = the fused kernel (orders 1-2) or, at order 3, the box-stage kernel + the per-primitive kernel
+    LAST = ("beam_expand_clustered_last_kernel", "beam_boxes_kernel", "beam_expand_pairs_kernel")
+    c = {}
+    for pat in LAST:
+        for k, (mean, cnt, tot) in counters(f"pmcbeam_{leg}_*counter_collection.csv", pat).items():
+            m0, c0, t0 = c.get(k, (0.0, 0, 0.0))
+            c[k] = (0.0, max(c0, cnt), t0 + tot)
     if not c:
         continue
     steps = 2
     names = set()
     for f in find(f"pmcbeam_{leg}_*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "beam_expand_clustered_last_kernel" in r["Kernel_Name"]:
+            if any(pat in r["Kernel_Name"] for pat in LAST):
                 names.add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
-    d = {"config": cfg, "kernel": sorted(names)[0] if names else None, "launches_per_step": c["SQ_INSTS_VALU"][1] / steps}
+    d = {"config": cfg, "kernel": " + ".join(sorted(names)) if names else None, "launches_per_step": c["SQ_INSTS_VALU"][1] / steps}
     for k, (_, _, tot) in c.items():
         d[f"{k}_per_step"] = tot / steps
     if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c:
@@ -139,8 +145,9 @@ for leg, key, cfg in (("cfg4", "order3", "configs[3], triangle mesh (coplanar-pa
     # kernel time of the same step from the kernel trace
     for f in find(f"beam_{leg}_kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
-            if "beam_expand_clustered_last_kernel" in r["Name"]:
-                d["kernel_ms_per_step_from_trace"] = float(r["TotalDurationNs"]) / 1e6 / steps
+            if any(pat in r["Name"] for pat in LAST):
+                d["kernel_ms_per_step_from_trace"] = d.get("kernel_ms_per_step_from_trace", 0.0) + float(r["TotalDurationNs"]) / 1e6 / steps
+                d.setdefault("kernel_ms_per_step_by_kernel", {})[r["Name"].split("(")[0].replace("void ", "")] = float(r["TotalDurationNs"]) / 1e6 / steps
     legs[key] = d
 if legs:
     brec = {"legs": legs, "source": "scratch/profile_r05.sh: rocprofv3 --pmc <set> -- python scratch/cfg_beam.py cfg4 [--quads] | cfg3 "

@@ -375,8 +375,8 @@ def test_order3_two_kernel_expansion_in_chunks(G, rng):
     cluster masks in the workspace; csrc/beam.hip, beam_boxes_kernel / beam_expand_pairs_kernel).  Small capacities force
     many chunks / slices in the synchronous entry, a capacity above 2^21 two chunks in the asynchronous one: the same
     paths as the exhaustive tracer and as the fused kernel (`expansion="fused"`), the same rows."""
-    V, Tr, c, h = S.manhattan(14, seed=11)
-    tx, rx = S.manhattan_tx_rx(c, h, 2, 12, seed=12)
+    V, Tr, c, h = S.manhattan(14, seed=5)  # (the scene of test_coplanar_pair_mode_...: it has order-3 paths)
+    tx, rx = S.manhattan_tx_rx(c, h, 3, 24, seed=6)
     tx[:, 2] = rng.uniform(2, 40, len(tx))
     R = S.random_rotation(rng)
     V, tx, rx = S.rotate_points(R, V, tx, rx)
@@ -386,7 +386,7 @@ def test_order3_two_kernel_expansion_in_chunks(G, rng):
     assert ex.objects.shape[0] > 0
     ref = tracer.trace_beam_pruned(scene, 3, expansion="fused")
     rows = tracer.last_beam_stats["rows"]
-    for kw in ({}, {"max_entries": 320, "max_records": 1 << 14}, {"max_entries": 64, "max_records": 1 << 13}, {"pairs": False, "max_entries": 192}):
+    for kw in ({}, {"max_entries": 320, "max_records": 1 << 14}, {"max_entries": 128, "max_records": 1 << 13}, {"pairs": False, "max_entries": 256}):
         bp = tracer.trace_beam_pruned(scene, 3, **kw)
         assert torch.equal(bp.objects, ex.objects) and torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32)), kw
         assert torch.equal(bp.keys, ref.keys)
