@@ -598,6 +598,17 @@ __device__ __forceinline__ bool box_pruned(const BeamCtx<SCALE, LEVEL> &c, const
     return separated;
 }
 
+// Wave-uniform reads of tables that no kernel of the call writes (the cluster boxes of a mesh): through the CONSTANT address
+// space, so that they are scalar loads whatever else the kernel does.  Next to an LDS-DMA builtin in the same loop the
+// compiler cannot prove them unclobbered and makes them vector loads with a full vmcnt(0) wait each -- 12 per cluster trip
+// of every clustered expansion kernel, three serialized memory latencies per trip.
+typedef const __attribute__((address_space(4))) float ro_float;
+__device__ __forceinline__ ro_float *ro(const float *p) { return (ro_float *)p; }
+typedef float ro_v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ro_v4f_t ro4(const float *p, int64_t i) {  // p 16-byte aligned, i in units of 16 bytes
+    return ((const __attribute__((address_space(4))) ro_v4f_t *)p)[i];
+}
+
 // value of lane `l` (wave-uniform index) on every lane, through v_readlane: no LDS round trip, no wait
 __device__ __forceinline__ float lane_bcast(float x, int l) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l));
@@ -1118,7 +1129,8 @@ __device__ __forceinline__ void expand_clustered_body(
                 for (int q = 0; q < 4; ++q) pl[t][q] = pl_ld[t][q];
         }
         // ---- lane = prefix: box of the cluster (wave-uniform scalar loads) ----
-        const float *bx = C.boxes + 8 * cl;
+        const ro_v4f_t bx0 = ro4(C.boxes, 2 * cl), bx1 = ro4(C.boxes, 2 * cl + 1);  // (lo, hi.x | hi.yz, sigma, planes)
+        const float bx[8] = {bx0.x, bx0.y, bx0.z, bx0.w, bx1.x, bx1.y, bx1.z, bx1.w};
         const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
         // bound of the candidates' own eps over the cluster: smallest plane distance of the apex over the
         // cluster's triangles (the SAME expression the per-primitive test evaluates), farthest box corner
@@ -1168,7 +1180,12 @@ __device__ __forceinline__ void expand_clustered_body(
         // city) -- a cluster's box is mostly streets, and half of the (prefix, cluster) pairs that passed it had no
         // child at all (debug counters, profiles/r03/beam.md).  The same test with the same (cluster-wide) bound.
         if (__any(alive)) {
-            const float *sb = C.subboxes + 24 * cl;
+            ro_v4f_t sq4[6];  // all four sub-boxes in one trip to memory (loaded one by one each costs its own latency)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sq4[k] = ro4(C.subboxes, 6 * cl + k);
+            const float sb[24] = {sq4[0].x, sq4[0].y, sq4[0].z, sq4[0].w, sq4[1].x, sq4[1].y, sq4[1].z, sq4[1].w,
+                                  sq4[2].x, sq4[2].y, sq4[2].z, sq4[2].w, sq4[3].x, sq4[3].y, sq4[3].z, sq4[3].w,
+                                  sq4[4].x, sq4[4].y, sq4[4].z, sq4[4].w, sq4[5].x, sq4[5].y, sq4[5].z, sq4[5].w};
             bool sub = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1390,14 +1407,26 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
     };
     if (cl_begin < cl_end) fetch_planes(cl_begin);
     unsigned long long *mrow = masks + (int64_t)blockIdx.x * C.nclusters;
+    // the box and the four sub-boxes of a trip are loaded during the PREVIOUS trip's tests (scalar loads, 32 registers,
+    // issued after the plane loop: LDS and scalar memory share one counter, so a scalar load in flight would make the
+    // loop's first ds_read wait for it): no memory latency between the plane loop and the tests
+    ro_v4f_t nb[2]{}, nq[6]{};
+    auto fetch_boxes = [&](int64_t c) {
+        nb[0] = ro4(C.boxes, 2 * c);
+        nb[1] = ro4(C.boxes, 2 * c + 1);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nq[k] = ro4(C.subboxes, 6 * c + k);
+    };
+    if (cl_begin < cl_end) fetch_boxes(cl_begin);
     for (int64_t cl = cl_begin; cl < cl_end; ++cl) {
         // (the box stage of expand_clustered_body, statement for statement: the same `todo`)
-        const float *bx = C.boxes + 8 * cl;
-        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
+        const ro_v4f_t b0 = nb[0], b1 = nb[1];
+        const ro_v4f_t sq[6] = {nq[0], nq[1], nq[2], nq[3], nq[4], nq[5]};
+        const float lo[3] = {b0.x, b0.y, b0.z}, hi[3] = {b0.w, b1.x, b1.y};
         __builtin_amdgcn_s_waitcnt(/*vmcnt 0; expcnt, lgkmcnt: no wait*/ 0x0f70);
         __builtin_amdgcn_wave_barrier();
         uint32_t hbits = 0x7f800000u;
-        const int nplanes = __builtin_amdgcn_readfirstlane((int)bx[7]);
+        const int nplanes = __builtin_amdgcn_readfirstlane((int)b1.w);
 #pragma unroll 8
         for (int k = 0; k < nplanes; ++k) {
             const float4 q = lds_planes[wave][k];
@@ -1409,13 +1438,16 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
         const float hmin = __uint_as_float(hbits);
         __builtin_amdgcn_wave_barrier();
         fetch_planes(cl + 1);
+        fetch_boxes((cl + 1 < cl_end) ? cl + 1 : cl);
         const V3 far = V3{fmaxf(__builtin_fabsf(ctx.I.x - lo[0]), __builtin_fabsf(ctx.I.x - hi[0])),
                           fmaxf(__builtin_fabsf(ctx.I.y - lo[1]), __builtin_fabsf(ctx.I.y - hi[1])),
                           fmaxf(__builtin_fabsf(ctx.I.z - lo[2]), __builtin_fabsf(ctx.I.z - hi[2]))};
-        const float eps_max = beam_eps(ctx.u, bx[6], margin_len(far) * 1.0001f, hmin);
+        const float eps_max = beam_eps(ctx.u, b1.z, margin_len(far) * 1.0001f, hmin);
         bool alive = have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max);
         if (__any(alive)) {
-            const float *sb = C.subboxes + 24 * cl;
+            const float sb[24] = {sq[0].x, sq[0].y, sq[0].z, sq[0].w, sq[1].x, sq[1].y, sq[1].z, sq[1].w,
+                                  sq[2].x, sq[2].y, sq[2].z, sq[2].w, sq[3].x, sq[3].y, sq[3].z, sq[3].w,
+                                  sq[4].x, sq[4].y, sq[4].z, sq[4].w, sq[5].x, sq[5].y, sq[5].z, sq[5].w};
             bool sub = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1543,7 +1575,10 @@ __global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(BEAM_
             const bool cand = act && (p != m || self_ok);
             V3 unused;
             float base1 = 0.0f;
-            const bool keep = cand && !prim_stage1<SCALE, LEVEL>(CtxScalar<SCALE, LEVEL>{te}, vx, pl, sg, unused, base1);
+            // (not `cand && ...`: the branch around the test would put the entry's scalar loads behind the wait for `m` --
+            // two memory latencies per pass instead of one; a wave without any candidate lane is a padded cluster)
+            const bool pruned1 = prim_stage1<SCALE, LEVEL>(CtxScalar<SCALE, LEVEL>{te}, vx, pl, sg, unused, base1);
+            const bool keep = cand & !pruned1;
             const unsigned long long record = (((unsigned long long)rec_off + gbase + (unsigned long long)l) << 32) | (uint32_t)p;
             const unsigned long long vote = __ballot(keep);
             if (vote) {
