@@ -1145,14 +1145,24 @@ __device__ __forceinline__ void expand_clustered_body(
         // that expansion, a branch per two planes, made this loop half of the kernel)
         uint32_t hbits = 0x7f800000u;
         const int nplanes = __builtin_amdgcn_readfirstlane((int)bx[7]);  // distinct planes of the cluster, first in the list
-#pragma unroll 8
-        for (int k = 0; k < nplanes; ++k) {
-            const float4 q = lds_planes[wave][k];  // same address on every lane: broadcast
+        // four planes per trip to the LDS (one wait for four reads; one at a time, each plane cost a whole LDS latency for
+        // five instructions of arithmetic); the minimum does not depend on the order
+        auto plane = [&](const float4 q) {  // (same address on every lane: broadcast)
             float sd = __builtin_fmaf(q.x, ctx.I.x, __builtin_fmaf(q.y, ctx.I.y, __builtin_fmaf(q.z, ctx.I.z, -q.w)));
             asm volatile("" : "+v"(sd));  // keeps the compiler from pairing planes into v_pk_fma_f32 + v_mov shuffles
             const uint32_t b = __float_as_uint(sd) & 0x7fffffffu;
             hbits = (b < hbits) ? b : hbits;
+        };
+        int k = 0;
+        for (; k + 4 <= nplanes; k += 4) {
+            const float4 q0 = lds_planes[wave][k], q1 = lds_planes[wave][k + 1], q2 = lds_planes[wave][k + 2],
+                         q3 = lds_planes[wave][k + 3];
+            plane(q0);
+            plane(q1);
+            plane(q2);
+            plane(q3);
         }
+        for (; k < nplanes; ++k) plane(lds_planes[wave][k]);
         hmin = __uint_as_float(hbits);
         __builtin_amdgcn_wave_barrier();  // reads done before the next cluster's planes arrive
         fetch_planes(cl + 1);
@@ -1427,14 +1437,24 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
         __builtin_amdgcn_wave_barrier();
         uint32_t hbits = 0x7f800000u;
         const int nplanes = __builtin_amdgcn_readfirstlane((int)b1.w);
-#pragma unroll 8
-        for (int k = 0; k < nplanes; ++k) {
-            const float4 q = lds_planes[wave][k];
+        // four planes per trip to the LDS (one wait for four reads: read one at a time, each plane cost a whole LDS latency
+        // for five instructions of arithmetic); the minimum does not depend on the order
+        auto plane = [&](const float4 q) {
             float sd = __builtin_fmaf(q.x, ctx.I.x, __builtin_fmaf(q.y, ctx.I.y, __builtin_fmaf(q.z, ctx.I.z, -q.w)));
             asm volatile("" : "+v"(sd));
             const uint32_t b = __float_as_uint(sd) & 0x7fffffffu;
             hbits = (b < hbits) ? b : hbits;
+        };
+        int k = 0;
+        for (; k + 4 <= nplanes; k += 4) {
+            const float4 q0 = lds_planes[wave][k], q1 = lds_planes[wave][k + 1], q2 = lds_planes[wave][k + 2],
+                         q3 = lds_planes[wave][k + 3];
+            plane(q0);
+            plane(q1);
+            plane(q2);
+            plane(q3);
         }
+        for (; k < nplanes; ++k) plane(lds_planes[wave][k]);
         const float hmin = __uint_as_float(hbits);
         __builtin_amdgcn_wave_barrier();
         fetch_planes(cl + 1);
