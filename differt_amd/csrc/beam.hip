@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(kExpandWG) BEAM_Q4_OCC void beam_expand_clustered_l
 }
 
 // ---------------------------------------------------------------------------------------------
-// The order-3 last expansion in TWO kernels (round 5).  The fused kernel above keeps the 64 prefix contexts of a wave in
+// The last expansion of orders 2 and 3 (levels 1 and 2) in TWO kernels (round 5; the numbers below: order 3).  The fused kernel above keeps the 64 prefix contexts of a wave in
 // 43 VGPRs per lane for its box stage (lane = prefix) and reads them back lane-to-wave with 27-43 v_readlane per pass of
 // its transposed stage (lane = primitive): 128 VGPRs, 4 waves per SIMD, 0.55 of the VALU issue ceiling with 43 % of the
 // wave-cycles waiting.  The two stages want different register files, so they are two launches:
@@ -1515,7 +1515,7 @@ __global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(BEAM_
     float u, unsigned long long *__restrict__ out, int64_t cap, unsigned long long *__restrict__ count,
     int64_t clusters_per_split, RxAll rxall, BeamDev dv, int64_t rec_off) {
     // (rec_off: position of this launch's first prefix in the list the records index -- a launch covers one chunk of it)
-    static_assert(LEVEL == 2, "the two-kernel expansion is the order-3 (level-2) last expansion");
+    static_assert(LEVEL == 1 || LEVEL == 2, "the two-kernel expansion is the LAST expansion of orders 2 and 3");
     using Sh = Shape<SCALE>;
     using Tab = CtxTab<SCALE, LEVEL>;
     beam_dev_apply(dv, M, u, n_in);
@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(BEAM_
         const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP];
         const V3 nc = V3{q.x, q.y, q.z};
         const float dc = q.w, sgc = C.sigma[pos];
-        mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);
+        if constexpr (LEVEL >= 2) mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);  // (level 1: the first stage was the whole test)
         const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, hpp, sp, nc, dc, sgc));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
@@ -2617,7 +2617,7 @@ struct BeamLayout {  // byte offsets into the caller's workspace
 
 struct BeamSizes {
     int64_t max_entries, max_records, max_rows, max_survivors;
-    int64_t ctx_cap;  // prefixes per launch of the two-kernel order-3 expansion (context table + cluster masks); 0: order < 3
+    int64_t ctx_cap;  // prefixes per launch of the two-kernel last expansion (context table + cluster masks); 0: order < 2
 };
 constexpr int64_t kCtxWordsMax = 72;  // CtxTab<2, 2>::kWords, the largest entry (shape known only once the clusters exist)
 
@@ -2661,11 +2661,13 @@ static BeamSizes beam_sizes(const drt_beam_params *bp, int64_t ntx, int64_t nrx,
     z.max_survivors = (bp && bp->max_survivors > 0) ? bp->max_survivors : std::min<int64_t>((int64_t)1 << 22, z.max_rows);
     // order 3: the last expansion runs over slices / chunks of at most ctx_cap level-2 prefixes (288 B of context per
     // prefix, 8 B of mask per (64 prefixes, cluster): at most 2^21 prefixes, masks of at most 256 MiB)
+    // (order 2: the same over the level-1 list, at most ntx * n prefixes)
     z.ctx_cap = 0;
-    if (order >= 3) {
+    if (order >= 2) {
         const int64_t ncl = ceil_div(nprim > 0 ? nprim : 1, 64);
         const int64_t by_masks = std::max<int64_t>(64, ((int64_t)1 << 25) / ncl * 64);  // 2^28 B / 8 B per mask word
-        z.ctx_cap = std::max<int64_t>(64, std::min({std::min(z.max_entries, z.max_records), (int64_t)1 << 21, by_masks}) / 64 * 64);
+        const int64_t list = (order >= 3) ? std::min(z.max_entries, z.max_records) : (n1 + 63) / 64 * 64;
+        z.ctx_cap = std::max<int64_t>(64, std::min({list, (int64_t)1 << 21, by_masks}) / 64 * 64);
     }
     return z;
 }
@@ -2777,7 +2779,7 @@ static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool cluster
                           float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s,
                           const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f}, BeamDev dv = BeamDev{nullptr, nullptr},
                           bool last = false, SplitWs sw = SplitWs{}) {
-    if constexpr (LEVEL == 2 && SCALE != 2) {  // (shape 2, the rare two-arbitrary-triangles quad, stays on the fused kernel)
+    if constexpr (LEVEL <= 2 && SCALE != 2) {  // (shape 2, the rare two-arbitrary-triangles quad, stays on the fused kernel)
         if (clustered && sw.ctxtab && (rxall.on || (last && dv.dyn))) {
             // two launches per chunk of at most sw.cap prefixes: box stage (lane = prefix) -> contexts + masks, then the
             // per-primitive stage (lane = primitive, prefix through the scalar unit); the chunks append to one record list
@@ -3256,8 +3258,8 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     const bool expand_clustered = !(flags & DRT_BEAM_EXPAND_PLAIN);
     const bool emit_clustered = (flags & DRT_BEAM_EMIT_CLUSTERED) || (!(flags & DRT_BEAM_EMIT_PLAIN) && nrx >= 128);
     const bool pair_blocks = !(flags & DRT_BEAM_ROWS_PLAIN);
-    SplitWs split_ws;  // order 3: the last expansion as two kernels (DRT_BEAM_EXPAND_FUSED: the single fused kernel)
-    if (order == 3 && z.ctx_cap > 0 && !(flags & DRT_BEAM_EXPAND_FUSED))
+    SplitWs split_ws;  // orders 2, 3: the last expansion as two kernels (DRT_BEAM_EXPAND_FUSED: the single fused kernel)
+    if (order >= 2 && z.ctx_cap > 0 && !(flags & DRT_BEAM_EXPAND_FUSED))
         split_ws = SplitWs{reinterpret_cast<float *>(base + L.ctx_table), reinterpret_cast<unsigned long long *>(base + L.ctx_masks), z.ctx_cap};
 
     DRT_HIP(fill_bytes_async(counters, 0, 256, s));
@@ -3379,7 +3381,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
             DRT_HIP(fill_bytes_async(counters, 0, 8, s));
             t_expand.start();
             if (order == 2) {
-#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall)
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, cur + i0, i1 - i0, u, records, z.max_records, counters, s, rxall, BeamDev{nullptr, nullptr}, true, split_ws)
                 BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
             } else {
@@ -3631,7 +3633,7 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     const bool expand_clustered = !(flags & DRT_BEAM_EXPAND_PLAIN);
     const bool emit_clustered = (flags & DRT_BEAM_EMIT_CLUSTERED) || (!(flags & DRT_BEAM_EMIT_PLAIN) && nrx >= 128);
     SplitWs split_ws;
-    if (order == 3 && z.ctx_cap > 0 && !(flags & DRT_BEAM_EXPAND_FUSED))
+    if (order >= 2 && z.ctx_cap > 0 && !(flags & DRT_BEAM_EXPAND_FUSED))
         split_ws = SplitWs{reinterpret_cast<float *>(base + L.ctx_table), reinterpret_cast<unsigned long long *>(base + L.ctx_masks), z.ctx_cap};
     hipLaunchKernelGGL(beam_dyn_kernel, dim3(1), dim3(64), 0, s, rx_bounds, tx_bounds, mesh->beam_max_abs, kappa,
                        expand_clustered ? 1 : 0, dyn);
@@ -3649,7 +3651,7 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     int64_t emit_cap = cap1;
     const unsigned long long *emit_count = c1;
     if (order == 2) {
-#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, entries1, cap1, u0, records, z.max_records, c3, s, rx_off, BeamDev{dyn, c1}, true)
+#define CALL(SC, K) launch_expand<SC, 1>(M, C, expand_clustered, entries1, cap1, u0, records, z.max_records, c3, s, rx_off, BeamDev{dyn, c1}, true, split_ws)
         BEAM_DISPATCH2(M.kind, 1, CALL);
 #undef CALL
         last_rec = records;

@@ -623,7 +623,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
         primitive ids).  Orders 0..3.
 
         ``expansion``: ``"clustered"`` (= ``"auto"``: primitives in Morton clusters of 64, box test per (prefix,
-        cluster); at order 3 the last expansion runs as two kernels, ``"fused"`` keeps it in one) or ``"plain"`` (every
+        cluster); the last expansion of orders 2 and 3 runs as two kernels, ``"fused"`` keeps it in one) or ``"plain"`` (every
         pair tested); ``emit``: ``"plain"``, ``"clustered"`` (receivers in Morton
         clusters) or ``"auto"`` (clustered from 128 receivers on) -- the same rows either way.
         ``prefix_shard=(rank, world)`` keeps the level-1 prefixes (transmitter ``t``, first mirror ``m``) with

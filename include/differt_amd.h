@@ -574,8 +574,8 @@ typedef struct drt_beam_stats {
 #define DRT_BEAM_EMIT_PLAIN 2     /* receiver stage: lane = prefix walks the receivers (after a vote on their clusters' boxes) */
 #define DRT_BEAM_EMIT_CLUSTERED 4 /* receiver stage: Morton clusters of 64 even below 128 receivers */
 #define DRT_BEAM_NO_PAIRS 8        /* triangle meshes: search triangle by triangle even when the pairing pass found pairs */
-#define DRT_BEAM_EXPAND_FUSED 32  /* order 3: the last expansion as ONE kernel (round 4's form) instead of box stage + per-primitive
-                                     stage as two launches (round 5; same records either way: A/B and cross-check) */
+#define DRT_BEAM_EXPAND_FUSED 32  /* orders 2, 3: the last expansion as ONE kernel (round 4's form) instead of box stage +
+                                     per-primitive stage as two launches (round 5; same records either way: A/B and cross-check) */
 #define DRT_BEAM_ROWS_PLAIN 16    /* coplanar-pair mode: trace the 2^order triangle rows of a primitive row one by one instead
                                      of as one DRT_CAND_PAIR_BLOCKS block (A/B and cross-check; same result) */
 /* (the mappings return the same rows; default: clustered expansion, clustered receivers from 128 on).

@@ -117,7 +117,7 @@ while time.time() - t0 < budget:
     st["valid_paths"] += len(ea)
     if st["cases"] % 4 == 0:
         for kw in ({"expansion": "plain"}, {"expansion": "fused"}, {"emit": "clustered"}, {"emit": "plain"}, {"pairs": False}, {"rows": "plain"}):
-            if kw.get("expansion") == "fused" and order != 3:
+            if kw.get("expansion") == "fused" and order < 2:
                 continue  # (the two-kernel form exists at order 3 only)
             if ("pairs" in kw or "rows" in kw) and not pair_mode:
                 continue

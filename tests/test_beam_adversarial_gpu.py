@@ -52,7 +52,7 @@ def check(G, V, Tr, tx, rx, orders=(1, 2, 3), assume_quads=False, kappas=(64.0,)
     for order in orders:
         ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
         for kappa in kappas:
-            for expansion in ("auto", "plain") + (("fused",) if order == 3 else ()):  # order 3: two kernels vs the fused one
+            for expansion in ("auto", "plain") + (("fused",) if order >= 2 else ()):  # orders 2, 3: two kernels vs the fused one
                 # triangle meshes of boxes are searched over their coplanar pairs by default: both forms
                 for pairs in ((True, False) if not assume_quads else (True,)):
                     bp = tracer.trace_beam_pruned(scene, order, kappa=kappa, expansion=expansion, max_paths=1 << 18,

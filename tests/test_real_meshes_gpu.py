@@ -139,7 +139,7 @@ def test_pruned_equals_exhaustive_whole_order2_space(G, name):
         ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 25, max_paths=1 << 20)
         for kappa in (64.0, 1.0):
             for pairs in (True, False):
-                for expansion in ("auto", "plain") if kappa == 64.0 else ("auto",):
+                for expansion in ("auto", "plain", "fused") if kappa == 64.0 else ("auto",):
                     bp = tracer.trace_beam_pruned(scene, order, kappa=kappa, pairs=pairs, expansion=expansion, max_paths=1 << 18)
                     _same(bp, ex, (name, order, kappa, pairs, expansion, tracer.last_beam_stats))
                     assert tracer.last_beam_stats["pair_mode"] == pairs
