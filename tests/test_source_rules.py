@@ -58,3 +58,18 @@ def test_capturable_entry_points_use_the_safe_configuration():
     assert "radix_sort_u64(" in safe and "radix_sort_keys<CaptureSafeSort>" in safe and "radix_sort_pairs<CaptureSafeSort>" in safe
     own = re.sub(r"//[^\n]*", "", (CSRC / "radix_sort.hip").read_text())
     assert "hipMemset" not in own and "rocprim::" not in own
+
+
+def test_cluster_boxes_are_read_through_the_constant_address_space():
+    """The cluster box tables are wave-uniform and read-only, but next to the LDS-DMA builtin of the same loop the compiler
+    makes a plain `C.boxes[...]` read a VECTOR load with a full vmcnt(0) wait (three memory latencies in series per cluster
+    trip of every clustered expansion kernel until round 5, profiles/r05/beam.md section 7): every device-side read goes
+    through ro() / ro4() (constant address space -> s_load)."""
+    beam = re.sub(r"//[^\n]*", "", (CSRC / "beam.hip").read_text())
+    reads = re.findall(r"[^\n]*\bC\.(?:sub)?boxes\b[^\n]*", beam)
+    device_reads = [ln for ln in reads if "=" not in ln.split("C.")[0] or "ro" in ln]
+    assert len(device_reads) >= 6
+    for ln in reads:
+        if re.search(r"C\.(?:sub)?boxes\s*=", ln):  # the host side filling the struct
+            continue
+        assert re.search(r"\bro4?\(C\.(?:sub)?boxes", ln), ln.strip()
