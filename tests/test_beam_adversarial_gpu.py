@@ -400,3 +400,27 @@ def test_order3_two_kernel_expansion_in_chunks(G, rng):
     assert cnt[2] == 0 and cnt[1] == ex.objects.shape[0]
     assert torch.equal(out["keys"][:cnt[1]], ref.keys) and torch.equal(out["objects"][:cnt[1]], ex.objects)
     assert torch.equal(out["vertices"][:cnt[1]].view(torch.int32), ex.vertices.view(torch.int32))
+
+
+def test_order2_two_kernel_expansion_on_a_large_mesh(G, rng):
+    """Order 2 at configs[4]'s mesh size (200 000 triangles -> 100 000 primitives, 1 563 clusters), 16 transmitters inside the
+    city: 3.2e9 records of the last expansion in ~50 slices.  The two-kernel last expansion (context table + cluster masks,
+    csrc/beam.hip) returns the keys, vertex bits and row count of the one-kernel mapping (`expansion="fused"`).  (More than
+    one CHUNK per launch -- a list longer than the 2^28 bytes of cluster masks allow -- needs the asynchronous entry with
+    tens of GB of records at this size; the chunk offsets are the order-3 test's, the loop is the same code.)"""
+    V, Tr, c, h = S.manhattan(20000, seed=3)
+    _, rx0 = S.manhattan_tx_rx(c, h, 1, 1, seed=9)
+    rx = (rx0[:1] + rng.uniform(-3, 3, (12, 3))).astype(np.float32)
+    rx[:, 2] = np.abs(rx[:, 2]) + 1.5
+    tx = (rx[:1] + rng.uniform(-60, 60, (16, 3))).astype(np.float32)
+    tx[:, 2] = rng.uniform(1.5, 30, 16)
+    mesh = G.Mesh(V, Tr)
+    scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(rx, device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer(accel="bvh")
+    ref = tracer.trace_beam_pruned(scene, 2, expansion="fused", max_paths=1 << 16)
+    st = dict(tracer.last_beam_stats)
+    bp = tracer.trace_beam_pruned(scene, 2, max_paths=1 << 16)
+    assert st["pair_mode"] and ref.keys.shape[0] > 0 and st["chunks"] > 4, st
+    assert torch.equal(bp.keys, ref.keys) and torch.equal(bp.objects, ref.objects)
+    assert torch.equal(bp.vertices.view(torch.int32), ref.vertices.view(torch.int32))
+    assert tracer.last_beam_stats["rows"] == st["rows"] and tracer.last_beam_stats["levels"] == st["levels"]
