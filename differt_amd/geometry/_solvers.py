@@ -697,7 +697,7 @@ class ExhaustivePathTracer(AbstractPathTracer):
     def trace_beam_pruned_static(self, scene, order: int, *, max_paths: int, kappa: float = 64.0,
                                  max_entries: int | None = None, max_records: int | None = None,
                                  max_rows: int | None = None, max_survivors: int | None = None, pairs: bool = True,
-                                 out: dict | None = None) -> dict:
+                                 expansion: str = "auto", out: dict | None = None) -> dict:
         """:meth:`trace_beam_pruned` with STATIC output shapes and no host synchronisation
         (``drt_trace_paths_beam_async``): the form a ``jax.ffi`` handler or a HIP graph needs (reference boundary:
         ``wp.jax_callable(func, output_dims=...)``, _mesh.py:266-276).  Returns device tensors ``keys [max_paths]``,
@@ -705,12 +705,15 @@ class ExhaustivePathTracer(AbstractPathTracer):
         ``masked_vertices`` order, then padding (key -1) -- and ``counts [4]`` (``[1]`` valid paths, ``[2]`` status word:
         non-zero = a capacity overflowed, re-run larger or use :meth:`trace_beam_pruned`).  Pass the returned dict
         back as ``out`` to reuse every buffer (capture + replay).  The mesh's primitive clusters (and its LBVH with
-        ``accel="bvh"``) are built here, outside any capture, on first use."""
+        ``accel="bvh"``) are built here, outside any capture, on first use.  ``expansion="fused"``: the last expansion as one
+        kernel (``DRT_BEAM_EXPAND_FUSED``: cross-check and A/B of the two-kernel default; same rows)."""
         if not 0 <= order <= 3:
             raise ValueError("beam pruning covers orders 0..3")
+        if expansion not in ("auto", "clustered", "fused"):
+            raise ValueError("expansion must be 'auto', 'clustered' or 'fused'")
         beam = _lib.BeamParams()
         beam.kappa = float(kappa)
-        beam.flags = 0 if pairs else _lib.DRT_BEAM_NO_PAIRS
+        beam.flags = (0 if pairs else _lib.DRT_BEAM_NO_PAIRS) | (_lib.DRT_BEAM_EXPAND_FUSED if expansion == "fused" else 0)
         beam.max_entries, beam.max_records = int(max_entries or 0), int(max_records or 0)
         beam.max_rows, beam.max_survivors = int(max_rows or 0), int(max_survivors or 0)
         tx = scene.transmitters.reshape(-1, 3).contiguous()
