@@ -42,6 +42,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_ISSUE_PEAK = 256 * 4 * 32 * 2.4e9  # non-FMA FP32 lane-operations/s: 7.86e13 (the 157.3 TFLOP/s peak counts an FMA as two)
+VALU_PER_TEST = 58.5  # executed one-rounding VALU instructions per ray-triangle test of mt_dense_aligned_kernel
 
 
 def make_cfg2(num_rays: int, num_triangles: int, seed: int = 1234):
@@ -54,6 +56,33 @@ def make_cfg2(num_rays: int, num_triangles: int, seed: int = 1234):
     e = (rng.normal(size=(num_triangles, 2, 3)) * 2).astype(np.float32)
     tv = np.concatenate([c, c + e[:, :1], c + e[:, 1:]], axis=1).astype(np.float32)
     return o, d, tv
+
+
+def reference_probe(o, d, tv) -> dict:
+    """SURVEY 8d / BASELINE.md section 4: "if (and only if) `import jax, differt` happens to succeed on the box, the harness
+    additionally times the installed package through public API calls" -- absence is reported, not hidden.  Nothing of the
+    reference travels with this repository; this only looks at what the box itself has installed."""
+    import importlib.util
+
+    have = {m: importlib.util.find_spec(m) is not None for m in ("jax", "differt")}
+    out = {"reference_installed": all(have.values()), "reference_probe": have}
+    if not out["reference_installed"]:
+        return out
+    try:  # (never reached in this image: no jax, Python 3.10)
+        os.environ.setdefault("JAX_PLATFORMS", "cpu")
+        import jax
+        from differt.geometry import rays_intersect_triangles  # the public operator of configs[1]
+
+        f = jax.jit(lambda a, b, c: rays_intersect_triangles(a[:, None, :], b[:, None, :], c))
+        jax.block_until_ready(f(o, d, tv))
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 5.0:
+            jax.block_until_ready(f(o, d, tv))
+            reps += 1
+        out["reference_tests_per_s"] = o.shape[0] * tv.shape[0] * reps / (time.perf_counter() - t0)
+    except Exception as exc:  # noqa: BLE001
+        out["reference_error"] = repr(exc)[:200]
+    return out
 
 
 def cpu_baseline(num_triangles: int, budget_s: float = 12.0):
@@ -91,6 +120,7 @@ def cpu_baseline(num_triangles: int, budget_s: float = 12.0):
         "unit": "ray-triangle tests/s",
         "cores": cores,
         "kind": "port",
+        **reference_probe(o[:256], d[:256], tv),
         "sample": f"{reps} passes of {rs} rays x {num_triangles} triangles (dense MT, same distribution), "
         f"{el:.1f} s; {kind_note}",
         "sample_short": f"{reps} x ({rs} rays x {num_triangles} triangles), {el:.1f} s",
@@ -125,12 +155,18 @@ def compact_line(full: dict, sidecar: str | None) -> dict:
                      "rays_per_gpu": full["config"]["rays_per_gpu"], "triangles": full["config"]["triangles"],
                      "rays_per_gpu_note": "ray axis extended from 256 (launch-bound) to fill one launch"}
     rf = full["roofline"]
-    out["roofline"] = {k: _r(rf.get(k), 6) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                     "kernel_ms", "pmc_stale")}
+    out["roofline"] = {k: _r(rf.get(k), 6) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "valu_frac",
+                                                     "valu_frac_of_157TF", "traffic", "kernel_ms", "pmc_stale")}
+    lit = full.get("cfg2_literal")
+    if isinstance(lit, dict):  # the literal 256-ray launch of configs[1] (latency-bound), next to the filled launch
+        out["cfg2_literal_us"] = _r(lit.get("us_per_launch_hipgraph") or lit.get("us_per_launch_back_to_back"))
+        out["cfg2_literal_hbm_frac"] = _r(lit.get("hbm_frac"))
     cb = full.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                               "sample": cb.get("sample_short", "")}
+                               "sample": cb.get("sample_short", ""), "reference_installed": cb.get("reference_installed")}
+        if cb.get("reference_tests_per_s"):
+            out["cpu_baseline"]["reference_tests_per_s"] = _r(cb["reference_tests_per_s"])
     p = full.get("paths")
     if isinstance(p, dict) and "error" not in p:
         beam = p.get("beam_pruned") if isinstance(p.get("beam_pruned"), dict) else {}
@@ -196,16 +232,26 @@ def _progress(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def run_legs(args, dev, rank: int, world: int, dist) -> dict:
-    """Every leg besides the headline: {"paths", "strong_scaling", "strong_headline" (N > 1), "queries"}."""
+def run_legs(args, dev, rank: int, world: int, dist, save=None) -> dict:
+    """Every leg besides the headline: {"paths", "strong_scaling", "strong_headline" (N > 1), "queries"}.
+    `save(dict)`: called with the legs finished so far (the child process of a 1-GPU run writes them to its JSON file after
+    every leg, so that a leg that dies or outlives the time limit costs its own numbers only)."""
     out: dict = {}
+
+    def keep():
+        if save is not None and rank == 0:
+            save(out)
     if not args.no_paths:  # every rank takes part: the candidate-rank space is sharded over the GPUs
         paths = None
         try:
             import bench_paths
 
+            def partial(p):
+                if save is not None and rank == 0:
+                    save({**out, "paths": p})
+
             paths = bench_paths.run(dev, cpu_sample=not args.no_cpu_baseline, rank=rank, world=world,
-                                    dist=dist)
+                                    dist=dist, checkpoint=partial)
         except ImportError:
             pass
         except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
@@ -214,6 +260,7 @@ def run_legs(args, dev, rank: int, world: int, dist) -> dict:
             out["paths"] = paths
 
     _progress("paths done")
+    keep()
     if not args.no_scaling:  # every rank takes part: configs[4], total work fixed, split over the ranks
         try:
             import bench_scaling
@@ -229,14 +276,22 @@ def run_legs(args, dev, rank: int, world: int, dist) -> dict:
                 # legs at the top level so that a SCALE run shows them without digging (`value` above stays
                 # the weak-scaling dense operator, identical to the single-GPU bench at N = 1)
                 heads = []
-                for leg in ("beam_sharded", "candidate_sharded"):
+                n1 = strong_n1_record()
+                # triangle_block is the leg configs[4] literally names (T/N triangles per rank, ONE MIN all-reduce of packed
+                # (t, tie) keys per batch); beam_sharded / candidate_sharded are the collective-free splits
+                for leg in ("triangle_block", "beam_sharded", "candidate_sharded"):
                     rec = sc.get(leg)
                     if isinstance(rec, dict) and rec.get("s_per_step") is not None:
-                        heads.append({"leg": leg, "s_per_step": rec["s_per_step"], "n_gpus": world,
-                                      "scaling": "strong", "valid_paths": rec.get("valid_paths")})
+                        h = {"leg": leg, "s_per_step": rec["s_per_step"], "n_gpus": world, "scaling": "strong"}
+                        if rec.get("valid_paths") is not None:
+                            h["valid_paths"] = rec["valid_paths"]
+                        if n1 and n1.get(leg):
+                            h["speedup_vs_n1"] = n1[leg] / rec["s_per_step"]
+                        heads.append(h)
                 out["strong_headline"] = heads
 
     _progress("scaling done")
+    keep()
     if rank == 0 and not args.no_paths:
         try:
             import bench_queries
@@ -246,6 +301,23 @@ def run_legs(args, dev, rank: int, world: int, dist) -> dict:
             out["queries"] = {"error": repr(exc)}
 
     return out
+
+
+def strong_n1_record() -> dict | None:
+    """{leg: s_per_step} of the committed ONE-GPU run of the strong-scaling legs (profiles/r*/strong_n1.json, written by
+    `bench.py --write-strong-n1`), or None when its source hashes do not describe the kernels in the tree."""
+    recs = sorted((ROOT / "profiles").glob("r*/strong_n1.json"))
+    if not recs:
+        return None
+    try:
+        from differt_amd._srchash import source_hash
+
+        rec = json.loads(recs[-1].read_text())
+        if any(rec["source_hash"].get(k) != source_hash(k) for k in ("beam", "trace_filter", "dense")):
+            return None
+        return rec["s_per_step"]
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def legs_in_child(args) -> dict:
@@ -266,10 +338,16 @@ def legs_in_child(args) -> dict:
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, timeout=1500)  # (its stderr = ours: the progress markers)
             if r.returncode == 0 and outp.exists():
                 return json.loads(outp.read_text())
-            return {"legs_error": f"the legs process exited with code {r.returncode} (negative: killed by that signal); "
-                                  "the last [bench] marker on stderr names the leg"}
+            err = (f"the legs process exited with code {r.returncode} (negative: killed by that signal); "
+                   "the last [bench] marker on stderr names the leg")
         except subprocess.TimeoutExpired:
-            return {"legs_error": "the legs process did not finish within 1500 s"}
+            err = "the legs process did not finish within 1500 s"
+        done = {}
+        try:  # what the child had finished (it rewrites its file after every leg)
+            done = json.loads(outp.read_text()) if outp.exists() else {}
+        except (OSError, ValueError):
+            done = {}
+        return {**done, "legs_error": err}
 
 
 def main() -> None:
@@ -289,6 +367,9 @@ def main() -> None:
     ap.add_argument("--cfg5-window", type=int, default=None, help="candidate ranks per pair of the strong-scaling leg")
     ap.add_argument("--cfg5-rx-side", type=int, default=32)
     ap.add_argument("--legs-in-process", action="store_true", help="run the extra legs in this process even on one GPU")
+    ap.add_argument("--write-strong-n1", default=None, metavar="JSON",
+                    help="one GPU: write {leg: s_per_step} of the strong-scaling legs + source hashes (what speedup_vs_n1 of an "
+                         "N > 1 run is computed against)")
     ap.add_argument("--legs-child", default=None, help=argparse.SUPPRESS)  # internal: run the legs only, write their JSON here
     args = ap.parse_args()
 
@@ -320,7 +401,12 @@ def main() -> None:
     lib.require_device()
     dev = torch.device("cuda", local_rank)
     if args.legs_child:  # the child of legs_in_child(): legs only, JSON to the given path, nothing on stdout
-        Path(args.legs_child).write_text(json.dumps(run_legs(args, dev, 0, 1, None)))
+        def save(d, path=Path(args.legs_child)):
+            tmp = path.with_suffix(".tmp")
+            tmp.write_text(json.dumps(d))
+            tmp.replace(path)  # (atomic: the parent never reads half a file)
+
+        save(run_legs(args, dev, 0, 1, None, save=save))
         return
 
     R, T = args.rays, args.triangles
@@ -425,11 +511,17 @@ def main() -> None:
             },
             "roofline": {
                 "kernel": "drt::mt_dense_aligned_kernel",
-                "bound": "hbm",
+                # co-limited: 5 B written per test against 8 TB/s AND 58.5 one-rounding VALU instructions
+                # per test (bit-identical to a no-FMA oracle) against the non-FMA issue ceiling of 256 CUs x 4 SIMDs x 32
+                # lanes x 2.4 GHz = 7.86e13 lane-operations/s (= half of the 157.3 TFLOP/s FP32 vector peak, which counts FMAs)
+                "bound": "hbm+valu",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "valu_frac": VALU_PER_TEST * R * T / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK,
+                "valu_frac_of_157TF": VALU_PER_TEST * R * T / (kernel_ms * 1e-3) / 157.3e12,
+                "valu_instructions_per_test": VALU_PER_TEST,
                 "traffic": traffic,
                 "traffic_source": "profiles/pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)",
                 "pmc_stale": pmc_stale,
@@ -552,8 +644,25 @@ def main() -> None:
             side_name = str(side.relative_to(ROOT)) if side.is_relative_to(ROOT) else str(side)
         except OSError:
             side_name = None
-        line = json.dumps(compact_line(result, side_name), separators=(",", ":"))
-        assert len(line) < LINE_LIMIT, len(line)
+        sc1 = result.get("strong_scaling")
+        if args.write_strong_n1 and world == 1 and isinstance(sc1, dict):
+            from differt_amd._srchash import source_hash
+
+            n1 = {leg: sc1[leg]["s_per_step"] for leg in ("triangle_block", "beam_sharded", "candidate_sharded")
+                  if isinstance(sc1.get(leg), dict) and sc1[leg].get("s_per_step") is not None}
+            Path(args.write_strong_n1).write_text(json.dumps(
+                {"what": "bench.py strong-scaling legs on ONE MI355X (fixed total work: configs[4])", "s_per_step": n1,
+                 "source_hash": {k: source_hash(k) for k in ("beam", "trace_filter", "dense")}}, indent=1) + "\n")
+        comp = compact_line(result, side_name)
+        line = json.dumps(comp, separators=(",", ":"))
+        # a line that outgrew the limit sheds its optional blocks (they stay in the sidecar) -- never the contract keys, and
+        # never the run: an assert here lost every measurement of a run whose line was a few characters too long
+        for drop in ("strong_headline", "paths", "legs_error", "paths_metric", "ranks_seen_by_backend"):
+            if len(line) < LINE_LIMIT:
+                break
+            comp.pop(drop, None)
+            comp["line_shed"] = comp.get("line_shed", []) + [drop]
+            line = json.dumps(comp, separators=(",", ":"))
         print(line, flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -21,7 +21,7 @@ import numpy as np
 
 def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16, num_rx: int = 64,
         num_boxes: int = 1000, steps: int = 2, cpu_sample: bool = True, rank: int = 0, world: int = 1,
-        dist=None) -> dict:
+        dist=None, checkpoint=None) -> dict:
     """With world > 1 the candidate-rank space is cut in one contiguous block per rank
     (differt_amd.distributed.shard_interval): no collective during compute.  Time = max over ranks,
     valid paths = sum over ranks (the gather / gradient all-reduce epilogue of
@@ -102,6 +102,8 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
 
     def note(msg):
         print(f"[bench_paths] {msg}", file=sys.stderr, flush=True)
+        if checkpoint is not None:  # the legs so far, on disk: a later leg that dies or times out does not take them along
+            checkpoint(out)
 
     if rank == 0 and world == 1 and num_ranks is None and order == 2:
         note("exhaustive done")
@@ -406,11 +408,18 @@ def exhaustive_record(config: str) -> dict | None:
     import json
     from pathlib import Path
 
+    from differt_amd._srchash import source_hash
+
     recs = sorted((Path(__file__).resolve().parent / "profiles").glob("r*/stress/exhaustive_pairs.json"))
     if not recs:
         return None
     try:
         data = json.loads(recs[-1].read_text())
+        # a record describes the kernels it was taken on: one from another tree (round 5 quoted round 4's, taken on a kernel
+        # that no longer was the default mapping) is not evidence for this one
+        stamp = data.get("source_hash") or {}
+        if any(stamp.get(k) != source_hash(k) for k in ("beam", "trace_filter")):
+            return None
         for r in data["records"]:
             if r["config"] == config:
                 return {"checked_pairs": r["checked_pairs"], "all_equal": r["all_equal"],

@@ -683,8 +683,9 @@ constexpr int kBeamTile = 128;         // primitives per LDS tile of the plain e
 // Threads per workgroup of the clustered expansion.  Its waves never synchronise, and a workgroup's resources are held
 // until its LAST wave ends: with two waves per workgroup the faster one's slot idles while its partner finishes (the
 // survivors per wave vary widely) -- one wave per workgroup: configs[3] last expansion 157.4 -> 154.0 ms, same box.
-#ifndef BEAM_EXPAND_WG
-#define BEAM_EXPAND_WG 64
+#if !(defined(DRT_LAB) && defined(BEAM_EXPAND_WG))
+#undef BEAM_EXPAND_WG
+#define BEAM_EXPAND_WG 64  // (a lab knob like the others: only a -DDRT_LAB build may change it)
 #endif
 constexpr int kExpandWG = BEAM_EXPAND_WG;
 constexpr int kBeamWaveBuf = 192;      // records staged per wave before one flush (>= 128: a flush moves 64+)
@@ -1366,6 +1367,9 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
                                                                int64_t clusters_per_split, RxAll rxall, BeamDev dv) {
     using Sh = Shape<SCALE>;
     using Tab = CtxTab<SCALE, LEVEL>;
+    // one mask row (C.nclusters words) per WORKGROUP, written by its only wave (beam_layout sizes the buffer as ctx_cap / 64
+    // rows): with more waves per workgroup they would overwrite each other's words
+    static_assert(kExpandWG == 64, "the two-kernel expansion keeps one cluster-mask row per workgroup of ONE wave");
     beam_dev_apply(dv, M, u, n_in);
     if (dv.dyn) rxall = dv.dyn->rxall;
     __shared__ __attribute__((aligned(16))) float4 lds_planes[kExpandWG / 64][64 * Sh::NP];
@@ -1516,6 +1520,7 @@ __global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(BEAM_
     int64_t clusters_per_split, RxAll rxall, BeamDev dv, int64_t rec_off) {
     // (rec_off: position of this launch's first prefix in the list the records index -- a launch covers one chunk of it)
     static_assert(LEVEL == 1 || LEVEL == 2, "the two-kernel expansion is the LAST expansion of orders 2 and 3");
+    static_assert(kExpandWG == 64, "the two-kernel expansion keeps one cluster-mask row per workgroup of ONE wave");
     using Sh = Shape<SCALE>;
     using Tab = CtxTab<SCALE, LEVEL>;
     beam_dev_apply(dv, M, u, n_in);
@@ -2897,9 +2902,15 @@ constexpr double kPairMinFraction = 0.30;
 // on the host (chains A -> B -> C ... around a shared first vertex: heads first, then whatever is left -- cycles), the
 // primitive table and the virtual mesh back on the GPU.
 static int32_t pair_triangles(drt_mesh_t mesh, hipStream_t s) {
-    mesh->pair_state = 0;
+    // pair_state is written only once the outcome is KNOWN (0: examined, too few pairs; 1: paired): an allocation that fails
+    // on the way leaves the handle "not run" (-1), so that a later call tries again instead of silently searching triangle by
+    // triangle for the rest of the handle's life
+    mesh->pair_state = -1;
     const int64_t T = mesh->num_triangles;
-    if (T < 2 || mesh->assume_quads) return DRT_OK;
+    if (T < 2 || mesh->assume_quads) {
+        mesh->pair_state = 0;
+        return DRT_OK;
+    }
     const size_t a8 = align_up((size_t)T * 8, 256), a4 = align_up((size_t)T * 4, 256);
     size_t tb = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
@@ -2945,7 +2956,10 @@ static int32_t pair_triangles(drt_mesh_t mesh, hipStream_t s) {
     for (int64_t a = 0; a < T; ++a)
         if (!has_pred[a]) walk(a);
     for (int64_t a = 0; a < T; ++a) walk(a);
-    if ((double)(2 * quads) < kPairMinFraction * (double)T) return DRT_OK;  // pair_state 0: triangle by triangle
+    if ((double)(2 * quads) < kPairMinFraction * (double)T) {
+        mesh->pair_state = 0;  // examined, too few pairs: triangle by triangle
+        return DRT_OK;
+    }
     const int64_t P = T - quads;
     std::vector<int32_t> table((size_t)(2 * P));
     int64_t p = 0;
@@ -3676,7 +3690,7 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
         emit_cap = z.max_records;
         emit_count = c3;
     }
-#define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, last_src, last_rec, emit_cap, rx, rx_sorted, rx_index, rx_boxes, nrx, u0, rows, rows_cap, c4, counters + 1, s, BeamDev{dyn, emit_count})
+#define CALL(SC, K) launch_emit<SC, K>(M, emit_clustered, last_src, last_rec, emit_cap, rx, rx_sorted, rx_index, rx_boxes, nrx, u0, rows, rows_cap, c4, counters + kCtrGrazing, s, BeamDev{dyn, emit_count})
     BEAM_DISPATCH2(M.kind, order, CALL);
 #undef CALL
     hipLaunchKernelGGL(rows_pad_kernel, dim3((unsigned)ceil_div(rows_cap, 256)), dim3(256), 0, s,

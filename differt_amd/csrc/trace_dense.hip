@@ -209,7 +209,16 @@ __global__ __launch_bounds__(256) DRT_DENSE_ATTR void trace_dense_kernel(
                     if (alive) {
                         const unsigned long long below = vote & ((1ull << lane) - 1ull);
                         const unsigned long long slot = base + (unsigned long long)__popcll(below);
-                        if ((int64_t)slot < q_cap) queue[slot] = rowg + lane;
+                        if ((int64_t)slot < q_cap) {
+                            queue[slot] = rowg + lane;
+                        } else {
+                            // the queue is full (drt_trace_paths_dense_capped): this row will never be occlusion-tested, so it
+                            // is not reported as a valid path either -- its mask byte, set by the flush above, is cleared
+                            // (after that store has completed: both come from this wave) and the status word names the
+                            // overflow.  A caller that forgets to read the status gets fewer paths, never unverified ones.
+                            __builtin_amdgcn_s_waitcnt(/*vmcnt 0; expcnt, lgkmcnt: no wait*/ 0x0f70);
+                            d_mask[rowg + lane] = 0;
+                        }
                     }
                 }
             }
@@ -337,7 +346,8 @@ int32_t drt_trace_paths_dense_capped(drt_mesh_t mesh, const drt_trace_params *pr
         const unsigned long long survivors = sv[0], blocked = sv[1];
         st->candidates = total;
         st->survivors = (int64_t)survivors;
-        st->valid = (int64_t)(survivors - blocked);
+        // (rows beyond a full queue are neither tested nor reported: their mask bytes are cleared)
+        st->valid = (int64_t)((survivors < (unsigned long long)qcap ? survivors : (unsigned long long)qcap) - blocked);
         st->filter_ms = timer.elapsed(0, 1);
         st->occlusion_ms = timer.elapsed(1, 2);
         st->sort_emit_ms = 0.0f;

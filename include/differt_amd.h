@@ -437,8 +437,10 @@ size_t drt_trace_dense_workspace_size(int64_t num_tx, int64_t num_rx, int64_t nu
  * the rows survive the geometric checks.  drt_trace_paths_dense_capped takes `max_survivors` instead (< 0: the worst
  * case) and a workspace of drt_trace_dense_capped_workspace_size(max_survivors) = 64 + 8 max_survivors bytes.  Same
  * outputs.  The counter block gains a third 64-bit word: [2] status, DRT_TRACE_OVERFLOW_SURVIVORS when more rows passed
- * the geometric checks than the queue holds -- the occlusion stage then has not seen the rows beyond the capacity (their
- * mask entries are still set): re-run with a larger capacity.  Counter [0] is the true number of survivors either way. */
+ * the geometric checks than the queue holds -- the occlusion stage then has not seen the rows beyond the capacity, and
+ * their mask entries are CLEARED (a row that was never occlusion-tested is not reported as a valid path; a caller that
+ * does not read the status word gets fewer paths, never unverified ones): re-run with a larger capacity.  Counter [0] is
+ * the true number of survivors either way; valid paths = min([0], max_survivors) - [1]. */
 size_t drt_trace_dense_capped_workspace_size(int64_t max_survivors);
 int32_t drt_trace_paths_dense(drt_mesh_t mesh, const drt_trace_params *params, const float *tx,
                               int64_t num_tx, const float *rx, int64_t num_rx,

@@ -2,7 +2,9 @@
 quads, optional masks, transmitters at random heights, 1-3 transmitters x 1-200 receivers, orders 1..3): the
 pruned search must return EXACTLY the exhaustive tracer's valid paths (keys, objects, vertex bits); every few
 cases the other expansion mappings and the other receiver stage are run too and must give the same candidate
-rows.  python scratch/beam_stress.py [seconds]"""
+rows.  Round 5: half of the cities rotated (yaw, tilt <= 10 degrees), triangle arrays shuffled / thinned, end points in
+triangle planes.  Round 6: half of the scenes are triangle SOUPS (synthetic_scenes.soup_city).
+    python scratch/beam_stress.py [seconds] [--kappa=64] [--seed=77] [--no-soup | --only-soup] [--no-rotate] [--no-in-plane]"""
 import json
 import sys
 import time
@@ -16,26 +18,37 @@ import synthetic_scenes as S  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 60.0
 KAPPA = float(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--kappa=")), "64"))  # error unit of the bounds
-rng = np.random.default_rng(77)
+rng = np.random.default_rng(int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--seed=")), "77")))
 st = {"cases": 0, "exhaustive_candidates": 0, "rows_traced": 0, "valid_paths": 0, "missed": 0, "extra": 0,
       "vertex_mismatch": 0, "mapping_row_mismatch": 0, "mapping_checks": 0}
 t0 = time.time()
 while time.time() - t0 < budget:
-    boxes = int(rng.integers(3, 40))
-    pitch = float(rng.uniform(18, 45))
-    V, Tr, c, h = S.manhattan(boxes, pitch=pitch, seed=int(rng.integers(1 << 30)))
-    ext = float(np.abs(V[:, :2]).max()) + 10
-    if rng.random() < 0.7:
-        gv = np.array([[-ext, -ext, 0], [ext, -ext, 0], [ext, ext, 0], [-ext, ext, 0]], np.float32)
-        Tr = np.concatenate((Tr, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V)))
-        V = np.concatenate((V, gv))
     order = int(rng.integers(1, 4))
     ntx = int(rng.integers(1, 4))
     nrx = int(rng.choice([1, 3, 8, 40, 130, 200])) if order < 3 else int(rng.choice([1, 3, 8, 20]))
-    tx, rx = S.manhattan_tx_rx(c, h, min(ntx, boxes), nrx, seed=int(rng.integers(1 << 30)), pitch=pitch)
-    tx[:, 2] = rng.uniform(1.5, 70, len(tx))
-    if rng.random() < 0.3:
-        rx[:, 2] = rng.uniform(1.0, 50, len(rx))
+    # round 6: half of the scenes are triangle SOUPS (synthetic_scenes.soup_city: polygon prisms with ear-clipped, gable and
+    # hip roofs, slivers of aspect >= 1e3, T-junctions, duplicated vertices, a uniform 3-D rotation, 1e4-1e5 m offsets)
+    soup = "--no-soup" not in sys.argv and ("--only-soup" in sys.argv or rng.random() < 0.5)
+    if soup:
+        V, Tr, info = S.soup_city(rng, int(rng.integers(1, 9 if order == 3 else 30)), extent=float(rng.uniform(40, 200)))
+        tx, rx = S.soup_end_points(rng, V, ntx, nrx)
+        st["soups"] = st.get("soups", 0) + 1
+        for k in ("gable", "hip", "nonconvex", "sliver_walls", "sliver_ears", "t_junctions", "duplicated"):
+            st["soup_" + k] = st.get("soup_" + k, 0) + info[k]
+        st["soup_far"] = st.get("soup_far", 0) + int(info["offset_m"] > 0)
+    else:
+        boxes = int(rng.integers(3, 40))
+        pitch = float(rng.uniform(18, 45))
+        V, Tr, c, h = S.manhattan(boxes, pitch=pitch, seed=int(rng.integers(1 << 30)))
+        ext = float(np.abs(V[:, :2]).max()) + 10
+        if rng.random() < 0.7:
+            gv = np.array([[-ext, -ext, 0], [ext, -ext, 0], [ext, ext, 0], [-ext, ext, 0]], np.float32)
+            Tr = np.concatenate((Tr, np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(V)))
+            V = np.concatenate((V, gv))
+        tx, rx = S.manhattan_tx_rx(c, h, min(ntx, boxes), nrx, seed=int(rng.integers(1 << 30)), pitch=pitch)
+        tx[:, 2] = rng.uniform(1.5, 70, len(tx))
+        if rng.random() < 0.3:
+            rx[:, 2] = rng.uniform(1.0, 50, len(rx))
     # round 3: adversarial perturbations -- end points in / next to wall planes, scenes far from the origin
     if rng.random() < 0.3:
         k = int(rng.integers(0, len(tx)))
@@ -47,15 +60,15 @@ while time.time() - t0 < budget:
             ax = int(rng.integers(0, 3))
             rx[k, ax] = V[int(rng.integers(0, len(V))), ax] + np.float32(rng.choice([0.0, 1e-6, -1e-4]))
         st["rx_on_planes"] = st.get("rx_on_planes", 0) + 1
-    if rng.random() < 0.15:
+    if not soup and rng.random() < 0.15:
         off = np.array([3000.0, -2000.0, 50.0], np.float32)
         V, tx, rx = (V + off).astype(np.float32), (tx + off).astype(np.float32), (rx + off).astype(np.float32)
         st["far_from_origin"] = st.get("far_from_origin", 0) + 1
-    assume_quads = bool(rng.random() < 0.4)
+    assume_quads = bool(rng.random() < 0.4) and not soup  # (a soup's triangles are in no order: no consecutive quads)
     # round 5: half of the cities are ROTATED (any yaw, tilt <= 10 degrees; a new float32 scene: nothing axis-aligned any
     # more), and triangle meshes are shuffled / thinned so that the pairing pass must find partners anywhere in the array
     # and single triangles sit among the pairs
-    if "--no-rotate" not in sys.argv and rng.random() < 0.5:
+    if "--no-rotate" not in sys.argv and not soup and rng.random() < 0.5:
         V, tx, rx = S.rotate_points(S.random_rotation(rng), V, tx, rx)
         st["rotated"] = st.get("rotated", 0) + 1
     if not assume_quads and rng.random() < 0.4:

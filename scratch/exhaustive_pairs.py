@@ -1,6 +1,6 @@
 """Completeness of the pruned ("beam") search at the BASELINE configs' OWN size, against the exhaustive tracer.
 
-    python scratch/exhaustive_pairs.py [--pairs3 4] [--pairs5 4] [--out profiles/r04/stress/exhaustive_pairs.json]
+    python scratch/exhaustive_pairs.py [--pairs3 4] [--pairs5 4] [--pairs-real 8] [--out profiles/r06/stress/exhaustive_pairs.json]
 
 configs[3] (order 3, 10 000 triangles): for each selected (tx, rx) pair, `trace_rank_range` evaluates ALL
 n(n-1)^2 = 9.998e11 candidates of that pair (reference: full enumeration, geometry/_solvers.py:803-848 +
@@ -32,10 +32,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs3", type=int, default=4)
     ap.add_argument("--pairs5", type=int, default=4)
-    ap.add_argument("--out", default="profiles/r04/stress/exhaustive_pairs.json")
+    ap.add_argument("--pairs-real", type=int, default=0,
+                    help="whole order-3 pair spaces on the reference's own meshes (bruxelles: 2.87e12 candidates each, manhattan)")
+    ap.add_argument("--real-meshes", default="bruxelles,manhattan")
+    ap.add_argument("--out", default="profiles/r06/stress/exhaustive_pairs.json")
     a = ap.parse_args()
+    import differt_amd.geometry as G
+    from differt_amd._srchash import source_hash
     out = {"what": "beam-pruned search == exhaustive tracer on whole candidate spaces of single (tx, rx) pairs at the "
-                   "BASELINE configs' own size: objects and vertex bits", "records": []}
+                   "BASELINE configs' own size: objects and vertex bits", "records": [],
+           # the kernels this record was taken on: bench_paths.exhaustive_record() quotes it only while these match the tree
+           "source_hash": {k: source_hash(k) for k in ("beam", "trace_filter")}}
     if a.pairs3:
         V, Tr, c, h = S.manhattan(1000)
         tx, rx = S.manhattan_tx_rx(c, h, 16, 64)
@@ -43,6 +50,13 @@ def main():
     if a.pairs5:
         V, Tr, tx, rx = S.cfg5_scene()
         out["records"].append(check_config("configs[4]", V, Tr, tx, rx, 2, a.pairs5, (64.0, 1.0), 4, 1 << 24))
+    if a.pairs_real:
+        # the reference's benchmark mesh (differt/tests/benchmarks/fixtures.py:43-68) and manhattan.obj, the end points of
+        # bench_real.py / tests/test_real_meshes_gpu.py: 16 TX x 64 RX in the open
+        for name in a.real_meshes.split(","):
+            V, Tr = S.load_real_mesh(name)
+            tx, rx = S.outdoor_end_points(G, V, Tr, 16, 64)
+            out["records"].append(check_config(f"{name} order 3", V, Tr, tx, rx, 3, a.pairs_real, (64.0, 1.0), 128, 1 << 24))
     out["all_equal"] = all(r["all_equal"] for r in out["records"])
     Path(a.out).parent.mkdir(parents=True, exist_ok=True)
     Path(a.out).write_text(json.dumps(out, indent=1) + "\n")

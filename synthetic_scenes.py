@@ -125,3 +125,185 @@ def random_rotation(rng, max_tilt_deg: float = 10.0) -> np.ndarray:
 def rotate_points(R: np.ndarray, *arrays):
     """Apply R (float64) to float32 point arrays, rounding the result to float32 (the rotated scene is a NEW float32 scene)."""
     return tuple((np.asarray(a, np.float64) @ R.T).astype(np.float32) for a in arrays)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Triangle SOUPS (round 6; VERDICT r05: "the stress geometry is still boxes").  Polygon prisms with the kinds of
+# faces real city meshes have -- the reference's own bruxelles.obj is walls that are fans of two triangles and roofs
+# that are ear-clipped polygons, in no particular order, with duplicated vertex positions -- plus the cases no
+# in-tree mesh has: gable and hip roofs (planes at any slope), slivers of aspect >= 1e3, T-junctions, full 3-D
+# rotations and scenes 1e4-1e5 m from the origin (ulp(M) up to 8 mm).
+# ---------------------------------------------------------------------------------------------------------------
+def random_rotation_3d(rng) -> np.ndarray:
+    """A rotation drawn uniformly from SO(3) (QR of a Gaussian matrix, signs fixed, det +1): float64 3x3."""
+    q, r = np.linalg.qr(rng.normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def _ear_clip(poly2d: np.ndarray) -> list[tuple[int, int, int]]:
+    """Triangles (index triples into `poly2d`, counter-clockwise simple polygon) by ear clipping; every triangle starts
+    at the ear's PREVIOUS vertex, so that consecutive ears around one vertex form fans the pairing pass can find."""
+    idx = list(range(len(poly2d)))
+    out: list[tuple[int, int, int]] = []
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    guard = 0
+    while len(idx) > 3 and guard < 10 * len(poly2d):
+        guard += 1
+        n = len(idx)
+        clipped = False
+        for i in range(n):
+            a, b, c = idx[(i - 1) % n], idx[i], idx[(i + 1) % n]
+            pa, pb, pc = poly2d[a], poly2d[b], poly2d[c]
+            if cross(pa, pb, pc) <= 0:  # reflex (or collinear) corner: not an ear
+                continue
+            if any(cross(pa, pb, poly2d[j]) >= 0 and cross(pb, pc, poly2d[j]) >= 0 and cross(pc, pa, poly2d[j]) >= 0
+                   for j in idx if j not in (a, b, c)):
+                continue
+            out.append((a, b, c))
+            idx.pop(i)
+            clipped = True
+            break
+        if not clipped:  # numerically stuck (collinear runs): fan what is left
+            break
+    for i in range(1, len(idx) - 1):
+        out.append((idx[0], idx[i], idx[i + 1]))
+    return out
+
+
+def soup_city(rng, num_prisms: int = 12, extent: float = 150.0, *, rotate: bool = True,
+              offset: float | None = None) -> tuple[np.ndarray, np.ndarray, dict]:
+    """Triangle soup of `num_prisms` polygon prisms scattered over an `extent`-metre square (prisms may touch or
+    overlap, like the merged footprints of real city meshes).  Returns (vertices f32[V,3], triangles i32[T,3], info).
+
+    Per prism, at random: footprint = convex polygon, star-shaped NON-convex polygon (3..9 corners), rectangle or a
+    rectangle with one 2-cm edge; walls = fans of two triangles (v0 v1 v2) + (v0 v2 v3), some split into two quads at a
+    random fraction (the roof keeps the unsplit edge: a T-JUNCTION) or with a 1e-3 strip split off (a SLIVER wall,
+    aspect >= 1e3); roof = ear-clipped flat polygon, a GABLE roof (rectangles: two sloped quads + two gable triangles),
+    or a HIP roof (fan to an apex); a nearly collinear extra corner makes sliver ears.  Half of the prisms give every face
+    its own copies of the vertices (DUPLICATED positions under different indices), the others share them.  Then the
+    whole scene is rotated (uniform SO(3): no axis, no plane of the scene stays aligned with anything), moved `offset`
+    metres from the origin (None: 0, or 1e4..1e5 with probability 1/3) and rounded to float32 -- a NEW float32 scene.
+    Triangle order is shuffled."""
+    V: list[np.ndarray] = []
+    T: list[tuple[int, int, int]] = []
+    info = {"prisms": num_prisms, "gable": 0, "hip": 0, "nonconvex": 0, "sliver_walls": 0, "sliver_ears": 0, "t_junctions": 0,
+            "duplicated": 0, "thin_edge": 0}
+
+    def add_face(pts, tris, share: dict | None):
+        """pts: list of 3-D points of one face; tris: index triples into pts.  share: position -> index map of the prism."""
+        ids = []
+        for p in pts:
+            key = tuple(np.round(p, 9))
+            if share is not None and key in share:
+                ids.append(share[key])
+                continue
+            V.append(np.asarray(p, np.float64))
+            ids.append(len(V) - 1)
+            if share is not None:
+                share[key] = ids[-1]
+        for a, b, c in tris:
+            T.append((ids[a], ids[b], ids[c]))
+
+    for _ in range(num_prisms):
+        kind = rng.choice(["convex", "star", "rect", "rect", "thin"])
+        R = rng.uniform(6, 22)
+        if kind in ("rect", "thin"):
+            lx, ly = rng.uniform(8, 30), (rng.uniform(8, 30) if kind == "rect" else 0.02)
+            poly = np.array([[-lx / 2, -ly / 2], [lx / 2, -ly / 2], [lx / 2, ly / 2], [-lx / 2, ly / 2]])
+            info["thin_edge"] += int(kind == "thin")
+        else:
+            n = int(rng.integers(3, 10))
+            # corners at jittered equal angles: every gap stays below pi, so the polygon is star-shaped about the origin --
+            # simple and counter-clockwise whatever the radii
+            ang = (np.arange(n) + rng.uniform(-0.2, 0.2, n)) * (2 * np.pi / n) + rng.uniform(0, 2 * np.pi)
+            rad = np.full(len(ang), R) if kind == "convex" else rng.uniform(0.4, 1.0, len(ang)) * R
+            poly = np.column_stack((np.cos(ang), np.sin(ang))) * rad[:, None]
+            info["nonconvex"] += int(kind == "star")
+        if rng.random() < 0.25 and len(poly) >= 3:  # a nearly collinear extra corner: sliver ears in the roof
+            i = int(rng.integers(0, len(poly)))
+            a, b = poly[i], poly[(i + 1) % len(poly)]
+            e = b - a
+            nrm = np.array([e[1], -e[0]]) / max(np.linalg.norm(e), 1e-9)  # outward for a CCW polygon
+            poly = np.insert(poly, i + 1, a + 0.5 * e + nrm * 1e-3 * np.linalg.norm(e) * rng.choice([0.3, 1.0]), axis=0)
+            info["sliver_ears"] += 1
+        yaw = rng.uniform(0, 2 * np.pi)
+        c, s = np.cos(yaw), np.sin(yaw)
+        poly = poly @ np.array([[c, s], [-s, c]]) + rng.uniform(-extent / 2, extent / 2, 2)
+        h = rng.uniform(6, 60)
+        z0 = rng.choice([0.0, 0.0, rng.uniform(0, 5)])
+        share = None if rng.random() < 0.5 else {}
+        info["duplicated"] += int(share is None)
+        n = len(poly)
+        lo3 = [np.array([p[0], p[1], z0]) for p in poly]
+        hi3 = [np.array([p[0], p[1], z0 + h]) for p in poly]
+        for i in range(n):  # walls
+            a, b, b2, a2 = lo3[i], lo3[(i + 1) % n], hi3[(i + 1) % n], hi3[i]
+            r = rng.random()
+            if r < 0.15:  # vertical split at a random fraction: T-junction with the roof edge a2-b2
+                f = rng.uniform(0.2, 0.8)
+                m, m2 = a + f * (b - a), a2 + f * (b2 - a2)
+                add_face([a, m, m2, a2], [(0, 1, 2), (0, 2, 3)], share)
+                add_face([m, b, b2, m2], [(0, 1, 2), (0, 2, 3)], share)
+                info["t_junctions"] += 1
+            elif r < 0.25:  # a 1e-3 strip split off: sliver wall of aspect >= 1e3 (and another T-junction)
+                f = 1e-3 * rng.choice([0.2, 1.0])
+                m, m2 = a + f * (b - a), a2 + f * (b2 - a2)
+                add_face([a, m, m2, a2], [(0, 1, 2), (0, 2, 3)], share)
+                add_face([m, b, b2, m2], [(0, 1, 2), (0, 2, 3)], share)
+                info["sliver_walls"] += 1
+            elif r < 0.33:  # horizontal split at mid height: T-junctions with the neighbouring walls' vertical edges
+                f = rng.uniform(0.3, 0.7)
+                ma, mb = a + f * (a2 - a), b + f * (b2 - b)
+                add_face([a, b, mb, ma], [(0, 1, 2), (0, 2, 3)], share)
+                add_face([ma, mb, b2, a2], [(0, 1, 2), (0, 2, 3)], share)
+                info["t_junctions"] += 1
+            else:
+                add_face([a, b, b2, a2], [(0, 1, 2), (0, 2, 3)], share)
+        rr = rng.random()
+        if n == 4 and rr < 0.4:  # gable roof: ridge parallel to edge 0-1, above the middle of edges 1-2 and 3-0
+            rise = rng.uniform(1, 10)
+            r1 = 0.5 * (hi3[1] + hi3[2]) + np.array([0, 0, rise])
+            r0 = 0.5 * (hi3[3] + hi3[0]) + np.array([0, 0, rise])
+            add_face([hi3[0], hi3[1], r1, r0], [(0, 1, 2), (0, 2, 3)], share)
+            add_face([hi3[2], hi3[3], r0, r1], [(0, 1, 2), (0, 2, 3)], share)
+            add_face([hi3[1], hi3[2], r1], [(0, 1, 2)], share)
+            add_face([hi3[3], hi3[0], r0], [(0, 1, 2)], share)
+            info["gable"] += 1
+        elif rr < 0.55:  # hip roof: fan to an apex above the centroid
+            apex = np.array([poly[:, 0].mean(), poly[:, 1].mean(), z0 + h + rng.uniform(1, 12)])
+            for i in range(n):
+                add_face([hi3[i], hi3[(i + 1) % n], apex], [(0, 1, 2)], share)
+            info["hip"] += 1
+        else:
+            add_face(hi3, _ear_clip(poly), share)
+    Vd = np.asarray(V, np.float64)
+    if rotate:
+        Vd = Vd @ random_rotation_3d(rng).T
+    if offset is None:
+        offset = 0.0 if rng.random() < 2 / 3 else float(10 ** rng.uniform(4, 5))
+    if offset:
+        d = rng.normal(size=3)
+        Vd = Vd + offset * d / np.linalg.norm(d)
+    info["offset_m"] = float(offset)
+    Tr = np.asarray(T, np.int32)
+    Tr = Tr[rng.permutation(len(Tr))]
+    info["triangles"] = int(len(Tr))
+    return Vd.astype(np.float32), Tr, info
+
+
+def soup_end_points(rng, V: np.ndarray, num_tx: int, num_rx: int) -> tuple[np.ndarray, np.ndarray]:
+    """End points for a soup (no street grid, no "up" after the rotation): uniform in the bounding box of the scene,
+    inflated by 10 %; some sit inside prisms (closed rooms have paths too) -- the exhaustive tracer decides what is valid."""
+    lo, hi = V.min(0).astype(np.float64), V.max(0).astype(np.float64)
+    c, e = (lo + hi) / 2, (hi - lo) / 2 * 1.1
+
+    def pts(n):
+        return (c + rng.uniform(-1, 1, (n, 3)) * e).astype(np.float32)
+
+    return pts(num_tx), pts(num_rx)
