@@ -48,7 +48,7 @@ def run(dev=None, order: int = 2, num_ranks: int | None = None, num_tx: int = 16
     def step(tr=tracer):
         txg = torch.tensor(tx, device="cuda", requires_grad=True)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
-        paths = tr.trace_rank_range(scene, order, lo, hi, max_survivors=1 << 24, max_paths=1 << 20)
+        paths = tr.trace_rank_range_literal(scene, order, lo, hi, max_survivors=1 << 24, max_paths=1 << 20)
         loss = torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum()
         loss.backward()
         return paths.objects.shape[0], txg.grad
@@ -381,7 +381,7 @@ def quads_legs(G, qmesh, tx, rx) -> dict:
     def step():
         txg = torch.tensor(tx, device="cuda", requires_grad=True)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), qmesh)
-        paths = tracer.trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
+        paths = tracer.trace_rank_range_literal(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
         torch.sqrt((torch.diff(paths.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
         return paths.objects.shape[0]
 

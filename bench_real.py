@@ -110,7 +110,7 @@ def beam_legs(G, V, Tr, ntx=16, nrx=64, orders=(2, 3)) -> dict:
     # the exhaustive order-2 space of the same end points: the count the pruned legs must reproduce
     try:
         scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
-        t, ex = _time(lambda: tracer.trace_rank_range(scene, 2, max_survivors=1 << 25, max_paths=1 << 20), reps=1)
+        t, ex = _time(lambda: tracer.trace_rank_range_literal(scene, 2, max_survivors=1 << 25, max_paths=1 << 20), reps=1)
         n = Tr.shape[0]
         out["exhaustive_order2"] = {"s_per_step": t, "valid_paths": int(ex.objects.shape[0]),
                                     "path_candidates_per_s": ntx * nrx * n * (n - 1) / t}

@@ -283,11 +283,11 @@ def emulate_shards(nshards: int = 8, *, window: int | None = None, reps: int = 2
             total = n * (n - 1)
             W = min(total, int(window) if window else max(int(3.4e12 // max(rx.shape[0], 1)), 1))
             ex = G.ExhaustivePathTracer()
-            fullc, _ = timed(lambda: ex.trace_rank_range(scene, 2, 0, W, max_survivors=1 << 22).objects.shape[0])
+            fullc, _ = timed(lambda: ex.trace_rank_range_literal(scene, 2, 0, W, max_survivors=1 << 22).objects.shape[0])
             tc = []
             for r in range(nshards):
                 lo, hi = shard_interval(W, nshards, r)
-                t, _ = timed(lambda lo=lo, hi=hi: ex.trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22).objects.shape[0])
+                t, _ = timed(lambda lo=lo, hi=hi: ex.trace_rank_range_literal(scene, 2, lo, hi, max_survivors=1 << 22).objects.shape[0])
                 tc.append(t)
             rec["candidate_sharded"] = {**summary(tc, fullc), "window": W}
         out[name] = rec

@@ -22,7 +22,7 @@ GROUPS = {
     "trace_dense": ("trace_dense.hip", "stores.hpp", "trace_stages.hpp", "trace_common.hpp", "image_chain.hpp", "geom.hpp",
                     "common.hpp"),
     "image_method": ("image_method.hip", "stores.hpp", "image_chain.hpp", "geom.hpp", "common.hpp"),
-    "beam": ("beam.hip", "mesh.hpp", "geom.hpp", "common.hpp"),
+    "beam": ("beam.hip", "beam_margins.hpp", "mesh.hpp", "geom.hpp", "common.hpp"),
 }
 
 

@@ -58,6 +58,7 @@
 
 #include "common.hpp"
 #include "geom.hpp"
+#include "beam_margins.hpp"
 #include "mesh.hpp"
 #include "sort_safe.hpp"
 
@@ -70,7 +71,7 @@ namespace drt {
 // their survivors stay identical.
 __device__ __forceinline__ float fdot(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
 // |w|, rounded up: v_sqrt_f32 (1 ulp) nudged, instead of the ~12-instruction correctly rounded square root
-__device__ __forceinline__ float margin_len(V3 w) { return __builtin_amdgcn_sqrtf(fdot(w, w)) * 1.000001f; }
+__device__ __forceinline__ float margin_len(V3 w) { return __builtin_amdgcn_sqrtf(fdot(w, w)) * margins::kLenRoundUp; }
 __device__ __forceinline__ float l1_len(V3 w) { return (__builtin_fabsf(w.x) + __builtin_fabsf(w.y)) + __builtin_fabsf(w.z); }
 
 struct BeamEntry {  // 32 bytes
@@ -173,7 +174,7 @@ __device__ __forceinline__ float plane_dist(V3 I, V3 n, float d) {
 // plane up to the arithmetic's resolution), NaN or overflow: +inf, which switches every test that uses it off.
 __device__ __forceinline__ float beam_eps(float u, float sigma, float D, float h) {
     const float us = u * sigma;
-    const float e = us * (D * __builtin_amdgcn_rcpf(h)) * 1.0001f;  // v_rcp_f32: 1 ulp, inside the 1.0001
+    const float e = us * (D * __builtin_amdgcn_rcpf(h)) * margins::kEpsRoundUp;  // v_rcp_f32: 1 ulp, inside the round-up
     return (h > us && e < kInf) ? e : kInf;
 }
 
@@ -271,9 +272,9 @@ __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, 
     if constexpr (TWO) s += fdot(third2 - I, N);
     const V3 e = b - a;
     const float el = __builtin_amdgcn_sqrtf(fdot(e, e));
-    const float rho = (el > 0.0f) ? 0.9999f * len * __builtin_amdgcn_rcpf(el) : 0.0f;
-    const float g = 1.0101f * delta * __builtin_amdgcn_rcpf(rho - delta) + 2e-6f;
-    const bool on = apex_off_plane && (rho > 1.05f * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
+    const float rho = (el > 0.0f) ? margins::kRhoRoundDown * len * __builtin_amdgcn_rcpf(el) : 0.0f;
+    const float g = margins::kSlopeFactor * delta * __builtin_amdgcn_rcpf(rho - delta) + margins::kSlopeRounding;
+    const bool on = apex_off_plane && (rho > margins::kFaceOffRatio * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
     const float inv = __builtin_amdgcn_rcpf(len);
     const float sc = on ? ((s > 0.0f) ? inv : -inv) : 0.0f;
     n_out = on ? N * sc : V3{0, 0, 0};  // (0 * inf = NaN for a huge N: the select, not the product, zeroes it)
@@ -297,7 +298,7 @@ __device__ __forceinline__ float apex_plane_distance(V3 I, V3 v0, V3 v1, V3 v2) 
 template <int NF>
 __device__ __forceinline__ PyrN<NF> make_pyr(V3 I, const V3 (&v)[NF], float delta) {
     PyrN<NF> P;
-    const bool apex_off_plane = apex_plane_distance(I, v[0], v[1], v[2]) * 0.9999f > 1.05f * delta;  // (NaN: off)
+    const bool apex_off_plane = apex_plane_distance(I, v[0], v[1], v[2]) * margins::kRhoRoundDown > margins::kPlaneOffRatio * delta;  // (NaN: off)
 #pragma unroll
     for (int f = 0; f < NF; ++f)
         pyr_face<NF == 4>(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], v[(f + 3) % NF], delta, apex_off_plane, P.n[f], P.g[f]);
@@ -351,7 +352,7 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
         if (Sh::TPP == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * Sh::TPP + 1]);
         lat += u * sg;
     }
-    const float delta = 2.0f * lat;  // +inf for a degenerate mirror: every face off
+    const float delta = margins::kLateralFactor * lat;  // +inf for a degenerate mirror: every face off
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
         const float *tv = M.tv + 9 * ((int64_t)e.id[j] * Sh::TPP);
@@ -503,10 +504,10 @@ __device__ __forceinline__ bool prim_stage1(const View &cv, const V3 (&vx)[Shape
 #if defined(DRT_LAB) && defined(BEAM_LAB_NO_PRIM_EPS)
     const float eps_c = 0.0f * (sigma + D2 + h);
 #else
-    const float eps_c = beam_eps(cu, sigma, __builtin_amdgcn_sqrtf(D2) * 1.000001f, h);
+    const float eps_c = beam_eps(cu, sigma, __builtin_amdgcn_sqrtf(D2) * margins::kLenRoundUp, h);
 #endif
-    const float base = -(2.0f * eps_c + cu);  // -inf for a candidate seen at grazing incidence: nothing separates
-    const int side_c = side_of_range(dmin, dmax, eps_c + 2.0f * cu);
+    const float base = -(margins::kFaceEpsFactor * eps_c + margins::kFaceUnits * cu);  // -inf for a candidate seen at grazing incidence: nothing separates
+    const int side_c = side_of_range(dmin, dmax, margins::kSideEpsFactor * eps_c + margins::kSideUnits * cu);
     bool pruned = !nan && (cside * side_c == -1);
     float worst = -kInf;  // max over the pyramids of min over the faces
 #pragma unroll
@@ -565,17 +566,17 @@ __device__ __forceinline__ bool box_pruned(const BeamCtx<SCALE, LEVEL> &c, const
                                            float eps_max) {
     const V3 ce = V3{0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
     // half extents, rounded up (the centre itself is rounded)
-    const V3 e = V3{(hi[0] - lo[0]) * 0.50001f, (hi[1] - lo[1]) * 0.50001f, (hi[2] - lo[2]) * 0.50001f};
+    const V3 e = V3{(hi[0] - lo[0]) * margins::kBoxHalfExtent, (hi[1] - lo[1]) * margins::kBoxHalfExtent, (hi[2] - lo[2]) * margins::kBoxHalfExtent};
     if (!(e.x >= 0.0f) || !(e.y >= 0.0f) || !(e.z >= 0.0f)) return false;  // NaN / empty box: keep
     if (c.side_prev != 0) {
         const float dc = fdot(ce - c.pm, c.nm);
         const float r = (__builtin_fabsf(c.nm.x) * e.x + __builtin_fabsf(c.nm.y) * e.y) + __builtin_fabsf(c.nm.z) * e.z;
-        const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, eps_max + 2.0f * c.u) : 0;
+        const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, margins::kSideEpsFactor * eps_max + margins::kSideUnits * c.u) : 0;
         if (c.side_prev * sb == -1) return true;
     }
     const V3 w = ce - c.I;
     const float wl = l1_len(w) + ((e.x + e.y) + e.z);  // largest |x - I|_1 inside the box
-    const float base = -(2.0f * eps_max + c.u);
+    const float base = -(margins::kFaceEpsFactor * eps_max + margins::kFaceUnits * c.u);
     bool separated = false;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) void beam_seed_kernel(BeamMesh M, const float 
         const V3 t = ld3(tx + 3 * it);
         const V3 I = image_of_vertex(t, pt, n);
         const float d = fdot(t - pt, n);
-        e.tx_side = pack_tx_side((int)it, (d == d) ? side_of_range(d, d, 2.0f * u) : 0);  // the transmitter is exact
+        e.tx_side = pack_tx_side((int)it, (d == d) ? side_of_range(d, d, margins::kSideUnits * u) : 0);  // the transmitter is exact
         e.id[0] = (int32_t)a;
         e.id[1] = e.id[2] = -1;
         e.apex[0] = I.x;
@@ -891,13 +892,13 @@ __device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamE
         }
         const float sv = fdot(w[2], N0);
         const float D = __builtin_amdgcn_sqrtf(D2);
-        const float tol = 64.0f * fmaxf(ulp_m, 1.2e-7f * D) * lensum;
+        const float tol = margins::kFlatTolUlps * fmaxf(ulp_m, margins::kFlatRelative * D) * lensum;
         const bool defined = fin && __builtin_fabsf(sv) > tol;
 #pragma unroll
         for (int f = 0; f < Sh::NF; ++f) {
             const V3 ed = v[(f + 1) % Sh::NF] - v[f];
             const float el = __builtin_amdgcn_sqrtf(fdot(ed, ed));
-            rho[t][f] = (el > 0.0f && defined) ? 0.9999f * len[f] * __builtin_amdgcn_rcpf(el) : 0.0f;  // pyr_face's rho
+            rho[t][f] = (el > 0.0f && defined) ? margins::kRhoRoundDown * len[f] * __builtin_amdgcn_rcpf(el) : 0.0f;  // pyr_face's rho
         }
     }
 }
@@ -917,30 +918,30 @@ __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const Be
     const float s2 = 2.0f * __builtin_fmaf(nc.x, I2.x, __builtin_fmaf(nc.y, I2.y, __builtin_fmaf(nc.z, I2.z, -dc)));
     const V3 I3 = V3{I2.x - nc.x * s2, I2.y - nc.y * s2, I2.z - nc.z * s2};
     const float uc = u0 * mag_scale(M, I3);
-    const float delta = 2.0f * uc * (sig_parent + sig_c) * 1.00002f;  // +inf for a degenerate mirror: every face off
+    const float delta = margins::kLateralFactor * uc * (sig_parent + sig_c) * margins::kChildDeltaRoundUp + margins::kChildRouteUnits * uc;  // +inf for a degenerate mirror: every face off
     const V3 ce = V3{0.5f * (rx.lo[0] + rx.hi[0]), 0.5f * (rx.lo[1] + rx.hi[1]), 0.5f * (rx.lo[2] + rx.hi[2])};
-    const V3 he = V3{(rx.hi[0] - rx.lo[0]) * 0.50001f, (rx.hi[1] - rx.lo[1]) * 0.50001f, (rx.hi[2] - rx.lo[2]) * 0.50001f};
+    const V3 he = V3{(rx.hi[0] - rx.lo[0]) * margins::kBoxHalfExtent, (rx.hi[1] - rx.lo[1]) * margins::kBoxHalfExtent, (rx.hi[2] - rx.lo[2]) * margins::kBoxHalfExtent};
     if (!(he.x >= 0.0f) || !(he.y >= 0.0f) || !(he.z >= 0.0f)) return false;
     const V3 w = ce - I3;
     const float wl = l1_len(w) + ((he.x + he.y) + he.z);
-    const float thr = -1.1f * uc;
+    const float thr = -margins::kChildFaceUnits * uc;
     // the receiver stage switches the child's whole pyramid off when ITS apex lies within 1.05 delta of the polygon's
     // plane (make_pyr); that distance equals the parent's up to the rounding of one more reflection (a few ulp(M') of
     // position), so this stage needs the parent's distance clear of the threshold by that much, whatever kappa is
-    const float hp_slack = 64.0f * rx.ulp_m * mag_scale(M, I3);
+    const float hp_slack = margins::kChildPlaneSlackUlps * rx.ulp_m * mag_scale(M, I3);
     bool all_t = true;
 #pragma unroll
     for (int t = 0; t < Sh::NP; ++t) {
-        const bool apex_off_plane = hp[t] * 0.999f > 1.06f * delta + hp_slack;  // (NaN: off)
+        const bool apex_off_plane = hp[t] * margins::kChildRhoRoundDown > margins::kChildPlaneOffRatio * delta + hp_slack;  // (NaN: off)
         float v[Sh::NF];
 #pragma unroll
         for (int f = 0; f < Sh::NF; ++f) {
             const V3 n = n0[t][f];
             const float k2 = 2.0f * fdot(n, nc);
             const V3 nr = V3{n.x - nc.x * k2, n.y - nc.y * k2, n.z - nc.z * k2};
-            const float r = rho[t][f] * 0.999f;
-            const float g = 1.0101f * delta * __builtin_amdgcn_rcpf(r - delta) + 2.1e-4f;
-            const bool on = apex_off_plane && r > 1.06f * delta;  // otherwise the child's face may be off: it never separates
+            const float r = rho[t][f] * margins::kChildRhoRoundDown;
+            const float g = margins::kSlopeFactor * delta * __builtin_amdgcn_rcpf(r - delta) + margins::kChildSlopeRounding;
+            const bool on = apex_off_plane && r > margins::kChildFaceOffRatio * delta;  // otherwise the child's face may be off: it never separates
             const float smax = fdot(w, nr) + ((__builtin_fabsf(nr.x) * he.x + __builtin_fabsf(nr.y) * he.y) +
                                               __builtin_fabsf(nr.z) * he.z);
             const float val = __builtin_fmaf(g, wl, smax);
@@ -1184,7 +1185,7 @@ __device__ __forceinline__ void expand_clustered_body(
 #if defined(DRT_LAB) && defined(BEAM_LAB_NO_HMIN)
         const float eps_max = 0.0f;
 #else
-        const float eps_max = beam_eps(ctx.u, bx[6], margin_len(far) * 1.0001f, hmin);  // ctx.u: the prefix's own unit
+        const float eps_max = beam_eps(ctx.u, bx[6], margin_len(far) * margins::kBoxFarRoundUp, hmin);  // ctx.u: the prefix's own unit
 #endif
         bool alive = have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max);
         // second level for the survivors: the four sub-boxes of 16 consecutive primitives (one or two buildings of a
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
         const V3 far = V3{fmaxf(__builtin_fabsf(ctx.I.x - lo[0]), __builtin_fabsf(ctx.I.x - hi[0])),
                           fmaxf(__builtin_fabsf(ctx.I.y - lo[1]), __builtin_fabsf(ctx.I.y - hi[1])),
                           fmaxf(__builtin_fabsf(ctx.I.z - lo[2]), __builtin_fabsf(ctx.I.z - hi[2]))};
-        const float eps_max = beam_eps(ctx.u, b1.z, margin_len(far) * 1.0001f, hmin);
+        const float eps_max = beam_eps(ctx.u, b1.z, margin_len(far) * margins::kBoxFarRoundUp, hmin);
         bool alive = have && !box_pruned<SCALE, LEVEL>(ctx, lo, hi, eps_max);
         if (__any(alive)) {
             const float sb[24] = {sq[0].x, sq[0].y, sq[0].z, sq[0].w, sq[1].x, sq[1].y, sq[1].z, sq[1].w,
@@ -1638,7 +1639,7 @@ __device__ __forceinline__ BeamEntry beam_child(const BeamMesh &M, const BeamEnt
     const float us = u * fmaxf(mag_scale(M, I), mag_scale(M, I2));
     o.esum = e.esum + prim_eps_global(M, c, I, us);
     // the previous reflection point lies within S_parent of the parent's last mirror
-    o.tx_side = pack_tx_side(entry_tx(e), side_of_prim(M, e.id[LEVEL - 1], pc, nc, e.esum + 2.0f * us));
+    o.tx_side = pack_tx_side(entry_tx(e), side_of_prim(M, e.id[LEVEL - 1], pc, nc, margins::kSideEpsFactor * e.esum + margins::kSideUnits * us));
     return o;
 }
 
@@ -1712,7 +1713,7 @@ __device__ __forceinline__ BeamEntry beam_child_from(const BeamMesh &M, const Be
     o.apex[2] = I2.z;
     const float us = u * fmaxf(mag_scale(M, I), mag_scale(M, I2));
     o.esum = e.esum + prim_eps_from<SCALE>(gc, I, us);
-    o.tx_side = pack_tx_side(entry_tx(e), side_from<SCALE>(glast, pc, nc, e.esum + 2.0f * us));
+    o.tx_side = pack_tx_side(entry_tx(e), side_from<SCALE>(glast, pc, nc, margins::kSideEpsFactor * e.esum + margins::kSideUnits * us));
     return o;
 }
 template <int SCALE, int LEVEL>  // build_ctx
@@ -1732,7 +1733,7 @@ __device__ __forceinline__ void build_ctx_from(const BeamMesh &M, const BeamEntr
     float lat = 0.0f;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) lat += u * geo[j].sg;
-    const float delta = 2.0f * lat;
+    const float delta = margins::kLateralFactor * lat;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
 #pragma unroll
@@ -1797,7 +1798,7 @@ __device__ __forceinline__ bool receiver_first(const BeamCtx<SCALE, ORDER> &c, V
         float fv[Shape<SCALE>::NF];
 #pragma unroll
         for (int f = 0; f < Shape<SCALE>::NF; ++f) fv[f] = __builtin_fmaf(P.g[f], wl, fdot(w, P.n[f]));
-        inside_any = inside_any | !(min_faces<Shape<SCALE>::NF>(fv) < -c.u);
+        inside_any = inside_any | !(min_faces<Shape<SCALE>::NF>(fv) < -margins::kFaceUnits * c.u);
     }
     return lane_on & inside_any;  // (& not &&: no branch around a handful of instructions)
 }
@@ -1812,7 +1813,7 @@ __device__ __forceinline__ bool receiver_rest(const BeamCtx<SCALE, ORDER> &c, V3
     const float wl = l1_len(w);
     const float d = fdot(r - c.pm, c.nm);
     // side_prev in {-1, 0, +1}; 0 or a NaN distance never rejects (the receiver is exact: margin 2u)
-    alive = alive & !((float)c.side_prev * d < -2.0f * c.u);
+    alive = alive & !((float)c.side_prev * d < -margins::kSideUnits * c.u);
 #pragma unroll
     for (int j = 1; j < ORDER; ++j) {
         if (WAVE_EXIT && !__any(alive)) return false;
@@ -1823,7 +1824,7 @@ __device__ __forceinline__ bool receiver_rest(const BeamCtx<SCALE, ORDER> &c, V3
             float fv[Shape<SCALE>::NF];
 #pragma unroll
             for (int f = 0; f < Shape<SCALE>::NF; ++f) fv[f] = __builtin_fmaf(P.g[f], wl, fdot(w, P.n[f]));
-            inside_any = inside_any | !(min_faces<Shape<SCALE>::NF>(fv) < -c.u);
+            inside_any = inside_any | !(min_faces<Shape<SCALE>::NF>(fv) < -margins::kFaceUnits * c.u);
         }
         alive = alive & inside_any;
     }
@@ -2250,7 +2251,7 @@ __device__ __forceinline__ bool fan_quad_convex(V3 n, const V3 (&q)[4]) {
         const V3 e0 = q[(k + 1) % 4] - q[k], e1 = q[(k + 2) % 4] - q[(k + 1) % 4];
         const float turn = fdot(cross(e0, e1), n);
         const float scale = __builtin_sqrtf(fdot(e0, e0) * fdot(e1, e1));
-        quad = quad && (turn > 1e-3f * scale) && is_finite(scale);
+        quad = quad && (turn > margins::kQuadConvexSin * scale) && is_finite(scale);
     }
     return quad;
 }
@@ -2665,7 +2666,10 @@ static BeamSizes beam_sizes(const drt_beam_params *bp, int64_t ntx, int64_t nrx,
     const int64_t rec_bound = (order >= 3) ? sat_mul(z.max_entries, nprim > 0 ? nprim : 1) : n2;
     const int64_t d_records = std::min(clamp64(pow2_at_least(sat_mul(est, 4)), (int64_t)1 << 18, (int64_t)1 << 27), std::max<int64_t>(rec_bound, 64));
     z.max_records = (bp && bp->max_records > 0) ? bp->max_records : d_records;
-    const int64_t row_bound = sat_mul(order >= 2 ? z.max_records : n1, rx1);
+    // (hard bound of the rows of one slice, times 2^order: in coplanar-pair mode a row of primitives becomes 2^order triangle
+    // rows of the table, and a soup of mostly single triangles has nearly as many primitives as triangles -- without the
+    // factor a 81-triangle scene whose every row survives asked for 176 table rows of 162: round 6's soup stress)
+    const int64_t row_bound = sat_mul(sat_mul(order >= 2 ? z.max_records : n1, rx1), (int64_t)1 << (order > 0 ? order : 0));
     const int64_t d_rows = std::min(clamp64(z.max_records / 2, (int64_t)1 << 18, (int64_t)1 << 26), std::max<int64_t>(row_bound, 64));
     z.max_rows = (bp && bp->max_rows > 0) ? bp->max_rows : d_rows;
     z.max_survivors = (bp && bp->max_survivors > 0) ? bp->max_survivors : std::min<int64_t>((int64_t)1 << 22, z.max_rows);
@@ -3146,7 +3150,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     DRT_REQUIRE(ntx >= 0 && nrx >= 0 && max_paths >= 0, "negative size");
     DRT_REQUIRE(order >= 0 && order <= 3, "beam pruning covers orders 0..3");
     DRT_REQUIRE(ntx < (1ll << 30) && nrx < (1ll << 31), "too many transmitters / receivers");
-    const float kappa = (bp && bp->kappa > 0.0f) ? bp->kappa : 64.0f;
+    const float kappa = (bp && bp->kappa > 0.0f) ? bp->kappa : margins::kKappaDefault;
     const int32_t flags = bp ? bp->flags : 0;
     const int64_t shard_world = (bp && bp->shard_world > 1) ? bp->shard_world : 1;
     const int64_t shard_rank = bp ? bp->shard_rank : 0;
@@ -3566,7 +3570,7 @@ int32_t drt_trace_paths_beam_async(drt_mesh_t mesh, const drt_trace_params *pr, 
     DRT_REQUIRE(order >= 0 && order <= 3, "beam pruning covers orders 0..3");
     DRT_REQUIRE(ntx < (1ll << 30) && nrx < (1ll << 31), "too many transmitters / receivers");
     DRT_REQUIRE(max_paths == 0 || (keys && vertices && objects), "null output");
-    const float kappa = (bp && bp->kappa > 0.0f) ? bp->kappa : 64.0f;
+    const float kappa = (bp && bp->kappa > 0.0f) ? bp->kappa : margins::kKappaDefault;
     const int32_t flags = bp ? bp->flags : 0;
     const int64_t shard_world = (bp && bp->shard_world > 1) ? bp->shard_world : 1;
     const int64_t shard_rank = bp ? bp->shard_rank : 0;

@@ -4,6 +4,8 @@
 // It replaces the reference's hidden, id()-keyed `_WARP_MESHES_CACHE` (_mesh.py:55, 170-174).
 #include "mesh.hpp"
 
+#include "beam_margins.hpp"
+
 #include "common.hpp"
 #include "geom.hpp"
 
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void mesh_prepare_kernel(const float *__restri
     const float la = __builtin_sqrtf(dot(ea, ea)), lb = __builtin_sqrtf(dot(eb, eb)), lc = __builtin_sqrtf(dot(ec, ec));
     const float pm = fmaxf(la * lb, fmaxf(lb * lc, lc * la));
     const float sg = (len > 0.0f) ? pm / len : kInf;
-    shape[t] = (sg >= 1.0f && sg < kInf) ? sg * 1.0001f : ((sg < 1.0f) ? 1.0f : kInf);
+    shape[t] = (sg >= 1.0f && sg < kInf) ? sg * margins::kSigmaRoundUp : ((sg < 1.0f) ? 1.0f : kInf);
 }
 
 }  // namespace drt

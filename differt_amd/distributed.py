@@ -272,7 +272,7 @@ def trace_rank_range_triangle_sharded(tracer, scene, order: int, rank_lo: int = 
         tri_lo, tri_hi = shard_interval(T, world, rank)
     tracer._skip_occlusion = True  # geometric survivors only (DRT_TRACE_SKIP_OCCLUSION)
     try:
-        p = tracer.trace_rank_range(scene, order, rank_lo, rank_hi, **kwargs)
+        p = tracer.trace_rank_range(scene, order, rank_lo, rank_hi, literal=True, **kwargs)  # (the filter stage itself, not the pruned search)
     finally:
         tracer._skip_occlusion = False
     S = p.objects.shape[0]
@@ -308,7 +308,7 @@ def trace_rank_range_sharded(tracer, scene, order: int, rank_lo: int = 0, rank_h
     hi = total if rank_hi is None else min(int(rank_hi), total)
     lo = min(int(rank_lo), hi)
     a, b = shard_interval(hi - lo, world, rank)
-    local = tracer.trace_rank_range(scene, order, lo + a, lo + b, **kwargs)
+    local = tracer.trace_rank_range(scene, order, lo + a, lo + b, literal=True, **kwargs)  # candidate-rank sharding IS the exhaustive path
     keys = globalize_keys(local.keys, b - a, a, hi - lo)
     if not gather or world == 1:
         return keys, local.vertices, local.objects

@@ -138,7 +138,9 @@ class Scene:
 
         Result batch shape: ``[*tx_batch, *rx_batch, num_candidates]`` (:762-764).  ``compact=True``
         (MI355X extension) returns only the valid paths, flattened, without building the dense
-        arrays or the candidate table.  ``solver="beam"`` (MI355X extension, orders 0..3): the valid paths of the
+        arrays or the candidate table; for orders 1..3 of the exhaustive solver it runs through the pruned search
+        (``drt_trace_paths_beam``) unless ``literal=True`` is among the solver arguments (``ExhaustivePathTracer.literal``:
+        every candidate through the filter kernel) -- same paths, order, vertex bits and keys either way.  ``solver="beam"`` (MI355X extension, orders 0..3): the valid paths of the
         exhaustive solver -- same objects, order and vertex bits -- through the geometrically pruned search
         (``drt_trace_paths_beam``), always compact; ``solver_kwargs`` go to ``ExhaustivePathTracer`` except
         ``kappa`` / ``max_paths``, which go to the search.

@@ -446,6 +446,13 @@ class ExhaustivePathTracer(AbstractPathTracer):
     """Fill :attr:`last_stats` (``drt_trace_stats``: candidates / survivors / valid paths and the
     HIP-event time of the filter, occlusion and sort+emit stages) on every compact trace; costs two
     extra stream synchronisations per call."""
+    literal: bool = False
+    """MI355X extension (round 6).  ``False``: a compact trace of a WHOLE candidate space of order 1..3
+    (``Scene.trace_paths(order, compact=True)``, ``trace_rank_range(scene, order)``) runs through the geometrically pruned
+    search (``drt_trace_paths_beam``: the same paths, order, vertex bits and keys, 100-1000x faster at 10k triangles;
+    DESIGN.md section 9 -- its one documented exclusion are float artifacts with two reflection points closer than
+    64 ulp(M), section 9.8).  ``True``: every candidate is evaluated by the filter kernel, literally as the reference
+    enumerates them (_solvers.py:803-848, 936-957)."""
 
     # ---- candidate generation (host graph classes; lexicographic like graph.rs) ----
     def _graph(self, scene):
@@ -580,10 +587,13 @@ class ExhaustivePathTracer(AbstractPathTracer):
         return mesh.num_primitives, None
 
     def trace_rank_range(self, scene, order: int, rank_lo: int = 0, rank_hi: int | None = None, *,
-                         max_survivors: int = 1 << 20, max_paths: int = 1 << 16) -> TracedPaths:
+                         max_survivors: int = 1 << 20, max_paths: int = 1 << 16, literal: bool | None = None) -> TracedPaths:
         """Trace candidates ``[rank_lo, rank_hi)`` of the lexicographic candidate order without
         materialising them; returns the valid paths only, in ``masked_vertices`` order.
-        ``keys`` holds ``(tx*num_rx + rx) * (rank_hi - rank_lo) + (rank - rank_lo)``."""
+        ``keys`` holds ``(tx*num_rx + rx) * (rank_hi - rank_lo) + (rank - rank_lo)``.
+
+        The WHOLE space of an order 1..3 goes through the pruned search unless ``literal`` (default: the tracer's
+        :attr:`literal`) is true -- same paths, same keys (see :attr:`literal`)."""
         if self.smoothing_factor is not None:
             raise NotImplementedError("the smoothed mode is dense by nature (every candidate gets a confidence): "
                                       "use trace_path_candidates / Scene.trace_paths without compact")
@@ -591,9 +601,41 @@ class ExhaustivePathTracer(AbstractPathTracer):
         total = 1 if order == 0 else n * (n - 1) ** (order - 1)
         hi = total if rank_hi is None else min(int(rank_hi), total)
         lo = min(int(rank_lo), hi)
+        lit = self.literal if literal is None else bool(literal)
+        if (not lit and type(self) is ExhaustivePathTracer and 1 <= order <= 3 and lo == 0 and hi == total and total > 0
+                and scene.transmitters.numel() and scene.receivers.numel()
+                and scene.transmitters.reshape(-1, 3).shape[0] * scene.receivers.reshape(-1, 3).shape[0]
+                * max(scene.mesh.num_primitives, 1) ** order < 2 ** 62):
+            return self._rank_keyed(scene, self.trace_beam_pruned(scene, order, max_paths=max_paths), order, n, node_map, total)
         desc = {"table": None, "order": order, "rank_lo": lo, "count": hi - lo, "num_nodes": max(n, 1),
                 "node_map": node_map}
         return self._trace_compact(scene, desc, max_survivors, max_paths)
+
+    def trace_rank_range_literal(self, *args, **kwargs) -> TracedPaths:
+        """:meth:`trace_rank_range` with every candidate evaluated (``literal=True``): what the tests, the stress drivers
+        and the exhaustive legs of the benches use as the EXHAUSTIVE side of a comparison."""
+        return self.trace_rank_range(*args, literal=True, **kwargs)
+
+    def _rank_keyed(self, scene, p: TracedPaths, order: int, n: int, node_map, total: int) -> TracedPaths:
+        """Paths of the pruned search with the keys of :meth:`trace_rank_range`: ``(tx*num_rx + rx) * total + rank``,
+        ``rank`` = position of ``(m_1 .. m_k)`` in the lexicographic enumeration of the complete graph over the nodes
+        (graph.rs:301-397): ``m_1 (n-1)^(k-1) + sum_j (m_j - [m_j > m_(j-1)]) (n-1)^(k-j)``.  Both key orders are the
+        lexicographic order of ``(tx, rx, m_1 .. m_k)``, so the rows keep their places."""
+        objs = p.objects
+        ids = objs[:, 1:-1].to(torch.int64)
+        mesh = scene.mesh
+        if mesh.assume_quads:
+            ids = ids // 2  # objects report the even triangle id of a quad (_solvers.py:736-744)
+        if node_map is not None:  # disconnect_inactive_triangles: nodes = active primitives, in order
+            inv = torch.full((max(mesh.num_primitives, 1),), -1, dtype=torch.int64, device=ids.device)
+            inv[node_map.to(torch.int64)] = torch.arange(node_map.shape[0], dtype=torch.int64, device=ids.device)
+            ids = inv[ids]
+        rank = ids[:, 0].clone() if order >= 1 else torch.zeros(objs.shape[0], dtype=torch.int64, device=objs.device)
+        for j in range(1, order):
+            rank = rank * (n - 1) + (ids[:, j] - (ids[:, j] > ids[:, j - 1]).to(torch.int64))
+        nrx = scene.receivers.reshape(-1, 3).shape[0]
+        keys = (objs[:, 0].to(torch.int64) * nrx + objs[:, -1].to(torch.int64)) * total + rank
+        return TracedPaths(p.vertices, p.objects, p.mask, p.interaction_types, p.confidence_threshold, keys)
 
     def trace_path_candidates_compact(self, scene, path_candidates, *, max_survivors: int = 1 << 20,
                                       max_paths: int = 1 << 16) -> TracedPaths:
@@ -997,7 +1039,7 @@ class HybridPathTracer(ExhaustivePathTracer):
         return int(first.shape[0]) * n ** (order - 2) * int(last.shape[0])
 
     def trace_rank_range(self, scene, order: int, rank_lo: int = 0, rank_hi: int | None = None, *,
-                         max_survivors: int = 1 << 20, max_paths: int = 1 << 16) -> TracedPaths:
+                         max_survivors: int = 1 << 20, max_paths: int = 1 << 16, literal: bool | None = None) -> TracedPaths:
         """GPU-resident counterpart of the pruned DiGraph enumeration (_solvers.py:996-1056): ranks
         address ``F x N^(order-2) x L`` (first interaction visible from a transmitter, last one from a
         receiver, inactive primitives removed) in lexicographic order -- the DFS order of the

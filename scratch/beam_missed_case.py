@@ -17,7 +17,7 @@ for f in sys.argv[1:]:
     mesh = G.Mesh(V, Tr, mask=mask, assume_quads=quads)
     scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
     tr = G.ExhaustivePathTracer()
-    ex = tr.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    ex = tr.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
     ea = set(map(tuple, ex.objects.cpu().tolist()))
     out = {"file": f.split("/")[-1], "order": order, "T": int(Tr.shape[0]), "quads": quads, "masked": mask is not None, "ntx": len(tx),
            "nrx": len(rx), "valid": len(ea), "saved_missed": d["missed"].tolist(), "axis_aligned": bool(np.all(np.isin(np.abs(mesh.handle().normals().cpu().numpy()), (0.0, 1.0))))}

@@ -13,6 +13,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import beam_degenerate as BD  # noqa: E402
 import differt_amd.geometry as G  # noqa: E402
 import synthetic_scenes as S  # noqa: E402
 
@@ -103,7 +105,7 @@ while time.time() - t0 < budget:
         order = 2
     scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
     tracer = G.ExhaustivePathTracer()
-    ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
     bp = tracer.trace_beam_pruned(scene, order, kappa=KAPPA)
     rows = tracer.last_beam_stats["rows"]
     pair_mode = tracer.last_beam_stats["pair_mode"]
@@ -112,9 +114,18 @@ while time.time() - t0 < budget:
     # exhaustive keys are (pair, candidate rank); compare through objects
     ea = [tuple(o) for o in ex.objects.cpu().tolist()]
     ba = [tuple(o) for o in bp.objects.cpu().tolist()]
-    st["missed"] += len(set(ea) - set(ba))
+    # paths with two consecutive reflection points closer than the error unit u = kappa ulp(M) are float artifacts
+    # of the reference (its inside test runs on a direction that is rounding noise); the pruned search does not promise them.
+    # Counted apart -- seen / lost -- so that the guarantee's one exclusion stays visible and small.
+    deg = BD.short_segment_mask(ex.vertices.cpu().numpy(), BD.ulp_of_scene(V, tx, rx)) if order >= 2 and len(ea) else np.zeros(len(ea), bool)
+    deg_set = {o for o, dg in zip(ea, deg) if dg}
+    st["short_segment_paths_seen"] = st.get("short_segment_paths_seen", 0) + len(deg_set)
+    lost = set(ea) - set(ba)
+    st["short_segment_paths_lost"] = st.get("short_segment_paths_lost", 0) + len(lost & deg_set)
+    st["missed"] += len(lost - deg_set)
     st["extra"] += len(set(ba) - set(ea))
-    if set(ea) != set(ba) and st.get("saved_cases", 0) < 40:  # keep the scene: a lost path must be reproducible
+    if (lost - deg_set or set(ba) - set(ea) or (lost and st.get("saved_short", 0) < 4)) and st.get("saved_cases", 0) < 40:  # keep the scene: a lost path must be reproducible
+        st["saved_short"] = st.get("saved_short", 0) + int(not (lost - deg_set))
         import os
         os.makedirs("gpurun_out/stress_mismatch", exist_ok=True)
         st["saved_cases"] = st.get("saved_cases", 0) + 1

@@ -49,7 +49,7 @@ if "--verify" in sys.argv:
     # exhaustive trace of all 4.1e13 candidates (about two minutes): the pruned search must not miss a path
     scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
     t0 = time.perf_counter()
-    ex = G.ExhaustivePathTracer().trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
+    ex = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
     torch.cuda.synchronize()
     a = set(map(tuple, ex.objects.cpu().numpy().tolist()))
     b = set(map(tuple, paths.objects.cpu().numpy().tolist()))

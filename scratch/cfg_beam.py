@@ -55,7 +55,7 @@ if "cfg3" in which or "cfg4" in which:
     if "cfg3" in which:
         def ver(mesh):
             scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
-            return G.ExhaustivePathTracer().trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
+            return G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
         run("configs[2]", V, Tr, tx, rx, 2, ver)
     if "cfg4" in which:
         run("configs[3]", V, Tr, tx, rx, 3)

@@ -12,9 +12,9 @@ scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda")
 tr = G.ExhaustivePathTracer()
 L = C.CDLL(str(lib.LIB_PATH))
 buf = (C.c_ulonglong * 8)()
-tr.trace_rank_range(scene, 2, 0, 2_000_000)
+tr.trace_rank_range_literal(scene, 2, 0, 2_000_000)
 L.drt_debug_counts(buf, 1)
-tr.trace_rank_range(scene, 2, 0, 20_000_000)
+tr.trace_rank_range_literal(scene, 2, 0, 20_000_000)
 L.drt_debug_counts(buf, 0)
 it = buf[0]
 print({"wave_iterations": it, "step_j0_guarded": buf[1] / it, "step_j1_guarded": buf[2] / it, "mt_literal": buf[3] / it,

@@ -14,7 +14,7 @@ for boxes, seed in ((30, 1), (60, 2), (100, 3), (150, 4)):
     V, Tr, c, h = S.manhattan(boxes, seed=seed)
     tx, rx = S.manhattan_tx_rx(c, h, 4, 16, seed=seed + 10)
     scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), G.Mesh(V, Tr))
-    ex = G.ExhaustivePathTracer().trace_rank_range(scene, 3, max_survivors=1 << 24, max_paths=1 << 18)
+    ex = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 3, max_survivors=1 << 24, max_paths=1 << 18)
     a = set(map(tuple, ex.objects.cpu().numpy().tolist()))
     row = {"triangles": int(Tr.shape[0]), "exhaustive_evals": 64 * Tr.shape[0] * (Tr.shape[0] - 1) ** 2, "exhaustive_valid": len(a)}
     for name, kw in (("lattice_1e6", {"num_rays": 1_000_000}), ("lattice_1e5_plus_samples", {"num_rays": 100_000, "sample_triangles": True})):

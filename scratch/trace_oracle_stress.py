@@ -56,7 +56,7 @@ while time.time() - t0 < budget:
         # neighbours in the table) that the GPU's own exhaustive tracer finds -- the oracle then decides every one of them
         n_tri = Tr.shape[0]
         if not quads and mask is None and n_tri * max(n_tri - 1, 1) ** (order - 1) < 4e9:
-            ex = G.ExhaustivePathTracer().trace_rank_range(G.Scene(tx, rx, G.Mesh(V, Tr)), order, max_survivors=1 << 22, max_paths=1 << 16)
+            ex = G.ExhaustivePathTracer().trace_rank_range_literal(G.Scene(tx, rx, G.Mesh(V, Tr)), order, max_survivors=1 << 22, max_paths=1 << 16)
             near = ex.objects.cpu().numpy()[:, 1:-1]
             if len(near):
                 jig = near[rng.integers(0, len(near), 2000)].copy()

@@ -39,8 +39,8 @@ while time.time() - t0 < budget:
     total = n * (n - 1) ** (order - 1)
     cnt = int(min(total, rng.integers(1, 40) * 1_000_000))
     lo = int(rng.integers(0, total - cnt + 1))
-    a = G.ExhaustivePathTracer().trace_rank_range(scene, order, lo, lo + cnt, max_survivors=1 << 23)
-    b = G.ExhaustivePathTracer(accel="bvh").trace_rank_range(scene, order, lo, lo + cnt, max_survivors=1 << 23)
+    a = G.ExhaustivePathTracer().trace_rank_range_literal(scene, order, lo, lo + cnt, max_survivors=1 << 23)
+    b = G.ExhaustivePathTracer(accel="bvh").trace_rank_range_literal(scene, order, lo, lo + cnt, max_survivors=1 << 23)
     st["cases"] += 1
     st["candidate_evals"] += cnt * ntx * nrx
     st["valid_paths"] += int(a.keys.shape[0])

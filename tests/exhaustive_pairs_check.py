@@ -60,7 +60,7 @@ def exhaustive_pair(mesh, tx1, rx1, order, n, windows, max_survivors):
     step = -(-total // windows)
     objs, verts = [], []
     for lo in range(0, total, step):
-        p = tracer.trace_rank_range(scene, order, lo, min(lo + step, total), max_survivors=max_survivors, max_paths=1 << 16)
+        p = tracer.trace_rank_range_literal(scene, order, lo, min(lo + step, total), max_survivors=max_survivors, max_paths=1 << 16)
         objs.append(p.objects.cpu().numpy())
         verts.append(p.vertices.cpu().numpy())
     return np.concatenate(objs), np.concatenate(verts), total

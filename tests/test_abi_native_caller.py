@@ -106,7 +106,7 @@ def test_native_beam_caller_cfg3_matches_the_exhaustive_keys(tmp_path):
     head, keys, objs, verts, gtx = _run_beam(exe, tmp_path, V, Tr, tx, rx, 2)
     txg = torch.tensor(tx, device="cuda", requires_grad=True)
     scene = G.Scene(txg, torch.tensor(rx, device="cuda"), G.Mesh(V, Tr))
-    ex = G.ExhaustivePathTracer().trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 16)
+    ex = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, max_survivors=1 << 24, max_paths=1 << 16)
     assert ex.objects.shape[0] == 54 and objs.shape[0] == 54
     assert np.array_equal(objs, ex.objects.cpu().numpy())
     assert np.array_equal(verts.view(np.uint32), ex.vertices.detach().cpu().numpy().view(np.uint32))
@@ -175,3 +175,66 @@ def test_two_host_threads_two_streams_equal_serial(tmp_path):
                        env={**os.environ, "LD_LIBRARY_PATH": f"{LIBDIR}:{os.environ.get('LD_LIBRARY_PATH', '')}"})
     assert r.returncode == 0 and r.stdout.startswith("OK 4 rounds"), r.stdout + r.stderr
     assert int(r.stdout.split()[3]) > 0  # the scene has valid paths
+
+
+SHARDED_SRC = ROOT / "tests" / "abi" / "abi_beam_sharded.cpp"
+
+
+def _write_scene(path, V, Tr, tx, rx, order, quads=False, max_paths=4096):
+    import numpy as np
+
+    with path.open("wb") as f:
+        f.write(np.asarray([len(V), len(Tr), int(quads), len(tx), len(rx), order, max_paths], np.int64).tobytes())
+        for a, dt in ((V, np.float32), (Tr, np.int32), (tx, np.float32), (rx, np.float32)):
+            f.write(np.ascontiguousarray(a, dt).tobytes())
+
+
+def test_sharded_beam_caller_compiles_against_the_header(tmp_path):
+    """CPU: BASELINE configs[4] end to end behind the C ABI (prefix-sharded pruned search + count / record all-gathers + key
+    sort + SUM all-reduce of grad(TX), no torch / Python / MPI in the process) builds against the header."""
+    assert _build(tmp_path, SHARDED_SRC).exists()
+
+
+def _run_sharded(exe, tmp_path, world, devices):
+    env = {**os.environ, "LD_LIBRARY_PATH": f"{LIBDIR}:{os.environ.get('LD_LIBRARY_PATH', '')}", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    idf = tmp_path / f"rccl{world}.id"
+    procs = [subprocess.Popen([str(exe), str(r), str(world), str(idf), str(tmp_path / "scene.bin"), str(devices[r])],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    oks = []
+    for p, (so, se) in zip(procs, outs):
+        ok = [ln for ln in so.splitlines() if ln.startswith("OK ")]  # (RCCL prints its banner on stdout first)
+        assert p.returncode == 0 and ok, so + se
+        oks.append([int(x) for x in ok[-1].split()[1:]])
+    return oks
+
+
+@pytest.mark.gpu
+def test_sharded_beam_caller_configs4_world_of_one(tmp_path):
+    """configs[4] itself (1 TX x 1024 RX, 200 000 triangles, order 2, fwd + grad) through tests/abi/abi_beam_sharded.cpp as ONE
+    rank: search, both all-gathers and the gradient all-reduce on RCCL, union == the unsharded call bit for bit (the
+    binary checks), 122 paths."""
+    import synthetic_scenes as S
+
+    V, Tr, tx, rx = S.cfg5_scene()
+    _write_scene(tmp_path / "scene.bin", V, Tr, tx, rx, 2)
+    exe = _build(tmp_path, SHARDED_SRC)
+    (total, mine), = _run_sharded(exe, tmp_path, 1, [0])
+    assert total == mine == 122
+
+
+@pytest.mark.gpu
+def test_sharded_beam_caller_two_ranks_when_two_gpus_are_visible(tmp_path):
+    """The same binary as two processes on two GPUs (RCCL refuses two ranks per device: 1-GPU boxes skip): the shards
+    partition the 122 paths, the sorted union equals the unsharded search, grad(TX) sums over the ranks."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL: one rank per device)")
+    import synthetic_scenes as S
+
+    V, Tr, tx, rx = S.cfg5_scene()
+    _write_scene(tmp_path / "scene.bin", V, Tr, tx, rx, 2)
+    exe = _build(tmp_path, SHARDED_SRC)
+    (t0, m0), (t1, m1) = _run_sharded(exe, tmp_path, 2, [0, 1])
+    assert t0 == t1 == 122 and m0 + m1 == 122 and 0 < m0 < 122

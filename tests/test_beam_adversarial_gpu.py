@@ -50,7 +50,7 @@ def check(G, V, Tr, tx, rx, orders=(1, 2, 3), assume_quads=False, kappas=(64.0,)
     tracer = G.ExhaustivePathTracer()
     total = 0
     for order in orders:
-        ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+        ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
         for kappa in kappas:
             for expansion in ("auto", "plain") + (("fused",) if order >= 2 else ()):  # orders 2, 3: two kernels vs the fused one
                 # triangle meshes of boxes are searched over their coplanar pairs by default: both forms
@@ -152,7 +152,7 @@ def test_receiver_counts_around_trip_and_cluster_boundaries(G, nrx):
             r[nrx // 2] = np.nan
         scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(r, device="cuda"), mesh)
         for order in (1, 2):
-            ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+            ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
             for emit in ("plain", "clustered"):
                 bp = tracer.trace_beam_pruned(scene, order, emit=emit, max_paths=1 << 18)
                 assert torch.equal(bp.objects, ex.objects), (order, emit, poison)
@@ -171,7 +171,7 @@ def test_child_filter_keeps_what_the_receiver_stage_keeps(G):
     scene = G.Scene(torch.as_tensor(d["tx"], device="cuda"), torch.as_tensor(d["rx"], device="cuda"), mesh)
     tracer = G.ExhaustivePathTracer()
     order = int(d["order"])
-    ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
     pairable = not bool(d["assume_quads"])  # a triangle mesh of boxes: also searched over its coplanar pairs
     for pairs in ((False, True) if pairable else (False,)):
         auto = tracer.trace_beam_pruned(scene, order, pairs=pairs)
@@ -310,7 +310,7 @@ def test_coplanar_pair_mode_engages_and_equals_the_triangle_search(G, rng):
             a, sa, ga, scene = run(V, Tr, mask, order, True)
             b, sb, gb, _ = run(V, Tr, mask, order, False)
             assert sa["pair_mode"] and not sb["pair_mode"] and 2 * sa["levels"][0] == sb["levels"][0]
-            ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+            ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
             for r in (a, b):
                 assert torch.equal(r.objects, ex.objects) and torch.equal(r.vertices.view(torch.int32), ex.vertices.view(torch.int32))
             assert torch.equal(a.keys, b.keys) and bool((a.keys[1:] > a.keys[:-1]).all())
@@ -330,7 +330,7 @@ def test_coplanar_pair_mode_engages_and_equals_the_triangle_search(G, rng):
                 assert npairs - 4 <= sa["paired_primitives"] < npairs
             else:
                 assert sa["paired_primitives"] == npairs - lost
-            ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+            ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
             assert torch.equal(a.objects, ex.objects) and torch.equal(a.vertices.view(torch.int32), ex.vertices.view(torch.int32))
             b = tracer.trace_beam_pruned(scene, order, rows="plain")
             assert torch.equal(b.objects, ex.objects) and torch.equal(a.keys, b.keys)
@@ -338,7 +338,7 @@ def test_coplanar_pair_mode_engages_and_equals_the_triangle_search(G, rng):
     few = np.concatenate([np.arange(0, 20), np.arange(20, Tr.shape[0], 2)])  # 10 pairs + the first halves of the others: 25 %
     a, sa, _, scene = run(V, Tr[few], None, 2, True)
     assert not sa["pair_mode"] and sa["paired_primitives"] == 0
-    ex = tracer.trace_rank_range(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
+    ex = tracer.trace_rank_range_literal(scene, 2, max_survivors=1 << 24, max_paths=1 << 20)
     assert torch.equal(a.objects, ex.objects)
 
 
@@ -357,7 +357,7 @@ def test_apex_in_the_mirror_plane_on_rotated_geometry(G, case):
     scene = G.Scene(torch.as_tensor(d["tx"], device="cuda"), torch.as_tensor(d["rx"], device="cuda"), mesh)
     tracer = G.ExhaustivePathTracer()
     order = int(d["order"])
-    ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
     lost = {tuple(r) for r in d["missed"].tolist()}
     assert lost <= {tuple(r) for r in ex.objects.cpu().tolist()}  # the exhaustive tracer still finds what the search had lost
     ref_rows = None
@@ -382,7 +382,7 @@ def test_order3_two_kernel_expansion_in_chunks(G, rng):
     V, tx, rx = S.rotate_points(R, V, tx, rx)
     scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(rx, device="cuda"), G.Mesh(V, Tr))
     tracer = G.ExhaustivePathTracer()
-    ex = tracer.trace_rank_range(scene, 3, max_survivors=1 << 24, max_paths=1 << 20)
+    ex = tracer.trace_rank_range_literal(scene, 3, max_survivors=1 << 24, max_paths=1 << 20)
     assert ex.objects.shape[0] > 0
     ref = tracer.trace_beam_pruned(scene, 3, expansion="fused")
     rows = tracer.last_beam_stats["rows"]
@@ -424,3 +424,67 @@ def test_order2_two_kernel_expansion_on_a_large_mesh(G, rng):
     assert torch.equal(bp.keys, ref.keys) and torch.equal(bp.objects, ref.objects)
     assert torch.equal(bp.vertices.view(torch.int32), ref.vertices.view(torch.int32))
     assert tracer.last_beam_stats["rows"] == st["rows"] and tracer.last_beam_stats["levels"] == st["levels"]
+
+
+def test_sub_ulp_segment_artifact_is_the_only_thing_the_search_may_lose(G):
+    """Round 6, found by the triangle-soup stress (scratch/beam_stress.py --only-soup, case 772 of 48 708): a scene 5e4 m from
+    the origin (ulp(M) = 3.9 mm), a wall whose two triangles are coplanar up to rounding, and an order-2 "path" that reflects
+    off BOTH of them at two points 2.2 mm -- 0.56 ulp(M) -- apart.  The reference accepts it: the direction of that segment
+    is the float32 difference of two points that coincide within the arithmetic's resolution, its inside test runs on rounding
+    noise (the second reflection point lies 13 cm outside the triangle it "hits") and its same-side test decides the sign of a
+    distance of 0.3 ulp(M).  The exhaustive tracer reproduces the artifact bit for bit (checked here against the C oracle);
+    the pruned search drops it, and that is the ONE documented exclusion of its guarantee (DESIGN.md section 9.8,
+    tests/beam_degenerate.py): nothing else may be missing."""
+    import beam_degenerate as BD
+    import oracle as orc
+
+    d = np.load(Path(__file__).parent / "golden" / "beam_cases" / "sub_ulp_segment_soup772.npz")
+    V, Tr, tx, rx, order = d["V"], d["Tr"], d["tx"], d["rx"], int(d["order"])
+    mesh = G.Mesh(V, Tr)
+    scene = G.Scene(torch.as_tensor(tx, device="cuda"), torch.as_tensor(rx, device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    exo = [tuple(r) for r in ex.objects.cpu().tolist()]
+    (lost,) = [tuple(r) for r in d["missed"].tolist()]
+    assert lost in exo
+    # the reference's arithmetic (C oracle) accepts that candidate, with the same vertex bits as the exhaustive tracer
+    it, ir = lost[0], lost[-1]
+    o = orc.trace_path_candidates(V, Tr, tx[it:it + 1], rx[ir:ir + 1], np.asarray([lost[1:-1]], np.int32))
+    assert bool(o["mask"].reshape(-1)[0])
+    row = exo.index(lost)
+    assert np.array_equal(ex.vertices[row].cpu().numpy().view(np.uint32), o["vertices"].reshape(-1, 3).view(np.uint32))
+    # it is a short-segment artifact: its two reflection points are closer than ONE ulp(M), let alone the unit u = 64 ulp(M)
+    ulp = BD.ulp_of_scene(V, tx, rx)
+    pv = ex.vertices[row].double().cpu().numpy()
+    assert np.linalg.norm(pv[2] - pv[1]) < ulp
+    deg = BD.short_segment_mask(ex.vertices.cpu().numpy(), ulp)
+    assert deg[row]
+    deg_set = {o_ for o_, g in zip(exo, deg) if g}
+    for kw in ({}, {"expansion": "plain"}, {"emit": "plain"}, {"pairs": False}):
+        bp = tracer.trace_beam_pruned(scene, order, **kw)
+        got = {tuple(r) for r in bp.objects.cpu().tolist()}
+        assert got <= set(exo), kw                      # never an extra path
+        assert set(exo) - got <= deg_set, (kw, set(exo) - got - deg_set)  # only artifacts of that class may be missing
+
+
+@pytest.mark.parametrize("case", sorted(p.name for p in (Path(__file__).parent / "golden" / "beam_cases").glob("child_filter_route_*.npz")))
+def test_child_filter_nesting_on_soups(G, case):
+    """Round 6, found by the triangle-soup stress: the child filter of the last expansion (clustered mapping) dropped 1-2
+    children per scene that the receiver stage of the plain mapping kept -- 8 scenes of 44 821 mapping checks, none of them
+    a valid path, but "what the filter drops, the receiver stage drops" is what makes the filter safe.  The two stages reach
+    the child's narrowest pyramid by different routes (reflected face normals vs faces rebuilt from vertices reflected once
+    more); their difference is a LATERAL distance of a few ulp(M) at the edge line, which the filter's fixed extra slope of
+    2.1e-4 does not cover when the apex is close to that line.  The filter's lateral tolerance now carries kChildRouteUnits u
+    (csrc/beam_margins.hpp; the bound is derived in oracle/studies/beam_bounds_check.py): same rows from both mappings."""
+    d = np.load(Path(__file__).parent / "golden" / "beam_cases" / case)
+    mesh = G.Mesh(d["V"], d["Tr"], assume_quads=bool(d["assume_quads"]))
+    scene = G.Scene(torch.as_tensor(d["tx"], device="cuda"), torch.as_tensor(d["rx"], device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    order = int(d["order"])
+    ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    rows = {}
+    for name, kw in (("auto", {}), ("plain", {"expansion": "plain"}), ("fused", {"expansion": "fused"})):
+        bp = tracer.trace_beam_pruned(scene, order, **kw)
+        rows[name] = tracer.last_beam_stats["rows"]
+        assert torch.equal(bp.objects, ex.objects), (case, name)
+    assert rows["auto"] == rows["plain"] == rows["fused"], rows

@@ -217,8 +217,8 @@ def test_cfg3_window_bvh_vs_brute(G):
     tx, rx = S.manhattan_tx_rx(centres, heights, 16, 64)
     scene = G.Scene(tx, rx, G.Mesh(V, Tr))
     lo, hi = 40_000_000, 45_000_000
-    a = G.ExhaustivePathTracer().trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
-    b = G.ExhaustivePathTracer(accel="bvh").trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
+    a = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, lo, hi, max_survivors=1 << 22)
+    b = G.ExhaustivePathTracer(accel="bvh").trace_rank_range_literal(scene, 2, lo, hi, max_survivors=1 << 22)
     assert torch.equal(a.keys, b.keys) and torch.equal(a.vertices, b.vertices)
 
 

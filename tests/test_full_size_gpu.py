@@ -114,7 +114,7 @@ def test_cfg3_full_size(G, manhattan):
     txg = torch.tensor(tx, device="cuda", requires_grad=True)
     scene = G.Scene(txg, rx, G.Mesh(V, Tr))
     tracer = G.ExhaustivePathTracer()
-    paths = tracer.trace_rank_range(scene, order, max_survivors=1 << 24)
+    paths = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24)
     nv = paths.objects.shape[0]
     assert nv >= 10
     keys = _oracle_revalidate(V, Tr, tx, rx, paths, total, order, n)
@@ -132,7 +132,7 @@ def test_cfg3_full_size(G, manhattan):
     got = []
     for r in range(7):
         lo, hi = shard_interval(total, 7, r)
-        w = tracer.trace_rank_range(scene, order, lo, hi, max_survivors=1 << 22)
+        w = tracer.trace_rank_range_literal(scene, order, lo, hi, max_survivors=1 << 22)
         got.append(_np(globalize_keys(w.keys, hi - lo, lo, total)))
     np.testing.assert_array_equal(np.sort(np.concatenate(got)), keys)
     # rejected candidates: random ones and near-misses (one mirror swapped) are rejected by the oracle too
@@ -164,7 +164,7 @@ def test_cfg3_full_size(G, manhattan):
     from differt_amd.distributed import trace_rank_range_triangle_sharded
 
     lo, hi = shard_interval(total, 7, 3)  # one rank window is enough (the geometric stage is the same code)
-    ref_keys = set(_np(tracer.trace_rank_range(scene, order, lo, hi, max_survivors=1 << 22).keys).tolist())
+    ref_keys = set(_np(tracer.trace_rank_range_literal(scene, order, lo, hi, max_survivors=1 << 22).keys).tolist())
     common = None
     for b in range(8):
         t0, t1 = shard_interval(n, 8, b)
@@ -203,9 +203,9 @@ def test_cfg4_order3_rank_window(G, manhattan):
     # start inside the space, across a first-mirror boundary: c0 = 4711 starts at 4711 * (n-1)^2
     lo = 4711 * (n - 1) ** 2 - (1 << 21)
     cnt = 1 << 22
-    whole = tracer.trace_rank_range(scene, order, lo, lo + cnt, max_survivors=1 << 22)
-    a = tracer.trace_rank_range(scene, order, lo, lo + cnt // 2, max_survivors=1 << 22)
-    b = tracer.trace_rank_range(scene, order, lo + cnt // 2, lo + cnt, max_survivors=1 << 22)
+    whole = tracer.trace_rank_range_literal(scene, order, lo, lo + cnt, max_survivors=1 << 22)
+    a = tracer.trace_rank_range_literal(scene, order, lo, lo + cnt // 2, max_survivors=1 << 22)
+    b = tracer.trace_rank_range_literal(scene, order, lo + cnt // 2, lo + cnt, max_survivors=1 << 22)
     from differt_amd.distributed import globalize_keys
 
     tot = n * (n - 1) ** 2
@@ -227,7 +227,7 @@ def test_cfg4_order3_rank_window(G, manhattan):
     sub = 3000
     cand = host[:sub].astype(np.int32)
     o = orc.trace_path_candidates(V, Tr, tx[:4], rx[:8], cand)
-    w = tracer.trace_rank_range(scene, order, lo, lo + sub)
+    w = tracer.trace_rank_range_literal(scene, order, lo, lo + sub)
     np.testing.assert_array_equal(_np(w.keys), np.flatnonzero(o["mask"].reshape(-1)))
 
 
@@ -369,7 +369,7 @@ def test_cfg5_200k_triangles(G):
     scene = G.Scene(tx, rx[:64], mesh)
     n = 200000
     lo = 123456 * (n - 1)
-    w = G.ExhaustivePathTracer().trace_rank_range(scene, 2, lo, lo + 3 * (n - 1), max_survivors=1 << 22)
+    w = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, lo, lo + 3 * (n - 1), max_survivors=1 << 22)
     _oracle_revalidate(V, Tr, tx, rx[:64], w, 3 * (n - 1), 2, n)
 
 
@@ -383,12 +383,12 @@ def test_sharded_driver_single_process(G, manhattan):
     tracer = G.ExhaustivePathTracer()
     lo, hi = 30_000_000, 60_000_000
     keys, verts, objs = trace_rank_range_sharded(tracer, scene, 2, lo, hi, max_survivors=1 << 22)
-    whole = tracer.trace_rank_range(scene, 2, lo, hi, max_survivors=1 << 22)
+    whole = tracer.trace_rank_range_literal(scene, 2, lo, hi, max_survivors=1 << 22)
     assert torch.equal(keys, whole.keys) and torch.equal(verts, whole.vertices) and torch.equal(objs, whole.objects)
     parts = []
     for r in range(3):
         a, b = shard_interval(hi - lo, 3, r)
-        p = tracer.trace_rank_range(scene, 2, lo + a, lo + b, max_survivors=1 << 22)
+        p = tracer.trace_rank_range_literal(scene, 2, lo + a, lo + b, max_survivors=1 << 22)
         parts.append((globalize_keys(p.keys, b - a, a, hi - lo), p.vertices, p.objects))
     k = torch.cat([p[0] for p in parts])
     perm = torch.argsort(k, stable=True)

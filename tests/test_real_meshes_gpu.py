@@ -136,7 +136,7 @@ def test_pruned_equals_exhaustive_whole_order2_space(G, name):
     tracer = G.ExhaustivePathTracer(accel="bvh")
     total = 0
     for order in (1, 2):
-        ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 25, max_paths=1 << 20)
+        ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 25, max_paths=1 << 20)
         for kappa in (64.0, 1.0):
             for pairs in (True, False):
                 for expansion in ("auto", "plain", "fused") if kappa == 64.0 else ("auto",):
@@ -157,7 +157,7 @@ def test_pruned_equals_exhaustive_whole_order3_spaces_manhattan_small(G):
     tx, rx = end_points(G, V, Tr, 2, 6)
     scene = G.Scene(tx, rx, G.Mesh(V, Tr))
     tracer = G.ExhaustivePathTracer(accel="bvh")
-    ex = tracer.trace_rank_range(scene, 3, max_survivors=1 << 25, max_paths=1 << 20)
+    ex = tracer.trace_rank_range_literal(scene, 3, max_survivors=1 << 25, max_paths=1 << 20)
     for kappa in (64.0, 1.0):
         for pairs in (True, False):
             bp = tracer.trace_beam_pruned(scene, 3, kappa=kappa, pairs=pairs, max_paths=1 << 18)

@@ -237,7 +237,7 @@ def test_trace_paths_beam_solver_equals_compact_exhaustive(G, two_buildings, gol
     scene = G.Scene(np.asarray([ex["tx"]], np.float32), np.asarray([ex["rx"]], np.float32),
                     G.Mesh(two_buildings["vertices"], two_buildings["triangles"]))
     for order in (0, 1, 2, 3):
-        a = scene.trace_paths(order, compact=True)
+        a = scene.trace_paths(order, compact=True, literal=True)  # every candidate through the filter kernel
         b = scene.trace_paths(order, solver="beam", kappa=64.0)
         assert b.objects.cpu().numpy().tolist() == ex["orders"][str(order)]["objects"]
         assert torch.equal(a.objects, b.objects) and torch.equal(a.vertices.view(torch.int32), b.vertices.view(torch.int32))
@@ -245,6 +245,48 @@ def test_trace_paths_beam_solver_equals_compact_exhaustive(G, two_buildings, gol
         scene.trace_paths(2, solver="beam", chunk_size=10)
     with pytest.raises(ValueError):
         scene.trace_paths(4, solver="beam")
+
+
+@pytest.mark.parametrize("assume_quads", [False, True])
+@pytest.mark.parametrize("with_mask", [False, True])
+@pytest.mark.parametrize("disconnect", [False, True])
+def test_default_compact_tracer_is_the_pruned_search_with_rank_keys(G, canyon, assume_quads, with_mask, disconnect):
+    """Round 6: ``Scene.trace_paths(order <= 3, compact=True)`` and a whole-space
+    ``ExhaustivePathTracer.trace_rank_range`` run through ``drt_trace_paths_beam``; ``literal=True`` keeps the filter kernel
+    (every candidate, as the reference enumerates them: _scene.py:650-764, _solvers.py:803-848).  Same objects, vertex bits,
+    gradients AND keys -- ``(tx*num_rx + rx) * total + rank`` over the nodes of the candidate graph, inactive primitives
+    removed from it with ``disconnect_inactive_triangles`` (_solvers.py:820-827)."""
+    mesh = canyon.mesh.set_assume_quads(assume_quads)
+    if with_mask:
+        m = torch.ones(mesh.num_triangles, dtype=torch.bool, device="cuda")
+        m[4:10] = False
+        mesh = mesh.set_mask(m)
+    tx = torch.tensor([[-15.0, 1.0, 8.0], [-12.0, -3.0, 5.0]], device="cuda")
+    rx = torch.tensor([[12.0, -2.0, 3.0], [10.0, 2.0, 4.0], [0.0, 0.5, 2.0]], device="cuda")
+    kw = {"disconnect_inactive_triangles": True} if disconnect else {}
+    found = 0
+    for order in (1, 2, 3):
+        txg = [tx.clone().requires_grad_(True) for _ in range(2)]
+        a = G.Scene(txg[0], rx, mesh).trace_paths(order, compact=True, **kw)
+        tracer = G.ExhaustivePathTracer(**kw)
+        assert not tracer.literal
+        b = G.Scene(txg[1], rx, mesh).trace_paths(order, compact=True, literal=True, **kw)
+        assert torch.equal(a.objects, b.objects) and torch.equal(a.keys, b.keys), order
+        assert torch.equal(a.vertices.view(torch.int32), b.vertices.view(torch.int32))
+        c = tracer.trace_rank_range(G.Scene(tx, rx, mesh), order)
+        assert torch.equal(c.keys, b.keys)
+        assert hasattr(tracer, "last_beam_stats")  # the whole-space call went through the pruned search
+        if a.objects.shape[0]:
+            for p, t in zip((a, b), txg):
+                torch.sqrt((torch.diff(p.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
+            assert torch.allclose(txg[0].grad, txg[1].grad, rtol=1e-5, atol=1e-6 * float(txg[1].grad.abs().max()))
+        found += a.objects.shape[0]
+        # a rank WINDOW is the filter kernel's business
+        tracer2 = G.ExhaustivePathTracer(**kw)
+        total = tracer2.num_path_candidates(G.Scene(tx, rx, mesh), order)
+        w = tracer2.trace_rank_range(G.Scene(tx, rx, mesh), order, 0, total // 2)
+        assert not hasattr(tracer2, "last_beam_stats") and w.objects.shape[0] <= a.objects.shape[0]
+    assert found > 0
 
 
 @pytest.mark.parametrize("assume_quads", [False, True])

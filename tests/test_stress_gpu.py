@@ -94,7 +94,7 @@ def test_cfg3_window_is_deterministic_run_to_run():
         vl = mesh.vertices.detach().clone().requires_grad_(True)  # the leaf (Mesh keeps a reshaped view)
         mv = mesh.with_vertices(vl)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mv)
-        p = G.ExhaustivePathTracer().trace_rank_range(scene, 2, 0, 5_000_000)
+        p = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, 0, 5_000_000)
         torch.sqrt((torch.diff(p.vertices, dim=-2) ** 2).sum(-1)).sum().backward()
         return p, txg.grad.clone(), vl.grad.clone()
 
@@ -128,7 +128,7 @@ def test_deterministic_grad_is_bit_identical_run_to_run(route):
         scene = G.Scene(txg, rxg, mesh.with_vertices(vl))
         tracer = G.ExhaustivePathTracer(deterministic_grad=det)
         if route == "rank_range":
-            p = tracer.trace_rank_range(scene, 2, max_survivors=1 << 22)
+            p = tracer.trace_rank_range_literal(scene, 2, max_survivors=1 << 22)
         elif route == "beam":
             p = tracer.trace_beam_pruned(scene, 2)
         else:

@@ -176,9 +176,13 @@ def test_two_buildings_goldens(G, goldens, two_buildings, order, assume_quads, m
     np.testing.assert_array_equal(_np(got.objects).reshape(-1), o["objects"].reshape(-1))
     np.testing.assert_array_equal(_bits(_np(got.vertices)).reshape(-1), _bits(o["vertices"]).reshape(-1))
     # compact == masked dense
-    cp = scene.trace_paths(order, compact=True)
-    np.testing.assert_array_equal(_np(cp.objects), _np(got.masked_objects))
-    np.testing.assert_array_equal(_bits(_np(cp.vertices)), _bits(_np(got.masked_vertices)))
+    # (round 6: for orders 1..3 the default compact tracer IS the pruned search, drt_trace_paths_beam; `literal=True` evaluates
+    # every candidate with the filter kernel -- the same rows and the same rank keys either way)
+    for kw in ({}, {"literal": True}):
+        cp = scene.trace_paths(order, compact=True, **kw)
+        np.testing.assert_array_equal(_np(cp.objects), _np(got.masked_objects))
+        np.testing.assert_array_equal(_bits(_np(cp.vertices)), _bits(_np(got.masked_vertices)))
+        np.testing.assert_array_equal(_np(cp.keys), np.flatnonzero(o["mask"].reshape(-1)))
 
 
 def test_two_buildings_order4_compact(G, goldens, two_buildings):
@@ -228,14 +232,14 @@ def test_rank_window_and_disconnect(G, goldens, two_buildings):
     mask = rng.random(24) > 0.3
     mask[[8, 9, 22]] = True
     scene = _scene(G, two_buildings, g["tx"], g["rx"], mask=mask)
-    full = G.ExhaustivePathTracer().trace_rank_range(scene, 2)
-    a = G.ExhaustivePathTracer().trace_rank_range(scene, 2, 0, 200)
-    b = G.ExhaustivePathTracer().trace_rank_range(scene, 2, 200, None)
+    full = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2)
+    a = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, 0, 200)
+    b = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 2, 200, None)
     keys = np.concatenate([_np(a.keys), _np(b.keys) + 200])
     np.testing.assert_array_equal(keys, _np(full.keys))
     np.testing.assert_array_equal(np.concatenate([_np(a.objects), _np(b.objects)]), _np(full.objects))
     dis = G.ExhaustivePathTracer(disconnect_inactive_triangles=True)
-    d = dis.trace_rank_range(scene, 2)
+    d = dis.trace_rank_range_literal(scene, 2)
     np.testing.assert_array_equal(_np(d.objects), _np(full.objects))
     np.testing.assert_array_equal(_bits(_np(d.vertices)), _bits(_np(full.vertices)))
     # candidate tables: GPU fill == host unranking == oracle odometer
@@ -312,7 +316,7 @@ def test_config1_box_beam_raw_call_with_the_queried_workspace(G):
     rx = scene.receivers.reshape(-1, 3).contiguous()
     L = _lib.load()
     for order in (0, 1, 2, 3):
-        ex = G.ExhaustivePathTracer().trace_rank_range(scene, order)
+        ex = G.ExhaustivePathTracer().trace_rank_range_literal(scene, order)
         mp = 256
         nbytes = L.drt_trace_beam_workspace_size(1, 1, 12, order, None, mp)
         assert nbytes < 64 << 20
@@ -336,7 +340,7 @@ def test_beam_order0_output_overflow_regrows(G, rng):
     tx = rng.uniform(-1, 1, (40, 3)).astype(np.float32) + np.array([0, 0, 50], np.float32)
     rx = rng.uniform(-1, 1, (50, 3)).astype(np.float32) + np.array([0, 0, 60], np.float32)
     scene = G.Scene(tx, rx, G.Mesh.box(with_top=True))
-    ex = G.ExhaustivePathTracer().trace_rank_range(scene, 0)
+    ex = G.ExhaustivePathTracer().trace_rank_range_literal(scene, 0)
     assert ex.objects.shape[0] == 2000
     bp = G.ExhaustivePathTracer().trace_beam_pruned(scene, 0, max_paths=64)
     assert torch.equal(bp.objects, ex.objects) and torch.equal(bp.vertices, ex.vertices)
@@ -445,7 +449,7 @@ def test_generate_path_candidates_gpu_fill(G, two_buildings, goldens, assume_qua
         assert (_np(types) == 0).all()
         # tracing the generated table == tracing the rank range
         a = tracer.trace_path_candidates_compact(scene, cands)
-        b = tracer.trace_rank_range(scene, order)
+        b = tracer.trace_rank_range_literal(scene, order)
         assert torch.equal(a.objects, b.objects) and torch.equal(a.vertices, b.vertices)
 
 
@@ -763,7 +767,7 @@ def test_beam_pruned_order3_equals_exhaustive(G, boxes, seed):
     tx, rx = S.manhattan_tx_rx(c, h, 4, 16, seed=seed + 10)
     scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), G.Mesh(V, Tr))
     tracer = G.ExhaustivePathTracer()
-    ex = tracer.trace_rank_range(scene, 3, max_survivors=1 << 24, max_paths=1 << 18)
+    ex = tracer.trace_rank_range_literal(scene, 3, max_survivors=1 << 24, max_paths=1 << 18)
     bp = tracer.trace_beam_pruned(scene, 3)
     _assert_same_paths(ex, bp)
     st_bvh = dict(tracer.last_beam_stats)
@@ -952,7 +956,7 @@ def test_beam_pair_blocks_equal_row_by_row_trace(G, rng, order):
         mesh = G.Mesh(V, Tr, mask=mask)
         scene = G.Scene(torch.tensor(tx, device="cuda"), torch.tensor(rx, device="cuda"), mesh)
         tracer = G.ExhaustivePathTracer()
-        ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 22, max_paths=1 << 18)
+        ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 22, max_paths=1 << 18)
         blocks = tracer.trace_beam_pruned(scene, order)
         st = dict(tracer.last_beam_stats)
         assert st["pair_mode"]
@@ -994,7 +998,7 @@ def test_beam_pruned_equals_exhaustive_quads_masks_orders(G, rng, order, assume_
         txg = torch.tensor(tx, device="cuda", requires_grad=True)
         scene = G.Scene(txg, torch.tensor(rx, device="cuda"), mesh)
         tracer = G.ExhaustivePathTracer()
-        ex = tracer.trace_rank_range(scene, order, max_survivors=1 << 22, max_paths=1 << 18)
+        ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 22, max_paths=1 << 18)
         bp = tracer.trace_beam_pruned(scene, order)
         _assert_same_paths(ex, bp)
         rows_bvh = tracer.last_beam_stats["rows"]
