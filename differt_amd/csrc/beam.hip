@@ -119,7 +119,18 @@ struct RxAll {
     float lo[3], hi[3];
     int32_t on;
     float ulp_m;  // ulp of the largest coordinate magnitude M (the error unit without its kappa)
+    // centre and half extents of the box as box_pruned forms them (0.5 (lo + hi), (hi - lo) kBoxHalfExtent), computed ONCE
+    // where the box is (rx_all_finish): kernel arguments live in scalar registers, and the child filter reads them as scalar
+    // operands -- computed in the kernel they were loop-invariant VECTOR values that the compiler kept in six registers
+    // across the whole expansion (three of them in scratch at the pairs kernel's 80-register budget)
+    float ce[3], he[3];
 };
+__host__ __device__ inline void rx_all_finish(RxAll &r) {
+    for (int k = 0; k < 3; ++k) {
+        r.ce[k] = 0.5f * (r.lo[k] + r.hi[k]);
+        r.he[k] = (r.hi[k] - r.lo[k]) * margins::kBoxHalfExtent;
+    }
+}
 // Scene-dependent scalars of a call, for the entry point that may not read anything back
 // (drt_trace_paths_beam_async): computed on the device by beam_dyn_kernel -- the same expressions the synchronous
 // entry point evaluates on the host -- and list sizes that live in device counters.  A kernel given a BeamDev with
@@ -260,9 +271,15 @@ __device__ __forceinline__ float min_faces(const float (&v)[NF]) {
 // triangle laid out as the degenerate quad (v0, v1, v2, v2) -- a single triangle among the coplanar pairs of a
 // triangle soup, drt_mesh::pair_* -- has one of the two ON the face's own edge, where the triple product is rounding
 // noise next to the other one's value.
-template <bool TWO>
+// CHILD: the same face with the child filter's constants (csrc/beam_margins.hpp: rho rounded down further, switched off
+// earlier, a larger rounding allowance in the slope) -- on the same inputs a CHILD face that is on implies the ordinary face
+// is on, with the same normal and a slope at least as large.
+template <bool TWO, bool CHILD = false>
 __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, float delta, bool apex_off_plane, V3 &n_out,
                                          float &g_out) {
+    constexpr float kRhoDown = CHILD ? margins::kChildRhoRoundDown : margins::kRhoRoundDown;
+    constexpr float kOff = CHILD ? margins::kChildFaceOffRatio : margins::kFaceOffRatio;
+    constexpr float kRound = CHILD ? margins::kChildSlopeRounding : margins::kSlopeRounding;
     // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded forms (~12 instructions each, five per face,
     // three faces per pyramid, up to three pyramids per prefix): these are margins, and the 2e-6 |x - I|_1 in the
     // slope covers the rounding of the normalisation and of <x - I, n_f>; rho is rounded DOWN by the 0.9999
@@ -272,9 +289,9 @@ __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, 
     if constexpr (TWO) s += fdot(third2 - I, N);
     const V3 e = b - a;
     const float el = __builtin_amdgcn_sqrtf(fdot(e, e));
-    const float rho = (el > 0.0f) ? margins::kRhoRoundDown * len * __builtin_amdgcn_rcpf(el) : 0.0f;
-    const float g = margins::kSlopeFactor * delta * __builtin_amdgcn_rcpf(rho - delta) + margins::kSlopeRounding;
-    const bool on = apex_off_plane && (rho > margins::kFaceOffRatio * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
+    const float rho = (el > 0.0f) ? kRhoDown * len * __builtin_amdgcn_rcpf(el) : 0.0f;
+    const float g = margins::kSlopeFactor * delta * __builtin_amdgcn_rcpf(rho - delta) + kRound;
+    const bool on = apex_off_plane && (rho > kOff * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
     const float inv = __builtin_amdgcn_rcpf(len);
     const float sc = on ? ((s > 0.0f) ? inv : -inv) : 0.0f;
     n_out = on ? N * sc : V3{0, 0, 0};  // (0 * inf = NaN for a huge N: the select, not the product, zeroes it)
@@ -295,13 +312,15 @@ __device__ __forceinline__ float apex_plane_distance(V3 I, V3 v0, V3 v1, V3 v2) 
 // on axis-aligned walls the triple product of such an apex is exactly 0 and the face test `s != 0` caught it, which is
 // why four rounds of box cities never saw it.  (The header of this file always said "h_P <= 2.1 S: off"; the
 // implementation had kept only the distance from the edge LINES.)
-template <int NF>
+template <int NF, bool CHILD = false>
 __device__ __forceinline__ PyrN<NF> make_pyr(V3 I, const V3 (&v)[NF], float delta) {
     PyrN<NF> P;
-    const bool apex_off_plane = apex_plane_distance(I, v[0], v[1], v[2]) * margins::kRhoRoundDown > margins::kPlaneOffRatio * delta;  // (NaN: off)
+    constexpr float kDown = CHILD ? margins::kChildRhoRoundDown : margins::kRhoRoundDown;
+    constexpr float kOff = CHILD ? margins::kChildPlaneOffRatio : margins::kPlaneOffRatio;
+    const bool apex_off_plane = apex_plane_distance(I, v[0], v[1], v[2]) * kDown > kOff * delta;  // (NaN: off)
 #pragma unroll
     for (int f = 0; f < NF; ++f)
-        pyr_face<NF == 4>(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], v[(f + 3) % NF], delta, apex_off_plane, P.n[f], P.g[f]);
+        pyr_face<NF == 4, CHILD>(I, v[f], v[(f + 1) % NF], v[(f + 2) % NF], v[(f + 3) % NF], delta, apex_off_plane, P.n[f], P.g[f]);
     return P;
 }
 
@@ -396,6 +415,7 @@ __device__ __forceinline__ V3 lane_bcast_pinned(V3 v, int l) {
 }
 template <int SCALE, int LEVEL>
 struct CtxOwn {
+    static constexpr bool kUniformPrefix = false;  // lane = prefix
     const BeamCtx<SCALE, LEVEL> &c;
     __device__ __forceinline__ V3 I() const { return c.I; }
     __device__ __forceinline__ V3 pm() const { return c.pm; }
@@ -406,6 +426,7 @@ struct CtxOwn {
 };
 template <int SCALE, int LEVEL>
 struct CtxBcast {
+    static constexpr bool kUniformPrefix = true;  // one prefix per pass
     const BeamCtx<SCALE, LEVEL> &c;
     int l;  // wave-uniform
     __device__ __forceinline__ V3 I() const { return lane_bcast_pinned(c.I, l); }
@@ -479,24 +500,32 @@ __device__ __forceinline__ bool prim_stage1(const View &cv, const V3 (&vx)[Shape
     for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
         for (int f = 0; f < Sh::NF; ++f) m1[t][f] = -kInf;
+    // Round 6: the distances from the last mirror's plane are computed only when the side test can reject -- side_prev != 0,
+    // which is uniform over the wave in the transposed mappings (the prefix of a pass is one prefix): 28 of a pass's 184
+    // instructions.  (Measured and NOT kept: D as the largest L1 distance instead of the Euclidean one -- 16 instructions
+    // fewer per pass, but the larger bound keeps 3-13 % more records and the step got slower, profiles/r06/beam.md.)
     float dmin = kInf, dmax = -kInf, D2 = 0.0f;
     bool nan = false;
 #pragma unroll
     for (int k = 0; k < Sh::NV; ++k) {
-        const V3 x = vx[k];
-        const float d = fdot(x - cpm, cnm);
-        dmin = fminf(dmin, d);
-        dmax = fmaxf(dmax, d);
-        const V3 w = x - cI;
+        const V3 w = vx[k] - cI;
         const float wl = l1_len(w);  // |w|_1 >= |w|_2: a slightly larger margin, no square root per face
-        const float chk = d + wl;    // NaN vertex, plane or apex (the maxima below ignore NaNs): never prune
-        nan = nan || !(chk == chk);
+        nan = nan || !(wl == wl);    // NaN vertex or apex (the maxima below ignore NaNs): never prune
         D2 = fmaxf(D2, fdot(w, w));
 #pragma unroll
         for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
             for (int f = 0; f < Sh::NF; ++f)
                 m1[t][f] = fmaxf(m1[t][f], __builtin_fmaf(P1[t].g[f], wl, fdot(w, P1[t].n[f])));
+    }
+    if (!View::kUniformPrefix || cside != 0) {  // (a per-lane prefix -- the plain mapping -- computes them unconditionally)
+#pragma unroll
+        for (int k = 0; k < Sh::NV; ++k) {
+            const float d = fdot(vx[k] - cpm, cnm);
+            nan = nan || !(d == d);  // NaN plane: never prune
+            dmin = fminf(dmin, d);
+            dmax = fmaxf(dmax, d);
+        }
     }
     float h = kInf;
 #pragma unroll
@@ -829,21 +858,18 @@ struct BeamClusters {
     int64_t nclusters;
 };
 
-// what that test needs from the PARENT prefix besides its context: per face of its narrowest pyramid the distance
-// rho of the apex from the edge line (pyr_face's expression; a reflection does not change it), and the sum of its
-// mirrors' shape factors
+// What the child filter of the LAST expansion needs from the PARENT prefix besides its apex: the vertices of its FIRST mirror
+// unfolded through its later mirrors -- build_ctx's own sequence of image_of_vertex calls, so the very float values the receiver
+// stage (build_ctx_from) reaches by the same calls -- and the sum of its mirrors' shape factors.
 template <int SCALE, int LEVEL>
-__device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamEntry &e, V3 I, bool have, float ulp_m,
-                                                  float (&rho)[Shape<SCALE>::NP][Shape<SCALE>::NF], float &sig_sum,
-                                                  float (&hp)[Shape<SCALE>::NP]) {
+__device__ __forceinline__ void first_mirror_unfolded(const BeamMesh &M, const BeamEntry &e, bool have,
+                                                      V3 (&v)[Shape<SCALE>::NP][Shape<SCALE>::NF], float &sig_sum) {
     using Sh = Shape<SCALE>;
 #pragma unroll
-    for (int t = 0; t < Sh::NP; ++t) {
-        hp[t] = 0.0f;  // distance of the apex from the unfolded first mirror's plane (a reflection does not change it)
+    for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
-        for (int f = 0; f < Sh::NF; ++f) rho[t][f] = 0.0f;
-    }
-    sig_sum = kInf;
+        for (int k = 0; k < Sh::NF; ++k) v[t][k] = V3{0, 0, 0};
+    sig_sum = kInf;  // (a lane without a prefix: every face of its "child" is off)
     if (!have) return;
     sig_sum = 0.0f;
 #pragma unroll
@@ -855,99 +881,58 @@ __device__ __forceinline__ void first_pyramid_rho(const BeamMesh &M, const BeamE
     const float *tv = M.tv + 9 * ((int64_t)e.id[0] * Sh::TPP);
 #pragma unroll
     for (int t = 0; t < Sh::NP; ++t) {
-        V3 v[Sh::NF];
 #pragma unroll
-        for (int k = 0; k < Sh::NF; ++k) v[k] = shape_vertex<SCALE>(tv, t * Sh::NF + k);
+        for (int k = 0; k < Sh::NF; ++k) v[t][k] = shape_vertex<SCALE>(tv, t * Sh::NF + k);
 #pragma unroll
         for (int r = 1; r < LEVEL; ++r) {
             V3 pt, n;
             prim_plane(M, e.id[r], pt, n);
 #pragma unroll
-            for (int k = 0; k < Sh::NF; ++k) v[k] = image_of_vertex(v[k], pt, n);
-        }
-        // pyr_face switches a face off when its orientation is undefined: s = <next vertex - I, N> exactly 0 (or NaN),
-        // non-finite lengths.  The child's pyramid is built from vertices reflected once more: a pyramid that is flat
-        // up to rounding HERE (apex in the plane of the unfolded mirror: axis-aligned walls, a transmitter placed in a
-        // wall plane) can be exactly flat THERE -- all faces off, every receiver kept (found by the stress driver:
-        // tests/golden/beam_cases/filter_case99516.npz).  s is a triple product of three apex-to-vertex vectors (for
-        // a planar polygon every face's s vanishes together); moving one of the points by d changes it by at most d times
-        // the sum of the |N_f|, and a reflection moves each point by a few ulp(M'), M' <= 3 M.  Below
-        // 64 ulp(M) sum |N_f| (or the rounding of the product itself, far from the scene) the pyramid counts as flat:
-        // rho = 0 for its faces, never "on" in child_misses_receivers.
-        hp[t] = apex_plane_distance(I, v[0], v[1], v[2]);
-        V3 w[Sh::NF];
-#pragma unroll
-        for (int k = 0; k < Sh::NF; ++k) w[k] = v[k] - I;
-        float len[Sh::NF], lensum = 0.0f, D2 = 0.0f;
-        bool fin = true;
-        V3 N0{0, 0, 0};
-#pragma unroll
-        for (int f = 0; f < Sh::NF; ++f) {
-            const V3 N = cross(w[f], w[(f + 1) % Sh::NF]);
-            if (f == 0) N0 = N;
-            len[f] = __builtin_amdgcn_sqrtf(fdot(N, N));
-            lensum = (f == 0) ? len[0] : lensum + len[f];
-            fin = fin && is_finite(len[f]);
-            D2 = fmaxf(D2, fdot(w[f], w[f]));
-        }
-        const float sv = fdot(w[2], N0);
-        const float D = __builtin_amdgcn_sqrtf(D2);
-        const float tol = margins::kFlatTolUlps * fmaxf(ulp_m, margins::kFlatRelative * D) * lensum;
-        const bool defined = fin && __builtin_fabsf(sv) > tol;
-#pragma unroll
-        for (int f = 0; f < Sh::NF; ++f) {
-            const V3 ed = v[(f + 1) % Sh::NF] - v[f];
-            const float el = __builtin_amdgcn_sqrtf(fdot(ed, ed));
-            rho[t][f] = (el > 0.0f && defined) ? margins::kRhoRoundDown * len[f] * __builtin_amdgcn_rcpf(el) : 0.0f;  // pyr_face's rho
+            for (int k = 0; k < Sh::NF; ++k) v[t][k] = image_of_vertex(v[t][k], pt, n);
         }
     }
 }
-// true: NO point of the receivers' box can lie inside the narrowest pyramid of the child (parent prefix + new mirror
-// with plane <nc, x> = dc and shape factor sig_c) -- the receiver stage would reject every receiver for that pyramid
-// alone.  The child's pyramid is the parent's, reflected in the new plane: apex I3, face normals reflected, the same
-// rho; its slopes use the CHILD's lateral tolerance.  Margins strictly wider than the receiver stage's own (which
-// builds the pyramid from reflected vertices): rho 0.1 % smaller, tolerance 2e-5 larger, 2e-4 of extra slope for the
-// rounding of the two routes to the normal, 10 % on the threshold -- whatever this test drops, that stage drops too.
+// true: NO point of the receivers' box can lie inside the narrowest pyramid of the child (parent prefix + the new mirror c
+// with plane point pc, normal nc and shape factor sig_c) -- the receiver stage would reject every receiver for that pyramid
+// alone.  Round 6: the child's pyramid is built HERE exactly as the receiver stage builds it -- apex = image_of_vertex(parent's
+// apex), polygon = the parent's unfolded first mirror reflected once more with the same function, make_pyr on those values --
+// so both stages hold THE SAME face normals and edge distances bit for bit, and "what this filter drops, the receiver stage
+// drops" is monotonicity in the constants: a lateral tolerance rounded up (kChildDeltaRoundUp: the two stages sum the shape
+// factors in different orders), faces and the pyramid switched off earlier, a larger rounding allowance in the slope, the
+// box's support instead of a receiver's own value, and a threshold kChildFaceUnits > kFaceUnits.  (Until round 5 the filter
+// reflected the parent's face NORMALS instead: a different route to the same planes, whose rounding difference the triangle
+// soups of round 6 caught dropping 1-2 children per 5 000 scenes that the receiver stage kept.)
 template <int SCALE>
 __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const BeamMesh &M, float u0, V3 I2,
-                                                       const V3 (&n0)[Shape<SCALE>::NP][Shape<SCALE>::NF],
-                                                       const float (&rho)[Shape<SCALE>::NP][Shape<SCALE>::NF],
-                                                       const float (&hp)[Shape<SCALE>::NP], float sig_parent, V3 nc, float dc,
-                                                       float sig_c) {
+                                                       const V3 (&vpar)[Shape<SCALE>::NP][Shape<SCALE>::NF], float sig_parent,
+                                                       V3 pc, V3 nc, float sig_c) {
     using Sh = Shape<SCALE>;
-    const float s2 = 2.0f * __builtin_fmaf(nc.x, I2.x, __builtin_fmaf(nc.y, I2.y, __builtin_fmaf(nc.z, I2.z, -dc)));
-    const V3 I3 = V3{I2.x - nc.x * s2, I2.y - nc.y * s2, I2.z - nc.z * s2};
+    const V3 I3 = image_of_vertex(I2, pc, nc);  // (beam_child_from's expression)
     const float uc = u0 * mag_scale(M, I3);
-    const float delta = margins::kLateralFactor * uc * (sig_parent + sig_c) * margins::kChildDeltaRoundUp + margins::kChildRouteUnits * uc;  // +inf for a degenerate mirror: every face off
-    const V3 ce = V3{0.5f * (rx.lo[0] + rx.hi[0]), 0.5f * (rx.lo[1] + rx.hi[1]), 0.5f * (rx.lo[2] + rx.hi[2])};
-    const V3 he = V3{(rx.hi[0] - rx.lo[0]) * margins::kBoxHalfExtent, (rx.hi[1] - rx.lo[1]) * margins::kBoxHalfExtent, (rx.hi[2] - rx.lo[2]) * margins::kBoxHalfExtent};
+    const float delta = margins::kLateralFactor * uc * (sig_parent + sig_c) * margins::kChildDeltaRoundUp;  // +inf for a degenerate mirror: every face off
+    const V3 ce = V3{rx.ce[0], rx.ce[1], rx.ce[2]}, he = V3{rx.he[0], rx.he[1], rx.he[2]};  // (rx_all_finish)
     if (!(he.x >= 0.0f) || !(he.y >= 0.0f) || !(he.z >= 0.0f)) return false;
     const V3 w = ce - I3;
     const float wl = l1_len(w) + ((he.x + he.y) + he.z);
     const float thr = -margins::kChildFaceUnits * uc;
-    // the receiver stage switches the child's whole pyramid off when ITS apex lies within 1.05 delta of the polygon's
-    // plane (make_pyr); that distance equals the parent's up to the rounding of one more reflection (a few ulp(M') of
-    // position), so this stage needs the parent's distance clear of the threshold by that much, whatever kappa is
-    const float hp_slack = margins::kChildPlaneSlackUlps * rx.ulp_m * mag_scale(M, I3);
     bool all_t = true;
 #pragma unroll
     for (int t = 0; t < Sh::NP; ++t) {
-        const bool apex_off_plane = hp[t] * margins::kChildRhoRoundDown > margins::kChildPlaneOffRatio * delta + hp_slack;  // (NaN: off)
-        float v[Sh::NF];
+        V3 v[Sh::NF];
+#pragma unroll
+        for (int k = 0; k < Sh::NF; ++k) v[k] = image_of_vertex(vpar[t][k], pc, nc);
+        // make_pyr<NF, true>, face by face (each face's value as soon as its normal exists: nothing of the pyramid stays live)
+        const bool apex_off_plane = apex_plane_distance(I3, v[0], v[1], v[2]) * margins::kChildRhoRoundDown > margins::kChildPlaneOffRatio * delta;  // (NaN: off)
+        float val[Sh::NF];
 #pragma unroll
         for (int f = 0; f < Sh::NF; ++f) {
-            const V3 n = n0[t][f];
-            const float k2 = 2.0f * fdot(n, nc);
-            const V3 nr = V3{n.x - nc.x * k2, n.y - nc.y * k2, n.z - nc.z * k2};
-            const float r = rho[t][f] * margins::kChildRhoRoundDown;
-            const float g = margins::kSlopeFactor * delta * __builtin_amdgcn_rcpf(r - delta) + margins::kChildSlopeRounding;
-            const bool on = apex_off_plane && r > margins::kChildFaceOffRatio * delta;  // otherwise the child's face may be off: it never separates
-            const float smax = fdot(w, nr) + ((__builtin_fabsf(nr.x) * he.x + __builtin_fabsf(nr.y) * he.y) +
-                                              __builtin_fabsf(nr.z) * he.z);
-            const float val = __builtin_fmaf(g, wl, smax);
-            v[f] = on ? val : 0.0f;  // (a parent face that is off has n = 0: val = g wl >= 0; NaNs compare false)
+            V3 n;
+            float g;
+            pyr_face<Sh::NF == 4, true>(I3, v[f], v[(f + 1) % Sh::NF], v[(f + 2) % Sh::NF], v[(f + 3) % Sh::NF], delta, apex_off_plane, n, g);
+            const float smax = fdot(w, n) + ((__builtin_fabsf(n.x) * he.x + __builtin_fabsf(n.y) * he.y) + __builtin_fabsf(n.z) * he.z);
+            val[f] = __builtin_fmaf(g, wl, smax);  // (a face that is off: n = 0, g = 0 -> 0, never below the threshold)
         }
-        all_t = all_t && (min_faces<Sh::NF>(v) < thr);
+        all_t = all_t && (min_faces<Sh::NF>(val) < thr);
     }
     return all_t;
 }
@@ -1004,23 +989,25 @@ __device__ __forceinline__ void expand_clustered_body(
     // still a candidate, the receiver-box test -- both on full waves, the parent's data gathered once for both.
     constexpr bool kTwoStage = FILTER && LEVEL == 2;
     __shared__ unsigned long long raw_rec[kExpandWG / 64][128];
-    __shared__ float raw_f[kExpandWG / 64][kTwoStage ? 2 : 5][128];  // two-stage: (sorted position, threshold)
+    __shared__ float raw_f[kExpandWG / 64][2][128];  // (sorted position of the candidate, threshold of the two-stage form)
     constexpr bool filter_on = FILTER;
-    // what the child filter needs of the PARENT besides its context (per face of the narrowest pyramid the distance of
-    // the apex from the edge line, and the sum of the shape factors): read once per 64 parked children, by the child's
-    // lane from the parent's slot -- kept in LDS, not in five registers that would be live across the whole cluster loop
-    __shared__ float lds_rho[kExpandWG / 64][Sh::NP * Sh::NF + 1 + Sh::NP][64];
+    // what the child filter needs of the PARENT besides its apex (its first mirror's vertices unfolded through its later
+    // mirrors, and the sum of the shape factors: first_mirror_unfolded): read once per 64 parked children, by the child's
+    // lane from the parent's slot -- kept in LDS, not in registers that would be live across the whole cluster loop
+    __shared__ float lds_par[kExpandWG / 64][Sh::NP * Sh::NF * 3 + 1][64];
     if (filter_on) {
-        float rho0[Sh::NP][Sh::NF], hp0[Sh::NP];
+        V3 vpar[Sh::NP][Sh::NF];
         float sig_sum = kInf;
-        first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum, hp0);
-#pragma unroll
-        for (int t = 0; t < Sh::NP; ++t) lds_rho[wave][Sh::NP * Sh::NF + 1 + t][lane] = hp0[t];
+        first_mirror_unfolded<SCALE, LEVEL>(M, e, have, vpar, sig_sum);
 #pragma unroll
         for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
-            for (int f = 0; f < Sh::NF; ++f) lds_rho[wave][t * Sh::NF + f][lane] = rho0[t][f];
-        lds_rho[wave][Sh::NP * Sh::NF][lane] = sig_sum;
+            for (int k = 0; k < Sh::NF; ++k) {
+                lds_par[wave][(t * Sh::NF + k) * 3 + 0][lane] = vpar[t][k].x;
+                lds_par[wave][(t * Sh::NF + k) * 3 + 1][lane] = vpar[t][k].y;
+                lds_par[wave][(t * Sh::NF + k) * 3 + 2][lane] = vpar[t][k].z;
+            }
+        lds_par[wave][Sh::NP * Sh::NF * 3][lane] = sig_sum;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1036,47 +1023,38 @@ __device__ __forceinline__ void expand_clustered_body(
         const unsigned long long rec = mine ? raw_rec[wave][j] : 0ull;
         const int l = (int)((rec >> 32) - gbase) & 63;  // the parent's lane
         const V3 I2 = V3{__shfl(ctx.I.x, l, 64), __shfl(ctx.I.y, l, 64), __shfl(ctx.I.z, l, 64)};
-        const float sp = lds_rho[wave][Sh::NP * Sh::NF][l];
-        V3 n0[Sh::NP][Sh::NF];
-        float rh[Sh::NP][Sh::NF], hpp[Sh::NP];
+        const float sp = lds_par[wave][Sh::NP * Sh::NF * 3][l];
+        V3 vpar[Sh::NP][Sh::NF];
 #pragma unroll
-        for (int t = 0; t < Sh::NP; ++t) {
-            hpp[t] = lds_rho[wave][Sh::NP * Sh::NF + 1 + t][l];
+        for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
-            for (int f = 0; f < Sh::NF; ++f) {
-                n0[t][f] = V3{__shfl(ctx.pyr[0][t].n[f].x, l, 64), __shfl(ctx.pyr[0][t].n[f].y, l, 64),
-                              __shfl(ctx.pyr[0][t].n[f].z, l, 64)};
-                rh[t][f] = lds_rho[wave][t * Sh::NF + f][l];
-            }
-        }
-        V3 nc{0, 0, 1};
-        float dc = 0.0f, sgc = 1.0f;
+            for (int k = 0; k < Sh::NF; ++k)
+                vpar[t][k] = V3{lds_par[wave][(t * Sh::NF + k) * 3 + 0][l], lds_par[wave][(t * Sh::NF + k) * 3 + 1][l],
+                                lds_par[wave][(t * Sh::NF + k) * 3 + 2][l]};
+        // the candidate's mirror (first vertex, normal) and shape factor, from the sorted arrays by position
+        const int64_t pos = mine ? (int64_t)__float_as_uint(raw_f[wave][0][j]) : 0;  // (position 0 always exists)
+        const V3 pc = ld3(C.verts + 3 * (pos * Sh::NV));
+        const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP];
+        const V3 nc = V3{q.x, q.y, q.z};
+        const float sgc = C.sigma[pos];
         if constexpr (kTwoStage) {
-            const int64_t pos = mine ? (int64_t)__float_as_uint(raw_f[wave][0][j]) : 0;  // (position 0 always exists)
             const float base = raw_f[wave][1][j & 127];
             V3 vq[Sh::NV];
 #pragma unroll
             for (int k = 0; k < Sh::NV; ++k) vq[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));
-            const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP];
-            nc = V3{q.x, q.y, q.z};
-            dc = q.w;
-            sgc = C.sigma[pos];
             PyrN<Sh::NF> P0[Sh::NP];
 #pragma unroll
             for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
                 for (int f = 0; f < Sh::NF; ++f) {
-                    P0[t].n[f] = n0[t][f];
+                    P0[t].n[f] = V3{__shfl(ctx.pyr[0][t].n[f].x, l, 64), __shfl(ctx.pyr[0][t].n[f].y, l, 64),
+                                    __shfl(ctx.pyr[0][t].n[f].z, l, 64)};
                     P0[t].g[f] = __shfl(ctx.pyr[0][t].g[f], l, 64);
                 }
             mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);
-        } else {
-            nc = mine ? V3{raw_f[wave][0][j], raw_f[wave][1][j], raw_f[wave][2][j]} : V3{0, 0, 1};
-            dc = mine ? raw_f[wave][3][j] : 0.0f;
-            sgc = mine ? raw_f[wave][4][j] : 1.0f;
         }
         // (rxall.on == 0 -- a non-finite receiver, known only on the device in the async entry point: every child passes)
-        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, hpp, sp, nc, dc, sgc));
+        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, vpar, sp, pc, nc, sgc));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
     };
@@ -1263,16 +1241,8 @@ __device__ __forceinline__ void expand_clustered_body(
                     if (keep) {
                         const int j = rawcount + __popcll(vote & ((1ull << lane) - 1ull));
                         raw_rec[wave][j] = record;
-                        if constexpr (kTwoStage) {
-                            raw_f[wave][0][j] = __uint_as_float((uint32_t)pos);  // cl * 64 + lane < 2^31 primitives
-                            raw_f[wave][1][j] = base1;
-                        } else {
-                            raw_f[wave][0][j] = pl[0][0];
-                            raw_f[wave][1][j] = pl[0][1];
-                            raw_f[wave][2][j] = pl[0][2];
-                            raw_f[wave][3][j] = pl[0][3];
-                            raw_f[wave][4][j] = sg;
-                        }
+                        raw_f[wave][0][j] = __uint_as_float((uint32_t)pos);  // cl * 64 + lane < 2^31 primitives
+                        if constexpr (kTwoStage) raw_f[wave][1][j] = base1;
                     }
                     rawcount += __popcll(vote);
                     if (rawcount >= 64) filter_parked(64);
@@ -1356,9 +1326,8 @@ struct CtxTab {
     // float offsets of one entry; every group starts on a 16-byte boundary
     static constexpr int kI = 0, kU = 3, kPm = 4, kSide = 7, kNm = 8, kSig = 11, kM = 12;  // head: 16 floats
     static constexpr int kPyr = 16;                                    // [LEVEL][NP][NF] x (n.x, n.y, n.z, g)
-    static constexpr int kRho = kPyr + 4 * LEVEL * Sh::NP * Sh::NF;    // [NP][NF] rho of the FIRST mirror's pyramid
-    static constexpr int kHp = kRho + Sh::NP * Sh::NF;                 // [NP]
-    static constexpr int kWords = (kHp + Sh::NP + 3) / 4 * 4;
+    static constexpr int kV0 = kPyr + 4 * LEVEL * Sh::NP * Sh::NF;     // [NP][NF][3] the FIRST mirror's vertices, unfolded (first_mirror_unfolded)
+    static constexpr int kWords = (kV0 + 3 * Sh::NP * Sh::NF + 3) / 4 * 4;
 };
 
 template <int SCALE, int LEVEL>
@@ -1384,9 +1353,9 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
     BeamCtx<SCALE, LEVEL> ctx;
     build_ctx<SCALE, LEVEL>(M, e, u, have, ctx);
     if (blockIdx.y == 0) {  // the table entry of this prefix (every lane writes one: lanes beyond the list hold "off" contexts)
-        float rho0[Sh::NP][Sh::NF], hp0[Sh::NP];
+        V3 vpar[Sh::NP][Sh::NF];
         float sig_sum = kInf;
-        first_pyramid_rho<SCALE, LEVEL>(M, e, ctx.I, have, rxall.ulp_m, rho0, sig_sum, hp0);
+        first_mirror_unfolded<SCALE, LEVEL>(M, e, have, vpar, sig_sum);
         float4 *t = reinterpret_cast<float4 *>(ctxtab + g * Tab::kWords);
         t[0] = float4{ctx.I.x, ctx.I.y, ctx.I.z, ctx.u};
         t[1] = float4{ctx.pm.x, ctx.pm.y, ctx.pm.z, __uint_as_float((uint32_t)ctx.side_prev)};
@@ -1403,11 +1372,9 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
                 }
         float *tf = ctxtab + g * Tab::kWords;
 #pragma unroll
-        for (int tt = 0; tt < Sh::NP; ++tt) {
-            tf[Tab::kHp + tt] = hp0[tt];
+        for (int tt = 0; tt < Sh::NP; ++tt)
 #pragma unroll
-            for (int f = 0; f < Sh::NF; ++f) tf[Tab::kRho + tt * Sh::NF + f] = rho0[tt][f];
-        }
+            for (int k = 0; k < Sh::NF; ++k) st3(tf + Tab::kV0 + 3 * (tt * Sh::NF + k), vpar[tt][k]);
     }
     const int64_t cl_begin = (int64_t)blockIdx.y * clusters_per_split;
     const int64_t cl_end = (cl_begin + clusters_per_split < C.nclusters) ? cl_begin + clusters_per_split : C.nclusters;
@@ -1489,6 +1456,7 @@ __global__ __launch_bounds__(kExpandWG) void beam_boxes_kernel(BeamMesh M, BeamC
 // the prefix of a pass, read from its table entry through the scalar unit (wave-uniform address, read-only memory)
 template <int SCALE, int LEVEL>
 struct CtxScalar {
+    static constexpr bool kUniformPrefix = true;  // one prefix per pass
     using Tab = CtxTab<SCALE, LEVEL>;
     const float *__restrict__ t;  // wave-uniform
     __device__ __forceinline__ V3 I() const { return V3{t[Tab::kI], t[Tab::kI + 1], t[Tab::kI + 2]}; }
@@ -1546,31 +1514,33 @@ __global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(BEAM_
         const float4 h0 = reinterpret_cast<const float4 *>(pe)[0];
         const V3 I2 = V3{h0.x, h0.y, h0.z};
         const float sp = pe[Tab::kSig];
-        V3 n0[Sh::NP][Sh::NF];
-        float rh[Sh::NP][Sh::NF], hpp[Sh::NP];
-        PyrN<Sh::NF> P0[Sh::NP];
+        V3 vpar[Sh::NP][Sh::NF];
 #pragma unroll
-        for (int t = 0; t < Sh::NP; ++t) {
-            hpp[t] = pe[Tab::kHp + t];
+        for (int t = 0; t < Sh::NP; ++t)
 #pragma unroll
-            for (int f = 0; f < Sh::NF; ++f) {
-                const float4 q = reinterpret_cast<const float4 *>(pe + Tab::kPyr)[t * Sh::NF + f];  // pyramid 0
-                n0[t][f] = V3{q.x, q.y, q.z};
-                P0[t].n[f] = n0[t][f];
-                P0[t].g[f] = q.w;
-                rh[t][f] = pe[Tab::kRho + t * Sh::NF + f];
-            }
-        }
+            for (int k = 0; k < Sh::NF; ++k) vpar[t][k] = ld3(pe + Tab::kV0 + 3 * (t * Sh::NF + k));
         const int64_t pos = mine ? (int64_t)__float_as_uint(raw_f[wave][0][j]) : 0;  // (position 0 always exists)
-        const float base = raw_f[wave][1][j & 127];
         V3 vq[Sh::NV];
 #pragma unroll
         for (int k = 0; k < Sh::NV; ++k) vq[k] = ld3(C.verts + 3 * (pos * Sh::NV + k));
         const float4 q = reinterpret_cast<const float4 *>(C.planes)[pos * Sh::NP];
         const V3 nc = V3{q.x, q.y, q.z};
-        const float dc = q.w, sgc = C.sigma[pos];
-        if constexpr (LEVEL >= 2) mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);  // (level 1: the first stage was the whole test)
-        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, n0, rh, hpp, sp, nc, dc, sgc));
+        const float sgc = C.sigma[pos];
+        if constexpr (LEVEL >= 2) {  // (level 1: the first stage was the whole test)
+            const float base = raw_f[wave][1][j & 127];
+            PyrN<Sh::NF> P0[Sh::NP];
+#pragma unroll
+            for (int t = 0; t < Sh::NP; ++t)
+#pragma unroll
+                for (int f = 0; f < Sh::NF; ++f) {
+                    const float4 pq = reinterpret_cast<const float4 *>(pe + Tab::kPyr)[t * Sh::NF + f];  // pyramid 0
+                    P0[t].n[f] = V3{pq.x, pq.y, pq.z};
+                    P0[t].g[f] = pq.w;
+                }
+            mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);
+        }
+        // (the candidate's mirror: first vertex and normal of its first triangle, prim_plane's pair)
+        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, vpar, sp, vq[0], nc, sgc));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
     };
@@ -2434,7 +2404,7 @@ __global__ void beam_dyn_kernel(const uint32_t *__restrict__ rx_bounds, const ui
     float mag = fmaxf(__uint_as_float(rx_bounds[6]), __uint_as_float(tx_bounds[6]));
     mag = fmaxf(fmaxf(mag, mesh_max_abs), 1e-30f);
     BeamDyn d;
-    d.rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f};
+    d.rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f, {0, 0, 0}, {0, 0, 0}};
     if (rx_bounds[7] == 0u && filter_allowed) {
         bool ok = true;
         for (int k = 0; k < 3; ++k) {
@@ -2450,6 +2420,7 @@ __global__ void beam_dyn_kernel(const uint32_t *__restrict__ rx_bounds, const ui
     d.u = kappa * ulp;
     d.inv_2m = 0.5f / mag;
     d.rxall.ulp_m = ulp;
+    rx_all_finish(d.rxall);
     *out = d;
 }
 
@@ -2630,7 +2601,10 @@ struct BeamSizes {
     int64_t max_entries, max_records, max_rows, max_survivors;
     int64_t ctx_cap;  // prefixes per launch of the two-kernel last expansion (context table + cluster masks); 0: order < 2
 };
-constexpr int64_t kCtxWordsMax = 72;  // CtxTab<2, 2>::kWords, the largest entry (shape known only once the clusters exist)
+constexpr int64_t kCtxWordsMax = 64;  // the largest entry of the shapes that take the two-kernel form (shape known only once the clusters exist)
+static_assert(CtxTab<1, 1>::kWords <= kCtxWordsMax && CtxTab<1, 2>::kWords <= kCtxWordsMax && CtxTab<4, 1>::kWords <= kCtxWordsMax &&
+                  CtxTab<4, 2>::kWords <= kCtxWordsMax,
+              "context table entries");
 
 // Default list capacities, sized from the scene (results never depend on them: a slice that overflows is retried
 // smaller, drt_trace_paths_beam; round 3 took 2^26 / 2^27 / 2^26 / 2^22 whatever the scene = 5.5 GiB of workspace
@@ -2791,7 +2765,7 @@ struct SplitWs {
 template <int SCALE, int LEVEL>
 static void launch_expand(const BeamMesh &M, const BeamClusters &C, bool clustered, const BeamEntry *in, int64_t n_in,
                           float u, unsigned long long *out, int64_t cap, unsigned long long *count, hipStream_t s,
-                          const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f}, BeamDev dv = BeamDev{nullptr, nullptr},
+                          const RxAll &rxall = RxAll{{0, 0, 0}, {0, 0, 0}, 0, 0.0f, {0, 0, 0}, {0, 0, 0}}, BeamDev dv = BeamDev{nullptr, nullptr},
                           bool last = false, SplitWs sw = SplitWs{}) {
     if constexpr (LEVEL <= 2 && SCALE != 2) {  // (shape 2, the rare two-arbitrary-triangles quad, stays on the fused kernel)
         if (clustered && sw.ctxtab && (rxall.on || (last && dv.dyn))) {
@@ -3274,6 +3248,7 @@ int32_t drt_trace_paths_beam(drt_mesh_t mesh, const drt_trace_params *pr, const 
     const float u = kappa * std::ldexp(1.0f, ex - 1 - 23);  // kappa * ulp(M)
     M.inv_2m = 0.5f / mag;
     rxall.ulp_m = std::ldexp(1.0f, ex - 1 - 23);
+    rx_all_finish(rxall);
     if (st) {
         st->unit_m = u;
         st->magnitude = mag;

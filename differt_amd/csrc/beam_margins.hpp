@@ -47,18 +47,15 @@ constexpr float kRhoRoundDown = 0.9999f;
 constexpr float kFaceOffRatio = 5.05f;       // keeps the slope of an active face below 1/4
 constexpr float kPlaneOffRatio = 1.05f;      // the whole pyramid: apex within this many delta of the polygon's plane
 
-// ---- child filter of the last expansion (must be strictly WIDER than the receiver stage: what it drops, that drops) ----
-constexpr float kChildDeltaRoundUp = 1.00002f;
+// ---- child filter of the last expansion ----------------------------------------------------------------------------
+// The filter builds the child's narrowest pyramid from THE SAME float values as the receiver stage (same apex, same unfolded
+// vertices, same make_pyr), so "what it drops, the receiver stage drops" is monotonicity in these constants:
+constexpr float kChildDeltaRoundUp = 1.00002f;  // the two stages sum the shape factors in different orders
 constexpr float kChildRhoRoundDown = 0.999f;  // < kRhoRoundDown
 constexpr float kChildFaceOffRatio = 5.1f;    // > kFaceOffRatio
 constexpr float kChildPlaneOffRatio = 1.06f;  // > kPlaneOffRatio
-constexpr float kChildRouteUnits = 6.0f;      // u of extra lateral tolerance: rounding between the two routes to the child's face normals
-constexpr float kChildSlopeRounding = 2.1e-4f;  // > kSlopeRounding: two routes to the child's face normal
-constexpr float kChildFaceUnits = 1.1f;       // > kFaceUnits
-constexpr float kChildPlaneSlackUlps = 128.0f; // ulp(M') of slack on the apex-plane distance (one more reflection)
-// a parent pyramid counts as flat (never "on" in the child filter) below kFlatTolUlps * max(ulp(M), kFlatRelative * D) * sum |N_f|
-constexpr float kFlatTolUlps = 64.0f;
-constexpr float kFlatRelative = 1.2e-7f;
+constexpr float kChildSlopeRounding = 2.1e-4f;  // > kSlopeRounding
+constexpr float kChildFaceUnits = 1.5f;       // > kFaceUnits + (rounding of the box's support against a receiver's own value) / kappa
 
 // ---- pairing pass: a coplanar pair is a convex fan quad when every corner turns by sin >= this -----------------------
 constexpr float kQuadConvexSin = 1e-3f;

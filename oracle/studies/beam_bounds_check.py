@@ -285,20 +285,18 @@ def check(m: dict[str, float] | None = None, d: dict | None = None) -> dict:
     need("kBoxHalfExtent covers the rounding of (hi - lo) and of the centre relative to the extent", 0.5 * (1 + 4 * EPS), m["kBoxHalfExtent"], "box_pruned")
     need("kSigmaRoundUp covers pm / len (two square roots, products, one division)", (1 + EPS) ** 6, m["kSigmaRoundUp"], "mesh_prepare_kernel")
 
-    # ---- child filter of the last expansion: strictly wider than the receiver stage ----
+    # ---- child filter of the last expansion ----
+    # It builds the child's narrowest pyramid from the SAME float values as the receiver stage (image_of_vertex of the parent's
+    # apex and of the parent's unfolded first mirror, then make_pyr): identical normals and edge distances, so "what the filter
+    # drops, the receiver stage drops" is monotonicity in the constants plus the rounding of the box's support function.
     need("child filter: rho rounded down further than the receiver stage's", m["kChildRhoRoundDown"], m["kRhoRoundDown"] * (1 - 1e-4), "")
     need("child filter: faces switch off earlier", m["kFaceOffRatio"] * 1.005, m["kChildFaceOffRatio"], "")
     need("child filter: whole pyramid switches off earlier", m["kPlaneOffRatio"] * 1.005, m["kChildPlaneOffRatio"], "")
-    need("child filter: larger threshold", m["kFaceUnits"] * 1.05, m["kChildFaceUnits"], "")
     need("child filter: larger relative slope allowance", m["kSlopeRounding"] * 10, m["kChildSlopeRounding"], "")
-    # the two routes to the child's narrowest pyramid -- the receiver stage builds it from vertices reflected once more, the
-    # filter reflects the parent's face normals -- differ by the rounding of one more reflection of two vertices and of the
-    # apex, as a lateral distance at the edge line:
-    route = d["image_apex_val"] + 2 * d["image_vertex2_val"]
-    need("child filter: kChildRouteUnits * kappa of extra lateral tolerance covers the rounding between the two routes to the "
-         "child's face normals", route, m["kChildRouteUnits"] * kappa, "child_misses_receivers: delta += kChildRouteUnits u")
-    need("child filter: kChildPlaneSlackUlps covers the change of the apex-plane distance under one more reflection",
-         d["image_apex_val"] + d["image_vertex2_val"], m["kChildPlaneSlackUlps"] * 2.0, "(slack is in ulp(M') with M' up to 2 M)")
+    need("child filter: its lateral tolerance is rounded up past the receiver stage's (sum of <= 3 products in another order: 4 eps)",
+         1.0 + 8 * EPS, m["kChildDeltaRoundUp"], "child_misses_receivers: delta = kLateralFactor u (sig_parent + sig_c) kChildDeltaRoundUp")
+    need("child filter: the extra threshold covers the rounding of the box's centre / half extents / support against a receiver's own value",
+         k_eval + 3 * hu(1.0), (m["kChildFaceUnits"] - m["kFaceUnits"]) * kappa, "child_misses_receivers: thr = -kChildFaceUnits u")
     return {"ok": all(c["ok"] for c in checks), "checks": checks, "kappa": kappa, "sigma_min": SIGMA_MIN,
             "derived": {"lateral_u0": lam, "plane_u0": nu, "side_sign_u0": side, "mt_first_u0": c1, "mt_third_per_sigma_u0": c3,
                         "image_apex_u0": d["image_apex_val"], "image_vertex_unfolded_once_u0": d["image_vertex1_val"],

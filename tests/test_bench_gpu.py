@@ -48,7 +48,8 @@ def test_single_gpu_line():
     d = _last_json(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
     rf = d["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] == "hbm"
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "valu_frac", "valu_frac_of_157TF"} <= set(rf)
+    assert rf["bound"] == "hbm+valu" and 0 < rf["valu_frac"] < 1 and abs(rf["valu_frac_of_157TF"] * 2 / rf["valu_frac"] - 1) < 0.01
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5  # (the line carries 6 significant digits)
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
     assert "strong_headline" not in d  # N = 1: the line is the plain single-GPU bench
@@ -84,7 +85,7 @@ def test_two_ranks_share_gpu():
     _check_strong(d["strong_scaling"], 2)
     # N > 1: the fixed-total-work legs are surfaced at top level (the north-star scaling claim), `value` stays weak
     heads = {h["leg"]: h for h in d["strong_headline"]}
-    assert set(heads) == {"beam_sharded", "candidate_sharded"}
+    assert set(heads) == {"triangle_block", "beam_sharded", "candidate_sharded"}  # triangle_block: the leg configs[4] names
     for leg, h in heads.items():
         assert h["n_gpus"] == 2 and h["scaling"] == "strong"
         assert h["s_per_step"] == pytest.approx(d["strong_scaling"][leg]["s_per_step"], rel=1e-4)  # (5 significant digits in the line)
@@ -116,7 +117,9 @@ def test_default_command_line_is_parseable_by_the_driver():
     d = json.loads(line)
     assert KEYS <= set(d) and d["full"] == str(side)
     assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"} <= set(d["roofline"])
-    assert {"value", "unit", "cores", "kind"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["value"] > 0
+    assert {"value", "unit", "cores", "kind", "reference_installed"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["value"] > 0
+    assert d["cpu_baseline"]["reference_installed"] is False  # (no jax / differt on these boxes: reported, not hidden)
+    assert d["roofline"]["bound"] == "hbm+valu" and d["cfg2_literal_us"] > 0 and 0 < d["cfg2_literal_hbm_frac"] < 1
     pm = d["paths_metric"]
     assert pm["unit"] == "valid order-2 paths/s (fwd+grad)" and pm["config"] == "configs[2]" and pm["value"] > 0
     assert pm["same_as_exhaustive"] is True
