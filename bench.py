@@ -209,6 +209,10 @@ def compact_line(full: dict, sidecar: str | None) -> dict:
             summ["bruxelles_order3_triangles_s"] = _get(real, "bruxelles", "beam_order3_triangles", "s_per_step")
             summ["bruxelles_pairs"] = _get(real, "bruxelles", "paired_primitives")
             summ["bruxelles_same_as_exhaustive"] = _get(real, "bruxelles", "beam_order2", "same_valid_paths_as_exhaustive")
+            b3 = _get(real, "bruxelles", "beam_order3", "same_valid_paths_as_exhaustive")
+            summ["bruxelles_order3_pairs_checked"] = b3.get("checked_pairs") if isinstance(b3, dict) and b3.get("all_equal") else None
+            c3 = _get(p, "beam_pruned_order3", "same_valid_paths_as_exhaustive")
+            summ["cfg3_pairs_checked"] = c3.get("checked_pairs") if isinstance(c3, dict) and c3.get("all_equal") else None
         out["paths"] = {k: _r(v) for k, v in summ.items()}
     elif isinstance(p, dict):
         out["paths"] = {"error": str(p["error"])[:200]}

@@ -129,6 +129,13 @@ def run(names=("bruxelles", "manhattan", "manhattan_small")) -> dict:
     for name in names:
         V, Tr = S.load_real_mesh(name)
         rec = beam_legs(G, V, Tr)
+        try:  # whole order-3 pair spaces of this mesh through the exhaustive tracer: the committed record, quoted while fresh
+            from bench_paths import exhaustive_record
+
+            if isinstance(rec.get("beam_order3"), dict) and "error" not in rec["beam_order3"]:
+                rec["beam_order3"]["same_valid_paths_as_exhaustive"] = exhaustive_record(f"{name} order 3")
+        except Exception:  # noqa: BLE001
+            pass
         if name == "bruxelles":
             rec["reference_harness"] = harness_legs(G, V, Tr)
         out[name] = rec

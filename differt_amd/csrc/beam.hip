@@ -600,12 +600,17 @@ __device__ __forceinline__ bool box_pruned(const BeamCtx<SCALE, LEVEL> &c, const
     if (c.side_prev != 0) {
         const float dc = fdot(ce - c.pm, c.nm);
         const float r = (__builtin_fabsf(c.nm.x) * e.x + __builtin_fabsf(c.nm.y) * e.y) + __builtin_fabsf(c.nm.z) * e.z;
-        const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, margins::kSideEpsFactor * eps_max + margins::kSideUnits * c.u) : 0;
+        const int sb = (dc == dc) ? side_of_range(dc - r, dc + r, margins::kSideEpsFactor * eps_max + (margins::kSideUnits + margins::kBoxExtraUnits) * c.u) : 0;
         if (c.side_prev * sb == -1) return true;
     }
     const V3 w = ce - c.I;
     const float wl = l1_len(w) + ((e.x + e.y) + e.z);  // largest |x - I|_1 inside the box
-    const float base = -(margins::kFaceEpsFactor * eps_max + margins::kFaceUnits * c.u);
+    // (kBoxExtraUnits: a box's centre, half extents and support are rounded on their own -- at 8e4 m from the origin the centre
+    // of a 170-m box is off by half an ulp(M) = 4 mm, more than the relative round-up of the half extents -- so a box test
+    // is half a unit MORE conservative than the point / vertex test it stands for: "box pruned => everything inside pruned"
+    // holds under rounding, not only in exact arithmetic.  Found by round 6's soups: 2 rows of 59 024 between the receiver
+    // stage's two mappings in one of 246 877 cross-checks, a scene 8.4e4 m from the origin.)
+    const float base = -(margins::kFaceEpsFactor * eps_max + (margins::kFaceUnits + margins::kBoxExtraUnits) * c.u);
     bool separated = false;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {

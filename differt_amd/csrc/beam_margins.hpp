@@ -27,7 +27,10 @@ constexpr float kSigmaRoundUp = 1.0001f;
 constexpr float kEpsRoundUp = 1.0001f;        // covers v_rcp_f32 (1 ulp) and the three products
 constexpr float kLenRoundUp = 1.000001f;      // v_sqrt_f32 (1 ulp) nudged up: |w| rounded up
 constexpr float kBoxFarRoundUp = 1.0001f;     // farthest box corner from the apex, rounded up
-constexpr float kBoxHalfExtent = 0.50001f;    // half extents of a box, rounded up (the centre itself is rounded)
+constexpr float kBoxHalfExtent = 0.50001f;    // half extents of a box, rounded up
+// a box test (cluster of primitives, cluster of receivers) uses thresholds this many units wider than the point test it stands
+// for: covers the rounding of the box's centre (half an ulp(M), whatever the box's size) and of its support function
+constexpr float kBoxExtraUnits = 0.5f;
 
 // ---- side tests (which side of a mirror plane a point set lies on) ---------------------------------------------------
 // exact points (transmitter, receivers): margin kSideUnits * u; computed points add their positional bound

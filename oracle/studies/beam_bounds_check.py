@@ -282,7 +282,10 @@ def check(m: dict[str, float] | None = None, d: dict | None = None) -> dict:
          (5 + 3 + 2) * EPS * 2, m["kSlopeRounding"], "pyr_face / pyramids_separate")
     need("kEpsRoundUp covers u sigma (D rcp(h)): v_rcp and three products", (1 + 2 * EPS) * (1 + EPS) ** 3, m["kEpsRoundUp"], "beam_eps")
     need("kLenRoundUp covers v_sqrt_f32 of a sum of three FMAs", (1 + 2 * EPS) * (1 + 2 * EPS), m["kLenRoundUp"] * (1 + 0.0), "margin_len")
-    need("kBoxHalfExtent covers the rounding of (hi - lo) and of the centre relative to the extent", 0.5 * (1 + 4 * EPS), m["kBoxHalfExtent"], "box_pruned")
+    need("kBoxHalfExtent covers the rounding of (hi - lo) * 0.5", 0.5 * (1 + 4 * EPS), m["kBoxHalfExtent"], "box_pruned")
+    need("kBoxExtraUnits * kappa covers what kBoxHalfExtent cannot -- the rounding of the box's CENTRE (half an ulp(M) per coordinate, "
+         "whatever the extent) -- and the rounding of its support against a point's own value", SQ3 * hu(1.0) + k_eval + 3 * hu(1.0),
+         m["kBoxExtraUnits"] * kappa, "box_pruned: thresholds (kFaceUnits + kBoxExtraUnits) u, (kSideUnits + kBoxExtraUnits) u")
     need("kSigmaRoundUp covers pm / len (two square roots, products, one division)", (1 + EPS) ** 6, m["kSigmaRoundUp"], "mesh_prepare_kernel")
 
     # ---- child filter of the last expansion ----

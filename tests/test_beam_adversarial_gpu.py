@@ -488,3 +488,24 @@ def test_child_filter_nesting_on_soups(G, case):
         rows[name] = tracer.last_beam_stats["rows"]
         assert torch.equal(bp.objects, ex.objects), (case, name)
     assert rows["auto"] == rows["plain"] == rows["fused"], rows
+
+
+def test_box_tests_dominate_point_tests_far_from_the_origin(G):
+    """Round 6, found by the 20-minute stress run (1 of 246 877 mapping cross-checks): a soup 8.4e4 m from the origin
+    (ulp(M) = 7.8 mm), 130 receivers.  The clustered receiver stage tests a cluster's BOX first; the box's centre
+    0.5 (lo + hi) is rounded to half an ulp(M) = 4 mm whatever the box's size, more than the relative round-up of its half
+    extents (1e-5 of 170 m), so the box test pruned two (prefix, cluster) pairs whose receivers passed their own test: 59 022
+    rows against the plain mapping's 59 024 (no valid path among them).  A box test now uses thresholds kBoxExtraUnits = 0.5 u
+    wider than the point test it stands for (csrc/beam_margins.hpp; the bound is in oracle/studies/beam_bounds_check.py)."""
+    d = np.load(Path(__file__).parent / "golden" / "beam_cases" / "box_rounding_case203752.npz")
+    mesh = G.Mesh(d["V"], d["Tr"])
+    scene = G.Scene(torch.as_tensor(d["tx"], device="cuda"), torch.as_tensor(d["rx"], device="cuda"), mesh)
+    tracer = G.ExhaustivePathTracer()
+    order = int(d["order"])
+    ex = tracer.trace_rank_range_literal(scene, order, max_survivors=1 << 24, max_paths=1 << 20)
+    rows = {}
+    for name, kw in (("auto", {}), ("emit_plain", {"emit": "plain"}), ("emit_clustered", {"emit": "clustered"}), ("plain", {"expansion": "plain"})):
+        bp = tracer.trace_beam_pruned(scene, order, **kw)
+        rows[name] = tracer.last_beam_stats["rows"]
+        assert torch.equal(bp.objects, ex.objects) and torch.equal(bp.vertices.view(torch.int32), ex.vertices.view(torch.int32)), name
+    assert len(set(rows.values())) == 1, rows

@@ -39,6 +39,7 @@ def test_the_constants_in_the_header_pass_the_check():
     ("kChildFaceUnits", 1.0),
     ("kChildFaceUnits", 1.1),       # round 5's value: 6 ulp(M), less than the rounding of the box's support
     ("kChildDeltaRoundUp", 1.0),
+    ("kBoxExtraUnits", 0.0),        # round 5: a box test no more conservative than the point test it stands for
     ("kRhoRoundDown", 1.0),
     ("kSlopeRounding", 1e-7),
 ])

@@ -38,3 +38,27 @@ def test_committed_records_carry_a_hash():
     for p in recs:
         rec = json.loads(p.read_text())
         assert isinstance(rec.get("source_hash"), str) and len(rec["source_hash"]) == 16, p
+
+
+def test_exhaustive_record_is_quoted_only_while_its_hash_matches_the_tree(monkeypatch):
+    """the bench line's `same_as_exhaustive` quoted round 4's record of a kernel that was no longer the default
+    mapping.  bench_paths.exhaustive_record returns the latest committed record of scratch/exhaustive_pairs.py only while the
+    source hashes stamped into it describe the kernels in the tree."""
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    import bench_paths
+
+    recs = sorted((ROOT / "profiles").glob("r*/stress/exhaustive_pairs.json"))
+    if not recs:
+        return
+    data = json.loads(recs[-1].read_text())
+    stamp = data.get("source_hash") or {}
+    fresh = all(stamp.get(k) == _srchash.source_hash(k) for k in ("beam", "trace_filter"))
+    got = bench_paths.exhaustive_record("configs[3]")
+    assert (got is not None) == fresh
+    if fresh:
+        assert got["all_equal"] is True and got["checked_pairs"] >= 16 and set(got["kappas"]) == {64.0, 1.0}
+        assert bench_paths.exhaustive_record("bruxelles order 3")["checked_pairs"] >= 8
+    monkeypatch.setattr(_srchash, "source_hash", lambda kind, root=None: "0" * 16)
+    assert bench_paths.exhaustive_record("configs[3]") is None
