@@ -12,6 +12,7 @@ if [ "$part" = "a" ]; then
   timeout 1400 python scratch/beam_stress.py 1200 --seed=601 > $out/beam_stress.json 2> $out/beam_stress.err; tail -c 500 $out/beam_stress.json; echo
   timeout 700 python scratch/beam_stress.py 600 --kappa=1 --seed=602 > $out/beam_stress_kappa1.json 2> $out/beam_stress_kappa1.err; tail -c 500 $out/beam_stress_kappa1.json; echo
 else
+  python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
   timeout 700 python scratch/beam_stress.py 600 --only-soup --seed=603 > $out/beam_stress_soups.json 2> $out/beam_stress_soups.err; tail -c 500 $out/beam_stress_soups.json; echo
   timeout 700 python scratch/trace_oracle_stress.py 600 > $out/trace_oracle_stress.json 2> $out/trace_oracle_stress.err; tail -c 500 $out/trace_oracle_stress.json; echo
   for k in 0.25 0.015625; do
