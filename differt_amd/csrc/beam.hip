@@ -292,10 +292,15 @@ __device__ __forceinline__ void pyr_face(V3 I, V3 a, V3 b, V3 third, V3 third2, 
     const float rho = (el > 0.0f) ? kRhoDown * len * __builtin_amdgcn_rcpf(el) : 0.0f;
     const float g = margins::kSlopeFactor * delta * __builtin_amdgcn_rcpf(rho - delta) + kRound;
     const bool on = apex_off_plane && (rho > kOff * delta) && (len > 0.0f) && (s == s) && (s != 0.0f) && is_finite(len) && (g < kInf);
-    const float inv = __builtin_amdgcn_rcpf(len);
+    // Round 6: normal and slope are stored DIVIDED by (1 + kSpreadFactor g), kSpreadFactor >= sqrt 3: moving a point by r moves
+    // the face expression <w, n> + g |w|_1 by at most r (1 + sqrt(3) g), so a threshold that must cover a positional error r
+    // has to grow with the slope; scaling the face instead keeps every test a comparison with the plain threshold
+    // (s v < -thr  <=>  v < -thr (1 + sqrt(3) g)) at no cost per test, and a steep face (apex near the edge line) stays usable.
+    const float spread = __builtin_amdgcn_rcpf(__builtin_fmaf(margins::kSpreadFactor, g, 1.0f)) * kRhoDown;  // (rounded down; further for the child filter)
+    const float inv = __builtin_amdgcn_rcpf(len) * spread;
     const float sc = on ? ((s > 0.0f) ? inv : -inv) : 0.0f;
     n_out = on ? N * sc : V3{0, 0, 0};  // (0 * inf = NaN for a huge N: the select, not the product, zeroes it)
-    g_out = on ? g : 0.0f;
+    g_out = on ? g * spread : 0.0f;
 }
 // pyramid over the polygon v[0..NF): face f spans the edge v[f] -> v[f+1]; the vertex after that edge fixes "inside"
 // distance of the apex from the polygon's plane (through v0, v1, v2); NaN for a degenerate polygon
@@ -369,9 +374,9 @@ __device__ __forceinline__ void build_ctx(const BeamMesh &M, const BeamEntry &e,
     for (int j = 0; j < LEVEL; ++j) {
         float sg = M.shape[(int64_t)e.id[j] * Sh::TPP];
         if (Sh::TPP == 2) sg = fmaxf(sg, M.shape[(int64_t)e.id[j] * Sh::TPP + 1]);
-        lat += u * sg;
+        lat += u * (margins::kLateralSigma * sg + margins::kLateralConst);
     }
-    const float delta = margins::kLateralFactor * lat;  // +inf for a degenerate mirror: every face off
+    const float delta = lat;  // sum over the mirrors of u (kLateralSigma sigma_l + kLateralConst); +inf for a degenerate mirror: every face off
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
         const float *tv = M.tv + 9 * ((int64_t)e.id[j] * Sh::TPP);
@@ -910,11 +915,13 @@ __device__ __forceinline__ void first_mirror_unfolded(const BeamMesh &M, const B
 template <int SCALE>
 __device__ __forceinline__ bool child_misses_receivers(const RxAll &rx, const BeamMesh &M, float u0, V3 I2,
                                                        const V3 (&vpar)[Shape<SCALE>::NP][Shape<SCALE>::NF], float sig_parent,
-                                                       V3 pc, V3 nc, float sig_c) {
+                                                       V3 pc, V3 nc, float sig_c, int mirrors) {
     using Sh = Shape<SCALE>;
     const V3 I3 = image_of_vertex(I2, pc, nc);  // (beam_child_from's expression)
     const float uc = u0 * mag_scale(M, I3);
-    const float delta = margins::kLateralFactor * uc * (sig_parent + sig_c) * margins::kChildDeltaRoundUp;  // +inf for a degenerate mirror: every face off
+    // (the receiver stage sums u (kLateralSigma sigma_l + kLateralConst) mirror by mirror; here the parent's sigmas arrive as one
+    // sum and `mirrors` counts them, the new one included: rounded up past any order of summation)
+    const float delta = uc * (margins::kLateralSigma * (sig_parent + sig_c) + margins::kLateralConst * (float)mirrors) * margins::kChildDeltaRoundUp;  // +inf for a degenerate mirror: every face off
     const V3 ce = V3{rx.ce[0], rx.ce[1], rx.ce[2]}, he = V3{rx.he[0], rx.he[1], rx.he[2]};  // (rx_all_finish)
     if (!(he.x >= 0.0f) || !(he.y >= 0.0f) || !(he.z >= 0.0f)) return false;
     const V3 w = ce - I3;
@@ -1059,7 +1066,7 @@ __device__ __forceinline__ void expand_clustered_body(
             mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);
         }
         // (rxall.on == 0 -- a non-finite receiver, known only on the device in the async entry point: every child passes)
-        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, vpar, sp, pc, nc, sgc));
+        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, vpar, sp, pc, nc, sgc, LEVEL + 1));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
     };
@@ -1545,7 +1552,7 @@ __global__ __launch_bounds__(kExpandWG) __attribute__((amdgpu_waves_per_eu(BEAM_
             mine = mine && !pyramids_separate<SCALE>(P0, I2, vq, base);
         }
         // (the candidate's mirror: first vertex and normal of its first triangle, prim_plane's pair)
-        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, vpar, sp, vq[0], nc, sgc));
+        const bool pass = mine && !(rxall.on && child_misses_receivers<SCALE>(rxall, M, u, I2, vpar, sp, vq[0], nc, sgc, LEVEL + 1));
         rawcount -= n;
         beam_stage<kBeamWaveBufBig>(pass, rec, wbuf[wave], wcount, lane, out, cap, count);
     };
@@ -1707,8 +1714,8 @@ __device__ __forceinline__ void build_ctx_from(const BeamMesh &M, const BeamEntr
     c.nm = geo[LEVEL - 1].n[0];
     float lat = 0.0f;
 #pragma unroll
-    for (int j = 0; j < LEVEL; ++j) lat += u * geo[j].sg;
-    const float delta = margins::kLateralFactor * lat;
+    for (int j = 0; j < LEVEL; ++j) lat += u * (margins::kLateralSigma * geo[j].sg + margins::kLateralConst);
+    const float delta = lat;
 #pragma unroll
     for (int j = 0; j < LEVEL; ++j) {
 #pragma unroll

@@ -18,8 +18,11 @@ namespace margins {
 // ---- the error unit -------------------------------------------------------------------------------------------------
 // u = kKappaDefault * ulp(M) * mag_scale, M = largest coordinate magnitude of mesh, transmitters and receivers.
 constexpr float kKappaDefault = 64.0f;
-// lateral tolerance of a prefix: delta = kLateralFactor * sum over its mirrors of u * sigma_l (both end points of a segment)
-constexpr float kLateralFactor = 4.0f;
+// lateral tolerance of a prefix: delta = sum over its mirrors of u * (kLateralSigma * sigma_l + kLateralConst) -- a part that
+// grows with the mirror's shape factor (Moller-Trumbore's third-edge uncertainty) and a part that does not (plane distance and
+// lateral error of the reflection points, rounding of the images: what every unfolding adds)
+constexpr float kLateralSigma = 1.0f;
+constexpr float kLateralConst = 3.0f;
 // shape factor sigma = largest 1 / sin(corner) of a triangle, rounded up by this factor and clamped to >= 1 (mesh.hip)
 constexpr float kSigmaRoundUp = 1.0001f;
 
@@ -45,9 +48,12 @@ constexpr float kFaceUnits = 1.0f;
 constexpr float kSlopeFactor = 1.0101f;
 constexpr float kSlopeRounding = 2e-6f;       // rounding of the face normal's normalisation and of <x - I, n_f> (fdot)
 constexpr float kRhoRoundDown = 0.9999f;
+// normal and slope of a face are stored divided by (1 + kSpreadFactor g_f), kSpreadFactor >= sqrt(3): a point moved by r moves the
+// face expression by at most r (1 + sqrt(3) g_f), so thresholds that cover a positional error hold for steep faces too
+constexpr float kSpreadFactor = 1.7321f;
 // a face is OFF while rho_f <= kFaceOffRatio * delta; a whole pyramid while its apex lies within kPlaneOffRatio * delta of
 // the polygon's plane (distance rounded down by kRhoRoundDown)
-constexpr float kFaceOffRatio = 5.05f;       // keeps the slope of an active face below 1/4
+constexpr float kFaceOffRatio = 1.05f;
 constexpr float kPlaneOffRatio = 1.05f;      // the whole pyramid: apex within this many delta of the polygon's plane
 
 // ---- child filter of the last expansion ----------------------------------------------------------------------------
@@ -55,7 +61,7 @@ constexpr float kPlaneOffRatio = 1.05f;      // the whole pyramid: apex within t
 // vertices, same make_pyr), so "what it drops, the receiver stage drops" is monotonicity in these constants:
 constexpr float kChildDeltaRoundUp = 1.00002f;  // the two stages sum the shape factors in different orders
 constexpr float kChildRhoRoundDown = 0.999f;  // < kRhoRoundDown
-constexpr float kChildFaceOffRatio = 5.1f;    // > kFaceOffRatio
+constexpr float kChildFaceOffRatio = 1.06f;   // > kFaceOffRatio
 constexpr float kChildPlaneOffRatio = 1.06f;  // > kPlaneOffRatio
 constexpr float kChildSlopeRounding = 2.1e-4f;  // > kSlopeRounding
 constexpr float kChildFaceUnits = 1.5f;       // > kFaceUnits + (rounding of the box's support against a receiver's own value) / kappa

@@ -239,12 +239,11 @@ def check(m: dict[str, float] | None = None, d: dict | None = None) -> dict:
     def c_pos(sig):
         return max(c1, c3 * sig) + 3 * shift + nu
 
-    # the largest slope a face that can still prune has: g < kSlopeFactor / (kFaceOffRatio - 1) + kSlopeRounding; moving a
-    # point by r changes the face expression <w, n> + g |w|_1 by at most r (1 + sqrt3 g)
-    g_cap = m["kSlopeFactor"] / (m["kFaceOffRatio"] - 1.0) + m["kSlopeRounding"]
-    need("a face that is ON has a slope below 1/4 (so that the factor below stays near 1)", g_cap, 0.25,
-         "pyr_face: on only while rho > kFaceOffRatio delta")
-    spread = 1.0 + SQ3 * g_cap
+    # moving a point by r changes the face expression <w, n> + g |w|_1 by at most r (1 + sqrt3 g); the kernels store n and g
+    # divided by (1 + kSpreadFactor g), which turns every comparison with a threshold T into one with T (1 + kSpreadFactor g):
+    # the thresholds below need to cover the positional error itself, whatever the slope
+    need("kSpreadFactor is at least sqrt(3) (|w|_1 <= sqrt(3) |w|_2)", SQ3, m["kSpreadFactor"], "pyr_face: n, g scaled by 1 / (1 + kSpreadFactor g)")
+    spread = 1.0
     for sig in (SIGMA_MIN, 1.5, 2.0, 4.0, 16.0, 1e3):
         need(f"side test, computed points (sigma = {sig:.4g}): kSideEpsFactor * kappa * sigma covers the positional coefficient",
              c_pos(sig), m["kSideEpsFactor"] * kappa * sig * m["kSigmaRoundUp"],
@@ -257,20 +256,21 @@ def check(m: dict[str, float] | None = None, d: dict | None = None) -> dict:
     need("face threshold: kFaceUnits * kappa covers (1 + sqrt3 g) x the plane distance of the point + the kernel's evaluation",
          spread * nu + k_eval, m["kFaceUnits"] * kappa, "")
 
-    # ---- lateral tolerance (slopes of the faces): delta = kLateralFactor * sum_l kappa sigma_l (x mag_scale) ----
+    # ---- lateral tolerance (slopes of the faces): delta = sum_l kappa (kLateralSigma sigma_l + kLateralConst) (x mag_scale) ----
     # pyramid over the prefix's LAST mirror: Moller-Trumbore's uncertainty, its input shifts, and the lateral distance between
-    # the tested ray's crossing point and the outgoing line (2 nu sin(phi) + lateral + shift)
-    budget = m["kLateralFactor"] * kappa
+    # the tested ray's crossing point and the outgoing line (2 nu sin(phi) + lateral + shift) -- against that mirror's own share
+    a, b = m["kLateralSigma"], m["kLateralConst"]
     for sig in (SIGMA_MIN, 1.5, 2.0, 4.0, 16.0, 1e3):
         first = max(c1, c3 * sig) + 3 * shift + (2 * nu + lam + shift)
-        need(f"lateral tolerance, last mirror (sigma = {sig:.4g})", first, budget * sig, "build_ctx: delta = kLateralFactor * sum u sigma")
+        need(f"lateral tolerance, last mirror (sigma = {sig:.4g})", first, kappa * (a * sig + b), "build_ctx: delta = sum u (kLateralSigma sigma + kLateralConst)")
     # every unfolding through a later mirror l adds: the reflection of the (nearly in-plane) reflection point (2 nu, stretched by
-    # the map's |n|^2), the lateral error of the next step, the rounding of the apex's image and of the unfolded vertices
+    # the map's |n|^2), the lateral error of the next step, the rounding of the apex's image and of the unfolded vertices --
+    # nothing that grows with a shape factor: it goes against the smallest share a later mirror can bring
     stretch = 1.0 + 8 * EPS
     unfold1 = 2 * nu * stretch + lam + d["image_apex_val"] + d["image_vertex1_val"]
     unfold2 = 2 * nu * stretch + lam + d["image_apex_val"] + d["image_vertex2_val"]
-    need("lateral tolerance, one unfolding: the later mirror's own share of delta covers it", unfold1, budget * SIGMA_MIN, "")
-    need("lateral tolerance, second unfolding (order 3)", unfold2, budget * SIGMA_MIN, "")
+    need("lateral tolerance, one unfolding: the later mirror's own share of delta covers it", unfold1, kappa * (a * SIGMA_MIN + b), "")
+    need("lateral tolerance, second unfolding (order 3)", unfold2, kappa * (a * SIGMA_MIN + b), "")
 
     # ---- the kernels' own approximations ----
     # v_rcp_f32 / v_sqrt_f32: 1 ulp = 2 eps relative each
@@ -304,7 +304,7 @@ def check(m: dict[str, float] | None = None, d: dict | None = None) -> dict:
             "derived": {"lateral_u0": lam, "plane_u0": nu, "side_sign_u0": side, "mt_first_u0": c1, "mt_third_per_sigma_u0": c3,
                         "image_apex_u0": d["image_apex_val"], "image_vertex_unfolded_once_u0": d["image_vertex1_val"],
                         "image_vertex_unfolded_twice_step_u0": d["image_vertex2_val"], "mt_input_shift_u0": shift,
-                        "largest_slope_of_an_active_face": g_cap}}
+                        }}
 
 
 # ---------------------------------------------------------------------------------------------------------------

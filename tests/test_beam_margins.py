@@ -30,12 +30,13 @@ def test_the_constants_in_the_header_pass_the_check():
 @pytest.mark.parametrize("name,value", [
     ("kKappaDefault", 16.0),        # a quarter of the unit: neither the positional nor the lateral budget holds
     ("kKappaDefault", 32.0),
-    ("kLateralFactor", 2.0),        # round 5's value: the second unfolding of an order-3 prefix is not covered
+    ("kLateralConst", 1.0),         # the constant share of a mirror must cover a second unfolding (255 ulp(M))
+    ("kLateralSigma", 0.5),         # the sigma share must cover Moller-Trumbore's third-edge uncertainty (56 sigma)
+    ("kSpreadFactor", 1.0),         # below sqrt(3)
     ("kSideEpsFactor", 1.0),        # round 5's value: kappa sigma < the positional coefficient
-    ("kFaceOffRatio", 1.05),        # round 5's value: a face with a slope of 20 stays on
     ("kFaceEpsFactor", 1.0),
     ("kSideUnits", 0.25),
-    ("kChildFaceOffRatio", 5.05),   # not wider than the receiver stage's
+    ("kChildFaceOffRatio", 1.05),   # not wider than the receiver stage's
     ("kChildFaceUnits", 1.0),
     ("kChildFaceUnits", 1.1),       # round 5's value: 6 ulp(M), less than the rounding of the box's support
     ("kChildDeltaRoundUp", 1.0),
