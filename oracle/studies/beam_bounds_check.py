@@ -297,7 +297,7 @@ def check(m: dict[str, float] | None = None, d: dict | None = None) -> dict:
     need("child filter: whole pyramid switches off earlier", m["kPlaneOffRatio"] * 1.005, m["kChildPlaneOffRatio"], "")
     need("child filter: larger relative slope allowance", m["kSlopeRounding"] * 10, m["kChildSlopeRounding"], "")
     need("child filter: its lateral tolerance is rounded up past the receiver stage's (sum of <= 3 products in another order: 4 eps)",
-         1.0 + 8 * EPS, m["kChildDeltaRoundUp"], "child_misses_receivers: delta = kLateralFactor u (sig_parent + sig_c) kChildDeltaRoundUp")
+         1.0 + 8 * EPS, m["kChildDeltaRoundUp"], "child_misses_receivers: delta = u (kLateralSigma (sig_parent + sig_c) + kLateralConst mirrors) kChildDeltaRoundUp")
     need("child filter: the extra threshold covers the rounding of the box's centre / half extents / support against a receiver's own value",
          k_eval + 3 * hu(1.0), (m["kChildFaceUnits"] - m["kFaceUnits"]) * kappa, "child_misses_receivers: thr = -kChildFaceUnits u")
     return {"ok": all(c["ok"] for c in checks), "checks": checks, "kappa": kappa, "sigma_min": SIGMA_MIN,
