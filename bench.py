@@ -231,6 +231,21 @@ def compact_line(full: dict, sidecar: str | None) -> dict:
     return out
 
 
+def fit_line(comp: dict, limit: int = LINE_LIMIT) -> str:
+    """The compact dict as ONE JSON line below `limit` characters.  A line that outgrew the limit sheds its optional blocks
+    (they stay in the sidecar) -- never the contract keys, `roofline` or `cpu_baseline`, and never the run: an assert here
+    once lost every measurement of a run whose line was a few characters too long."""
+    line = json.dumps(comp, separators=(",", ":"))
+    for drop in ("strong_headline", "paths", "legs_error", "paths_metric", "ranks_seen_by_backend"):
+        if len(line) < limit:
+            break
+        if drop in comp:
+            comp.pop(drop)
+            comp["line_shed"] = comp.get("line_shed", []) + [drop]
+            line = json.dumps(comp, separators=(",", ":"))
+    return line
+
+
 def _progress(msg: str) -> None:
     """Leg markers on stderr (the line on stdout stays the only thing there): a leg that dies is then named."""
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
@@ -657,17 +672,7 @@ def main() -> None:
             Path(args.write_strong_n1).write_text(json.dumps(
                 {"what": "bench.py strong-scaling legs on ONE MI355X (fixed total work: configs[4])", "s_per_step": n1,
                  "source_hash": {k: source_hash(k) for k in ("beam", "trace_filter", "dense")}}, indent=1) + "\n")
-        comp = compact_line(result, side_name)
-        line = json.dumps(comp, separators=(",", ":"))
-        # a line that outgrew the limit sheds its optional blocks (they stay in the sidecar) -- never the contract keys, and
-        # never the run: an assert here lost every measurement of a run whose line was a few characters too long
-        for drop in ("strong_headline", "paths", "legs_error", "paths_metric", "ranks_seen_by_backend"):
-            if len(line) < LINE_LIMIT:
-                break
-            comp.pop(drop, None)
-            comp["line_shed"] = comp.get("line_shed", []) + [drop]
-            line = json.dumps(comp, separators=(",", ":"))
-        print(line, flush=True)
+        print(fit_line(compact_line(result, side_name)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
