@@ -62,3 +62,27 @@ def test_exhaustive_record_is_quoted_only_while_its_hash_matches_the_tree(monkey
         assert bench_paths.exhaustive_record("bruxelles order 3")["checked_pairs"] >= 8
     monkeypatch.setattr(_srchash, "source_hash", lambda kind, root=None: "0" * 16)
     assert bench_paths.exhaustive_record("configs[3]") is None
+
+
+def test_round6_stress_records_are_clean_and_stamped():
+    """The stress records DESIGN.md section 9.6 quotes: zero lost / extra paths, vertex-bit differences and mapping row mismatches
+    at every unit >= 1/4 (the run at 1/64 is the one that is SUPPOSED to lose paths: it shows where the margins stop being loose),
+    short-segment artifacts counted apart, every record stamped with the hash of the kernels it was taken on."""
+    recs = sorted((ROOT / "profiles" / "r06" / "stress").glob("beam_stress*.json"))
+    assert len(recs) >= 5
+    scenes = 0
+    for p in recs:
+        rec = json.loads(p.read_text())
+        assert set(rec["source_hash"]) >= {"beam", "trace_filter"} and len(rec["source_hash"]["beam"]) == 16, p
+        assert rec["extra"] == 0 and rec["vertex_mismatch"] == 0 and rec["mapping_row_mismatch"] == 0, p
+        if rec["kappa"] >= 0.25:
+            assert rec["missed"] == 0, p
+            scenes += rec["cases"]
+        else:
+            assert rec["missed"] > 0, p
+        assert rec["short_segment_paths_lost"] <= rec["short_segment_paths_seen"] < 1e-3 * rec["valid_paths"]
+    assert scenes > 800_000
+    ex = json.loads((ROOT / "profiles" / "r06" / "stress" / "exhaustive_pairs.json").read_text())
+    assert ex["all_equal"] and {r["config"]: r["checked_pairs"] for r in ex["records"]} == {
+        "configs[3]": 16, "configs[4]": 16, "bruxelles order 3": 8, "manhattan order 3": 8}
+    assert ex["source_hash"]["beam"] == json.loads(recs[0].read_text())["source_hash"]["beam"]  # one tree for all of them
